@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/protocol.json by importing the REFERENCE's pure-Python protocol code.
+
+Runs only in the build container (needs /root/reference); the JSON it writes is data (request
+strings, parsed replies, selection outcomes) -- no reference source travels.
+
+  * /root/reference/frontend_connector.py is imported with a stub `zmq` module whose REQ socket
+    records every request and plays back scripted replies.
+  * /root/reference/redis_channelizer_manager.py is imported with stub `redis` + `config` modules;
+    `get_channelizer_for_frequency` is exercised on hand-built channelizer tables.
+"""
+import json
+import os
+import random
+import sys
+import time
+import types
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "protocol.json")
+
+# ---------------------------------------------------------------- stub zmq
+sent = []
+replies = []
+
+
+class _Sock:
+    def setsockopt(self, *a): pass
+    def getsockopt(self, *a): return 1000
+    def connect(self, addr): sent.append(("CONNECT", addr))
+    def close(self): pass
+    def send_string(self, s): sent.append(("REQ", s))
+    def recv_string(self):
+        return replies.pop(0)
+
+
+class _Ctx:
+    def socket(self, kind): return _Sock()
+    def term(self): pass
+    def destroy(self): pass
+
+
+zmq = types.ModuleType("zmq")
+zmq.Context = _Ctx
+zmq.REQ, zmq.RCVTIMEO, zmq.SNDTIMEO, zmq.LINGER = 3, 27, 28, 17
+sys.modules["zmq"] = zmq
+
+# ---------------------------------------------------------------- stub redis / config
+redis = types.ModuleType("redis")
+class _R:
+    def __init__(self, *a, **k): pass
+    def smembers(self, k): return set()
+    def get(self, k): return None
+redis.StrictRedis = _R
+sys.modules["redis"] = redis
+config = types.ModuleType("config")
+class rc_config:
+    redis_servers = [("127.0.0.1", 6379)]
+config.rc_config = rc_config
+sys.modules["config"] = config
+
+sys.path.insert(0, REF)
+import frontend_connector as FC          # noqa: E402
+# the 0.25 s heartbeat thread (frontend_connector.py:197-229) would race the scripted replies; its
+# one request ('hb,<cid>', :210) is captured explicitly through the same send() path instead.
+FC.frontend_connector.connection_handler = lambda self: None
+import redis_channelizer_manager as RCM  # noqa: E402
+
+
+class FakeRCM:
+    def get_channelizer_for_frequency(self, f):
+        return ("10.0.0.5", 4242)
+
+
+golden = {"connector": [], "rcm": []}
+
+
+def run_case(name, script):
+    """script: list of (method, args, [replies...])"""
+    global sent, replies
+    fc = FC.frontend_connector("parent-uuid", FakeRCM())
+    steps = []
+    for method, args, reps in script:
+        sent.clear()
+        replies[:] = list(reps)
+        ret = getattr(fc, method)(*args)
+        steps.append({"call": method, "args": list(args), "replies": list(reps),
+                      "requests": [s for k, s in sent if k == "REQ"],
+                      "connects": [s for k, s in sent if k == "CONNECT"],
+                      "returns": list(ret) if isinstance(ret, tuple) else ret,
+                      "host": fc.host})
+    golden["connector"].append({"name": name, "steps": steps})
+
+
+run_case("create_release", [
+    ("create_channel", (12500, 855000000), ["connect,7", "create,abc-uuid,12345"]),
+    ("report_offset", (0.25,), ["offset,7"]),
+    ("release_channel", (), ["release,abc-uuid"]),
+])
+run_case("heartbeat", [
+    ("create_channel", (12500, 855000000), ["connect,7", "create,abc-uuid,12345"]),
+    ("send", ("hb,7",), ["hb,7"]),
+    ("send", ("hb,7",), ["fail,7"]),
+    ("send", ("quit,7",), ["quit,7"]),
+])
+run_case("create_refused", [
+    ("create_channel", (12500, 100), ["connect,3", "na,100"]),
+    ("release_channel", (), []),
+    ("report_offset", (1.5,), []),
+])
+run_case("release_refused", [
+    ("create_channel", (25000, 851000000), ["connect,0", "create,u-1,10001"]),
+    ("release_channel", (), ["na,u-1"]),
+])
+run_case("scan_mode", [
+    ("create_channel", (12500, 5000), ["connect,1", "create,u-2,20002"]),
+    ("scan_mode_set_freq", (770000000,), ["success"]),
+])
+
+# ---------------------------------------------------------------- rcm selection rule
+mgr = RCM.redis_channelizer_manager.__new__(RCM.redis_channelizer_manager)
+import logging
+mgr.log = logging.getLogger("x")
+mgr.clients = ["dummy"]
+tables = {
+    "two_sources_nearest_wins": {
+        "A": {"address": "10.0.0.1", "port": 5001, "sources": [[855000000, 2400000]]},
+        "B": {"address": "10.0.0.2", "port": 5002, "sources": [[855900000, 2400000]]},
+    },
+    "edge_exclusive": {
+        "A": {"address": "10.0.0.1", "port": 5001, "sources": [[855000000, 2400000]]},
+    },
+    "multi_source_channelizer": {
+        "A": {"address": "10.0.0.1", "port": 5001,
+              "sources": [[851000000, 2400000], [853000000, 2400000]]},
+        "B": {"address": "10.0.0.2", "port": 5002, "sources": [[852900000, 10000000]]},
+    },
+}
+queries = {
+    "two_sources_nearest_wins": [855100000, 855500000, 856900000, 853700000, 860000000],
+    "edge_exclusive": [856200000, 856199999, 853800000, 853800001],
+    "multi_source_channelizer": [852000000, 853000001, 850000000, 857899999, 857900000],
+}
+for name, table in tables.items():
+    mgr.channelizers = table
+    for q in queries[name]:
+        random.seed(0)
+        got = mgr.get_channelizer_for_frequency(q)
+        golden["rcm"].append({"table": name, "channelizers": table, "frequency": q,
+                              "result": list(got)})
+
+with open(OUT, "w") as f:
+    json.dump(golden, f, indent=1, sort_keys=True)
+print("wrote", OUT, len(golden["connector"]), "connector cases,", len(golden["rcm"]), "rcm queries")
+os._exit(0)
