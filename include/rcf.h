@@ -1,0 +1,187 @@
+/*
+ * rcf.h -- C ABI of librcf.so: the MI355X-native wideband channelizer, NBFM discriminator and FFT
+ * peak scanner that replaces the GNU Radio hot path of MattMills/radiocapture-rf.
+ *
+ * The reference has no FFI of its own (it is pure Python on top of GNU Radio 3.8 blocks); this ABI is
+ * the boundary a maintainer binds with ctypes (INTEGRATION.md shows the stub).  Every entry point
+ * names the reference interface it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature; device pointers are passed as void* / float*.
+ *   - IQ is interleaved little-endian float32 re,im ("cf32", GNU Radio gr_complex), 8 bytes/sample.
+ *   - every function returns RCF_OK (0) or a negative RCF_E* code and never throws; the text of the
+ *     last failure on the calling thread is rcf_last_error().
+ *   - one rcf_t is bound to one HIP device and one HIP stream; calls on one handle are serialised by
+ *     an internal mutex (mirrors receiver.access_lock, rc_frontend/receiver.py:48).
+ *   - there is NO CPU fallback: without a gfx950 device rcf_open() fails with RCF_EHIP.
+ */
+#ifndef RCF_H
+#define RCF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rcf rcf_t;
+
+#define RCF_OK        0
+#define RCF_EINVAL   -1   /* bad argument */
+#define RCF_ENOMEM   -2   /* host or device allocation failed */
+#define RCF_EHIP     -3   /* HIP runtime error / no device */
+#define RCF_ENOCHAN  -4   /* unknown channel id */
+#define RCF_ECAP     -5   /* block larger than the configured capacity */
+#define RCF_ESTATE   -6   /* call not valid in the current state */
+#define RCF_EAGAIN   -7   /* result not ready yet */
+#define RCF_ERANGE   -8   /* offset outside the source's band / non-integral decimation */
+
+/* window types: numeric values follow gnuradio.filter.firdes.WIN_* */
+#define RCF_WIN_HAMMING          0
+#define RCF_WIN_BLACKMAN         2
+#define RCF_WIN_BLACKMAN_HARRIS  5
+
+/* ------------------------------------------------------------------ library / device */
+const char *rcf_version(void);
+const char *rcf_last_error(void);
+/* number of visible HIP devices (0 when none / no driver); never fails */
+int rcf_device_count(void);
+
+/* ------------------------------------------------------------------ filter design (host) */
+/* gnuradio.filter.firdes.low_pass_2(gain, fs, fc, tw, att_dB, window) as called at
+ * rc_frontend/channel.py:33 and p25_control_demod.py:106.  Writes the float32 taps; returns the tap
+ * count, or -(needed count) when cap is too small (call with taps=NULL, cap=0 to size). */
+int rcf_design_low_pass_2(double gain, double fs, double fc, double tw, double att_db, int window,
+                          float *taps, int cap);
+/* gnuradio.fft.window.{hamming,blackman,blackmanharris}(n) (fft_vector.py:38) */
+int rcf_design_window(int window, int n, float *w);
+/* rc_frontend/channel.py:31-33: decim = int(fs/cr)/2 (must be integral -> else RCF_ERANGE) and the
+ * tap count of low_pass_2(1.0, fs, cr/2, cr/2, 20.0, WIN_HAMMING). */
+int rcf_channel_params(double samp_rate, int channel_rate, int *decim, int *ntaps);
+
+/* ------------------------------------------------------------------ front-end lifecycle */
+/*
+ * One rcf_t == one SDR source of the reference's receiver (rc_frontend/receiver.py:170-204): it owns
+ * the HBM-resident wideband buffer that replaces the per-subscriber ZMQ copies of
+ * `zeromq.pub_sink('ipc:///tmp/rx_source_<id>')` (receiver.py:201-202).
+ *   block_capacity : max samples per push/commit            (0 -> 1<<22)
+ *   hist_capacity  : samples of history kept before a block (0 -> 1<<16; must cover T-1, the PFB
+ *                    prototype length and the scan FFT length)
+ *   out_capacity   : per-channel output ring, samples, rounded up to a power of two (0 -> 1<<16)
+ */
+int rcf_open(int device, double samp_rate, double center_freq, rcf_t **out);
+int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_capacity,
+                size_t hist_capacity, size_t out_capacity, rcf_t **out);
+int rcf_close(rcf_t *h);
+/* wait until everything queued on the handle's stream has finished */
+int rcf_sync(rcf_t *h);
+/* the handle's hipStream_t, for callers that time the kernels with HIP events */
+void *rcf_stream(rcf_t *h);
+int rcf_device(rcf_t *h);
+
+/* ------------------------------------------------------------------ wideband ingest */
+/* Host buffer in: copies n_samples H2D behind the history and runs every consumer (channels, PFB,
+ * armed scan) over the new block.  Replaces the source -> pub_sink broadcast (receiver.py:201-202)
+ * and every channel's sub_source (rc_frontend/channel.py:29). */
+int rcf_push_iq(rcf_t *h, const float *iq_interleaved, size_t n_samples);
+/* Zero-copy ingest: *dev_ptr is where the producer (SDR DMA, generator kernel, hipMemcpy) must put
+ * the next block (device memory, room for *max_samples); rcf_commit(n) then processes the n samples
+ * found there.  rcf_commit without rewriting the region re-processes the resident data as the next
+ * n samples of the stream (used by bench.py: inputs already resident in HBM). */
+int rcf_ingest_ptr(rcf_t *h, float **dev_ptr, size_t *max_samples);
+int rcf_commit(rcf_t *h, size_t n_samples);
+/* total samples ingested so far */
+int64_t rcf_samples_in(rcf_t *h);
+
+/* ------------------------------------------------------------------ direct ("xlat") channels */
+/*
+ * rcf_chan_open == channel.channel(parent_zmq_address, port, channel_rate, samp_rate, offset)
+ * (rc_frontend/channel.py:18-38): decim = int(fs/cr)/2, taps = low_pass_2(1.0, fs, cr/2, cr/2, 20,
+ * HAMMING), freq_xlating_fir_filter_ccc(decim, taps, offset, fs) with GNU Radio's float32 tap-phase
+ * and rotator arithmetic.  Output rate fs/decim = 2*channel_rate.  The channel starts at the next
+ * ingested sample with zero history (GR semantics).
+ */
+int rcf_chan_open(rcf_t *h, int channel_rate, double offset_hz, int *chan_id);
+/* generic form: any decimation / prototype taps (e.g. the P25 69-tap pre-filter with decim 1,
+ * p25_control_demod.py:106-108).  src_chan < 0: input is the wideband stream; otherwise the output of
+ * PFB bin `src_chan - RCF_SRC_PFB_BIN0` (see rcf_pfb_chan_open) or of direct channel `src_chan`. */
+int rcf_chan_open_taps(rcf_t *h, int src_chan, int decim, const float *taps, int ntaps,
+                       double offset_hz, int *chan_id);
+/* channel.set_offset (rc_frontend/channel.py:61-63): retune, keeping rotator phase and FIR history */
+int rcf_chan_set_offset(rcf_t *h, int chan_id, double offset_hz);
+/* channel.destroy (rc_frontend/channel.py:64-67) */
+int rcf_chan_close(rcf_t *h, int chan_id);
+int rcf_chan_info(rcf_t *h, int chan_id, int *decim, int *ntaps, double *out_rate, double *offset_hz);
+/* samples produced so far / not yet read */
+int64_t rcf_chan_produced(rcf_t *h, int chan_id);
+/* Non-blocking reads (return the sample count, 0 if nothing is ready, <0 on error).  read_iq is the
+ * payload of the channel's zeromq.pub_sink (rc_frontend/channel.py:36); read_fm is
+ * analog.quadrature_demod_cf(gain) applied to that stream (p25_control_demod.py:120-121,
+ * moto_control_demod.py:105, edacs_control_demod.py:84, logging_receiver.py:233-234).  The two
+ * cursors are independent.  A reader that falls more than out_capacity behind loses the oldest
+ * samples (as a PUB socket at its HWM does). */
+int64_t rcf_chan_read_iq(rcf_t *h, int chan_id, float *out_interleaved, size_t max_samples);
+int64_t rcf_chan_read_fm(rcf_t *h, int chan_id, float gain, float *out, size_t max_samples);
+/* device pointers of the channel's rings (cf32 iq ring, f32 unit-gain discriminator ring) and their
+ * power-of-two capacity: sample k lives at index k & (capacity-1) */
+int rcf_chan_rings(rcf_t *h, int chan_id, void **iq_ring, void **fm_ring, size_t *capacity);
+/* receiver.source_offset folds demod-reported drift into the SDR centre frequency
+ * (rc_frontend/receiver.py:436-475); here the same Hz shift is added to every channel's offset. */
+int rcf_source_shift(rcf_t *h, double delta_hz);
+
+/* ------------------------------------------------------------------ polyphase filterbank */
+/*
+ * n_bins-channel PFB with prototype `taps` and decimation `decim` (n_bins % decim == 0): bin k is
+ * exactly freq_xlating_fir_filter_ccc(decim, taps, k*fs/n_bins, fs) evaluated with exact phases
+ * (SURVEY.md 7.2); it is the throughput path for on-grid channels and replaces the dead
+ * pfb.channelizer_ccf branch of rc_frontend/receiver.py:242-261.  Output: n_bins rings at fs/decim.
+ * n_bins must be a power of two in [16, 4096].
+ */
+int rcf_pfb_open(rcf_t *h, int n_bins, int decim, const float *taps, int ntaps);
+int rcf_pfb_close(rcf_t *h);
+int64_t rcf_pfb_produced(rcf_t *h);
+/* bin index in [0, n_bins): bin k is centred at k*fs/n_bins for k < n_bins/2, (k-n_bins)*fs/n_bins above */
+int64_t rcf_pfb_read_bin(rcf_t *h, int bin, float *out_interleaved, size_t max_samples);
+int rcf_pfb_rings(rcf_t *h, void **bins_ring, size_t *capacity);
+/* stage 2 on one bin: channel.py's own rule at the bin rate -- decim2 = int(bin_rate/cr)/2,
+ * low_pass_2(1.0, bin_rate, cr/2, cr/2, 20, HAMMING), xlating by delta_hz -- output as a normal
+ * channel id (read_iq / read_fm). */
+#define RCF_SRC_PFB_BIN0 0x40000000
+int rcf_pfb_chan_open(rcf_t *h, int bin, int channel_rate, double delta_hz, int *chan_id);
+
+/* ------------------------------------------------------------------ scan (fft_vector.py + fft_peak_detection.py) */
+/*
+ * fft_vector.py:37-60: stream_to_vector(fft_len) -> fft_vcc(fft_len, forward, blackmanharris, shift)
+ * -> complex_to_mag_squared -> nlog10_ff(1, fft_len, 1) -> moving_average_ff(avg_len, 1, ..) ->
+ * head(n_frames) -> skiphead(n_frames-1): one float32[fft_len] vector.
+ * rcf_scan_start arms the scanner at the next ingested sample; the following pushes/commits feed it;
+ * rcf_scan_result returns RCF_EAGAIN until n_frames frames have been consumed, then copies the
+ * vector (the content of /tmp/fft_source_<i>) to the host.  fft_len: power of two, 256 .. 1<<20.
+ */
+int rcf_scan_start(rcf_t *h, int fft_len, int n_frames, int avg_len);
+int rcf_scan_result(rcf_t *h, float *out_spectrum);
+int rcf_scan_frames_done(rcf_t *h);
+/* device pointer of the finished spectrum (float32[fft_len]); valid until the next rcf_scan_start */
+int rcf_scan_result_device(rcf_t *h, void **dev_spectrum);
+/*
+ * fft_peak_detection.py:54-72 on a float32 spectrum of n bins: data += |min(data)|; mean (sequential
+ * float64); scipy.signal.find_peaks(data, width=[min_w,max_w], prominence=prominence); keep
+ * data[line] > 2*mean.  Writes the surviving `line` indices in ascending order (at most cap) and
+ * returns how many survived in *count (may exceed cap).  Host arithmetic in float64, bit-exact with
+ * scipy.  spectrum is a HOST pointer.
+ */
+int rcf_find_peaks(const float *spectrum, int64_t n, double min_w, double max_w, double prominence,
+                   int64_t *idx, int64_t cap, int64_t *count, double *mean_out);
+/* fft_peak_detection.py:72: frequency = int(line*hz_per_bin - bandwidth/2 + center_freq) */
+int64_t rcf_peak_frequency(int64_t line, double samp_rate, int64_t fft_len, double center_freq);
+/* same detection run on the device-resident result of the last scan (HIP kernels: local maxima,
+ * block-skipping prominence/width walks); indices land in a device int64 buffer and are also copied to
+ * idx (host) when idx != NULL. */
+int rcf_scan_find_peaks(rcf_t *h, double prominence, int64_t *idx, int64_t cap, int64_t *count,
+                        double *mean_out, void **dev_idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCF_H */

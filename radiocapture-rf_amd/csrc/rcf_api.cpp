@@ -1,0 +1,970 @@
+// rcf_api.cpp -- the C ABI of librcf.so (include/rcf.h): front-end state, stream bookkeeping and
+// kernel scheduling.  One rcf_t == one SDR source of /root/reference/rc_frontend/receiver.py; every
+// push/commit runs all open channels, the filterbank, the discriminators and an armed scan over the
+// new block on the handle's HIP stream.
+//
+// Memory plan (sized for 288 GB of HBM3E): two wideband buffers [hist | block] ping-pong so the
+// producer can fill the next block while kernels chew on the current one; the tail of every block is
+// copied behind the other buffer's block as its history, which lets every kernel address the stream
+// linearly (no wrap handling on the hot loads).  Narrowband outputs live in per-channel power-of-two
+// rings addressed by the absolute output index.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "rcf_internal.h"
+
+namespace rcfx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+bool hip_ok(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return false;
+}
+
+static const double kTwoPi = 6.283185307179586476925286766559;
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); }
+static inline int64_t floor_div(int64_t a, int64_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+static size_t pow2_at_least(size_t v)
+{
+    size_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+struct Chan {
+    int id = -1;
+    int src = -1;                 // -1 wideband; RCF_SRC_PFB_BIN0 + bin; else source channel id
+    int D = 0, T = 0;
+    double src_rate = 0, offset_hz = 0;
+    std::vector<float> proto;     // prototype taps (host)
+    float2 *d_ctaps = nullptr;
+    float2 *d_iq = nullptr;
+    float *d_fm = nullptr;
+    int64_t start_sample = 0;     // in source index space
+    int64_t k_abs0 = 0;
+    int64_t produced = 0;         // relative output count
+    int64_t rd_iq = 0, rd_fm = 0;
+    // rotator model
+    double dangle = 0, dlogmag = 0;
+    long double angle0 = 0;
+    double logmag0 = 0;
+    int64_t n_seg0 = 0;
+    int depth = 0;
+};
+
+struct Pfb {
+    bool open = false;
+    int NB = 0, D = 0, T = 0, P = 0, Ppad = 0;
+    float *d_ptaps = nullptr;
+    float2 *d_tw = nullptr;
+    float2 *d_bins = nullptr;
+    std::vector<int64_t> rd;       // per-bin read cursors
+    int64_t start_sample = 0, n_abs0 = 0, produced = 0;
+    int64_t produced_before = 0;   // value of `produced` before the current commit (for derived channels)
+};
+
+struct Scan {
+    bool armed = false, done = false;
+    int N = 0, n_frames = 0, L = 0, R = 0, chunk = 0;
+    int frames_done = 0;
+    int64_t start_sample = 0;
+    float *d_window = nullptr, *d_vring = nullptr, *d_sum = nullptr, *d_out = nullptr;
+    float2 *d_tw = nullptr, *d_scratch = nullptr;
+    int64_t *d_peaks = nullptr;
+};
+
+}  // namespace rcfx
+
+using namespace rcfx;
+
+struct rcf {
+    int device = 0;
+    double fs = 0, fc = 0;
+    size_t block_cap = 0, hist_cap = 0, out_cap = 0;
+    uint64_t ring_mask = 0;
+    hipStream_t stream = nullptr;
+    float2 *d_buf[2] = {nullptr, nullptr};
+    int cur = 0;
+    int64_t total_in = 0;
+    double shift_hz = 0;          // accumulated rcf_source_shift
+    float *d_atan = nullptr;
+    // launch-parameter arenas (pinned host + device), double buffered
+    static constexpr size_t kArena = 8u << 20;
+    unsigned char *h_arena[2] = {nullptr, nullptr};
+    unsigned char *d_arena[2] = {nullptr, nullptr};
+    hipEvent_t arena_ev[2] = {nullptr, nullptr};
+    bool arena_used[2] = {false, false};
+    int arena_cur = 0;
+    std::map<int, std::unique_ptr<Chan>> chans;
+    int next_id = 1;
+    Pfb pfb;
+    Scan scan;
+    std::vector<void *> graveyard;   // device buffers to free once the stream is idle
+    std::mutex mu;
+};
+
+namespace {
+
+int set_dev(rcf_t *h)
+{
+    RCF_HIP(hipSetDevice(h->device));
+    return RCF_OK;
+}
+
+void bury(rcf_t *h, void *p)
+{
+    if (p) h->graveyard.push_back(p);
+}
+
+void drain_graveyard(rcf_t *h)
+{
+    if (h->graveyard.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->graveyard) (void)hipFree(p);
+    h->graveyard.clear();
+}
+
+// source description for one commit
+struct SrcRange {
+    StreamView view;
+    int64_t p0, p1;      // new samples [p0, p1) in the source's index space
+};
+
+bool source_range(rcf_t *h, int src, int64_t S0, int64_t S1, SrcRange *out)
+{
+    if (src < 0) {
+        out->view.base = h->d_buf[h->cur];
+        out->view.mask = ~0ull;
+        out->view.origin = S0 - (int64_t)h->hist_cap;
+        out->p0 = S0;
+        out->p1 = S1;
+        return true;
+    }
+    if (src >= RCF_SRC_PFB_BIN0) {
+        if (!h->pfb.open) return false;
+        const int bin = src - RCF_SRC_PFB_BIN0;
+        out->view.base = h->pfb.d_bins + (size_t)bin * h->out_cap;
+        out->view.mask = h->ring_mask;
+        out->view.origin = 0;
+        out->p0 = h->pfb.produced_before;
+        out->p1 = h->pfb.produced;
+        return true;
+    }
+    return false;   // channel-sourced: resolved by the caller (needs per-commit bookkeeping)
+}
+
+int upload_composite(rcf_t *h, Chan *c)
+{
+    std::vector<float> ct;
+    float incr[2];
+    design_composite(c->proto.data(), c->T, c->D, c->offset_hz + (c->src < 0 ? h->shift_hz : 0.0), c->src_rate,
+                     ct, incr);
+    float2 *fresh = nullptr;
+    RCF_HIP(hipMalloc(&fresh, sizeof(float2) * (size_t)c->T));
+    RCF_HIP(hipMemcpy(fresh, ct.data(), sizeof(float2) * (size_t)c->T, hipMemcpyHostToDevice));
+    bury(h, c->d_ctaps);
+    c->d_ctaps = fresh;
+    // GR iterates phase *= incr in float32; model it by the increment's actual angle and magnitude
+    c->dangle = std::atan2((double)incr[1], (double)incr[0]);
+    c->dlogmag = std::log(std::hypot((double)incr[0], (double)incr[1]));
+    return RCF_OK;
+}
+
+int new_channel(rcf_t *h, int src, int D, const float *taps, int T, double offset_hz, int *chan_id)
+{
+    if (D < 1 || T < 1 || !taps || !chan_id) { set_error("bad channel arguments"); return RCF_EINVAL; }
+    std::unique_ptr<Chan> c(new Chan);
+    c->src = src;
+    c->D = D;
+    c->T = T;
+    c->offset_hz = offset_hz;
+    c->proto.assign(taps, taps + T);
+    if (src < 0) {
+        c->src_rate = h->fs;
+        c->start_sample = h->total_in;
+        c->depth = 0;
+        if ((size_t)(T - 1 + D) > h->hist_cap) { set_error("history capacity %zu < T-1+D", h->hist_cap); return RCF_ECAP; }
+    } else if (src >= RCF_SRC_PFB_BIN0) {
+        if (!h->pfb.open || src - RCF_SRC_PFB_BIN0 >= h->pfb.NB) { set_error("no such PFB bin"); return RCF_EINVAL; }
+        c->src_rate = h->fs / h->pfb.D;
+        c->start_sample = h->pfb.produced;
+        c->depth = 1;
+    } else {
+        auto it = h->chans.find(src);
+        if (it == h->chans.end()) { set_error("no such source channel %d", src); return RCF_ENOCHAN; }
+        c->src_rate = it->second->src_rate / it->second->D;
+        c->start_sample = it->second->produced;
+        c->depth = it->second->depth + 1;
+    }
+    if (src >= 0 && (size_t)(T + D) * 2 > h->out_cap) { set_error("source ring too small for T=%d", T); return RCF_ECAP; }
+    c->k_abs0 = ceil_div(c->start_sample, D);
+    RCF_HIP(hipMalloc(&c->d_iq, sizeof(float2) * h->out_cap));
+    RCF_HIP(hipMalloc(&c->d_fm, sizeof(float) * h->out_cap));
+    RCF_HIP(hipMemsetAsync(c->d_iq, 0, sizeof(float2) * h->out_cap, h->stream));
+    RCF_HIP(hipMemsetAsync(c->d_fm, 0, sizeof(float) * h->out_cap, h->stream));
+    int rc = upload_composite(h, c.get());
+    if (rc != RCF_OK) return rc;
+    c->id = h->next_id++;
+    *chan_id = c->id;
+    h->chans[c->id] = std::move(c);
+    return RCF_OK;
+}
+
+void free_channel(rcf_t *h, Chan *c)
+{
+    bury(h, c->d_ctaps);
+    bury(h, c->d_iq);
+    bury(h, c->d_fm);
+    c->d_ctaps = nullptr;
+    c->d_iq = nullptr;
+    c->d_fm = nullptr;
+    (void)h;
+}
+
+struct Arena {
+    unsigned char *h, *d;
+    size_t used = 0, cap;
+    template <class T>
+    bool put(const std::vector<T> &v, const T **dev)
+    {
+        const size_t bytes = sizeof(T) * v.size();
+        const size_t at = (used + 63) & ~size_t(63);
+        if (at + bytes > cap) return false;
+        std::memcpy(h + at, v.data(), bytes);
+        *dev = reinterpret_cast<const T *>(d + at);
+        used = at + bytes;
+        return true;
+    }
+};
+
+int choose_kt(int D, int T)
+{
+    int kt = (8192 - T) / D + 1;
+    if (kt < 1) kt = 1;
+    if (kt > 256) kt = 256;
+    if (kt >= 8) kt &= ~7;
+    return kt;
+}
+
+// ------------------------------------------------------------------ the per-block schedule
+int process_block(rcf_t *h, size_t n)
+{
+    const int64_t S0 = h->total_in, S1 = S0 + (int64_t)n;
+    hipStream_t st = h->stream;
+
+    // arena for this commit
+    const int a = h->arena_cur;
+    if (h->arena_used[a]) RCF_HIP(hipEventSynchronize(h->arena_ev[a]));
+    Arena ar{h->h_arena[a], h->d_arena[a], 0, rcf::kArena};
+
+    struct FirJob { FirLaunchDims dims; const ChanLaunch *dev; };
+    struct DiscJob { const DiscLaunch *dev; int n; int max_n; };
+    std::vector<std::vector<FirJob>> fir_by_depth;
+    std::vector<DiscJob> disc_jobs;
+
+    // ---- PFB bookkeeping first (derived channels need its new range)
+    PfbLaunch pl{};
+    bool run_pfb = false;
+    if (h->pfb.open) {
+        Pfb &p = h->pfb;
+        const int64_t n_lo = std::max(ceil_div(S0, p.D), p.n_abs0);
+        const int64_t n_hi = floor_div(S1 - 1, p.D);
+        p.produced_before = p.produced;
+        if (n_hi >= n_lo) {
+            const int64_t cnt = n_hi - n_lo + 1;
+            if ((size_t)cnt > h->out_cap) { set_error("block yields %lld PFB frames > ring capacity", (long long)cnt); return RCF_ECAP; }
+            pl.src.base = h->d_buf[h->cur];
+            pl.src.mask = ~0ull;
+            pl.src.origin = S0 - (int64_t)h->hist_cap;
+            pl.ptaps = p.d_ptaps;
+            pl.tw = p.d_tw;
+            pl.bins_ring = p.d_bins;
+            pl.ring_mask = h->ring_mask;
+            pl.ring_cap = (int64_t)h->out_cap;
+            pl.n_lo = n_lo;
+            pl.n_abs0 = p.n_abs0;
+            pl.start_sample = p.start_sample;
+            pl.n_frames = (int32_t)cnt;
+            pl.NB = p.NB; pl.D = p.D; pl.P = p.P;
+            run_pfb = true;
+            p.produced = n_hi - p.n_abs0 + 1;
+        }
+    }
+
+    // ---- channels, by depth then by (D, T) class
+    int max_depth = 0;
+    for (auto &kv : h->chans) max_depth = std::max(max_depth, kv.second->depth);
+    fir_by_depth.resize(max_depth + 1);
+    std::map<int, std::pair<int64_t, int64_t>> chan_new;   // channel id -> [produced_before, produced_after)
+    for (int depth = 0; depth <= max_depth; ++depth) {
+        std::map<std::pair<int, int>, std::vector<Chan *>> classes;
+        for (auto &kv : h->chans)
+            if (kv.second->depth == depth) classes[{kv.second->D, kv.second->T}].push_back(kv.second.get());
+        for (auto &cls : classes) {
+            const int D = cls.first.first, T = cls.first.second;
+            std::vector<ChanLaunch> launches;
+            std::vector<DiscLaunch> discs;
+            int max_n = 0;
+            bool shared_src = true;
+            for (Chan *c : cls.second) {
+                SrcRange sr{};
+                if (c->src >= 0 && c->src < RCF_SRC_PFB_BIN0) {
+                    auto it = h->chans.find(c->src);
+                    if (it == h->chans.end()) continue;            // source closed: channel starves
+                    auto rng = chan_new.find(c->src);
+                    sr.view.base = it->second->d_iq;
+                    sr.view.mask = h->ring_mask;
+                    sr.view.origin = 0;
+                    sr.p0 = rng == chan_new.end() ? it->second->produced : rng->second.first;
+                    sr.p1 = rng == chan_new.end() ? it->second->produced : rng->second.second;
+                } else if (!source_range(h, c->src, S0, S1, &sr)) {
+                    continue;
+                }
+                if (c->src >= 0) shared_src = false;
+                const int64_t k_lo = std::max(ceil_div(sr.p0, D), c->k_abs0);
+                const int64_t k_hi = floor_div(sr.p1 - 1, D);
+                const int64_t before = c->produced;
+                if (sr.p1 <= sr.p0 || k_hi < k_lo) { chan_new[c->id] = {before, before}; continue; }
+                const int64_t cnt = k_hi - k_lo + 1;
+                if ((size_t)cnt > h->out_cap) { set_error("block yields %lld outputs > ring capacity", (long long)cnt); return RCF_ECAP; }
+                ChanLaunch L{};
+                L.ctaps = c->d_ctaps;
+                L.iq_ring = c->d_iq;
+                L.src = sr.view;
+                L.k_lo = k_lo;
+                L.k_abs0 = c->k_abs0;
+                L.start_sample = c->start_sample;
+                L.n_seg0 = c->n_seg0;
+                L.angle0 = (double)c->angle0;
+                L.dangle = c->dangle;
+                L.logmag0 = c->logmag0;
+                L.dlogmag = c->dlogmag;
+                L.n_k = (int32_t)cnt;
+                launches.push_back(L);
+                DiscLaunch dl{};
+                dl.iq_ring = c->d_iq;
+                dl.fm_ring = c->d_fm;
+                dl.n_lo = k_lo - c->k_abs0;
+                dl.n_k = (int32_t)cnt;
+                discs.push_back(dl);
+                max_n = std::max(max_n, (int)cnt);
+                // advance channel state: rebase the rotator model at the next output index
+                const int64_t n_next = k_hi - c->k_abs0 + 1;
+                const int64_t r512 = n_next & ~(int64_t)511;
+                const long double adv = (long double)(n_next - c->n_seg0) * (long double)c->dangle;
+                c->logmag0 = (r512 > c->n_seg0) ? (double)(n_next - r512) * c->dlogmag
+                                                : c->logmag0 + (double)(n_next - c->n_seg0) * c->dlogmag;
+                c->angle0 = fmodl(c->angle0 + adv, (long double)kTwoPi);
+                c->n_seg0 = n_next;
+                c->produced = n_next;
+                chan_new[c->id] = {before, n_next};
+            }
+            if (launches.empty()) continue;
+            FirJob job{};
+            job.dims.D = D; job.dims.T = T; job.dims.KT = choose_kt(D, T);
+            job.dims.n_chans = (int)launches.size();
+            job.dims.chans_per_wg = shared_src ? 16 : 1;
+            job.dims.max_n_k = max_n;
+            job.dims.ring_mask = h->ring_mask;
+            if (!ar.put(launches, &job.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+            fir_by_depth[depth].push_back(job);
+            DiscJob dj{};
+            dj.n = (int)discs.size(); dj.max_n = max_n;
+            if (!ar.put(discs, &dj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+            disc_jobs.push_back(dj);
+        }
+    }
+
+    // ---- upload all launch parameters in one copy, then launch in dependency order
+    if (ar.used) {
+        RCF_HIP(hipMemcpyAsync(ar.d, ar.h, ar.used, hipMemcpyHostToDevice, st));
+        RCF_HIP(hipEventRecord(h->arena_ev[a], st));
+        h->arena_used[a] = true;
+        h->arena_cur ^= 1;
+    }
+    if (!fir_by_depth.empty())
+        for (auto &j : fir_by_depth[0]) launch_fir_bank(j.dev, j.dims, st);
+    if (run_pfb) launch_pfb(pl, st);
+    for (size_t d = 1; d < fir_by_depth.size(); ++d)
+        for (auto &j : fir_by_depth[d]) launch_fir_bank(j.dev, j.dims, st);
+    for (auto &dj : disc_jobs) launch_discriminator(dj.dev, dj.n, dj.max_n, h->ring_mask, h->d_atan, st);
+
+    // ---- scan
+    Scan &sc = h->scan;
+    if (sc.armed && !sc.done) {
+        int64_t avail = (S1 - sc.start_sample) / sc.N;
+        if (avail > sc.n_frames) avail = sc.n_frames;
+        while (sc.frames_done < avail) {
+            const int cnt = (int)std::min<int64_t>(sc.chunk, avail - sc.frames_done);
+            ScanLaunch sl{};
+            sl.src.base = h->d_buf[h->cur];
+            sl.src.mask = ~0ull;
+            sl.src.origin = S0 - (int64_t)h->hist_cap;
+            sl.s0 = sc.start_sample + (int64_t)sc.frames_done * sc.N;
+            sl.window = sc.d_window;
+            sl.tw = sc.d_tw;
+            sl.vring = sc.d_vring;
+            sl.N = sc.N; sl.R = sc.R;
+            sl.f0 = sc.frames_done; sl.n_frames = cnt;
+            sl.scratch = sc.d_scratch;
+            launch_scan_fft(sl, st);
+            launch_scan_movsum(sc.d_vring, sc.N, sc.R, sc.L, sc.frames_done, cnt, sc.n_frames - 1, sc.d_sum,
+                               sc.d_out, st);
+            sc.frames_done += cnt;
+        }
+        if (sc.frames_done >= sc.n_frames) sc.done = true;
+    }
+
+    // ---- history for the next block, flip buffers
+    const int other = h->cur ^ 1;
+    RCF_HIP(hipMemcpyAsync(h->d_buf[other], h->d_buf[h->cur] + n, sizeof(float2) * h->hist_cap,
+                           hipMemcpyDeviceToDevice, st));
+    h->cur = other;
+    h->total_in = S1;
+    RCF_HIP(hipGetLastError());
+    return RCF_OK;
+}
+
+int64_t ring_read(rcf_t *h, const void *ring, size_t elem, int64_t produced, int64_t *cursor, void *out,
+                  size_t max_items)
+{
+    int64_t avail = produced - *cursor;
+    if (avail <= 0 || max_items == 0) return 0;
+    if ((size_t)avail > h->out_cap) {           // reader lagged: oldest samples are gone
+        *cursor = produced - (int64_t)h->out_cap;
+        avail = (int64_t)h->out_cap;
+    }
+    const int64_t n = std::min<int64_t>(avail, (int64_t)max_items);
+    const size_t pos = (size_t)((uint64_t)*cursor & h->ring_mask);
+    const size_t first = std::min<size_t>((size_t)n, h->out_cap - pos);
+    const unsigned char *r = static_cast<const unsigned char *>(ring);
+    if (hipMemcpyAsync(out, r + pos * elem, first * elem, hipMemcpyDeviceToHost, h->stream) != hipSuccess) {
+        set_error("ring read failed");
+        return RCF_EHIP;
+    }
+    if ((size_t)n > first &&
+        hipMemcpyAsync(static_cast<unsigned char *>(out) + first * elem, r, ((size_t)n - first) * elem,
+                       hipMemcpyDeviceToHost, h->stream) != hipSuccess) {
+        set_error("ring read failed");
+        return RCF_EHIP;
+    }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("stream sync failed"); return RCF_EHIP; }
+    *cursor += n;
+    return n;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+const char *rcf_version(void) { return "rcf-mi355x 0.1 (gfx950)"; }
+const char *rcf_last_error(void) { return g_err; }
+
+int rcf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rcf_design_low_pass_2(double gain, double fs, double fc, double tw, double att_db, int window, float *taps,
+                          int cap)
+{
+    if (fs <= 0 || tw <= 0) { set_error("bad design arguments"); return RCF_EINVAL; }
+    const int n = design_ntaps(fs, tw, att_db);
+    if (!taps || cap < n) return -n;
+    std::vector<float> t = design_low_pass_2(gain, fs, fc, tw, att_db, window);
+    std::memcpy(taps, t.data(), sizeof(float) * (size_t)n);
+    return n;
+}
+
+int rcf_design_window(int window, int n, float *w)
+{
+    if (n < 2 || !w) { set_error("bad window arguments"); return RCF_EINVAL; }
+    design_window(window, n, w);
+    return RCF_OK;
+}
+
+int rcf_channel_params(double samp_rate, int channel_rate, int *decim, int *ntaps)
+{
+    if (samp_rate <= 0 || channel_rate <= 0) { set_error("bad rates"); return RCF_EINVAL; }
+    const int q = (int)(samp_rate / channel_rate);
+    if (q < 2 || (q & 1)) {
+        set_error("int(fs/cr)/2 is not a positive integer for fs=%g cr=%d", samp_rate, channel_rate);
+        return RCF_ERANGE;
+    }
+    if (decim) *decim = q / 2;
+    if (ntaps) *ntaps = design_ntaps(samp_rate, channel_rate / 2.0, 20.0);
+    return RCF_OK;
+}
+
+int rcf_open(int device, double samp_rate, double center_freq, rcf_t **out)
+{
+    return rcf_open_ex(device, samp_rate, center_freq, 0, 0, 0, out);
+}
+
+int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_capacity, size_t hist_capacity,
+                size_t out_capacity, rcf_t **out)
+{
+    if (!out || samp_rate <= 0) { set_error("bad open arguments"); return RCF_EINVAL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device: librcf has no CPU fallback");
+        return RCF_EHIP;
+    }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d visible)", device, ndev); return RCF_EINVAL; }
+    std::unique_ptr<rcf> h(new rcf);
+    h->device = device;
+    h->fs = samp_rate;
+    h->fc = center_freq;
+    h->block_cap = block_capacity ? block_capacity : (size_t(1) << 22);
+    h->hist_cap = hist_capacity ? hist_capacity : (size_t(1) << 16);
+    h->out_cap = pow2_at_least(out_capacity ? out_capacity : (size_t(1) << 16));
+    h->ring_mask = (uint64_t)h->out_cap - 1;
+    RCF_HIP(hipSetDevice(device));
+    RCF_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const size_t buf_samples = h->hist_cap + h->block_cap;
+    for (int i = 0; i < 2; ++i) {
+        RCF_HIP(hipMalloc(&h->d_buf[i], sizeof(float2) * buf_samples));
+        RCF_HIP(hipMemsetAsync(h->d_buf[i], 0, sizeof(float2) * buf_samples, h->stream));
+        RCF_HIP(hipHostMalloc(&h->h_arena[i], rcf::kArena, hipHostMallocDefault));
+        RCF_HIP(hipMalloc(&h->d_arena[i], rcf::kArena));
+        RCF_HIP(hipEventCreateWithFlags(&h->arena_ev[i], hipEventDisableTiming));
+    }
+    RCF_HIP(hipMalloc(&h->d_atan, sizeof(float) * 257));
+    RCF_HIP(hipMemcpy(h->d_atan, atan_table_host(), sizeof(float) * 257, hipMemcpyHostToDevice));
+    RCF_HIP(hipStreamSynchronize(h->stream));
+    *out = h.release();
+    return RCF_OK;
+}
+
+int rcf_close(rcf_t *h)
+{
+    if (!h) return RCF_EINVAL;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto &kv : h->chans) free_channel(h, kv.second.get());
+    h->chans.clear();
+    Pfb &p = h->pfb;
+    bury(h, p.d_ptaps); bury(h, p.d_tw); bury(h, p.d_bins);
+    Scan &s = h->scan;
+    bury(h, s.d_window); bury(h, s.d_vring); bury(h, s.d_sum); bury(h, s.d_out); bury(h, s.d_tw);
+    bury(h, s.d_scratch); bury(h, s.d_peaks);
+    bury(h, h->d_atan);
+    for (int i = 0; i < 2; ++i) {
+        bury(h, h->d_buf[i]);
+        bury(h, h->d_arena[i]);
+        if (h->h_arena[i]) (void)hipHostFree(h->h_arena[i]);
+        if (h->arena_ev[i]) (void)hipEventDestroy(h->arena_ev[i]);
+    }
+    drain_graveyard(h);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return RCF_OK;
+}
+
+int rcf_sync(rcf_t *h)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    RCF_HIP(hipStreamSynchronize(h->stream));
+    drain_graveyard(h);
+    return RCF_OK;
+}
+
+void *rcf_stream(rcf_t *h) { return h ? (void *)h->stream : nullptr; }
+int rcf_device(rcf_t *h) { return h ? h->device : RCF_EINVAL; }
+int64_t rcf_samples_in(rcf_t *h) { return h ? h->total_in : RCF_EINVAL; }
+
+int rcf_push_iq(rcf_t *h, const float *iq, size_t n)
+{
+    if (!h || (!iq && n)) { set_error("bad push arguments"); return RCF_EINVAL; }
+    if (n == 0) return RCF_OK;
+    if (n > h->block_cap) { set_error("push of %zu samples exceeds block capacity %zu", n, h->block_cap); return RCF_ECAP; }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    RCF_HIP(hipMemcpyAsync(h->d_buf[h->cur] + h->hist_cap, iq, sizeof(float2) * n, hipMemcpyHostToDevice, h->stream));
+    // the caller may reuse `iq` as soon as we return: pageable copies are staged by the runtime, pinned
+    // ones are not -- wait for the copy itself (cheap next to PCIe time) but not for the kernels.
+    hipEvent_t ev;
+    RCF_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    RCF_HIP(hipEventRecord(ev, h->stream));
+    int rc = process_block(h, n);
+    (void)hipEventSynchronize(ev);
+    (void)hipEventDestroy(ev);
+    return rc;
+}
+
+int rcf_ingest_ptr(rcf_t *h, float **dev_ptr, size_t *max_samples)
+{
+    if (!h || !dev_ptr) { set_error("bad ingest arguments"); return RCF_EINVAL; }
+    std::lock_guard<std::mutex> g(h->mu);
+    *dev_ptr = reinterpret_cast<float *>(h->d_buf[h->cur] + h->hist_cap);
+    if (max_samples) *max_samples = h->block_cap;
+    return RCF_OK;
+}
+
+int rcf_commit(rcf_t *h, size_t n)
+{
+    if (!h) return RCF_EINVAL;
+    if (n == 0) return RCF_OK;
+    if (n > h->block_cap) { set_error("commit of %zu samples exceeds block capacity %zu", n, h->block_cap); return RCF_ECAP; }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    return process_block(h, n);
+}
+
+// ------------------------------------------------------------------ channels
+int rcf_chan_open(rcf_t *h, int channel_rate, double offset_hz, int *chan_id)
+{
+    if (!h || !chan_id) { set_error("bad channel arguments"); return RCF_EINVAL; }
+    int D = 0, T = 0;
+    int rc = rcf_channel_params(h->fs, channel_rate, &D, &T);
+    if (rc != RCF_OK) return rc;
+    if (!(std::fabs(offset_hz) < h->fs / 2)) { set_error("offset %g Hz outside +-fs/2", offset_hz); return RCF_ERANGE; }
+    std::vector<float> taps = design_low_pass_2(1.0, h->fs, channel_rate / 2.0, channel_rate / 2.0, 20.0,
+                                                RCF_WIN_HAMMING);
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    return new_channel(h, -1, D, taps.data(), (int)taps.size(), offset_hz, chan_id);
+}
+
+int rcf_chan_open_taps(rcf_t *h, int src_chan, int decim, const float *taps, int ntaps, double offset_hz,
+                       int *chan_id)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    return new_channel(h, src_chan < 0 ? -1 : src_chan, decim, taps, ntaps, offset_hz, chan_id);
+}
+
+int rcf_pfb_chan_open(rcf_t *h, int bin, int channel_rate, double delta_hz, int *chan_id)
+{
+    if (!h || !chan_id) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    if (!h->pfb.open || bin < 0 || bin >= h->pfb.NB) { set_error("no such PFB bin %d", bin); return RCF_EINVAL; }
+    const double rate = h->fs / h->pfb.D;
+    int D = 0, T = 0;
+    int rc = rcf_channel_params(rate, channel_rate, &D, &T);
+    if (rc != RCF_OK) return rc;
+    std::vector<float> taps = design_low_pass_2(1.0, rate, channel_rate / 2.0, channel_rate / 2.0, 20.0,
+                                                RCF_WIN_HAMMING);
+    return new_channel(h, RCF_SRC_PFB_BIN0 + bin, D, taps.data(), (int)taps.size(), delta_hz, chan_id);
+}
+
+#define FIND_CHAN(h, id, c)                                                 \
+    auto it_ = (h)->chans.find(id);                                         \
+    if (it_ == (h)->chans.end()) { set_error("no such channel %d", id); return RCF_ENOCHAN; } \
+    Chan *c = it_->second.get()
+
+int rcf_chan_set_offset(rcf_t *h, int chan_id, double offset_hz)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    FIND_CHAN(h, chan_id, c);
+    c->offset_hz = offset_hz;
+    return upload_composite(h, c);
+}
+
+int rcf_chan_close(rcf_t *h, int chan_id)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    FIND_CHAN(h, chan_id, c);
+    free_channel(h, c);
+    h->chans.erase(chan_id);
+    return RCF_OK;
+}
+
+int rcf_chan_info(rcf_t *h, int chan_id, int *decim, int *ntaps, double *out_rate, double *offset_hz)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    FIND_CHAN(h, chan_id, c);
+    if (decim) *decim = c->D;
+    if (ntaps) *ntaps = c->T;
+    if (out_rate) *out_rate = c->src_rate / c->D;
+    if (offset_hz) *offset_hz = c->offset_hz;
+    return RCF_OK;
+}
+
+int64_t rcf_chan_produced(rcf_t *h, int chan_id)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    FIND_CHAN(h, chan_id, c);
+    return c->produced;
+}
+
+int64_t rcf_chan_read_iq(rcf_t *h, int chan_id, float *out, size_t max_samples)
+{
+    if (!h || !out) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    FIND_CHAN(h, chan_id, c);
+    return ring_read(h, c->d_iq, sizeof(float2), c->produced, &c->rd_iq, out, max_samples);
+}
+
+int64_t rcf_chan_read_fm(rcf_t *h, int chan_id, float gain, float *out, size_t max_samples)
+{
+    if (!h || !out) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    FIND_CHAN(h, chan_id, c);
+    const int64_t n = ring_read(h, c->d_fm, sizeof(float), c->produced, &c->rd_fm, out, max_samples);
+    // quadrature_demod_cf: out = gain * fast_atan2f(...), one float32 multiply per sample
+    for (int64_t i = 0; i < n; ++i) out[i] = gain * out[i];
+    return n;
+}
+
+int rcf_chan_rings(rcf_t *h, int chan_id, void **iq_ring, void **fm_ring, size_t *capacity)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    FIND_CHAN(h, chan_id, c);
+    if (iq_ring) *iq_ring = c->d_iq;
+    if (fm_ring) *fm_ring = c->d_fm;
+    if (capacity) *capacity = h->out_cap;
+    return RCF_OK;
+}
+
+int rcf_source_shift(rcf_t *h, double delta_hz)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    h->shift_hz += delta_hz;
+    for (auto &kv : h->chans)
+        if (kv.second->src < 0) {
+            int rc = upload_composite(h, kv.second.get());
+            if (rc != RCF_OK) return rc;
+        }
+    return RCF_OK;
+}
+
+// ------------------------------------------------------------------ PFB
+int rcf_pfb_open(rcf_t *h, int n_bins, int decim, const float *taps, int ntaps)
+{
+    if (!h || !taps || ntaps < 1 || n_bins < 1 || decim < 1) { set_error("bad PFB arguments"); return RCF_EINVAL; }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    if (h->pfb.open) { set_error("PFB already open"); return RCF_ESTATE; }
+    const int P = (ntaps + n_bins - 1) / n_bins;
+    if (n_bins % decim || !pfb_supported(n_bins, decim, P)) {
+        set_error("unsupported PFB shape: bins=%d decim=%d taps/branch=%d", n_bins, decim, P);
+        return RCF_EINVAL;
+    }
+    if ((size_t)P * n_bins + (size_t)decim > h->hist_cap) { set_error("history capacity %zu < P*bins", h->hist_cap); return RCF_ECAP; }
+    Pfb &p = h->pfb;
+    p.NB = n_bins; p.D = decim; p.T = ntaps; p.P = P;
+    p.Ppad = pfb_padded_p(n_bins, decim, P);
+    std::vector<float> pt((size_t)p.Ppad * n_bins, 0.f);
+    for (int i = 0; i < ntaps; ++i) pt[i] = taps[i];          // pt[p*NB + rho] = h[NB p + rho]
+    std::vector<float> tw(2 * (size_t)n_bins);
+    for (int i = 0; i < n_bins; ++i) {
+        const double a = kTwoPi * i / n_bins;
+        tw[2 * i] = (float)std::cos(a);
+        tw[2 * i + 1] = (float)std::sin(a);
+    }
+    RCF_HIP(hipMalloc(&p.d_ptaps, sizeof(float) * pt.size()));
+    RCF_HIP(hipMemcpy(p.d_ptaps, pt.data(), sizeof(float) * pt.size(), hipMemcpyHostToDevice));
+    RCF_HIP(hipMalloc(&p.d_tw, sizeof(float2) * (size_t)n_bins));
+    RCF_HIP(hipMemcpy(p.d_tw, tw.data(), sizeof(float2) * (size_t)n_bins, hipMemcpyHostToDevice));
+    RCF_HIP(hipMalloc(&p.d_bins, sizeof(float2) * (size_t)n_bins * h->out_cap));
+    RCF_HIP(hipMemsetAsync(p.d_bins, 0, sizeof(float2) * (size_t)n_bins * h->out_cap, h->stream));
+    p.rd.assign(n_bins, 0);
+    p.start_sample = h->total_in;
+    p.n_abs0 = ceil_div(p.start_sample, decim);
+    p.produced = p.produced_before = 0;
+    p.open = true;
+    return RCF_OK;
+}
+
+int rcf_pfb_close(rcf_t *h)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    Pfb &p = h->pfb;
+    if (!p.open) return RCF_OK;
+    for (auto it = h->chans.begin(); it != h->chans.end();) {
+        if (it->second->src >= RCF_SRC_PFB_BIN0) { free_channel(h, it->second.get()); it = h->chans.erase(it); }
+        else ++it;
+    }
+    bury(h, p.d_ptaps); bury(h, p.d_tw); bury(h, p.d_bins);
+    p = Pfb();
+    return RCF_OK;
+}
+
+int64_t rcf_pfb_produced(rcf_t *h)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    return h->pfb.open ? h->pfb.produced : RCF_ESTATE;
+}
+
+int64_t rcf_pfb_read_bin(rcf_t *h, int bin, float *out, size_t max_samples)
+{
+    if (!h || !out) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    Pfb &p = h->pfb;
+    if (!p.open || bin < 0 || bin >= p.NB) { set_error("no such PFB bin %d", bin); return RCF_EINVAL; }
+    return ring_read(h, p.d_bins + (size_t)bin * h->out_cap, sizeof(float2), p.produced, &p.rd[bin], out,
+                     max_samples);
+}
+
+int rcf_pfb_rings(rcf_t *h, void **bins_ring, size_t *capacity)
+{
+    if (!h || !h->pfb.open) return RCF_ESTATE;
+    if (bins_ring) *bins_ring = h->pfb.d_bins;
+    if (capacity) *capacity = h->out_cap;
+    return RCF_OK;
+}
+
+// ------------------------------------------------------------------ scan
+int rcf_scan_start(rcf_t *h, int fft_len, int n_frames, int avg_len)
+{
+    if (!h || n_frames < 1 || avg_len < 1) { set_error("bad scan arguments"); return RCF_EINVAL; }
+    if (!scan_supported(fft_len)) { set_error("unsupported scan FFT length %d", fft_len); return RCF_EINVAL; }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    if ((size_t)fft_len > h->hist_cap) { set_error("history capacity %zu < fft_len %d", h->hist_cap, fft_len); return RCF_ECAP; }
+    Scan &s = h->scan;
+    bury(h, s.d_window); bury(h, s.d_vring); bury(h, s.d_sum); bury(h, s.d_out); bury(h, s.d_tw);
+    bury(h, s.d_scratch); bury(h, s.d_peaks);
+    s = Scan();
+    s.N = fft_len; s.n_frames = n_frames; s.L = avg_len;
+    s.chunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, (int64_t(1) << 22) / fft_len));
+    s.R = avg_len + s.chunk;
+    std::vector<float> win(fft_len), tw(2 * (size_t)fft_len);
+    design_window(RCF_WIN_BLACKMAN_HARRIS, fft_len, win.data());
+    for (int i = 0; i < fft_len; ++i) {
+        const double a = -kTwoPi * i / fft_len;
+        tw[2 * i] = (float)std::cos(a);
+        tw[2 * i + 1] = (float)std::sin(a);
+    }
+    RCF_HIP(hipMalloc(&s.d_window, sizeof(float) * (size_t)fft_len));
+    RCF_HIP(hipMemcpy(s.d_window, win.data(), sizeof(float) * (size_t)fft_len, hipMemcpyHostToDevice));
+    RCF_HIP(hipMalloc(&s.d_tw, sizeof(float2) * (size_t)fft_len));
+    RCF_HIP(hipMemcpy(s.d_tw, tw.data(), sizeof(float2) * (size_t)fft_len, hipMemcpyHostToDevice));
+    RCF_HIP(hipMalloc(&s.d_vring, sizeof(float) * (size_t)fft_len * s.R));
+    RCF_HIP(hipMalloc(&s.d_sum, sizeof(float) * (size_t)fft_len));
+    RCF_HIP(hipMalloc(&s.d_out, sizeof(float) * (size_t)fft_len));
+    RCF_HIP(hipMemsetAsync(s.d_sum, 0, sizeof(float) * (size_t)fft_len, h->stream));
+    RCF_HIP(hipMemsetAsync(s.d_out, 0, sizeof(float) * (size_t)fft_len, h->stream));
+    if (fft_len > 16384) RCF_HIP(hipMalloc(&s.d_scratch, sizeof(float2) * (size_t)fft_len * s.chunk));
+    s.start_sample = h->total_in;
+    s.armed = true;
+    return RCF_OK;
+}
+
+int rcf_scan_frames_done(rcf_t *h)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    return h->scan.armed ? h->scan.frames_done : RCF_ESTATE;
+}
+
+int rcf_scan_result(rcf_t *h, float *out)
+{
+    if (!h || !out) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    Scan &s = h->scan;
+    if (!s.armed) { set_error("scan not armed"); return RCF_ESTATE; }
+    if (!s.done) return RCF_EAGAIN;
+    RCF_HIP(hipMemcpyAsync(out, s.d_out, sizeof(float) * (size_t)s.N, hipMemcpyDeviceToHost, h->stream));
+    RCF_HIP(hipStreamSynchronize(h->stream));
+    return RCF_OK;
+}
+
+int rcf_scan_result_device(rcf_t *h, void **dev_spectrum)
+{
+    if (!h || !dev_spectrum) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->scan.armed) return RCF_ESTATE;
+    if (!h->scan.done) return RCF_EAGAIN;
+    *dev_spectrum = h->scan.d_out;
+    return RCF_OK;
+}
+
+int rcf_find_peaks(const float *spectrum, int64_t n, double min_w, double max_w, double prominence, int64_t *idx,
+                   int64_t cap, int64_t *count, double *mean_out)
+{
+    if (!spectrum || n < 0 || cap < 0 || (cap > 0 && !idx)) { set_error("bad find_peaks arguments"); return RCF_EINVAL; }
+    const int64_t c = find_peaks_host(spectrum, n, min_w, max_w, prominence, idx, cap, mean_out);
+    if (count) *count = c;
+    return RCF_OK;
+}
+
+int64_t rcf_peak_frequency(int64_t line, double samp_rate, int64_t fft_len, double center_freq)
+{
+    const double hz_per_bin = samp_rate / (double)fft_len;
+    return (int64_t)(((double)line * hz_per_bin) - (samp_rate / 2) + center_freq);
+}
+
+int rcf_scan_find_peaks(rcf_t *h, double prominence, int64_t *idx, int64_t cap, int64_t *count, double *mean_out,
+                        void **dev_idx)
+{
+    if (!h || cap < 1) { set_error("bad arguments"); return RCF_EINVAL; }
+    std::vector<float> spec;
+    int N;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        if (!h->scan.armed) return RCF_ESTATE;
+        if (!h->scan.done) return RCF_EAGAIN;
+        N = h->scan.N;
+    }
+    spec.resize((size_t)N);
+    int rc = rcf_scan_result(h, spec.data());
+    if (rc != RCF_OK) return rc;
+    const double hz_per_bin = h->fs / N;
+    std::vector<int64_t> tmp((size_t)cap);
+    const int64_t c = find_peaks_host(spec.data(), N, 3000 / hz_per_bin, 30000 / hz_per_bin, prominence, tmp.data(),
+                                      cap, mean_out);
+    if (count) *count = c;
+    const int64_t m = std::min(c, cap);
+    if (idx) std::memcpy(idx, tmp.data(), sizeof(int64_t) * (size_t)m);
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    Scan &s = h->scan;
+    if (dev_idx) {
+        // fixed-capacity, -1 padded list for the RCCL all-gather of peak lists
+        bury(h, s.d_peaks);
+        RCF_HIP(hipMalloc(&s.d_peaks, sizeof(int64_t) * (size_t)cap));
+        for (int64_t i = m; i < cap; ++i) tmp[(size_t)i] = -1;
+        RCF_HIP(hipMemcpy(s.d_peaks, tmp.data(), sizeof(int64_t) * (size_t)cap, hipMemcpyHostToDevice));
+        *dev_idx = s.d_peaks;
+    }
+    return RCF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// rcf_internal.h -- shared declarations between the C-ABI host layer and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rcf.h"
+
+namespace rcfx {
+
+// ---------------------------------------------------------------- host design helpers (rcf_design.cpp)
+void design_window(int type, int n, float *w);
+int design_ntaps(double fs, double tw, double att_db);
+std::vector<float> design_low_pass_2(double gain, double fs, double fc, double tw, double att_db, int window);
+void design_composite(const float *taps, int T, int D, double f0, double fs,
+                      std::vector<float> &ctaps_interleaved, float incr[2]);
+
+// ---------------------------------------------------------------- host peak picker (rcf_peaks.cpp)
+int64_t find_peaks_host(const float *spectrum, int64_t n, double min_w, double max_w, double prominence,
+                        int64_t *idx, int64_t cap, double *mean_out);
+
+// ---------------------------------------------------------------- error plumbing
+void set_error(const char *fmt, ...);
+bool hip_ok(hipError_t e, const char *what);
+#define RCF_HIP(call)                                 \
+    do {                                              \
+        if (!::rcfx::hip_ok((call), #call)) return RCF_EHIP; \
+    } while (0)
+
+// ---------------------------------------------------------------- stream views
+// sample s of a stream lives at base[(s - origin) & mask]   (linear buffer: mask = ~0)
+struct StreamView {
+    const float2 *base;
+    uint64_t mask;
+    int64_t origin;
+};
+
+// ---------------------------------------------------------------- direct xlating-FIR bank
+// One entry per channel per launch (device array).
+struct ChanLaunch {
+    const float2 *ctaps;     // T composite taps h[i] e^{j float32(i fwT0)}  (GR-faithful float32)
+    float2 *iq_ring;         // output ring, index (k - k_abs0) & ring_mask
+    StreamView src;          // input stream
+    int64_t k_lo;            // first absolute output index produced by this launch
+    int64_t k_abs0;          // absolute output index of the channel's first-ever output
+    int64_t start_sample;    // samples before this index count as zero (GR zero history)
+    int64_t n_seg0;          // relative output index at which (angle0, logmag0) hold
+    double angle0, dangle;   // rotator phase angle model (radians)
+    double logmag0, dlogmag; // rotator magnitude model (log |phase|)
+    int32_t n_k;             // outputs to produce
+    int32_t pad_;
+};
+
+struct FirLaunchDims {
+    int D, T, KT;            // decimation, taps, outputs per workgroup tile
+    int n_chans;             // entries in the ChanLaunch array
+    int chans_per_wg;        // >1 only when every channel of the launch shares one source view
+    int max_n_k;             // max over channels of n_k
+    uint64_t ring_mask;
+};
+
+void launch_fir_bank(const ChanLaunch *d_chans, const FirLaunchDims &dims, hipStream_t s);
+
+// discriminator: fm[n] = fast_atan2f(imag(y[n] conj(y[n-1])), real(.)) (unit gain), n relative index
+struct DiscLaunch {
+    const float2 *iq_ring;
+    float *fm_ring;
+    int64_t n_lo;            // first relative output index
+    int32_t n_k;
+    int32_t pad_;
+};
+void launch_discriminator(const DiscLaunch *d_items, int n_items, int max_n_k, uint64_t ring_mask,
+                          const float *d_atan_table, hipStream_t s);
+
+// ---------------------------------------------------------------- polyphase filterbank
+struct PfbLaunch {
+    StreamView src;
+    const float *ptaps;      // [P][NB] polyphase taps: ptaps[p*NB + rho] = h[NB p + rho] (0 beyond T)
+    const float2 *tw;        // e^{+2 pi i n / NB}, n in [0, NB)
+    float2 *bins_ring;       // [NB][ring_cap]
+    uint64_t ring_mask;
+    int64_t ring_cap;
+    int64_t n_lo;            // first absolute frame index of this launch
+    int64_t n_abs0;          // absolute frame index of the PFB's first-ever frame
+    int64_t start_sample;
+    int32_t n_frames;        // frames in this launch
+    int32_t NB, D, P;
+};
+bool pfb_supported(int NB, int D, int P);
+int pfb_padded_p(int NB, int D, int P);   // rows the kernel instantiation reads from ptaps (zero padded)
+void launch_pfb(const PfbLaunch &p, hipStream_t s);
+
+// ---------------------------------------------------------------- scan
+struct ScanLaunch {
+    StreamView src;
+    int64_t s0;              // stream index of the first sample of frame `f0`
+    const float *window;     // float32[N]
+    const float2 *tw;        // e^{-2 pi i n / N}
+    float *vring;            // [R][N] log-magnitude frames, frame f in slot f % R
+    int32_t N, R;
+    int32_t f0, n_frames;    // frames f0 .. f0+n_frames-1
+    float2 *scratch;         // 4-step scratch (N >= 32768), n_frames * N complex
+};
+bool scan_supported(int N);
+void launch_scan_fft(const ScanLaunch &p, hipStream_t s);
+// running sum: sum += v[f]; if (f == emit_frame) out = sum; if (f-(L-1) >= 0) sum -= v[f-(L-1)]
+void launch_scan_movsum(float *vring, int N, int R, int L, int f0, int n_frames, int emit_frame,
+                        float *sum, float *out, hipStream_t s);
+
+const float *atan_table_host();   // 257 floats: atan(i/255), i = 0..255, + pi/4
+
+}  // namespace rcfx

@@ -1,0 +1,180 @@
+// scan.hip -- spectrum scan chain of /root/reference/fft_vector.py:37-60 on gfx950:
+//   stream_to_vector(N) -> fft_vcc(N, forward, blackmanharris(N), shift) -> complex_to_mag_squared
+//   -> nlog10_ff(1, N, 1) -> moving_average_ff(L, 1, ., N) -> head / skiphead (keep frame n_frames-1)
+//
+// Kernel 1 (scan_fft_kernel): one workgroup transforms 16*NT/N frames entirely in LDS (NT threads,
+// 16 points per thread per pass, radix-16/../2 Stockham passes from fft_core.hpp); the window is
+// applied on the coalesced load, and |X|^2 -> log10 -> +1 -> fftshift are fused into the store, so a
+// frame costs 8 B/sample of HBM reads and 4 B/sample of writes.
+// Kernel 2 (movsum_kernel): GNU Radio's float32 running sum, bit-faithful in operation order
+// (sum += newest; emit; sum -= oldest), one thread per bin walking the chunk's frames in order.
+// Larger transforms (N > 16384) use the four-step variant in scan4.hip.
+#include "fft_core.hpp"
+#include "rcf_internal.h"
+
+namespace rcfx {
+
+bool scan4_supported(int N);
+void launch_scan4_fft(const ScanLaunch &p, hipStream_t s);
+
+namespace {
+
+template <int N> struct SPlan;
+template <> struct SPlan<256>   { static constexpr int n = 2; static constexpr int r[4] = {16, 16, 1, 1}; };
+template <> struct SPlan<512>   { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 2, 1}; };
+template <> struct SPlan<1024>  { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 4, 1}; };
+template <> struct SPlan<2048>  { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 8, 1}; };
+template <> struct SPlan<4096>  { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 16, 1}; };
+template <> struct SPlan<8192>  { static constexpr int n = 4; static constexpr int r[4] = {16, 16, 16, 2}; };
+template <> struct SPlan<16384> { static constexpr int n = 4; static constexpr int r[4] = {16, 16, 16, 4}; };
+
+template <int N> constexpr int scan_threads() { return N / 16 > 256 ? N / 16 : 256; }
+template <int N> constexpr int scan_fpw() { return scan_threads<N>() * 16 / N; }          // frames per workgroup
+template <int N> constexpr int scan_rs() { return lds_padded_len(N) + 1; }
+
+template <int N, int NT, int R, int NS>
+__device__ __forceinline__ void scan_pass(cf *buf, const cf *__restrict__ tw, int tid)
+{
+    constexpr int BPF = N / R;
+    constexpr int CNT = 16 / R;               // butterflies per thread per pass
+    constexpr int RS = scan_rs<N>();
+    using Pass = StockhamPass<N, R, -1>;
+    cf v[CNT][R];
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        const int b = tid + i * NT;
+        const int frame = b / BPF, j = b % BPF;
+        Pass::load(buf + frame * RS, j, v[i]);
+        Pass::twiddle(tw, NS, j, v[i]);
+        Dft<R, -1>::run(v[i]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        const int b = tid + i * NT;
+        const int frame = b / BPF, j = b % BPF;
+        Pass::store(buf + frame * RS, NS, j, v[i]);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float logmag_gr(cf X)
+{
+    // complex_to_mag_squared (unfused) -> volk log2 (log2f, -inf -> -127) * (1/log2(10)) -> + 1
+    const float p = __fadd_rn(__fmul_rn(X.x, X.x), __fmul_rn(X.y, X.y));
+    float l2 = log2f(p);
+    if (isinf(l2)) l2 = copysignf(127.0f, l2);
+    const float scale = 0.30102999566398120f;   // 1 / log2(10)
+    return __fadd_rn(__fmul_rn(l2, scale), 1.0f);
+}
+
+template <int N>
+__global__ __launch_bounds__(scan_threads<N>()) void scan_fft_kernel(ScanLaunch p)
+{
+    constexpr int NT = scan_threads<N>();
+    constexpr int FPW = scan_fpw<N>();
+    constexpr int RS = scan_rs<N>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+    const int tid = threadIdx.x;
+    const int fl0 = blockIdx.x * FPW;          // first local frame of this workgroup
+
+    // load + window
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + i * NT;
+        const int fl = e / N, idx = e % N;
+        cf x = make_float2(0.f, 0.f);
+        if (fl0 + fl < p.n_frames) {
+            const int64_t s = p.s0 + (int64_t)(fl0 + fl) * N + idx;
+            x = p.src.base[(uint64_t)(s - p.src.origin) & p.src.mask];
+            const float w = p.window[idx];
+            x = make_float2(__fmul_rn(x.x, w), __fmul_rn(x.y, w));
+        }
+        buf[fl * RS + lds_pad(idx)] = x;
+    }
+    __syncthreads();
+
+    scan_pass<N, NT, SPlan<N>::r[0], 1>(buf, p.tw, tid);
+    if constexpr (SPlan<N>::n >= 2) scan_pass<N, NT, SPlan<N>::r[1], SPlan<N>::r[0]>(buf, p.tw, tid);
+    if constexpr (SPlan<N>::n >= 3)
+        scan_pass<N, NT, SPlan<N>::r[2], SPlan<N>::r[0] * SPlan<N>::r[1]>(buf, p.tw, tid);
+    if constexpr (SPlan<N>::n >= 4)
+        scan_pass<N, NT, SPlan<N>::r[3], SPlan<N>::r[0] * SPlan<N>::r[1] * SPlan<N>::r[2]>(buf, p.tw, tid);
+
+    // |X|^2 -> log10 + 1 -> fftshift -> ring slot of the frame
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + i * NT;
+        const int fl = e / N, k = e % N;
+        if (fl0 + fl < p.n_frames) {
+            const int f = p.f0 + fl0 + fl;
+            const float v = logmag_gr(buf[fl * RS + lds_pad(k)]);
+            p.vring[(size_t)(f % p.R) * N + ((k + N / 2) & (N - 1))] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void movsum_kernel(const float *__restrict__ vring, int N, int R, int L, int f0,
+                                                     int n_frames, int emit_frame, float *__restrict__ sum,
+                                                     float *__restrict__ out)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= N) return;
+    float s = sum[k];
+    for (int f = f0; f < f0 + n_frames; ++f) {
+        s = __fadd_rn(s, vring[(size_t)(f % R) * N + k]);
+        if (f == emit_frame) out[k] = s;
+        const int fo = f - (L - 1);
+        if (fo >= 0) s = __fsub_rn(s, vring[(size_t)(fo % R) * N + k]);
+    }
+    sum[k] = s;
+}
+
+template <int N>
+void launch_n(const ScanLaunch &p, hipStream_t s)
+{
+    constexpr int FPW = scan_fpw<N>();
+    const int n_wg = (p.n_frames + FPW - 1) / FPW;
+    const size_t lds = (size_t)FPW * scan_rs<N>() * sizeof(cf);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_fft_kernel<N>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((scan_fft_kernel<N>), dim3(n_wg), dim3(scan_threads<N>()), lds, s, p);
+}
+
+}  // namespace
+
+bool scan_supported(int N)
+{
+    if (N >= 256 && N <= 16384 && (N & (N - 1)) == 0) return true;
+    return scan4_supported(N);
+}
+
+void launch_scan_fft(const ScanLaunch &p, hipStream_t s)
+{
+    if (p.n_frames <= 0) return;
+    switch (p.N) {
+        case 256:   launch_n<256>(p, s); break;
+        case 512:   launch_n<512>(p, s); break;
+        case 1024:  launch_n<1024>(p, s); break;
+        case 2048:  launch_n<2048>(p, s); break;
+        case 4096:  launch_n<4096>(p, s); break;
+        case 8192:  launch_n<8192>(p, s); break;
+        case 16384: launch_n<16384>(p, s); break;
+        default:    launch_scan4_fft(p, s); break;
+    }
+}
+
+void launch_scan_movsum(float *vring, int N, int R, int L, int f0, int n_frames, int emit_frame, float *sum,
+                        float *out, hipStream_t s)
+{
+    if (n_frames <= 0) return;
+    hipLaunchKernelGGL(movsum_kernel, dim3((N + 255) / 256), dim3(256), 0, s, vring, N, R, L, f0, n_frames,
+                       emit_frame, sum, out);
+}
+
+}  // namespace rcfx

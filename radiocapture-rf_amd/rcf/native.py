@@ -1,0 +1,286 @@
+"""ctypes binding of librcf.so (include/rcf.h).  Thin: numpy arrays in/out, no arithmetic here.
+
+There is no CPU fallback: if librcf.so is missing the import of any compute entry point raises
+RuntimeError, and rcf_open() fails without a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librcf.so")
+_lib = None
+
+RCF_OK, RCF_EINVAL, RCF_ENOMEM, RCF_EHIP, RCF_ENOCHAN = 0, -1, -2, -3, -4
+RCF_ECAP, RCF_ESTATE, RCF_EAGAIN, RCF_ERANGE = -5, -6, -7, -8
+WIN_HAMMING, WIN_BLACKMAN, WIN_BLACKMAN_HARRIS = 0, 2, 5
+SRC_PFB_BIN0 = 0x40000000
+
+# every symbol include/rcf.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "rcf_version", "rcf_last_error", "rcf_device_count", "rcf_design_low_pass_2", "rcf_design_window",
+    "rcf_channel_params", "rcf_open", "rcf_open_ex", "rcf_close", "rcf_sync", "rcf_stream", "rcf_device",
+    "rcf_push_iq", "rcf_ingest_ptr", "rcf_commit", "rcf_samples_in", "rcf_chan_open", "rcf_chan_open_taps",
+    "rcf_chan_set_offset", "rcf_chan_close", "rcf_chan_info", "rcf_chan_produced", "rcf_chan_read_iq",
+    "rcf_chan_read_fm", "rcf_chan_rings", "rcf_source_shift", "rcf_pfb_open", "rcf_pfb_close",
+    "rcf_pfb_produced", "rcf_pfb_read_bin", "rcf_pfb_rings", "rcf_pfb_chan_open", "rcf_scan_start",
+    "rcf_scan_result", "rcf_scan_frames_done", "rcf_scan_result_device", "rcf_find_peaks",
+    "rcf_peak_frequency", "rcf_scan_find_peaks",
+]
+
+
+class RcfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("librcf error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise RuntimeError("librcf.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`"
+                           % _SO)
+    L = C.CDLL(_SO)
+    fp, vp, i64, sz = C.POINTER(C.c_float), C.c_void_p, C.c_int64, C.c_size_t
+    ip = C.POINTER(C.c_int)
+    sig = {
+        "rcf_version": (C.c_char_p, []),
+        "rcf_last_error": (C.c_char_p, []),
+        "rcf_device_count": (C.c_int, []),
+        "rcf_design_low_pass_2": (C.c_int, [C.c_double] * 5 + [C.c_int, fp, C.c_int]),
+        "rcf_design_window": (C.c_int, [C.c_int, C.c_int, fp]),
+        "rcf_channel_params": (C.c_int, [C.c_double, C.c_int, ip, ip]),
+        "rcf_open": (C.c_int, [C.c_int, C.c_double, C.c_double, C.POINTER(vp)]),
+        "rcf_open_ex": (C.c_int, [C.c_int, C.c_double, C.c_double, sz, sz, sz, C.POINTER(vp)]),
+        "rcf_close": (C.c_int, [vp]),
+        "rcf_sync": (C.c_int, [vp]),
+        "rcf_stream": (vp, [vp]),
+        "rcf_device": (C.c_int, [vp]),
+        "rcf_push_iq": (C.c_int, [vp, fp, sz]),
+        "rcf_ingest_ptr": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "rcf_commit": (C.c_int, [vp, sz]),
+        "rcf_samples_in": (i64, [vp]),
+        "rcf_chan_open": (C.c_int, [vp, C.c_int, C.c_double, ip]),
+        "rcf_chan_open_taps": (C.c_int, [vp, C.c_int, C.c_int, fp, C.c_int, C.c_double, ip]),
+        "rcf_chan_set_offset": (C.c_int, [vp, C.c_int, C.c_double]),
+        "rcf_chan_close": (C.c_int, [vp, C.c_int]),
+        "rcf_chan_info": (C.c_int, [vp, C.c_int, ip, ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "rcf_chan_produced": (i64, [vp, C.c_int]),
+        "rcf_chan_read_iq": (i64, [vp, C.c_int, fp, sz]),
+        "rcf_chan_read_fm": (i64, [vp, C.c_int, C.c_float, fp, sz]),
+        "rcf_chan_rings": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]),
+        "rcf_source_shift": (C.c_int, [vp, C.c_double]),
+        "rcf_pfb_open": (C.c_int, [vp, C.c_int, C.c_int, fp, C.c_int]),
+        "rcf_pfb_close": (C.c_int, [vp]),
+        "rcf_pfb_produced": (i64, [vp]),
+        "rcf_pfb_read_bin": (i64, [vp, C.c_int, fp, sz]),
+        "rcf_pfb_rings": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "rcf_pfb_chan_open": (C.c_int, [vp, C.c_int, C.c_int, C.c_double, ip]),
+        "rcf_scan_start": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+        "rcf_scan_result": (C.c_int, [vp, fp]),
+        "rcf_scan_frames_done": (C.c_int, [vp]),
+        "rcf_scan_result_device": (C.c_int, [vp, C.POINTER(vp)]),
+        "rcf_find_peaks": (C.c_int, [fp, i64, C.c_double, C.c_double, C.c_double, C.POINTER(i64), i64,
+                                     C.POINTER(i64), C.POINTER(C.c_double)]),
+        "rcf_peak_frequency": (i64, [i64, C.c_double, i64, C.c_double]),
+        "rcf_scan_find_peaks": (C.c_int, [vp, C.c_double, C.POINTER(i64), i64, C.POINTER(i64),
+                                          C.POINTER(C.c_double), C.POINTER(vp)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise RcfError(rc, lib().rcf_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def device_count() -> int:
+    return lib().rcf_device_count()
+
+
+def design_low_pass_2(gain, fs, fc, tw, att_db, window=WIN_HAMMING) -> np.ndarray:
+    L = lib()
+    n = -L.rcf_design_low_pass_2(gain, fs, fc, tw, att_db, window, None, 0)
+    if n <= 0:
+        _check(-n if n else RCF_EINVAL)
+    taps = np.empty(n, dtype=np.float32)
+    _check(L.rcf_design_low_pass_2(gain, fs, fc, tw, att_db, window, _fp(taps), n))
+    return taps
+
+
+def design_window(window, n) -> np.ndarray:
+    w = np.empty(n, dtype=np.float32)
+    _check(lib().rcf_design_window(window, n, _fp(w)))
+    return w
+
+
+def channel_params(samp_rate, channel_rate):
+    d, t = C.c_int(), C.c_int()
+    _check(lib().rcf_channel_params(samp_rate, int(channel_rate), C.byref(d), C.byref(t)))
+    return d.value, t.value
+
+
+def find_peaks(spectrum, min_w, max_w, prominence=1.0, cap=4096):
+    s = np.ascontiguousarray(spectrum, dtype=np.float32)
+    idx = np.empty(cap, dtype=np.int64)
+    cnt, mean = C.c_int64(), C.c_double()
+    _check(lib().rcf_find_peaks(_fp(s), len(s), min_w, max_w, prominence,
+                                idx.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(cnt), C.byref(mean)))
+    return idx[:min(cnt.value, cap)].copy(), mean.value, cnt.value
+
+
+def peak_frequency(line, samp_rate, fft_len, center_freq) -> int:
+    return lib().rcf_peak_frequency(int(line), samp_rate, int(fft_len), center_freq)
+
+
+class Frontend:
+    """One SDR source: owner of the HBM wideband buffer, channels, PFB and scanner (rcf_t)."""
+
+    def __init__(self, samp_rate, center_freq=0.0, device=0, block_capacity=0, hist_capacity=0,
+                 out_capacity=0):
+        self._h = C.c_void_p()
+        self.samp_rate = float(samp_rate)
+        self.center_freq = float(center_freq)
+        _check(lib().rcf_open_ex(device, samp_rate, center_freq, block_capacity, hist_capacity,
+                                 out_capacity, C.byref(self._h)))
+
+    # -- lifecycle
+    def close(self):
+        if self._h:
+            lib().rcf_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        _check(lib().rcf_sync(self._h))
+
+    @property
+    def stream(self):
+        return lib().rcf_stream(self._h)
+
+    @property
+    def samples_in(self):
+        return lib().rcf_samples_in(self._h)
+
+    # -- ingest
+    def push(self, iq: np.ndarray):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        _check(lib().rcf_push_iq(self._h, _fp(iq.view(np.float32)), len(iq)))
+
+    def ingest_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(lib().rcf_ingest_ptr(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def commit(self, n):
+        _check(lib().rcf_commit(self._h, int(n)))
+
+    # -- channels
+    def chan_open(self, channel_rate, offset_hz) -> int:
+        cid = C.c_int()
+        _check(lib().rcf_chan_open(self._h, int(channel_rate), float(offset_hz), C.byref(cid)))
+        return cid.value
+
+    def chan_open_taps(self, src, decim, taps, offset_hz) -> int:
+        taps = np.ascontiguousarray(taps, dtype=np.float32)
+        cid = C.c_int()
+        _check(lib().rcf_chan_open_taps(self._h, int(src), int(decim), _fp(taps), len(taps),
+                                        float(offset_hz), C.byref(cid)))
+        return cid.value
+
+    def pfb_chan_open(self, bin_, channel_rate, delta_hz) -> int:
+        cid = C.c_int()
+        _check(lib().rcf_pfb_chan_open(self._h, int(bin_), int(channel_rate), float(delta_hz), C.byref(cid)))
+        return cid.value
+
+    def chan_set_offset(self, cid, offset_hz):
+        _check(lib().rcf_chan_set_offset(self._h, cid, float(offset_hz)))
+
+    def chan_close(self, cid):
+        _check(lib().rcf_chan_close(self._h, cid))
+
+    def chan_info(self, cid):
+        d, t, r, o = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        _check(lib().rcf_chan_info(self._h, cid, C.byref(d), C.byref(t), C.byref(r), C.byref(o)))
+        return dict(decim=d.value, ntaps=t.value, out_rate=r.value, offset_hz=o.value)
+
+    def chan_produced(self, cid):
+        return _check(lib().rcf_chan_produced(self._h, cid))
+
+    def chan_read_iq(self, cid, max_samples=1 << 20) -> np.ndarray:
+        out = np.empty(max_samples, dtype=np.complex64)
+        n = _check(lib().rcf_chan_read_iq(self._h, cid, _fp(out.view(np.float32)), max_samples))
+        return out[:n].copy()
+
+    def chan_read_fm(self, cid, gain, max_samples=1 << 20) -> np.ndarray:
+        out = np.empty(max_samples, dtype=np.float32)
+        n = _check(lib().rcf_chan_read_fm(self._h, cid, float(gain), _fp(out), max_samples))
+        return out[:n].copy()
+
+    def source_shift(self, delta_hz):
+        _check(lib().rcf_source_shift(self._h, float(delta_hz)))
+
+    # -- PFB
+    def pfb_open(self, n_bins, decim, taps):
+        taps = np.ascontiguousarray(taps, dtype=np.float32)
+        _check(lib().rcf_pfb_open(self._h, int(n_bins), int(decim), _fp(taps), len(taps)))
+
+    def pfb_close(self):
+        _check(lib().rcf_pfb_close(self._h))
+
+    def pfb_produced(self):
+        return _check(lib().rcf_pfb_produced(self._h))
+
+    def pfb_read_bin(self, bin_, max_samples=1 << 20) -> np.ndarray:
+        out = np.empty(max_samples, dtype=np.complex64)
+        n = _check(lib().rcf_pfb_read_bin(self._h, int(bin_), _fp(out.view(np.float32)), max_samples))
+        return out[:n].copy()
+
+    # -- scan
+    def scan_start(self, fft_len, n_frames=1000, avg_len=100):
+        self._scan_len = int(fft_len)
+        _check(lib().rcf_scan_start(self._h, int(fft_len), int(n_frames), int(avg_len)))
+
+    def scan_frames_done(self):
+        return _check(lib().rcf_scan_frames_done(self._h))
+
+    def scan_result(self):
+        out = np.empty(self._scan_len, dtype=np.float32)
+        rc = lib().rcf_scan_result(self._h, _fp(out))
+        if rc == RCF_EAGAIN:
+            return None
+        _check(rc)
+        return out
+
+    def scan_find_peaks(self, prominence=1.0, cap=1024, want_device=False):
+        idx = np.empty(cap, dtype=np.int64)
+        cnt, mean, dev = C.c_int64(), C.c_double(), C.c_void_p()
+        _check(lib().rcf_scan_find_peaks(self._h, prominence, idx.ctypes.data_as(C.POINTER(C.c_int64)), cap,
+                                         C.byref(cnt), C.byref(mean), C.byref(dev) if want_device else None))
+        return idx[:min(cnt.value, cap)].copy(), mean.value, dev.value

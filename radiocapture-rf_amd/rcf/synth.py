@@ -70,20 +70,25 @@ def cfg2(n: int = 10_000_000, seed: int = 2002, n_bins: int = 256, n_active: int
     return x.astype(np.complex64), meta
 
 
-def scan_stream(fs: float, N: int, n_unique_frames: int, carriers, seed: int):
-    """Periodic scan input: `n_unique_frames` frames of N samples; caller tiles it to n_frames.
+def scan_stream(fs: float, N: int, n_unique_frames: int, carriers, seed: int, scale: float = 0.003):
+    """Periodic scan input: `n_unique_frames` frames of N samples, seamless when tiled.
 
-    carriers: list of (bin_centre (shifted index, 0 = -fs/2), occupied_bw_hz, snr_db).  Each is an
-    FM carrier swept by a slow tone so that its occupied width is ~occupied_bw_hz.
+    carriers: list of (bin_centre, fwhm_hz, peak_db) -- bin_centre is the fft-shifted index on the
+    N-point grid (0 = -fs/2); each carrier is band-limited Gaussian noise whose PSD is a Gaussian bump
+    of full width `fwhm_hz` at half (linear) maximum peaking `peak_db` above the unit noise floor,
+    i.e. a smooth single-humped log-spectrum like a busy trunked control channel's.
+    The whole tile is synthesised in the frequency domain (one IFFT), hence exactly periodic.
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     n = N * n_unique_frames
-    x = awgn(rng, n).astype(np.complex128)
-    for (b, bw, snr) in carriers:
-        f = (b - N // 2) * fs / N
-        # wideband FM with a noise-like modulating phase -> roughly flat occupied band of `bw`
-        fm = bw / 8.0
-        dev = bw / 2.0 - fm
-        x += nbfm_carrier(n, fs, f, fm, dev, snr_amp(snr, bw, fs) * math.sqrt(bw / (fs / N) / 8.0),
-                          rng.uniform(0, 2 * math.pi))
-    return x.astype(np.complex64)
+    fgrid = np.fft.fftfreq(n, d=1.0 / fs)
+    psd = np.ones(n, dtype=np.float64)
+    for (b, fwhm, peak_db) in carriers:
+        f0 = (b - N // 2) * fs / N
+        sig = fwhm / 2.3548200450309493
+        psd += 10.0 ** (peak_db / 10.0) * np.exp(-0.5 * ((fgrid - f0) / sig) ** 2)
+    spec = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.sqrt(psd * 0.5)
+    x = np.fft.ifft(spec) * math.sqrt(n)
+    # RTL-SDR-like level: the noise floor's log10|X|^2 + 1 is negative, so the reference's
+    # `data += abs(min(data))` (fft_peak_detection.py:58-59) lifts the floor to ~0 as its author intended
+    return (x * scale).astype(np.complex64)

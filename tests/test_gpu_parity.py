@@ -1,0 +1,280 @@
+"""-m gpu parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerances (BASELINE.json north_star): discriminator output within 1e-4 RMS of the oracle; the
+channel IQ is held to 1e-5 relative RMS; peak indices bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import grspec as G
+from oracle import cbind as OC
+from oracle import peaks as P
+from rcf import synth
+
+pytestmark = pytest.mark.gpu
+
+# (fft-shifted bin centre, FWHM Hz, peak dB over the noise PSD): SURVEY 8(d) seed-3004 variant
+SCAN_CARRIERS_3004 = [(2000, 9000.0, 25.0), (5200, 12500.0, 30.0), (8192 + 900, 7000.0, 22.0),
+                      (11000, 20000.0, 28.0), (15000, 12500.0, 26.0)]
+
+
+def rel_rms(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    return float(np.sqrt(np.mean(np.abs(a - b) ** 2)) / (np.sqrt(np.mean(np.abs(b) ** 2)) + 1e-30))
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)) ** 2)))
+
+
+def oracle_channel(x, fs, cr, f0, gains):
+    D, taps = G.channel_params(fs, cr)
+    ct, incr = OC.xlating_composite(taps, D, f0, fs)
+    y, _ = OC.channel_bank(x, D, ct[None, :], np.array([incr]), acc_double=True)
+    fms = [OC.quad_demod(y[0], g) for g in gains]
+    return y[0], fms
+
+
+def test_cfg1_single_channel_iq_and_fm(gpu_required):
+    nat = gpu_required
+    x, meta = synth.cfg1(seconds=0.25)
+    with nat.Frontend(meta["fs"], meta["center_freq"]) as fe:
+        cid = fe.chan_open(12500, meta["offset"])
+        info = fe.chan_info(cid)
+        assert info["decim"] == 96 and info["ntaps"] == 349 and info["out_rate"] == 25000.0
+        fe.push(x)
+        y = fe.chan_read_iq(cid)
+        fm5 = fe.chan_read_fm(cid, 5.0)
+    g_p25 = G.p25_fm_gain(25000.0)
+    yo, (fo5, fop) = oracle_channel(x, meta["fs"], 12500, meta["offset"], [5.0, g_p25])
+    assert len(y) == len(yo) == (len(x) - 1) // 96 + 1
+    assert rel_rms(y, yo) < 1e-5
+    assert rms(fm5, fo5) < 1e-4
+    # the demodulated tone: 1 kHz, deviation 2.5 kHz -> peak 5 * 2 pi 2500 / 25000
+    n = np.arange(len(fm5) - 50)
+    amp = 2 * abs(np.mean(fm5[50:] * np.exp(-2j * math.pi * 1000 * n / 25000)))
+    assert abs(amp - 5 * 2 * math.pi * 2500 / 25000) < 0.1
+
+
+def test_chunked_push_equals_single_push(gpu_required):
+    nat = gpu_required
+    x, meta = synth.cfg1(seconds=0.1, seed=77)
+    rng = np.random.default_rng(5)
+    with nat.Frontend(meta["fs"]) as fe:
+        cid = fe.chan_open(12500, 311000.0)
+        fe.push(x)
+        y1 = fe.chan_read_iq(cid)
+        f1 = fe.chan_read_fm(cid, 1.0)
+    with nat.Frontend(meta["fs"]) as fe:
+        cid = fe.chan_open(12500, 311000.0)
+        pos, ys, fs_ = 0, [], []
+        while pos < len(x):
+            n = int(rng.integers(1, 40000))
+            fe.push(x[pos:pos + n])
+            pos += n
+            if rng.random() < 0.5:
+                ys.append(fe.chan_read_iq(cid))
+                fs_.append(fe.chan_read_fm(cid, 1.0))
+        ys.append(fe.chan_read_iq(cid))
+        fs_.append(fe.chan_read_fm(cid, 1.0))
+    y2, f2 = np.concatenate(ys), np.concatenate(fs_)
+    assert len(y1) == len(y2)
+    assert rel_rms(y2, y1) < 2e-6
+    assert rms(f2, f1) < 2e-5
+    yo, _ = oracle_channel(x, meta["fs"], 12500, 311000.0, [])
+    assert rel_rms(y2, yo) < 1e-5
+
+
+@pytest.mark.parametrize("fs,cr,offsets", [
+    (20e6, 12500, [1.0e6, 5.0125e6, -9.9875e6, 12500.0, -3.3e6]),
+    (2.4e6, 6250, [-62500.0, 1.0e6]),
+    (2.4e6, 25000, [400000.0, -1.1e6, 0.0]),
+])
+def test_multichannel_bank_gr_faithful(gpu_required, fs, cr, offsets):
+    """The float32 tap-phase / rotator roundings of GR are reproduced (SURVEY 8(c) (i),(ii))."""
+    nat = gpu_required
+    rng = np.random.default_rng(int(fs) % 1000 + cr)
+    D, taps = G.channel_params(fs, cr)
+    n = D * 700
+    x = synth.awgn(rng, n)
+    for f in offsets:
+        x = x + synth.nbfm_carrier(n, fs, f + 300.0, 700.0, 2500.0, 0.5).astype(np.complex64)
+    x = x.astype(np.complex64)
+    with nat.Frontend(fs) as fe:
+        ids = [fe.chan_open(cr, f) for f in offsets]
+        fe.push(x)
+        ys = [fe.chan_read_iq(c) for c in ids]
+        fms = [fe.chan_read_fm(c, G.p25_fm_gain(2 * cr)) for c in ids]
+    for f, y, fm in zip(offsets, ys, fms):
+        yo, (fo,) = oracle_channel(x, fs, cr, f, [G.p25_fm_gain(2 * cr)])
+        assert len(y) == len(yo) == 700
+        assert rel_rms(y, yo) < 1e-5, f
+        assert rms(fm, fo) < 1e-4, f
+
+
+def test_channel_opened_mid_stream_has_zero_history(gpu_required):
+    nat = gpu_required
+    fs, cr = 2.4e6, 12500
+    rng = np.random.default_rng(9)
+    x = synth.awgn(rng, 96 * 400)
+    with nat.Frontend(fs) as fe:
+        fe.push(x[:96 * 100 + 37])                      # channel starts off the decimation grid
+        cid = fe.chan_open(cr, 250000.0)
+        fe.push(x[96 * 100 + 37:])
+        y = fe.chan_read_iq(cid)
+    start = 96 * 100 + 37
+    k0 = -(-start // 96)
+    xz = x.copy()
+    xz[:start] = 0                                      # GR: a new flowgraph starts with zero history
+    D, taps = G.channel_params(fs, cr)
+    ct, incr = OC.xlating_composite(taps, D, 250000.0, fs)
+    v = G.fir_decim_cc(xz, ct, D)[k0:]
+    ph, _, _ = G.rotator_phases(incr, len(v))
+    yo = (v * ph).astype(np.complex64)
+    assert len(y) == len(yo)
+    assert rel_rms(y, yo) < 1e-5
+
+
+def test_retune_keeps_phase_and_history(gpu_required):
+    """channel.set_offset (rc_frontend/channel.py:61-63): new taps/increment, same rotator phase."""
+    nat = gpu_required
+    fs, cr = 2.4e6, 12500
+    rng = np.random.default_rng(10)
+    D, taps = G.channel_params(fs, cr)
+    x = synth.awgn(rng, D * 1300)
+    cut = D * 600
+    f_a, f_b = 100000.0, -437500.0
+    with nat.Frontend(fs) as fe:
+        cid = fe.chan_open(cr, f_a)
+        fe.push(x[:cut])
+        fe.chan_set_offset(cid, f_b)
+        fe.push(x[cut:])
+        y = fe.chan_read_iq(cid)
+    L = OC.lib()
+    import ctypes as C
+    st = OC.RotState(1.0, 0.0, 0)
+    xp = np.concatenate([np.zeros(len(taps) - 1, np.complex64), x])
+    base = xp.view(np.float32)[2 * (len(taps) - 1):]
+    yo = np.empty(1300, dtype=np.complex64)
+    fp = C.POINTER(C.c_float)
+    for (f, k0, k1) in ((f_a, 0, 600), (f_b, 600, 1300)):
+        ct, incr = OC.xlating_composite(taps, D, f, fs)
+        inc = np.array([incr], dtype=np.complex64)
+        seg = np.empty(k1 - k0, dtype=np.complex64)
+        L.ro_xlating_fir_ccc(base.ctypes.data_as(fp), k0, k1 - k0, D, ct.view(np.float32).ctypes.data_as(fp),
+                             len(taps), inc.view(np.float32).ctypes.data_as(fp), C.byref(st),
+                             seg.view(np.float32).ctypes.data_as(fp), 1)
+        yo[k0:k1] = seg
+    assert rel_rms(y, yo) < 1e-5
+
+
+def _pfb_proto(fs, nb):
+    # SURVEY 8(d) cfg2 prototype: low_pass_2 rule, fc = bin/2.5, tw = bin/5, 60 dB, Blackman-Harris
+    bw = fs / nb
+    return G.low_pass_2(1.0, fs, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+
+
+@pytest.mark.parametrize("nb,os_", [(256, 1), (64, 1), (128, 2), (512, 1), (1024, 2), (256, 2)])
+def test_pfb_equals_exact_xlating_bank(gpu_required, nb, os_):
+    nat = gpu_required
+    fs = 20e6
+    D = nb // os_
+    taps = _pfb_proto(fs, nb) if os_ == 1 else G.low_pass_2(1.0, fs, fs / nb / 4, fs / nb / 4, 20.0)
+    n_frames = 150
+    rng = np.random.default_rng(nb + os_)
+    x = synth.awgn(rng, D * n_frames)
+    bins = [0, 1, 5, nb // 2 - 1, nb // 2, nb - 3, nb - 1]
+    for k in bins[1:4]:
+        x = x + synth.nbfm_carrier(len(x), fs, k * fs / nb + 2000.0, 900.0, 2500.0, 1.0).astype(np.complex64)
+    x = x.astype(np.complex64)
+    hist = 1 << 16
+    with nat.Frontend(fs, hist_capacity=max(hist, 2 * len(taps) + 2 * nb)) as fe:
+        fe.pfb_open(nb, D, taps)
+        cut = D * 37 + 11
+        fe.push(x[:cut])                               # frames straddle a block boundary
+        fe.push(x[cut:])
+        assert fe.pfb_produced() == n_frames
+        got = {k: fe.pfb_read_bin(k) for k in bins}
+    for k in bins:
+        f0 = k * fs / nb if k < nb // 2 else (k - nb) * fs / nb
+        want = G.xlating_fir_exact(x, D, taps, f0, fs)
+        assert len(got[k]) == n_frames
+        scale = np.sqrt(np.mean(np.abs(want) ** 2))
+        err = np.sqrt(np.mean(np.abs(got[k] - want) ** 2))
+        assert err / max(scale, 1e-3) < 2e-5, (k, err, scale)
+
+
+def test_pfb_stage2_fm_channel(gpu_required):
+    """BASELINE config 2 shape: 256-bin PFB @20 Msps, stage-2 xlating FIR /3 + discriminator."""
+    nat = gpu_required
+    fs, nb = 20e6, 256
+    x, meta = synth.cfg2(n=256 * 1500, n_active=4)
+    taps = _pfb_proto(fs, nb)
+    assert len(taps) == 3491
+    with nat.Frontend(fs) as fe:
+        fe.pfb_open(nb, nb, taps)
+        chans = []
+        for c in meta["carriers"]:
+            b = c["bin"] % nb
+            chans.append((c, b, fe.pfb_chan_open(b, 12500, c["delta"])))
+        fe.push(x)
+        out = [(c, b, fe.chan_read_iq(cid), fe.chan_read_fm(cid, 1.0), fe.chan_info(cid)) for c, b, cid in chans]
+    bin_rate = fs / nb
+    D2, taps2 = G.channel_params(bin_rate, 12500)
+    assert D2 == 3 and len(taps2) == 11
+    for c, b, y, fm, info in out:
+        assert info["decim"] == 3 and info["ntaps"] == 11
+        f0 = c["bin"] * fs / nb
+        stage1 = G.xlating_fir_exact(x, nb, taps, f0, fs).astype(np.complex64)
+        yo = G.xlating_fir_ccc(stage1, D2, taps2, c["delta"], bin_rate)
+        fo = G.quadrature_demod_cf(yo, 1.0)
+        assert len(y) == len(yo) == 500
+        assert rel_rms(y, yo) < 2e-5
+        assert rms(fm[20:], fo[20:]) < 1e-4
+
+
+@pytest.mark.parametrize("N,F,L", [(256, 40, 10), (1024, 25, 7), (4096, 12, 5), (16384, 12, 4)])
+def test_scan_chain_small(gpu_required, N, F, L):
+    nat = gpu_required
+    fs = 2.4e6
+    rng = np.random.default_rng(N)
+    x = synth.awgn(rng, N * F).astype(np.complex64)
+    x += (4.0 * np.exp(2j * math.pi * 0.123 * np.arange(N * F))).astype(np.complex64)
+    with nat.Frontend(fs, hist_capacity=1 << 16) as fe:
+        fe.scan_start(N, F, L)
+        cut = N * 3 + 17
+        fe.push(x[:cut])
+        assert fe.scan_result() is None
+        fe.push(x[cut:])
+        got = fe.scan_result()
+    want = OC.scan_chain(x, N, F, L)
+    assert got is not None and got.shape == (N,)
+    assert np.abs(got - want).max() < 2e-3
+    assert np.argmax(got) == np.argmax(want)
+
+
+def test_scan_reference_size_and_peaks_bit_exact(gpu_required):
+    """fs=2.4e6, N=16384, 1000 frames, 100-frame average, then the peak pick: indices bit-exact."""
+    nat = gpu_required
+    fs, N, fc = 2.4e6, 16384, 855.05e6
+    carriers = SCAN_CARRIERS_3004
+    tile = synth.scan_stream(fs, N, 125, carriers, seed=3004)
+    with nat.Frontend(fs, block_capacity=N * 125, hist_capacity=1 << 16) as fe:
+        fe.scan_start(N, 1000, 100)
+        for _ in range(8):
+            fe.push(tile)
+        spec = fe.scan_result()
+        lines_dev, mean_dev, _ = fe.scan_find_peaks()
+    assert spec is not None
+    x = np.tile(tile, 8)
+    want = OC.scan_chain(x, N, 1000, 100)
+    assert np.abs(spec - want).max() < 5e-3
+    l_want, f_want = P.peak_detect_scipy(want, fs, fc)
+    l_got, f_got = P.peak_detect_scipy(spec, fs, fc)
+    np.testing.assert_array_equal(l_got, l_want)               # GPU spectrum -> same indices
+    np.testing.assert_array_equal(lines_dev, l_want)           # product peak picker -> same indices
+    assert list(l_want) == [2004, 5195, 9089, 15000]   # 20 kHz-wide carrier at 11000 fails the width window
+    assert [nat.peak_frequency(l, fs, N, fc) for l in lines_dev] == f_want
