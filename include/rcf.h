@@ -80,6 +80,21 @@ int rcf_sync(rcf_t *h);
 void *rcf_stream(rcf_t *h);
 int rcf_device(rcf_t *h);
 
+/* ------------------------------------------------------------------ measurement */
+/* Per-kernel-class timing with HIP events recorded on the handle's own stream around each launch
+ * (torch.cuda.Event would only see torch's stream).  Used by bench.py for roofline.achieved. */
+#define RCF_T_FIR          0   /* direct xlating-FIR bank on the wideband stream */
+#define RCF_T_PFB          1   /* polyphase filterbank kernel */
+#define RCF_T_FIR_DERIVED  2   /* stage-2 / pre-filter FIRs on narrowband rings */
+#define RCF_T_DISC         3   /* discriminator */
+#define RCF_T_SCAN_FFT     4   /* scan FFT + log-magnitude */
+#define RCF_T_SCAN_MOVSUM  5   /* scan running sum */
+#define RCF_T_HISTORY      6   /* history carry-over copy */
+#define RCF_T_COUNT        7
+int rcf_timing_enable(rcf_t *h, int on);
+/* accumulated milliseconds and launch count of one class since the last reset (syncs the stream) */
+int rcf_timing_read(rcf_t *h, int what, double *total_ms, int64_t *launches, int reset);
+
 /* ------------------------------------------------------------------ wideband ingest */
 /* Host buffer in: copies n_samples H2D behind the history and runs every consumer (channels, PFB,
  * armed scan) over the new block.  Replaces the source -> pub_sink broadcast (receiver.py:201-202)
@@ -90,6 +105,9 @@ int rcf_push_iq(rcf_t *h, const float *iq_interleaved, size_t n_samples);
  * found there.  rcf_commit without rewriting the region re-processes the resident data as the next
  * n samples of the stream (used by bench.py: inputs already resident in HBM). */
 int rcf_ingest_ptr(rcf_t *h, float **dev_ptr, size_t *max_samples);
+/* copy n_samples host samples to offset `at` (samples) of the pending block without processing them:
+ * for drivers that deliver a block in pieces, and for pre-loading resident data */
+int rcf_ingest_write(rcf_t *h, const float *iq_interleaved, size_t n_samples, size_t at);
 int rcf_commit(rcf_t *h, size_t n_samples);
 /* total samples ingested so far */
 int64_t rcf_samples_in(rcf_t *h);

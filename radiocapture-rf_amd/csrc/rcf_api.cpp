@@ -122,6 +122,13 @@ struct rcf {
     Pfb pfb;
     Scan scan;
     std::vector<void *> graveyard;   // device buffers to free once the stream is idle
+    // optional per-kernel-class HIP-event timing (rcf_timing_*)
+    bool timing = false;
+    struct TimeRec { int what; hipEvent_t a, b; };
+    std::vector<TimeRec> time_pending;
+    std::vector<hipEvent_t> time_pool;
+    double time_ms[RCF_T_COUNT] = {0};
+    int64_t time_n[RCF_T_COUNT] = {0};
     std::mutex mu;
 };
 
@@ -144,6 +151,40 @@ void drain_graveyard(rcf_t *h)
     (void)hipStreamSynchronize(h->stream);
     for (void *p : h->graveyard) (void)hipFree(p);
     h->graveyard.clear();
+}
+
+hipEvent_t time_event(rcf_t *h)
+{
+    hipEvent_t e = nullptr;
+    if (!h->time_pool.empty()) { e = h->time_pool.back(); h->time_pool.pop_back(); return e; }
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Timed {   // RAII: brackets the launches issued in its scope with two events on the stream
+    rcf_t *h; int what; hipEvent_t a = nullptr;
+    Timed(rcf_t *h_, int what_) : h(h_), what(what_)
+    {
+        if (h->timing) { a = time_event(h); (void)hipEventRecord(a, h->stream); }
+    }
+    ~Timed()
+    {
+        if (!a) return;
+        hipEvent_t b = time_event(h);
+        (void)hipEventRecord(b, h->stream);
+        h->time_pending.push_back({what, a, b});
+    }
+};
+
+void time_collect(rcf_t *h)
+{
+    for (auto &r : h->time_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { h->time_ms[r.what] += ms; h->time_n[r.what] += 1; }
+        h->time_pool.push_back(r.a);
+        h->time_pool.push_back(r.b);
+    }
+    h->time_pending.clear();
 }
 
 // source description for one commit
@@ -405,11 +446,14 @@ int process_block(rcf_t *h, size_t n)
         h->arena_cur ^= 1;
     }
     if (!fir_by_depth.empty())
-        for (auto &j : fir_by_depth[0]) launch_fir_bank(j.dev, j.dims, st);
-    if (run_pfb) launch_pfb(pl, st);
+        for (auto &j : fir_by_depth[0]) { Timed t(h, RCF_T_FIR); launch_fir_bank(j.dev, j.dims, st); }
+    if (run_pfb) { Timed t(h, RCF_T_PFB); launch_pfb(pl, st); }
     for (size_t d = 1; d < fir_by_depth.size(); ++d)
-        for (auto &j : fir_by_depth[d]) launch_fir_bank(j.dev, j.dims, st);
-    for (auto &dj : disc_jobs) launch_discriminator(dj.dev, dj.n, dj.max_n, h->ring_mask, h->d_atan, st);
+        for (auto &j : fir_by_depth[d]) { Timed t(h, RCF_T_FIR_DERIVED); launch_fir_bank(j.dev, j.dims, st); }
+    for (auto &dj : disc_jobs) {
+        Timed t(h, RCF_T_DISC);
+        launch_discriminator(dj.dev, dj.n, dj.max_n, h->ring_mask, h->d_atan, st);
+    }
 
     // ---- scan
     Scan &sc = h->scan;
@@ -429,9 +473,12 @@ int process_block(rcf_t *h, size_t n)
             sl.N = sc.N; sl.R = sc.R;
             sl.f0 = sc.frames_done; sl.n_frames = cnt;
             sl.scratch = sc.d_scratch;
-            launch_scan_fft(sl, st);
-            launch_scan_movsum(sc.d_vring, sc.N, sc.R, sc.L, sc.frames_done, cnt, sc.n_frames - 1, sc.d_sum,
-                               sc.d_out, st);
+            { Timed t(h, RCF_T_SCAN_FFT); launch_scan_fft(sl, st); }
+            {
+                Timed t(h, RCF_T_SCAN_MOVSUM);
+                launch_scan_movsum(sc.d_vring, sc.N, sc.R, sc.L, sc.frames_done, cnt, sc.n_frames - 1, sc.d_sum,
+                                   sc.d_out, st);
+            }
             sc.frames_done += cnt;
         }
         if (sc.frames_done >= sc.n_frames) sc.done = true;
@@ -439,8 +486,11 @@ int process_block(rcf_t *h, size_t n)
 
     // ---- history for the next block, flip buffers
     const int other = h->cur ^ 1;
-    RCF_HIP(hipMemcpyAsync(h->d_buf[other], h->d_buf[h->cur] + n, sizeof(float2) * h->hist_cap,
-                           hipMemcpyDeviceToDevice, st));
+    {
+        Timed t(h, RCF_T_HISTORY);
+        RCF_HIP(hipMemcpyAsync(h->d_buf[other], h->d_buf[h->cur] + n, sizeof(float2) * h->hist_cap,
+                               hipMemcpyDeviceToDevice, st));
+    }
     h->cur = other;
     h->total_in = S1;
     RCF_HIP(hipGetLastError());
@@ -581,6 +631,8 @@ int rcf_close(rcf_t *h)
         if (h->arena_ev[i]) (void)hipEventDestroy(h->arena_ev[i]);
     }
     drain_graveyard(h);
+    time_collect(h);
+    for (hipEvent_t e : h->time_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return RCF_OK;
@@ -593,6 +645,30 @@ int rcf_sync(rcf_t *h)
     if (set_dev(h)) return RCF_EHIP;
     RCF_HIP(hipStreamSynchronize(h->stream));
     drain_graveyard(h);
+    return RCF_OK;
+}
+
+int rcf_timing_enable(rcf_t *h, int on)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    RCF_HIP(hipStreamSynchronize(h->stream));
+    time_collect(h);
+    h->timing = on != 0;
+    return RCF_OK;
+}
+
+int rcf_timing_read(rcf_t *h, int what, double *total_ms, int64_t *launches, int reset)
+{
+    if (!h || what < 0 || what >= RCF_T_COUNT) { set_error("bad timing class"); return RCF_EINVAL; }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    RCF_HIP(hipStreamSynchronize(h->stream));
+    time_collect(h);
+    if (total_ms) *total_ms = h->time_ms[what];
+    if (launches) *launches = h->time_n[what];
+    if (reset) { h->time_ms[what] = 0; h->time_n[what] = 0; }
     return RCF_OK;
 }
 
@@ -625,6 +701,18 @@ int rcf_ingest_ptr(rcf_t *h, float **dev_ptr, size_t *max_samples)
     std::lock_guard<std::mutex> g(h->mu);
     *dev_ptr = reinterpret_cast<float *>(h->d_buf[h->cur] + h->hist_cap);
     if (max_samples) *max_samples = h->block_cap;
+    return RCF_OK;
+}
+
+int rcf_ingest_write(rcf_t *h, const float *iq, size_t n, size_t at)
+{
+    if (!h || (!iq && n)) { set_error("bad ingest arguments"); return RCF_EINVAL; }
+    if (at + n > h->block_cap) { set_error("ingest write past block capacity"); return RCF_ECAP; }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    RCF_HIP(hipMemcpyAsync(h->d_buf[h->cur] + h->hist_cap + at, iq, sizeof(float2) * n, hipMemcpyHostToDevice,
+                           h->stream));
+    RCF_HIP(hipStreamSynchronize(h->stream));
     return RCF_OK;
 }
 

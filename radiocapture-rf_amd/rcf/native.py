@@ -28,8 +28,10 @@ SYMBOLS = [
     "rcf_chan_read_fm", "rcf_chan_rings", "rcf_source_shift", "rcf_pfb_open", "rcf_pfb_close",
     "rcf_pfb_produced", "rcf_pfb_read_bin", "rcf_pfb_rings", "rcf_pfb_chan_open", "rcf_scan_start",
     "rcf_scan_result", "rcf_scan_frames_done", "rcf_scan_result_device", "rcf_find_peaks",
-    "rcf_peak_frequency", "rcf_scan_find_peaks",
+    "rcf_peak_frequency", "rcf_scan_find_peaks", "rcf_timing_enable", "rcf_timing_read",
+    "rcf_ingest_write",
 ]
+T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY = range(7)
 
 
 class RcfError(RuntimeError):
@@ -64,6 +66,7 @@ def lib():
         "rcf_push_iq": (C.c_int, [vp, fp, sz]),
         "rcf_ingest_ptr": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "rcf_commit": (C.c_int, [vp, sz]),
+        "rcf_ingest_write": (C.c_int, [vp, fp, sz, sz]),
         "rcf_samples_in": (i64, [vp]),
         "rcf_chan_open": (C.c_int, [vp, C.c_int, C.c_double, ip]),
         "rcf_chan_open_taps": (C.c_int, [vp, C.c_int, C.c_int, fp, C.c_int, C.c_double, ip]),
@@ -88,6 +91,8 @@ def lib():
         "rcf_find_peaks": (C.c_int, [fp, i64, C.c_double, C.c_double, C.c_double, C.POINTER(i64), i64,
                                      C.POINTER(i64), C.POINTER(C.c_double)]),
         "rcf_peak_frequency": (i64, [i64, C.c_double, i64, C.c_double]),
+        "rcf_timing_enable": (C.c_int, [vp, C.c_int]),
+        "rcf_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(i64), C.c_int]),
         "rcf_scan_find_peaks": (C.c_int, [vp, C.c_double, C.POINTER(i64), i64, C.POINTER(i64),
                                           C.POINTER(C.c_double), C.POINTER(vp)]),
     }
@@ -188,6 +193,15 @@ class Frontend:
     def samples_in(self):
         return lib().rcf_samples_in(self._h)
 
+    # -- measurement
+    def timing_enable(self, on=True):
+        _check(lib().rcf_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self, what, reset=True):
+        ms, n = C.c_double(), C.c_int64()
+        _check(lib().rcf_timing_read(self._h, int(what), C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
     # -- ingest
     def push(self, iq: np.ndarray):
         iq = np.ascontiguousarray(iq, dtype=np.complex64)
@@ -197,6 +211,10 @@ class Frontend:
         p, n = C.c_void_p(), C.c_size_t()
         _check(lib().rcf_ingest_ptr(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def ingest_write(self, iq: np.ndarray, at=0):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        _check(lib().rcf_ingest_write(self._h, _fp(iq.view(np.float32)), len(iq), int(at)))
 
     def commit(self, n):
         _check(lib().rcf_commit(self._h, int(n)))
