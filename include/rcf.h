@@ -161,7 +161,10 @@ int rcf_pfb_close(rcf_t *h);
 int64_t rcf_pfb_produced(rcf_t *h);
 /* bin index in [0, n_bins): bin k is centred at k*fs/n_bins for k < n_bins/2, (k-n_bins)*fs/n_bins above */
 int64_t rcf_pfb_read_bin(rcf_t *h, int bin, float *out_interleaved, size_t max_samples);
-int rcf_pfb_rings(rcf_t *h, void **bins_ring, size_t *capacity);
+/* device layout of the bin rings: sample n of bin k lives at bins_ring[k * pitch + (n & (capacity-1))]
+ * (complex samples); pitch = capacity + pad is deliberately not a power of two so that the 256+
+ * concurrently written rings do not alias onto one HBM channel */
+int rcf_pfb_rings(rcf_t *h, void **bins_ring, size_t *capacity, size_t *pitch);
 /* stage 2 on one bin: channel.py's own rule at the bin rate -- decim2 = int(bin_rate/cr)/2,
  * low_pass_2(1.0, bin_rate, cr/2, cr/2, 20, HAMMING), xlating by delta_hz -- output as a normal
  * channel id (read_iq / read_fm). */

@@ -34,6 +34,27 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// GNU Radio's rotator (phase *= incr in float32, renormalised every 512 calls) in closed form: the
+// float32 increment's true angle and magnitude drive a float64 model, rebased by the host every block.
+__device__ __forceinline__ void rotate_store(const ChanLaunch &L, int64_t k, float vr, float vi, uint64_t ring_mask)
+{
+    if (k < L.k_lo || k >= L.k_lo + L.n_k || k < L.k_abs0) return;
+    const int64_t n = k - L.k_abs0;
+    const int64_t dk = n - L.n_seg0;
+    const int64_t r512 = n & ~(int64_t)511;
+    const double ang = L.angle0 + (double)dk * L.dangle;
+    const double lm = (r512 > L.n_seg0) ? (double)(n - r512) * L.dlogmag : L.logmag0 + (double)dk * L.dlogmag;
+    double sn, cs;
+    sincos(ang, &sn, &cs);
+    const double mag = exp(lm);
+    const float pr = (float)(mag * cs), pi = (float)(mag * sn);
+    // rotator::rotate(): z = in * phase, float32 complex multiply, unfused
+    float2 y;
+    y.x = __fsub_rn(__fmul_rn(vr, pr), __fmul_rn(vi, pi));
+    y.y = __fadd_rn(__fmul_rn(vr, pi), __fmul_rn(vi, pr));
+    L.iq_ring[(uint64_t)n & ring_mask] = y;
+}
+
 template <bool MASK>
 __device__ __forceinline__ void fir_item(const float2 *xs, const ChanLaunch *__restrict__ ch, const int (&cidx)[CT],
                                          int D, int T, int o_base, int kt_n, int64_t kt0, uint64_t ring_mask,
@@ -105,28 +126,34 @@ __device__ __forceinline__ void fir_item(const float2 *xs, const ChanLaunch *__r
         for (int cc = 0; cc < CT; ++cc)
             if (c == cc) ci = cidx[cc];
         const int rr = o_base + r;
-        if (ci >= 0 && rr < kt_n) {
-            const ChanLaunch &L = ch[ci];
-            const int64_t k = kt0 + rr;
-            if (k >= L.k_lo && k < L.k_lo + L.n_k && k >= L.k_abs0) {
-                const int64_t n = k - L.k_abs0;
-                const int64_t dk = n - L.n_seg0;
-                const int64_t r512 = n & ~(int64_t)511;
-                const double ang = L.angle0 + (double)dk * L.dangle;
-                const double lm = (r512 > L.n_seg0) ? (double)(n - r512) * L.dlogmag
-                                                    : L.logmag0 + (double)dk * L.dlogmag;
-                double sn, cs;
-                sincos(ang, &sn, &cs);
-                const double mag = exp(lm);
-                const float pr = (float)(mag * cs), pi = (float)(mag * sn);
-                // rotator::rotate(): z = in * phase, float32 complex multiply, unfused
-                float2 y;
-                y.x = __fsub_rn(__fmul_rn(vr, pr), __fmul_rn(vi, pi));
-                y.y = __fadd_rn(__fmul_rn(vr, pi), __fmul_rn(vi, pr));
-                L.iq_ring[(uint64_t)n & ring_mask] = y;
-            }
-        }
+        if (ci >= 0 && rr < kt_n) rotate_store(ch[ci], kt0 + rr, vr, vi, ring_mask);
     }
+}
+
+// Small-T path (stage-2 FIRs on narrowband rings, e.g. D = 3, T = 11; the P25 69-tap pre-filter):
+// one thread per output, taps broadcast from the scalar cache, the few overlapping input reads served
+// by L1.  The lanes-over-taps kernel above would idle 53 of 64 lanes at T = 11.
+__global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *__restrict__ chans, int D, int T,
+                                                             uint64_t ring_mask)
+{
+    const ChanLaunch &L = chans[blockIdx.y];
+    const int j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= L.n_k) return;
+    const int64_t k = L.k_lo + j;
+    const int64_t s0 = k * (int64_t)D;
+    const int64_t lim = s0 - L.start_sample;             // taps i <= lim see real samples
+    const int tmax = lim + 1 < (int64_t)T ? (int)(lim + 1) : T;
+    const StreamView sv = L.src;
+    float ar = 0.f, ai = 0.f;
+    for (int i = 0; i < tmax; ++i) {
+        const float2 t = L.ctaps[i];
+        const float2 xv = sv.base[(uint64_t)(s0 - i - sv.origin) & sv.mask];
+        ar = fmaf(t.x, xv.x, ar);
+        ar = fmaf(-t.y, xv.y, ar);
+        ai = fmaf(t.x, xv.y, ai);
+        ai = fmaf(t.y, xv.x, ai);
+    }
+    rotate_store(L, k, ar, ai, ring_mask);
 }
 
 __global__ __launch_bounds__(kThreads) void fir_bank_kernel(const ChanLaunch *__restrict__ chans, FirLaunchDims d)
@@ -227,6 +254,11 @@ __global__ __launch_bounds__(kThreads) void disc_kernel(const DiscLaunch *__rest
 void launch_fir_bank(const ChanLaunch *d_chans, const FirLaunchDims &dims, hipStream_t s)
 {
     if (dims.n_chans <= 0 || dims.max_n_k <= 0) return;
+    if (dims.T <= 96 && dims.chans_per_wg == 1) {
+        hipLaunchKernelGGL(fir_small_kernel, dim3((dims.max_n_k + kThreads - 1) / kThreads, dims.n_chans),
+                           dim3(kThreads), 0, s, d_chans, dims.D, dims.T, dims.ring_mask);
+        return;
+    }
     const int tiles = (dims.max_n_k + dims.KT - 1) / dims.KT;
     const int groups = (dims.n_chans + dims.chans_per_wg - 1) / dims.chans_per_wg;
     const size_t lds = (size_t)((dims.KT - 1) * dims.D + dims.T) * sizeof(float2);

@@ -103,6 +103,7 @@ struct rcf {
     int device = 0;
     double fs = 0, fc = 0;
     size_t block_cap = 0, hist_cap = 0, out_cap = 0;
+    size_t bin_pitch = 0;          // samples between consecutive PFB bin rings (out_cap + pad: not a power of two)
     uint64_t ring_mask = 0;
     hipStream_t stream = nullptr;
     float2 *d_buf[2] = {nullptr, nullptr};
@@ -206,7 +207,7 @@ bool source_range(rcf_t *h, int src, int64_t S0, int64_t S1, SrcRange *out)
     if (src >= RCF_SRC_PFB_BIN0) {
         if (!h->pfb.open) return false;
         const int bin = src - RCF_SRC_PFB_BIN0;
-        out->view.base = h->pfb.d_bins + (size_t)bin * h->out_cap;
+        out->view.base = h->pfb.d_bins + (size_t)bin * h->bin_pitch;
         out->view.mask = h->ring_mask;
         out->view.origin = 0;
         out->p0 = h->pfb.produced_before;
@@ -343,10 +344,11 @@ int process_block(rcf_t *h, size_t n)
             pl.tw = p.d_tw;
             pl.bins_ring = p.d_bins;
             pl.ring_mask = h->ring_mask;
-            pl.ring_cap = (int64_t)h->out_cap;
+            pl.ring_cap = (int64_t)h->bin_pitch;
             pl.n_lo = n_lo;
             pl.n_abs0 = p.n_abs0;
             pl.start_sample = p.start_sample;
+            pl.src_len = (int64_t)(h->hist_cap + n);
             pl.n_frames = (int32_t)cnt;
             pl.NB = p.NB; pl.D = p.D; pl.P = p.P;
             run_pfb = true;
@@ -594,6 +596,10 @@ int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_c
     h->hist_cap = hist_capacity ? hist_capacity : (size_t(1) << 16);
     h->out_cap = pow2_at_least(out_capacity ? out_capacity : (size_t(1) << 16));
     h->ring_mask = (uint64_t)h->out_cap - 1;
+    {
+        const char *e = getenv("RCF_PFB_PITCH_PAD");
+        h->bin_pitch = h->out_cap + (e ? (size_t)atol(e) : 80);
+    }
     RCF_HIP(hipSetDevice(device));
     RCF_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     const size_t buf_samples = h->hist_cap + h->block_cap;
@@ -869,6 +875,11 @@ int rcf_pfb_open(rcf_t *h, int n_bins, int decim, const float *taps, int ntaps)
         set_error("unsupported PFB shape: bins=%d decim=%d taps/branch=%d", n_bins, decim, P);
         return RCF_EINVAL;
     }
+    if ((uint64_t)n_bins * h->bin_pitch * sizeof(float2) >= (1ull << 31) ||
+        (uint64_t)(h->hist_cap + h->block_cap) * sizeof(float2) >= (1ull << 31)) {
+        set_error("PFB rings / wideband buffer exceed the 2 GiB range of 32-bit buffer offsets");
+        return RCF_ECAP;
+    }
     if ((size_t)P * n_bins + (size_t)decim > h->hist_cap) { set_error("history capacity %zu < P*bins", h->hist_cap); return RCF_ECAP; }
     Pfb &p = h->pfb;
     p.NB = n_bins; p.D = decim; p.T = ntaps; p.P = P;
@@ -885,8 +896,8 @@ int rcf_pfb_open(rcf_t *h, int n_bins, int decim, const float *taps, int ntaps)
     RCF_HIP(hipMemcpy(p.d_ptaps, pt.data(), sizeof(float) * pt.size(), hipMemcpyHostToDevice));
     RCF_HIP(hipMalloc(&p.d_tw, sizeof(float2) * (size_t)n_bins));
     RCF_HIP(hipMemcpy(p.d_tw, tw.data(), sizeof(float2) * (size_t)n_bins, hipMemcpyHostToDevice));
-    RCF_HIP(hipMalloc(&p.d_bins, sizeof(float2) * (size_t)n_bins * h->out_cap));
-    RCF_HIP(hipMemsetAsync(p.d_bins, 0, sizeof(float2) * (size_t)n_bins * h->out_cap, h->stream));
+    RCF_HIP(hipMalloc(&p.d_bins, sizeof(float2) * (size_t)n_bins * h->bin_pitch));
+    RCF_HIP(hipMemsetAsync(p.d_bins, 0, sizeof(float2) * (size_t)n_bins * h->bin_pitch, h->stream));
     p.rd.assign(n_bins, 0);
     p.start_sample = h->total_in;
     p.n_abs0 = ceil_div(p.start_sample, decim);
@@ -925,15 +936,16 @@ int64_t rcf_pfb_read_bin(rcf_t *h, int bin, float *out, size_t max_samples)
     if (set_dev(h)) return RCF_EHIP;
     Pfb &p = h->pfb;
     if (!p.open || bin < 0 || bin >= p.NB) { set_error("no such PFB bin %d", bin); return RCF_EINVAL; }
-    return ring_read(h, p.d_bins + (size_t)bin * h->out_cap, sizeof(float2), p.produced, &p.rd[bin], out,
+    return ring_read(h, p.d_bins + (size_t)bin * h->bin_pitch, sizeof(float2), p.produced, &p.rd[bin], out,
                      max_samples);
 }
 
-int rcf_pfb_rings(rcf_t *h, void **bins_ring, size_t *capacity)
+int rcf_pfb_rings(rcf_t *h, void **bins_ring, size_t *capacity, size_t *pitch)
 {
     if (!h || !h->pfb.open) return RCF_ESTATE;
     if (bins_ring) *bins_ring = h->pfb.d_bins;
     if (capacity) *capacity = h->out_cap;
+    if (pitch) *pitch = h->bin_pitch;
     return RCF_OK;
 }
 

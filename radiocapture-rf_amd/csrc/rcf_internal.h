@@ -85,6 +85,7 @@ struct PfbLaunch {
     int64_t n_lo;            // first absolute frame index of this launch
     int64_t n_abs0;          // absolute frame index of the PFB's first-ever frame
     int64_t start_sample;
+    int64_t src_len;         // samples addressable from src.base (linear view), for the buffer descriptor
     int32_t n_frames;        // frames in this launch
     int32_t NB, D, P;
 };

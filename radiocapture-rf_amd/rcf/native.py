@@ -82,7 +82,7 @@ def lib():
         "rcf_pfb_close": (C.c_int, [vp]),
         "rcf_pfb_produced": (i64, [vp]),
         "rcf_pfb_read_bin": (i64, [vp, C.c_int, fp, sz]),
-        "rcf_pfb_rings": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "rcf_pfb_rings": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
         "rcf_pfb_chan_open": (C.c_int, [vp, C.c_int, C.c_int, C.c_double, ip]),
         "rcf_scan_start": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "rcf_scan_result": (C.c_int, [vp, fp]),

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the PFB kernel alone (HIP-event timing from librcf): prints ms and GB/s."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "radiocapture-rf_amd")]
+import numpy as np
+from rcf import native
+
+nb = int(os.environ.get("NB", 256)); osf = int(os.environ.get("OS", 1))
+B = int(os.environ.get("BLOCK", 1 << 25)); steps = int(os.environ.get("STEPS", 10))
+fs = 20e6
+D = nb // osf
+bw = fs / nb
+taps = native.design_low_pass_2(1.0, fs, 0.4 * bw, 0.2 * bw, 60.0, native.WIN_BLACKMAN_HARRIS) if osf == 1 \
+    else native.design_low_pass_2(1.0, fs, bw / 4, bw / 4, 20.0)
+frames = B // D
+cap = 1
+while cap < 2 * frames: cap <<= 1
+fe = native.Frontend(fs, block_capacity=B, hist_capacity=1 << 17, out_capacity=cap)
+fe.pfb_open(nb, D, taps)
+rng = np.random.default_rng(1)
+tile = (rng.standard_normal(1 << 20) + 1j * rng.standard_normal(1 << 20)).astype(np.complex64)
+for _ in range(2):
+    for at in range(0, B, len(tile)):
+        fe.ingest_write(tile[: min(len(tile), B - at)], at)
+    fe.commit(B)
+for _ in range(3): fe.commit(B)
+fe.timing_enable(True); fe.timing_read(native.T_PFB)
+for _ in range(steps): fe.commit(B)
+ms, n = fe.timing_read(native.T_PFB)
+ms /= n
+gbs = (8.0 * B + 8.0 * B * osf) / (ms * 1e-3) / 1e9
+print("NB=%d OS=%d taps=%d variant=%s pad=%s fpw=%s : %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (
+    nb, osf, len(taps), os.environ.get("RCF_PFB_VARIANT", "0"), os.environ.get("RCF_PFB_PITCH_PAD", "dflt"),
+    os.environ.get("RCF_PFB_FPW", "auto"), ms, gbs, gbs / 80.0))
