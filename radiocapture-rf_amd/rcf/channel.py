@@ -1,0 +1,77 @@
+"""Drop-in for /root/reference/rc_frontend/channel.py: one narrowband channel of a front-end.
+
+The reference builds a GNU Radio top_block per channel (sub_source -> freq_xlating_fir_filter_ccc ->
+pub_sink, channel.py:29-38).  Here a channel is a slot in the batched HIP FIR bank of a
+`native.Frontend`; this class keeps the reference's attributes and methods so that `receiver` (and
+anything poking at `receiver.channels`) reads the same.
+"""
+from __future__ import annotations
+
+import time
+
+
+class channel:
+    def __init__(self, frontend, port, channel_rate, samp_rate, offset):
+        """frontend: rcf.native.Frontend (the HBM-resident source that replaces `parent_zmq_address`)."""
+        self.frontend = frontend
+        self.samp_rate = samp_rate
+        self.channel_rate = channel_rate
+        self.port = port
+        self.offset = offset
+        self.in_use = False
+        self.source_id = None
+        self.block_id = None
+        # rc_frontend/channel.py:31-35: decim = int(fs/cr)/2, low_pass_2(1.0, fs, cr/2, cr/2, 20, HAMMING);
+        # the C ABI derives both (rcf_chan_open) and rejects non-integral decimations
+        self.chan_id = frontend.chan_open(channel_rate, offset)
+        info = frontend.chan_info(self.chan_id)
+        self.decim = info["decim"]
+        self.ntaps = info["ntaps"]
+        self.out_rate = info["out_rate"]
+        self.init_time = time.time()
+        self.channel_close_time = 0
+        self._started = False
+
+    def __str__(self):
+        return "Channel: port:%s channel_rate:%s samp_rate:%s offset:%s init_time:%s" % (
+            self.port, self.channel_rate, self.samp_rate, self.offset, self.init_time)
+
+    def __repr__(self):
+        return "<Channel port:%s channel_rate:%s samp_rate:%s offset:%s init_time:%s>" % (
+            self.port, self.channel_rate, self.samp_rate, self.offset, self.init_time)
+
+    # gr.top_block surface used by the reference's receiver
+    def start(self):
+        self._started = True
+
+    def stop(self):
+        self._started = False
+
+    def get_samp_rate(self):
+        return self.samp_rate
+
+    def get_channel_rate(self):
+        return self.channel_rate
+
+    def get_offset(self):
+        return self.offset
+
+    def set_offset(self, offset):
+        """channel.py:61-63 -> prefilter.set_center_freq: retune, rotator phase and history kept."""
+        self.offset = offset
+        self.frontend.chan_set_offset(self.chan_id, offset)
+
+    def destroy(self):
+        """channel.py:64-67"""
+        if self.chan_id is not None:
+            self.frontend.chan_close(self.chan_id)
+            self.chan_id = None
+        self.stop()
+
+    # data plane (what the reference's zeromq.pub_sink at channel.py:36 would carry)
+    def read_iq(self, max_samples=1 << 20):
+        return self.frontend.chan_read_iq(self.chan_id, max_samples)
+
+    def read_fm(self, gain, max_samples=1 << 20):
+        """analog.quadrature_demod_cf(gain) of the channel stream (p25_control_demod.py:120-121)."""
+        return self.frontend.chan_read_fm(self.chan_id, gain, max_samples)

@@ -1,0 +1,180 @@
+"""Drop-in for the in-process surface of /root/reference/rc_frontend/receiver.py (SURVEY 8(b) (1')).
+
+Keeps: `connect_channel(channel_rate, freq) -> (block_id, port)`, `release_channel(block_id)`,
+`source_offset(block_id, offset)`, attributes `channels`, `sources`, `realsources`, `access_lock`,
+`last_channel_cleanup`, `channel_idle_timeout`, `scan_mode` -- same argument meaning and error
+behaviour (exceptions signal failure; the protocol handler maps them to 'na').
+
+Replaces: the GNU Radio top_block.  Each configured source owns one `native.Frontend` (an HBM-resident
+wideband buffer on one MI355X); channels are slots in that front-end's batched HIP kernels instead of
+per-channel flowgraphs fed by ZMQ copies of the whole stream (receiver.py:201-202, channel.py:29).
+`feed(source_id, iq)` is where an SDR driver / replay file / synthetic generator delivers samples.
+"""
+from __future__ import annotations
+
+import logging
+import random
+import threading
+import time
+import uuid
+
+from . import channel as channel_mod
+
+
+class receiver:
+    def __init__(self, config, index=None, frontend_factory=None, device=0):
+        """config: an object shaped like the reference's `rc_config` (configs/*.py): `.sources` dict of
+        {type, center_freq, samp_rate, ...}, `.frontend_mode`, optional `.scan_mode`.
+        index: as `receiver.py -i <index>`: keep only that source (receiver.py:67-70).
+        frontend_factory(samp_rate, center_freq, device) -> native.Frontend-like (tests inject a stub)."""
+        self.log = logging.getLogger("frontend" if index is None else "frontend-%s" % index)
+        self.access_lock = threading.RLock()
+        self.access_lock.acquire()
+        self.config = config
+        self.channel_idle_timeout = 10                     # receiver.py:51
+        self.last_channel_cleanup = time.time()
+        self.scan_mode = bool(getattr(config, "scan_mode", False))
+        if frontend_factory is None:
+            from . import native
+
+            def frontend_factory(samp_rate, center_freq, device):
+                return native.Frontend(samp_rate, center_freq, device=device)
+        self.realsources = dict(config.sources)
+        if index is not None:                              # receiver.py:67-70
+            index = int(index)
+            self.realsources = {index: config.sources[index]}
+        self.sources = {}
+        numsources = 0
+        for source in sorted(self.realsources):
+            src = self.realsources[source]
+            fe = frontend_factory(float(src["samp_rate"]), float(src["center_freq"]), device)
+            self.sources[numsources] = {
+                "center_freq": src["center_freq"], "samp_rate": src["samp_rate"],
+                "block": fe, "source_id": source, "offset": src.get("offset", 0),
+            }
+            numsources += 1
+        if getattr(config, "frontend_mode", "xlat") not in ("xlat", "pfb"):
+            self.access_lock.release()
+            raise Exception("No frontend_mode selected")
+        self.channels = {}
+        self.access_lock.release()
+
+    # ------------------------------------------------------------------ data plane
+    def feed(self, source_id, iq):
+        """Deliver wideband cf32 samples for one source (replaces source -> pub_sink, receiver.py:201)."""
+        self.sources[source_id]["block"].push(iq)
+
+    # ------------------------------------------------------------------ control plane
+    def connect_channel(self, channel_rate, freq):
+        mode = getattr(self.config, "frontend_mode", "xlat")
+        if mode in ("xlat", "pfb"):
+            # the reference's 'pfb' branch is dead code (receiver.py:403 calls channel() with 4 args);
+            # on-grid requests are served by the PFB transparently, the API is the xlat one
+            return self.connect_channel_xlat(channel_rate, freq)
+        raise Exception("No frontend_mode selected")
+
+    def connect_channel_xlat(self, channel_rate, freq):
+        """receiver.py:282-341"""
+        source_id = None
+        source_distance = None
+        if not self.scan_mode:
+            for i in list(self.sources):
+                if abs(freq - self.sources[i]["center_freq"]) < self.sources[i]["samp_rate"] / 2:
+                    if source_distance is None or abs(freq - self.sources[i]["center_freq"]) < source_distance:
+                        source_id = i
+                        source_distance = abs(freq - self.sources[i]["center_freq"])
+            if source_id is None:
+                raise Exception("Unable to find source for frequency %s" % freq)
+        else:
+            source_id = 0
+        source_center_freq = self.sources[source_id]["center_freq"]
+        source_samp_rate = self.sources[source_id]["samp_rate"]
+        frontend = self.sources[source_id]["block"]
+
+        offset = freq - source_center_freq
+        if freq < 10000000:
+            offset = freq                                   # scan mode, relative freq (receiver.py:304-305)
+
+        with self.access_lock:
+            block = None
+            for c in list(self.channels):
+                ch = self.channels[c]
+                if ch.source_id == source_id and ch.channel_rate == channel_rate and not ch.in_use:
+                    block = ch                              # re-use an idling channel (receiver.py:311-319)
+                    block.set_offset(offset)
+                    block.channel_close_time = 0
+                    break
+            if block is None:
+                port = random.randint(10000, 60000)         # receiver.py:323 (kept: the egress pump binds it)
+                block = channel_mod.channel(frontend, port, channel_rate, source_samp_rate, offset)
+                block.source_id = source_id
+                block.block_id = "%s" % uuid.uuid4()
+                self.channels[block.block_id] = block
+                block.start()
+            block.in_use = True
+            return block.block_id, block.port
+
+    def release_channel(self, block_id):
+        """receiver.py:424-435: release only marks the channel idle; the sweep destroys it later."""
+        with self.access_lock:
+            if block_id not in self.channels:
+                return True
+            self.channels[block_id].in_use = False
+            self.channels[block_id].channel_close_time = time.time()
+            return True
+
+    def source_offset(self, block_id, offset):
+        """receiver.py:436-475: demod-reported drift -> Hz -> retune.  The reference retunes the SDR
+        hardware; here the same Hz correction is applied to every channel's NCO (rcf_source_shift)."""
+        if self.scan_mode:
+            return False
+        try:
+            src = self.sources[self.channels[block_id].source_id]
+        except Exception:
+            return False
+        accumulated_offset = src.get("accumulated_offset", 0)
+        if offset > 1 or offset < -1:
+            hz_offset = offset * 50
+        elif offset > 0.5 or offset < -0.5:
+            hz_offset = offset * 10
+        else:
+            hz_offset = offset * 4
+        if -5 < hz_offset < 5:
+            return True
+        total_offset = accumulated_offset + hz_offset
+        if abs(total_offset) > self.channels[block_id].channel_rate / 2:
+            total_offset = (total_offset / 2) * -1
+        with self.access_lock:
+            # hardware: set_center_freq(center + total) moves every signal by -total at baseband while the
+            # channel NCOs stay put; moving every NCO by +total instead leaves the same signal-to-NCO
+            # distance, so the shift to apply is the change of the accumulated offset
+            src["block"].source_shift(total_offset - accumulated_offset)
+            src["accumulated_offset"] = total_offset
+        return True
+
+    def scan_mode_set_freq(self, freq):
+        """handler 'scan_mode_set_freq' (receiver.py:556-566): retune source 0's centre frequency."""
+        self.sources[0]["center_freq"] = freq
+        return True
+
+    def sweep_idle_channels(self, now=None):
+        """receiver.py:635-648: destroy channels idle for longer than channel_idle_timeout."""
+        now = time.time() if now is None else now
+        deleted = []
+        with self.access_lock:
+            for c in list(self.channels):
+                ch = self.channels[c]
+                if ch.channel_close_time != 0 and now - ch.channel_close_time > self.channel_idle_timeout:
+                    ch.destroy()
+                    del self.channels[c]
+                    deleted.append(c)
+            self.last_channel_cleanup = now
+        return deleted
+
+    def close(self):
+        with self.access_lock:
+            for c in list(self.channels):
+                self.channels[c].destroy()
+            self.channels.clear()
+            for s in self.sources.values():
+                s["block"].close()

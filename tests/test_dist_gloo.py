@@ -1,0 +1,81 @@
+"""N > 1 path on CPU: world_size-2 gloo.  The hot path has no data-path collective (front-ends are
+independent); what is exercised is the sharding rule, max-over-ranks timing and the all-gather of
+detected-peak lists that bench.py / a multi-GPU scan perform over RCCL on the real node."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "radiocapture-rf_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from rcf import multigpu, scan
+    from oracle import peaks as P
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = multigpu.sources_for_rank(8, world, rank)
+        # each rank owns a spectrum slice: a synthetic float32 spectrum with rank-specific carriers
+        rng = np.random.default_rng(40 + rank)
+        n, fs = 16384, 2.4e6
+        fc = 855e6 + rank * fs
+        x = rng.normal(-40.0, 5.5, n)
+        for c in (3000 + 500 * rank, 9000 + 300 * rank):
+            x += 300 * np.exp(-0.5 * ((np.arange(n) - c) / 30.0) ** 2)
+        x = x.astype(np.float32)
+        lines, freqs = scan.peak_detect(x, fs, fc)              # product host picker (librcf, no GPU needed)
+        l_ref, f_ref = P.peak_detect_scipy(x, fs, fc)
+        assert list(lines) == list(l_ref) and freqs == f_ref and len(freqs) == 2
+        everyone = multigpu.allgather_peaks(dist, torch, freqs, "cpu")
+        tmax = multigpu.max_over_ranks(dist, torch, 1.0 + rank, "cpu")
+        q.put((rank, mine, freqs, everyone, tmax))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_peak_allgather_and_sharding():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, f0, all0, t0), (r1, s1, f1, all1, t1) = res
+    assert s0 == [0, 2, 4, 6] and s1 == [1, 3, 5, 7]
+    assert all0 == all1 == sorted(f0 + f1) and len(all0) == 4
+    assert t0 == t1 == 2.0
+
+
+def test_routing_and_packing_rules():
+    from rcf import multigpu
+    centers = [851e6 + 25e6 * g for g in range(8)]
+    rates = [25e6] * 8
+    assert multigpu.route_frequency(851e6 + 1e6, centers, rates) == 0
+    assert multigpu.route_frequency(851e6 + 13e6, centers, rates) == 1       # nearest centre wins
+    assert multigpu.route_frequency(700e6, centers, rates) is None
+    rec = multigpu.pack_peaks([5, 3, 9], cap=8)
+    assert rec.tolist() == [3, 5, 3, 9, -1, -1, -1, -1, -1]
+    assert multigpu.unpack_peaks([rec, multigpu.pack_peaks([], cap=8)]) == [3, 5, 9]

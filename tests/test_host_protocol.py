@@ -1,0 +1,215 @@
+"""Host-side mirror of the reference's control plane, checked against goldens captured from the
+reference itself (tests/golden/protocol.json, made by tests/golden/make_protocol_goldens.py)."""
+import json
+import os
+import random
+import types
+
+import pytest
+
+from rcf import frontend_connector as FC
+from rcf import protocol, receiver, registry
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "protocol.json")))
+
+
+class ScriptedSocket:
+    def __init__(self, replies, log):
+        self.replies, self.log = replies, log
+
+    def send_string(self, s):
+        self.log.append(s)
+
+    def recv_string(self):
+        return self.replies.pop(0)
+
+    def close(self):
+        pass
+
+
+class FakeRCM:
+    def get_channelizer_for_frequency(self, f):
+        return ("10.0.0.5", 4242)
+
+
+@pytest.mark.parametrize("case", GOLD["connector"], ids=lambda c: c["name"])
+def test_connector_emits_reference_wire_strings(case):
+    sent, replies, connects = [], [], []
+
+    def factory(host, port):
+        connects.append("tcp://%s:%s" % (host, port))
+        return ScriptedSocket(replies, sent)
+
+    fc = FC.frontend_connector("parent-uuid", FakeRCM(), transport_factory=factory, heartbeat=False)
+    for step in case["steps"]:
+        del sent[:], connects[:]
+        replies[:] = list(step["replies"])
+        ret = getattr(fc, step["call"])(*step["args"])
+        ret = list(ret) if isinstance(ret, tuple) else ret
+        assert sent == step["requests"], step
+        assert connects == step["connects"]
+        assert ret == step["returns"], step          # incl. port as STRING, (False, False) on failure
+        assert fc.host == step["host"]
+
+
+@pytest.mark.parametrize("q", GOLD["rcm"], ids=lambda q: "%s-%s" % (q["table"], q["frequency"]))
+def test_channelizer_selection_rule(q):
+    mgr = registry.redis_channelizer_manager(clients=[], start_thread=False)
+    mgr.channelizers = q["channelizers"]
+    random.seed(0)
+    assert list(mgr.get_channelizer_for_frequency(q["frequency"])) == q["result"]
+
+
+# ------------------------------------------------------------------ server side, with a stub front-end
+class StubFrontend:
+    """Stands in for native.Frontend on GPU-less boxes: records calls, mimics the C ABI's checks."""
+    instances = []
+
+    def __init__(self, samp_rate, center_freq, device=0):
+        self.samp_rate, self.center_freq = samp_rate, center_freq
+        self.chans, self.next, self.shift, self.closed = {}, 1, 0.0, False
+        StubFrontend.instances.append(self)
+
+    def chan_open(self, cr, off):
+        q = int(self.samp_rate / cr)
+        if q < 2 or q % 2 or not abs(off) < self.samp_rate / 2:
+            raise RuntimeError("librcf error -8")
+        cid = self.next
+        self.next += 1
+        self.chans[cid] = dict(cr=cr, off=off, D=q // 2)
+        return cid
+
+    def chan_info(self, cid):
+        c = self.chans[cid]
+        return dict(decim=c["D"], ntaps=1, out_rate=self.samp_rate / c["D"], offset_hz=c["off"])
+
+    def chan_set_offset(self, cid, off):
+        self.chans[cid]["off"] = off
+
+    def chan_close(self, cid):
+        del self.chans[cid]
+
+    def source_shift(self, d):
+        self.shift += d
+
+    def close(self):
+        self.closed = True
+
+
+def make_receiver(scan_mode=False):
+    cfg = types.SimpleNamespace(
+        sources={0: dict(type="synthetic", center_freq=855050000, samp_rate=2400000),
+                 1: dict(type="synthetic", center_freq=857000000, samp_rate=2400000)},
+        frontend_mode="xlat", scan_mode=scan_mode)
+    StubFrontend.instances = []
+    return receiver.receiver(cfg, frontend_factory=StubFrontend)
+
+
+def test_server_protocol_roundtrip_with_own_connector():
+    tb = make_receiver()
+    now = [1000.0]
+    srv = protocol.FrontendServer(tb, clock=lambda: now[0])
+    rcm = FakeRCM()
+    fc = FC.frontend_connector("p", rcm, transport_factory=lambda h, p: protocol.LoopbackTransport(srv),
+                               heartbeat=False)
+    cid, port = fc.create_channel(12500, 854987500)
+    assert cid in tb.channels and isinstance(port, str) and 10000 <= int(port) <= 60000
+    ch = tb.channels[cid]
+    assert ch.in_use and ch.source_id == 0 and ch.offset == 854987500 - 855050000 and ch.decim == 96
+    assert fc.heartbeat_once() is True
+    assert fc.report_offset(0.25) is True               # 1 Hz: inside the +-5 Hz dead band
+    assert StubFrontend.instances[0].shift == 0.0
+    assert fc.report_offset(2.0) is True                # > 1 -> x50 = 100 Hz
+    assert StubFrontend.instances[0].shift == 100.0
+    assert tb.sources[0]["accumulated_offset"] == 100.0
+    assert fc.release_channel() == cid
+    assert not tb.channels[cid].in_use and tb.channels[cid].channel_close_time > 0
+    # idle channel of the same (source, rate) is re-used and retuned (receiver.py:311-319)
+    cid2, _ = fc.create_channel(12500, 855500000)
+    assert cid2 == cid and tb.channels[cid].offset == 450000 and tb.channels[cid].in_use
+    # nearest source wins (receiver.py:288-291)
+    cid3, _ = fc.create_channel(12500, 856500000)
+    assert tb.channels[cid3].source_id == 1
+    # out of band -> 'na' -> (False, False)
+    assert fc.create_channel(12500, 900000000) == (False, False)
+    # non-integral decimation is refused by the ABI -> 'na'
+    assert fc.create_channel(800000, 855000000) == (False, False)   # int(fs/cr) = 3
+
+
+def test_server_edge_cases_follow_reference_handler():
+    tb = make_receiver()
+    now = [0.0]
+    srv = protocol.FrontendServer(tb, clock=lambda: now[0])
+    assert srv.handle("hb,5") == "fail,5"
+    assert srv.handle("hb,x") == "fail,0"
+    # create before connect: channel is made, then released, 'na' (receiver.py:527-533)
+    assert srv.handle("create,9,12500,855000000") == "na,855000000"
+    assert len(tb.channels) == 1 and not list(tb.channels.values())[0].in_use
+    assert srv.handle("connect") == "connect,0"
+    assert srv.handle("connect") == "connect,1"
+    r = srv.handle("create,0,12500,855000000").split(",")
+    assert r[0] == "create" and r[1] in tb.channels
+    assert srv.handle("release,0,%s" % r[1]) == "release,%s" % r[1]
+    assert srv.handle("release,zz") == "na\n"
+    assert srv.handle("release,0,not-a-channel") == "release,not-a-channel"     # release_channel -> True
+    assert srv.handle("offset,0,%s,0.1" % r[1]) == "offset,0"
+    assert srv.handle("scan_mode_set_freq,770000000") == "success"
+    assert tb.sources[0]["center_freq"] == 770000000
+    # heartbeat expiry after 5 s releases the client's channels (receiver.py:652-680)
+    r2 = srv.handle("create,1,12500,857100000").split(",")
+    assert tb.channels[r2[1]].in_use
+    now[0] = 4.0
+    assert srv.handle("hb,0") == "hb,0"
+    now[0] = 6.0
+    assert srv.tick() == [1]
+    assert not tb.channels[r2[1]].in_use and 1 not in srv.clients and 0 in srv.clients
+    assert srv.handle("quit,0") == "quit,0" and 0 not in srv.clients
+    # idle sweep: 10 s idle timeout, checked at most every 20 s (receiver.py:51,635-648)
+    n_before = len(tb.channels)
+    now[0] = 6.0 + 25.0
+    tb.last_channel_cleanup = 0.0
+    for ch in tb.channels.values():
+        if ch.channel_close_time:
+            ch.channel_close_time = 6.0
+    srv.last_status = 0.0
+    srv.tick()
+    assert len(tb.channels) < n_before
+    assert all(c.in_use or now[0] - c.channel_close_time <= 10 for c in tb.channels.values())
+
+
+def test_scan_mode_relative_frequency():
+    tb = make_receiver(scan_mode=True)
+    bid, _ = tb.connect_channel(12500, 25000)             # freq < 10 MHz: offset = freq (receiver.py:304)
+    assert tb.channels[bid].offset == 25000 and tb.channels[bid].source_id == 0
+    assert tb.source_offset(bid, 3.0) is False            # scan mode ignores drift reports
+
+
+def test_registry_publish_and_expiry():
+    class FakeRedis:
+        def __init__(self): self.kv, self.sets = {}, {}
+        def sadd(self, k, v): self.sets.setdefault(k, set()).add(v)
+        def set(self, k, v): self.kv[k] = v
+        def smembers(self, k): return set(self.sets.get(k, set()))
+        def get(self, k): return self.kv.get(k)
+        def srem(self, k, v): self.sets.get(k, set()).discard(v)
+        def delete(self, k): self.kv.pop(k, None)
+    r = FakeRedis()
+    sources = {0: {"center_freq": 855050000, "samp_rate": 2400000}}
+    pub = registry.redis_channel_publisher(sources=sources, channels={}, port=5555, index=3, client=r,
+                                           address="10.1.2.3", start_thread=False,
+                                           extra=lambda: {"msps_in": 2.4})
+    d = pub.publish_once(now=100.0)
+    for key in ("instance_uuid", "start_time", "current_time", "hostname", "pid", "address", "port",
+                "channel_count", "source_count", "sources", "index"):
+        assert key in d                                  # redis_channel_publisher.py:63-80 key set
+    assert d["sources"] == [(855050000, 2400000)] and d["port"] == 5555 and d["msps_in"] == 2.4
+    mgr = registry.redis_channelizer_manager(index=3, clients=[r], start_thread=False)
+    mgr.poll_once(now=101.0)
+    assert mgr.get_channelizer_for_frequency(855000000) == ("10.1.2.3", 5555)
+    assert mgr.get_channelizer_for_frequency(900000000) == (None, None)
+    mgr.poll_once(now=106.5)                             # > 5 s stale: expired and deleted
+    assert mgr.channelizers == {} and r.smembers("channelizers") == set()
+    other = registry.redis_channelizer_manager(index=4, clients=[r], start_thread=False)
+    pub.publish_once(now=200.0)
+    other.poll_once(now=200.5)
+    assert other.channelizers == {}                      # index filter (redis_channelizer_manager.py:94)
