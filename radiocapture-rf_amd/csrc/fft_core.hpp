@@ -137,10 +137,20 @@ __device__ __forceinline__ void twiddle_powers(cf w1, cf (&w)[R])
 //   write phase : buf[pad((j / Ns) Ns R + k + f Ns)] = X[f]
 template <int N, int R, int SIGN>
 struct StockhamPass {
+    // Padded indices are written as "pad(first) + t * constant" wherever the stride is a multiple of
+    // 16 (pad(a + 16c) = pad(a) + 17c): the compiler then folds every access of a butterfly into ONE
+    // address VGPR plus immediate offsets.  The naive pad(j + t*stride) form costs one address VGPR per
+    // access (the shift hides the linearity), ~64 VGPRs across a two-pass kernel.
     static __device__ __forceinline__ void load(const cf *buf, int j, cf (&v)[R])
     {
+        if constexpr ((N / R) % 16 == 0) {
+            const cf *b = buf + lds_pad(j);
 #pragma unroll
-        for (int t = 0; t < R; ++t) v[t] = buf[lds_pad(j + t * (N / R))];
+            for (int t = 0; t < R; ++t) v[t] = b[t * ((N / R) + (N / R) / 16)];
+        } else {
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[t] = buf[lds_pad(j + t * (N / R))];
+        }
     }
     // tw: table of e^{SIGN 2 pi i n / N}, n in [0, N)
     static __device__ __forceinline__ void twiddle(const cf *tw, int Ns, int j, cf (&v)[R])
@@ -151,6 +161,24 @@ struct StockhamPass {
         twiddle_powers<R>(tw[k * (N / (Ns * R))], w);
 #pragma unroll
         for (int t = 1; t < R; ++t) v[t] = cmul(v[t], w[t]);
+    }
+    template <int NS>
+    static __device__ __forceinline__ void store_t(cf *buf, int j, cf (&v)[R])
+    {
+        const int k = j & (NS - 1);
+        const int j0 = (j - k) * R + k;
+        if constexpr (NS % 16 == 0) {
+            cf *b = buf + lds_pad(j0);
+#pragma unroll
+            for (int f = 0; f < R; ++f) b[f * (NS + NS / 16)] = v[Dft<R, SIGN>::reg_of(f)];
+        } else if constexpr (NS == 1 && R == 16) {
+            cf *b = buf + lds_pad(j0);            // j0 = 16 j: (j0 + f) >> 4 == j for f < 16
+#pragma unroll
+            for (int f = 0; f < R; ++f) b[f] = v[Dft<R, SIGN>::reg_of(f)];
+        } else {
+#pragma unroll
+            for (int f = 0; f < R; ++f) buf[lds_pad(j0 + f * NS)] = v[Dft<R, SIGN>::reg_of(f)];
+        }
     }
     static __device__ __forceinline__ void store(cf *buf, int Ns, int j, cf (&v)[R])
     {

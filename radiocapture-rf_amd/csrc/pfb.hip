@@ -32,6 +32,7 @@ namespace rcfx {
 namespace {
 
 constexpr int F = 16;   // frames per LDS chunk
+int env_int(const char *name, int dflt);
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -56,10 +57,11 @@ __device__ __forceinline__ void wave_sync()
 // When NB/R divides 64 every frame's butterflies sit in a single wavefront (frame = b / (NB/R)), so
 // the read->write hazard of the in-place pass is wave-local; END_WG says whether the NEXT consumer of
 // the buffer uses a different frame->wave map (then the trailing barrier must be workgroup-wide).
-template <int NB, int R, int NS, bool END_WG>
+template <int NB, int R, int NS, bool END_WG, bool NOWG = false>
 __device__ __forceinline__ void pfb_pass(cf *buf, const cf *tw_lds, int tid)
 {
     constexpr bool WAVE_LOCAL = (64 % (NB / R)) == 0;
+    static_assert(!NOWG || WAVE_LOCAL, "role-split passes must be wave-local");
     constexpr int BPF = NB / R;          // butterflies per frame
     constexpr int CNT = F / R;           // butterflies per thread (F * BPF / NB)
     static_assert(F % R == 0, "F must be a multiple of every radix");
@@ -79,20 +81,23 @@ __device__ __forceinline__ void pfb_pass(cf *buf, const cf *tw_lds, int tid)
             const cf w = tw_lds[(k * t) * (NB / (NS * R))];   // exact table entry e^{+2 pi i k t / (NS R)}
 #pragma unroll
             for (int i = 0; i < CNT; ++i) v[i][t] = cmul(v[i][t], w);
+            // role-split build: stop the scheduler from issuing all R-1 table reads at once (2 VGPRs
+            // each); a compiler-level memory barrier every 4 twiddles keeps the FFT role under 128 VGPRs
+            if (NOWG && (t & 3) == 0) asm volatile("" ::: "memory");
         }
     }
 #pragma unroll
     for (int i = 0; i < CNT; ++i) Dft<R, +1>::run(v[i]);
-    if (WAVE_LOCAL) wave_sync(); else __syncthreads();   // every butterfly has read before any writes
+    if (WAVE_LOCAL || NOWG) wave_sync(); else __syncthreads();   // every butterfly has read before any writes
 #pragma unroll
     for (int i = 0; i < CNT; ++i) {
         const int frame = (tid + i * NB) / BPF;
-        Pass::store(buf + frame * RS, NS, j, v[i]);
+        Pass::template store_t<NS>(buf + frame * RS, j, v[i]);
     }
-    if (WAVE_LOCAL && !END_WG) wave_sync(); else __syncthreads();
+    if ((WAVE_LOCAL && !END_WG) || NOWG) wave_sync(); else __syncthreads();
 }
 
-template <int NB, int OS, int P, int MINW, int FB, int POL, bool ZH>
+template <int NB, int OS, int P, int MINW, int FB, int POL, bool ZH, int ABL = 0>
 __global__ __launch_bounds__(NB, MINW) void pfb_kernel(PfbLaunch p, int frames_per_wg, int n_wg)
 {
     constexpr int D = NB / OS;
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel(PfbLaunch p, int frames_p
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ur[j] = ui[j] = 0.f;
 #pragma unroll
-                for (int q = 0; q < P; ++q)
+                for (int q = 0; q < ((ABL & 1) ? 1 : P); ++q)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const v2f xv = w[f0 + j + HALO - OS * q];
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel(PfbLaunch p, int frames_p
         }
         __syncthreads();
 
-        {
+        if (!(ABL & 2)) {
             using PL = Plan<NB>;
             // a pass hands over wave-locally only to a pass with the same radix (same frame->wave map)
             pfb_pass<NB, PL::r[0], 1, (PL::n < 2 || PL::r[1] != PL::r[0])>(buf, tw_lds, tid);
@@ -207,7 +212,8 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel(PfbLaunch p, int frames_p
 #pragma unroll
                 for (int i = 0; i < F; ++i) {
                     const int k = k0 + i * (NB / F);
-                    cf v = buf[f_lane * RS + lds_pad(k)];
+                    cf v = ((NB / F) % 16 == 0) ? buf[f_lane * RS + lds_pad(k0) + i * ((NB / F) + (NB / F) / 16)]
+                                                : buf[f_lane * RS + lds_pad(k)];
                     if (OS == 2) {
                         if ((k & 1) && (n & 1)) v = make_float2(-v.x, -v.y);
                     } else if (OS == 4) {
@@ -227,25 +233,204 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel(PfbLaunch p, int frames_p
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Role-split variant: a workgroup is 2*NB threads.  Waves [0, NB/64) are the FIR role (thread rho =
+// branch rho: global loads -> sliding-window FIR -> LDS chunk), waves [NB/64, 2NB/64) are the FFT role
+// (Stockham passes -> transposed non-temporal stores).  The roles work on the two halves of a
+// double-buffered LDS chunk, one chunk apart, and meet at two s_barriers per chunk, so global loads,
+// FMAs, butterflies and stores of neighbouring chunks overlap inside ONE workgroup instead of only
+// across workgroups; each role's loop has its own (small) register footprint.
+//   iteration it:   FIR role : rows 0-7 of chunk it | B1 | rows 8-15, slide, prefetch chunk it+1 | B2
+//                   FFT role : passes of chunk it-1 | B1 | epilogue stores of chunk it-1         | B2
+__device__ __forceinline__ void wg_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int NB, int OS, int P, int POL, bool ZH>
+__global__ __launch_bounds__(2 * NB, 4) void pfb_kernel_rs(PfbLaunch p, int frames_per_wg, int n_wg)
+{
+    constexpr int D = NB / OS;
+    constexpr int HALO = OS * (P - 1);
+    constexpr int RS = row_stride<NB>();
+    constexpr int FH = F / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf0 = reinterpret_cast<cf *>(smem_raw);
+    cf *tw_lds = buf0 + 2 * F * RS;
+
+    int wg;
+    {
+        const int b = blockIdx.x, q = n_wg / 8, r = n_wg % 8, xcd = b % 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    }
+    const int fb0 = wg * frames_per_wg;
+    if (fb0 >= p.n_frames) return;
+    const int nfr = min(frames_per_wg, p.n_frames - fb0);
+    const int nchunks = (nfr + F - 1) / F;
+    const int64_t n0 = p.n_lo + fb0;
+    static_assert(Plan<NB>::n == 2 && Plan<NB>::r[0] == Plan<NB>::r[1], "role split needs one frame->wave map");
+    const bool fir_role = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < NB;
+
+#ifdef RS_ONLY_FFT
+    if (false) {
+#else
+    if (fir_role) {
+#endif
+        const int tid = threadIdx.x;
+        float h[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) h[q] = p.ptaps[q * NB + tid];
+        const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<cf *>(p.src.base), 0, (int)(p.src_len * (int64_t)sizeof(cf)), 0x00020000);
+        const int64_t m_min = (p.start_sample + tid + D - 1) / D;
+        auto frame_off = [&](int64_t m) -> int {
+            return (int)((m * D - tid - p.src.origin) * (int64_t)sizeof(cf));
+        };
+        auto ld = [&](int vo, int so, int64_t m) -> v2f {
+            const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, vo, so, (POL & 1) ? 2 : 0);
+            v2f x;
+            x.x = __uint_as_float(r.x);
+            x.y = __uint_as_float(r.y);
+            if (ZH && m < m_min) x = (v2f)(0.f);
+            return x;
+        };
+        v2f w[F + HALO];
+        {
+            const int64_t m0 = n0 - HALO;
+            const int vo = frame_off(m0);
+#pragma unroll
+            for (int i = 0; i < F + HALO; ++i) w[i] = ld(vo, i * D * (int)sizeof(cf), m0 + i);
+        }
+        auto fir_rows = [&](cf *buf, int f_lo) {
+#pragma unroll
+            for (int f0 = 0; f0 < FH; f0 += 4) {
+                float ur[4], ui[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ur[j] = ui[j] = 0.f;
+#pragma unroll
+                for (int q = 0; q < P; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const v2f xv = w[f_lo + f0 + j + HALO - OS * q];
+                        ur[j] = fmaf(h[q], xv.x, ur[j]);
+                        ui[j] = fmaf(h[q], xv.y, ui[j]);
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    buf[(f_lo + f0 + j) * RS + lds_pad(tid)] = make_float2(ur[j], ui[j]);
+            }
+        };
+        for (int it = 0; it < nchunks; ++it) {
+            cf *buf = buf0 + (it & 1) * F * RS;
+            fir_rows(buf, 0);
+            wg_barrier();
+            fir_rows(buf, FH);
+#pragma unroll
+            for (int i = 0; i < HALO; ++i) w[i] = w[i + F];
+            {
+                const int64_t m0 = n0 + (int64_t)(it + 1) * F;
+                const int vo = frame_off(m0);
+#pragma unroll
+                for (int f = 0; f < F; ++f) w[HALO + f] = ld(vo, f * D * (int)sizeof(cf), m0 + f);
+            }
+            wg_barrier();
+        }
+        wg_barrier();      // drain iteration: the FFT role finishes the last chunk
+        wg_barrier();
+#ifdef RS_ONLY_FIR
+    } else if (false) {
+#else
+    } else {
+#endif
+        const int tid = threadIdx.x - NB;
+        tw_lds[tid] = p.tw[tid];
+        const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.bins_ring, 0, (int)((int64_t)NB * p.ring_cap * (int64_t)sizeof(cf)), 0x00020000);
+        const int k0 = tid / F, f_lane = tid % F;
+        const int out_so_step = (int)((int64_t)(NB / F) * p.ring_cap * (int64_t)sizeof(cf));
+        wg_barrier();      // iteration 0: nothing to transform yet
+        wg_barrier();
+        for (int it = 1; it <= nchunks; ++it) {
+            cf *buf = buf0 + ((it - 1) & 1) * F * RS;
+            const int ch = (it - 1) * F;
+            const int nf = min(F, nfr - ch);
+            {
+                using PL = Plan<NB>;
+                pfb_pass<NB, PL::r[0], 1, false, true>(buf, tw_lds, tid);
+                if constexpr (PL::n >= 2) pfb_pass<NB, PL::r[1], PL::r[0], false, true>(buf, tw_lds, tid);
+                if constexpr (PL::n >= 3) pfb_pass<NB, PL::r[2], PL::r[0] * PL::r[1], false, true>(buf, tw_lds, tid);
+            }
+            wg_barrier();
+            {
+                const int64_t n = n0 + ch + f_lane;
+                const int ridx = (int)((uint64_t)(n - p.n_abs0) & p.ring_mask);
+                const int vo = (int)(((int64_t)k0 * p.ring_cap + ridx) * (int64_t)sizeof(cf));
+                if (f_lane < nf) {
+#pragma unroll
+                    for (int i = 0; i < F; ++i) {
+                        const int k = k0 + i * (NB / F);
+                        cf v = ((NB / F) % 16 == 0) ? buf[f_lane * RS + lds_pad(k0) + i * ((NB / F) + (NB / F) / 16)]
+                                                : buf[f_lane * RS + lds_pad(k)];
+                        if (OS == 2) {
+                            if ((k & 1) && (n & 1)) v = make_float2(-v.x, -v.y);
+                        }
+                        u32x2 o;
+                        o.x = __float_as_uint(v.x);
+                        o.y = __float_as_uint(v.y);
+                        __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, vo, i * out_so_step, (POL & 2) ? 2 : 0);
+                    }
+                }
+            }
+            wg_barrier();
+        }
+    }
+}
+
+template <int NB, int OS, int P, int POL>
+void launch_rs(const PfbLaunch &p, hipStream_t s)
+{
+    static const int fpw_env = env_int("RCF_PFB_FPW", 0);
+    int fpw = 64;
+    while (fpw > 2 * F && (p.n_frames + fpw - 1) / fpw < 1024) fpw >>= 1;
+    if (fpw_env > 0) fpw = fpw_env;
+    const int n_wg = (p.n_frames + fpw - 1) / fpw;
+    const size_t lds = ((size_t)2 * F * row_stride<NB>() + NB) * sizeof(cf);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pfb_kernel_rs<NB, OS, P, POL, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pfb_kernel_rs<NB, OS, P, POL, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const bool zh = (p.n_lo - (int64_t)OS * (P - 1)) * (NB / OS) - (NB - 1) < p.start_sample;
+    if (zh) hipLaunchKernelGGL((pfb_kernel_rs<NB, OS, P, POL, true>), dim3(n_wg), dim3(2 * NB), lds, s, p, fpw, n_wg);
+    else    hipLaunchKernelGGL((pfb_kernel_rs<NB, OS, P, POL, false>), dim3(n_wg), dim3(2 * NB), lds, s, p, fpw, n_wg);
+}
+
 int env_int(const char *name, int dflt)
 {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
 }
 
-template <int NB, int OS, int P, int MINW, int FB, int POL>
+template <int NB, int OS, int P, int MINW, int FB, int POL, int ABL = 0>
 void launch_one(const PfbLaunch &p, hipStream_t s)
 {
     static const int fpw_env = env_int("RCF_PFB_FPW", 0);
-    int fpw = 32;
-    while (fpw > F && (p.n_frames + fpw - 1) / fpw < 2048) fpw >>= 1;
+    // One 16-frame chunk per workgroup measured fastest on MI355X: more, shorter workgroups hide the
+    // serial load -> FIR -> FFT -> store phases of a chunk better than a longer chunk loop saves on
+    // halo re-reads (the halo rows are served by L2 / Infinity Cache, not HBM).
+    int fpw = F;
     if (fpw_env > 0) fpw = fpw_env;
     const int n_wg = (p.n_frames + fpw - 1) / fpw;
     const size_t lds = ((size_t)F * row_stride<NB>() + NB) * sizeof(cf);
     // zero-history handling is needed only while a launch can still reach samples before start_sample
     const bool zh = (p.n_lo - (int64_t)OS * (P - 1)) * (NB / OS) - (NB - 1) < p.start_sample;
-    if (zh) hipLaunchKernelGGL((pfb_kernel<NB, OS, P, MINW, FB, POL, true>), dim3(n_wg), dim3(NB), lds, s, p, fpw, n_wg);
-    else    hipLaunchKernelGGL((pfb_kernel<NB, OS, P, MINW, FB, POL, false>), dim3(n_wg), dim3(NB), lds, s, p, fpw, n_wg);
+    if (zh) hipLaunchKernelGGL((pfb_kernel<NB, OS, P, MINW, FB, POL, true, ABL>), dim3(n_wg), dim3(NB), lds, s, p, fpw, n_wg);
+    else    hipLaunchKernelGGL((pfb_kernel<NB, OS, P, MINW, FB, POL, false, ABL>), dim3(n_wg), dim3(NB), lds, s, p, fpw, n_wg);
 }
 
 int round_p(int P)
@@ -278,7 +463,10 @@ bool dispatch(const PfbLaunch &p, bool probe, hipStream_t s)
                 case 1:  launch_one<256, 1, 14, 3, 16, 2>(p, s); break;
                 case 2:  launch_one<256, 1, 14, 4, 8, 2>(p, s); break;
                 case 3:  launch_one<256, 1, 14, 3, 8, 2>(p, s); break;
-                case 4:  launch_one<256, 1, 14, 4, 4, 2>(p, s); break;
+                case 4:  launch_rs<256, 1, 14, 2>(p, s); break;
+                case 5:  launch_one<256, 1, 14, 2, 16, 2, 1>(p, s); break;   // ablation: 1-tap FIR
+                case 6:  launch_one<256, 1, 14, 2, 16, 2, 2>(p, s); break;   // ablation: no FFT passes
+                case 7:  launch_one<256, 1, 14, 2, 16, 2, 3>(p, s); break;   // ablation: both
                 default: launch_one<256, 1, 14, 2, 16, 2>(p, s); break;
             }
         }

@@ -53,7 +53,7 @@ __device__ __forceinline__ void scan_pass(cf *buf, const cf *__restrict__ tw, in
     for (int i = 0; i < CNT; ++i) {
         const int b = tid + i * NT;
         const int frame = b / BPF, j = b % BPF;
-        Pass::store(buf + frame * RS, NS, j, v[i]);
+        Pass::template store_t<NS>(buf + frame * RS, j, v[i]);
     }
     __syncthreads();
 }

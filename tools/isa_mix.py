@@ -6,7 +6,7 @@ src, pat = sys.argv[1], sys.argv[2]
 d = "/tmp/asm"; os.makedirs(d, exist_ok=True)
 base = os.path.splitext(os.path.basename(src))[0]
 r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.dirname(os.path.abspath(src)),
-                    "-c", os.path.abspath(src), "-o", base + ".o", "-save-temps", "-Rpass-analysis=kernel-resource-usage"],
+                    *os.environ.get("XFLAGS","").split(), "-c", os.path.abspath(src), "-o", base + ".o", "-save-temps", "-Rpass-analysis=kernel-resource-usage"],
                    cwd=d, capture_output=True, text=True)
 cur = None
 for l in r.stderr.splitlines():

@@ -14,7 +14,7 @@ __global__ void copy_lin(const float2* __restrict__ in, float2* __restrict__ out
 
 // one workgroup (256 thr) handles FPW frames of 256 samples; per SEG-frame chunk: thread reads SEG samples
 // (its column), stages through LDS, writes bin-major: lane -> (frame f = tid % SEG, bin k0 = tid / SEG)
-template <int SEG, int NT>
+template <int SEG, int NT, int REV>
 __global__ __launch_bounds__(256) void copy_scatter(const float2* __restrict__ in, float2* __restrict__ out,
                                                    int n_frames, int fpw, long pitch) {
     __shared__ float2 buf[SEG * 258];
@@ -22,7 +22,11 @@ __global__ __launch_bounds__(256) void copy_scatter(const float2* __restrict__ i
     const long f0 = (long)blockIdx.x * fpw;
     const int kper = 256 / SEG;            // bins covered by one store instruction's 256 threads
     for (int ch = 0; ch < fpw; ch += SEG) {
-        for (int f = 0; f < SEG; ++f) buf[f * 258 + tid] = in[(f0 + ch + f) * 256 + tid];
+        for (int f = 0; f < SEG; ++f) {
+            long m = f0 + ch + f + 1;
+            long idx = REV == 0 ? (m - 1) * 256 + tid : (REV == 1 ? m * 256 - tid : (tid == 0 ? m * 256 : m * 256 - 256 + tid));
+            buf[f * 258 + tid] = in[idx];
+        }
         __syncthreads();
         const int fl = tid % SEG, k0 = tid / SEG;
         for (int i = 0; i < SEG; ++i) {
@@ -36,13 +40,13 @@ __global__ __launch_bounds__(256) void copy_scatter(const float2* __restrict__ i
     }
 }
 
-template <int SEG, int NT>
+template <int SEG, int NT, int REV>
 float run_scatter(const float2* in, float2* out, int n_frames, int fpw, long pitch, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     dim3 g(n_frames / fpw);
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((copy_scatter<SEG, NT>), g, dim3(256), 0, 0, in, out, n_frames, fpw, pitch);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((copy_scatter<SEG, NT, REV>), g, dim3(256), 0, 0, in, out, n_frames, fpw, pitch);
     CK(hipEventRecord(a));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((copy_scatter<SEG, NT>), g, dim3(256), 0, 0, in, out, n_frames, fpw, pitch);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((copy_scatter<SEG, NT, REV>), g, dim3(256), 0, 0, in, out, n_frames, fpw, pitch);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / reps;
 }
@@ -50,7 +54,7 @@ float run_scatter(const float2* in, float2* out, int n_frames, int fpw, long pit
 int main() {
     const size_t n = 1ull << 25; const int n_frames = n / 256; const long cap = 1 << 18;
     float2 *in, *out;
-    CK(hipMalloc(&in, n * 8)); CK(hipMalloc(&out, (size_t)256 * (cap + 1040) * 8));
+    CK(hipMalloc(&in, n * 8 + 4096)); CK(hipMalloc(&out, (size_t)256 * (cap + 1040) * 8));
     CK(hipMemset(in, 1, n * 8));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(copy_lin, dim3(4096), dim3(256), 0, 0, in, out, n);
@@ -59,13 +63,12 @@ int main() {
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 10;
     printf("linear copy 8B/lane          : %.4f ms  %.0f GB/s\n", ms, 16.0 * n / ms / 1e6);
-    const long pitches[2] = {cap, cap + 80};
-    for (long pitch : pitches) {
-        float t;
-        t = run_scatter<16, 0>(in, out, n_frames, 32, pitch, 10); printf("scatter seg=16 (128B) pitch=%ld     : %.4f ms  %.0f GB/s\n", pitch, t, 16.0 * n / t / 1e6);
-        t = run_scatter<16, 1>(in, out, n_frames, 32, pitch, 10); printf("scatter seg=16 (128B) pitch=%ld nt  : %.4f ms  %.0f GB/s\n", pitch, t, 16.0 * n / t / 1e6);
-        t = run_scatter<32, 1>(in, out, n_frames, 64, pitch, 10); printf("scatter seg=32 (256B) pitch=%ld nt  : %.4f ms  %.0f GB/s\n", pitch, t, 16.0 * n / t / 1e6);
-        t = run_scatter<64, 1>(in, out, n_frames, 64, pitch, 10); printf("scatter seg=64 (512B) pitch=%ld nt  : %.4f ms  %.0f GB/s\n", pitch, t, 16.0 * n / t / 1e6);
+    {
+        float t; const long pitch = cap + 80;
+        t = run_scatter<16, 1, 0>(in, out, n_frames, 32, pitch, 10); printf("scatter seg=16 nt aligned ascending   : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
+        t = run_scatter<16, 1, 1>(in, out, n_frames, 32, pitch, 10); printf("scatter seg=16 nt x[mD - tid] (PFB)   : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
+        t = run_scatter<16, 1, 2>(in, out, n_frames, 32, pitch, 10); printf("scatter seg=16 nt ascending + stray   : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
+        t = run_scatter<16, 0, 0>(in, out, n_frames, 32, pitch, 10); printf("scatter seg=16 plain stores aligned   : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
     }
     return 0;
 }
