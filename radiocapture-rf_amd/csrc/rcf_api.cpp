@@ -966,10 +966,21 @@ int rcf_scan_start(rcf_t *h, int fft_len, int n_frames, int avg_len)
     s.R = avg_len + s.chunk;
     std::vector<float> win(fft_len), tw(2 * (size_t)fft_len);
     design_window(RCF_WIN_BLACKMAN_HARRIS, fft_len, win.data());
-    for (int i = 0; i < fft_len; ++i) {
-        const double a = -kTwoPi * i / fft_len;
-        tw[2 * i] = (float)std::cos(a);
-        tw[2 * i + 1] = (float)std::sin(a);
+    auto fill = [&](size_t at, int count, double step) {      // tw[at + i] = e^{-j step i}
+        for (int i = 0; i < count; ++i) {
+            tw[2 * (at + i)] = (float)std::cos(-step * i);
+            tw[2 * (at + i) + 1] = (float)std::sin(-step * i);
+        }
+    };
+    int n1 = 0, n2 = 0;
+    if (fft_len > 16384 && scan4_split(fft_len, &n1, &n2)) {
+        // four-step tables: [e^{-2 pi i n/N1} | e^{-2 pi i n/N2} | W_N^i, i<1024 | W_N^{1024 j}]
+        fill(0, n1, kTwoPi / n1);
+        fill((size_t)n1, n2, kTwoPi / n2);
+        fill((size_t)n1 + n2, 1024, kTwoPi / fft_len);
+        fill((size_t)n1 + n2 + 1024, fft_len / 1024, kTwoPi * 1024.0 / fft_len);
+    } else {
+        fill(0, fft_len, kTwoPi / fft_len);
     }
     RCF_HIP(hipMalloc(&s.d_window, sizeof(float) * (size_t)fft_len));
     RCF_HIP(hipMemcpy(s.d_window, win.data(), sizeof(float) * (size_t)fft_len, hipMemcpyHostToDevice));

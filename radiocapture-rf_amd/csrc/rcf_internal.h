@@ -105,6 +105,7 @@ struct ScanLaunch {
     float2 *scratch;         // 4-step scratch (N >= 32768), n_frames * N complex
 };
 bool scan_supported(int N);
+bool scan4_split(int N, int *N1, int *N2);   // four-step factorisation for N > 16384
 void launch_scan_fft(const ScanLaunch &p, hipStream_t s);
 // running sum: sum += v[f]; if (f == emit_frame) out = sum; if (f-(L-1) >= 0) sum -= v[f-(L-1)]
 void launch_scan_movsum(float *vring, int N, int R, int L, int f0, int n_frames, int emit_frame,

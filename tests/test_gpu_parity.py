@@ -278,3 +278,54 @@ def test_scan_reference_size_and_peaks_bit_exact(gpu_required):
     np.testing.assert_array_equal(lines_dev, l_want)           # product peak picker -> same indices
     assert list(l_want) == [2004, 5195, 9089, 15000]   # 20 kHz-wide carrier at 11000 fails the width window
     assert [nat.peak_frequency(l, fs, N, fc) for l in lines_dev] == f_want
+
+
+@pytest.mark.parametrize("N,F,L", [(32768, 6, 3), (65536, 5, 2), (131072, 4, 2), (262144, 3, 2), (524288, 3, 2),
+                                   (1048576, 5, 3)])
+def test_scan_four_step_fft(gpu_required, N, F, L):
+    """N > 16384: the four-step (N1 x N2) scan FFT against the oracle's radix-2 chain."""
+    nat = gpu_required
+    fs = 100e6
+    rng = np.random.default_rng(N % 1000)
+    x = synth.awgn(rng, N * F).astype(np.complex64)
+    x += (3.0 * np.exp(2j * math.pi * 0.31 * np.arange(N * F))).astype(np.complex64)
+    with nat.Frontend(fs, block_capacity=N * 2, hist_capacity=N) as fe:
+        fe.scan_start(N, F, L)
+        pos = 0
+        step = N * 2 - 12345                      # frames straddle block boundaries
+        while pos < len(x):
+            fe.push(x[pos:pos + step])
+            pos += step
+        got = fe.scan_result()
+    want = OC.scan_chain(x, N, F, L)
+    assert got is not None and got.shape == (N,)
+    assert np.abs(got - want).max() < 3e-3
+    assert np.argmax(got) == np.argmax(want)
+
+
+def test_scan_1m_point_peaks_bit_exact(gpu_required):
+    """BASELINE configs[2] shape: 1M-point scan at 100 Msps, 12 carriers -> exactly 12 indices."""
+    nat = gpu_required
+    fs, N, fc = 100e6, 1 << 20, 860e6
+    rng = np.random.default_rng(3003)
+    centres = [40000 + 80000 * i + int(rng.integers(-3000, 3000)) for i in range(12)]
+    carriers = [(c, float(rng.uniform(4000, 9000)), 45.0) for c in centres]
+    tile = synth.scan_stream(fs, N, 8, carriers, seed=3003)
+    F, L = 16, 8
+    with nat.Frontend(fs, block_capacity=N * 8, hist_capacity=N) as fe:
+        fe.scan_start(N, F, L)
+        fe.push(tile)
+        fe.push(tile)
+        spec = fe.scan_result()
+        lines_dev, _, _ = fe.scan_find_peaks(cap=4096)
+    want = OC.scan_chain(np.tile(tile, 2), N, F, L)
+    # two different float32 FFTs (oracle radix-2 vs four-step radix-16): 65 dB of dynamic range puts the
+    # deepest bins ~1e-2 apart in sum-of-log10 units; the indices below are what must be bit-exact
+    assert np.abs(spec - want).max() < 2e-2
+    assert np.sqrt(np.mean((spec - want) ** 2)) < 2e-4
+    l_want, f_want = P.peak_detect_scipy(want, fs, fc)
+    l_got, _ = P.peak_detect_scipy(spec, fs, fc)
+    np.testing.assert_array_equal(l_got, l_want)
+    np.testing.assert_array_equal(lines_dev, l_want)
+    assert len(l_want) == 12
+    assert all(abs(int(a) - b) < 40 for a, b in zip(l_want, centres))
