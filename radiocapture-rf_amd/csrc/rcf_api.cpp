@@ -93,6 +93,7 @@ struct Scan {
     float *d_window = nullptr, *d_vring = nullptr, *d_sum = nullptr, *d_out = nullptr;
     float2 *d_tw = nullptr, *d_scratch = nullptr;
     int64_t *d_peaks = nullptr;
+    void *d_peak_ws = nullptr;
 };
 
 }  // namespace rcfx
@@ -628,7 +629,7 @@ int rcf_close(rcf_t *h)
     bury(h, p.d_ptaps); bury(h, p.d_tw); bury(h, p.d_bins);
     Scan &s = h->scan;
     bury(h, s.d_window); bury(h, s.d_vring); bury(h, s.d_sum); bury(h, s.d_out); bury(h, s.d_tw);
-    bury(h, s.d_scratch); bury(h, s.d_peaks);
+    bury(h, s.d_scratch); bury(h, s.d_peaks); bury(h, s.d_peak_ws);
     bury(h, h->d_atan);
     for (int i = 0; i < 2; ++i) {
         bury(h, h->d_buf[i]);
@@ -958,11 +959,27 @@ int rcf_scan_start(rcf_t *h, int fft_len, int n_frames, int avg_len)
     if (set_dev(h)) return RCF_EHIP;
     if ((size_t)fft_len > h->hist_cap) { set_error("history capacity %zu < fft_len %d", h->hist_cap, fft_len); return RCF_ECAP; }
     Scan &s = h->scan;
+    // frames per launch: enough workgroups to fill 256 CUs (2^25 samples per launch), bounded so that
+    // the log-magnitude ring ((avg_len + chunk) x N floats) and the four-step scratch stay modest
+    int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(512, (int64_t(1) << 25) / fft_len));
+    chunk = std::min(chunk, n_frames);
+    if (s.d_vring && s.N == fft_len && s.L == avg_len && s.chunk == chunk) {
+        // same geometry as the previous scan: keep every buffer (fresh device allocations cost tens of
+        // milliseconds of first-touch page faults), just reset the running state
+        s.n_frames = n_frames;
+        s.frames_done = 0;
+        s.done = false;
+        s.start_sample = h->total_in;
+        RCF_HIP(hipMemsetAsync(s.d_sum, 0, sizeof(float) * (size_t)fft_len, h->stream));
+        RCF_HIP(hipMemsetAsync(s.d_out, 0, sizeof(float) * (size_t)fft_len, h->stream));
+        s.armed = true;
+        return RCF_OK;
+    }
     bury(h, s.d_window); bury(h, s.d_vring); bury(h, s.d_sum); bury(h, s.d_out); bury(h, s.d_tw);
-    bury(h, s.d_scratch); bury(h, s.d_peaks);
+    bury(h, s.d_scratch); bury(h, s.d_peaks); bury(h, s.d_peak_ws);
     s = Scan();
     s.N = fft_len; s.n_frames = n_frames; s.L = avg_len;
-    s.chunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, (int64_t(1) << 22) / fft_len));
+    s.chunk = chunk;
     s.R = avg_len + s.chunk;
     std::vector<float> win(fft_len), tw(2 * (size_t)fft_len);
     design_window(RCF_WIN_BLACKMAN_HARRIS, fft_len, win.data());
@@ -1046,35 +1063,29 @@ int rcf_scan_find_peaks(rcf_t *h, double prominence, int64_t *idx, int64_t cap, 
                         void **dev_idx)
 {
     if (!h || cap < 1) { set_error("bad arguments"); return RCF_EINVAL; }
-    std::vector<float> spec;
-    int N;
-    {
-        std::lock_guard<std::mutex> g(h->mu);
-        if (!h->scan.armed) return RCF_ESTATE;
-        if (!h->scan.done) return RCF_EAGAIN;
-        N = h->scan.N;
-    }
-    spec.resize((size_t)N);
-    int rc = rcf_scan_result(h, spec.data());
-    if (rc != RCF_OK) return rc;
-    const double hz_per_bin = h->fs / N;
-    std::vector<int64_t> tmp((size_t)cap);
-    const int64_t c = find_peaks_host(spec.data(), N, 3000 / hz_per_bin, 30000 / hz_per_bin, prominence, tmp.data(),
-                                      cap, mean_out);
-    if (count) *count = c;
-    const int64_t m = std::min(c, cap);
-    if (idx) std::memcpy(idx, tmp.data(), sizeof(int64_t) * (size_t)m);
+    if (cap > 4096) cap = 4096;                       // device sort capacity
     std::lock_guard<std::mutex> g(h->mu);
     if (set_dev(h)) return RCF_EHIP;
     Scan &s = h->scan;
-    if (dev_idx) {
-        // fixed-capacity, -1 padded list for the RCCL all-gather of peak lists
-        bury(h, s.d_peaks);
-        RCF_HIP(hipMalloc(&s.d_peaks, sizeof(int64_t) * (size_t)cap));
-        for (int64_t i = m; i < cap; ++i) tmp[(size_t)i] = -1;
-        RCF_HIP(hipMemcpy(s.d_peaks, tmp.data(), sizeof(int64_t) * (size_t)cap, hipMemcpyHostToDevice));
-        *dev_idx = s.d_peaks;
-    }
+    if (!s.armed) return RCF_ESTATE;
+    if (!s.done) return RCF_EAGAIN;
+    const int N = s.N;
+    const double hz_per_bin = h->fs / N;              // fft_peak_detection.py:46-52
+    if (!s.d_peak_ws) RCF_HIP(hipMalloc(&s.d_peak_ws, peaks_workspace_bytes(N)));
+    if (!s.d_peaks) RCF_HIP(hipMalloc(&s.d_peaks, sizeof(int64_t) * 4096));
+    int *d_count = nullptr;
+    double *d_mean = nullptr;
+    launch_find_peaks(s.d_out, N, 3000 / hz_per_bin, 30000 / hz_per_bin, prominence, s.d_peak_ws, s.d_peaks,
+                      (int)cap, &d_count, &d_mean, h->stream);
+    int c = 0;
+    double mean = 0.0;
+    RCF_HIP(hipMemcpyAsync(&c, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    RCF_HIP(hipMemcpyAsync(&mean, d_mean, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (idx) RCF_HIP(hipMemcpyAsync(idx, s.d_peaks, sizeof(int64_t) * (size_t)cap, hipMemcpyDeviceToHost, h->stream));
+    RCF_HIP(hipStreamSynchronize(h->stream));
+    if (count) *count = c;
+    if (mean_out) *mean_out = mean;
+    if (dev_idx) *dev_idx = s.d_peaks;                // sorted ascending, -1 padded to `cap`
     return RCF_OK;
 }
 

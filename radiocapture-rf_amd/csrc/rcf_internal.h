@@ -111,6 +111,11 @@ void launch_scan_fft(const ScanLaunch &p, hipStream_t s);
 void launch_scan_movsum(float *vring, int N, int R, int L, int f0, int n_frames, int emit_frame,
                         float *sum, float *out, hipStream_t s);
 
+// device peak picker (peaks.hip)
+size_t peaks_workspace_bytes(int n);
+void launch_find_peaks(const float *d_spec, int n, double min_w, double max_w, double prominence, void *ws,
+                       int64_t *d_out, int cap, int **d_count_out, double **d_mean_out, hipStream_t s);
+
 const float *atan_table_host();   // 257 floats: atan(i/255), i = 0..255, + pi/4
 
 }  // namespace rcfx

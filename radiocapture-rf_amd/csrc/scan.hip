@@ -115,14 +115,36 @@ __global__ __launch_bounds__(scan_threads<N>()) void scan_fft_kernel(ScanLaunch 
     }
 }
 
-__global__ __launch_bounds__(256) void movsum_kernel(const float *__restrict__ vring, int N, int R, int L, int f0,
-                                                     int n_frames, int emit_frame, float *__restrict__ sum,
-                                                     float *__restrict__ out)
+// One thread per bin; the add/subtract chain is inherently sequential in float32 (that IS the
+// specified result), but the loads are not: U frames' newest/oldest values are fetched up front so the
+// chain runs on registers.  64-thread workgroups so that a 16384-bin spectrum still spreads over all CUs.
+constexpr int kMovThreads = 64;
+__global__ __launch_bounds__(kMovThreads) void movsum_kernel(const float *__restrict__ vring, int N, int R, int L, int f0,
+                                                            int n_frames, int emit_frame, float *__restrict__ sum,
+                                                            float *__restrict__ out)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    constexpr int U = 8;
+    const int k = blockIdx.x * kMovThreads + threadIdx.x;
     if (k >= N) return;
     float s = sum[k];
-    for (int f = f0; f < f0 + n_frames; ++f) {
+    int f = f0;
+    const int f_end = f0 + n_frames;
+    for (; f + U <= f_end; f += U) {
+        float vn[U], vo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            vn[u] = vring[(size_t)((f + u) % R) * N + k];
+            const int fo = f + u - (L - 1);
+            vo[u] = fo >= 0 ? vring[(size_t)(fo % R) * N + k] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s = __fadd_rn(s, vn[u]);
+            if (f + u == emit_frame) out[k] = s;
+            if (f + u - (L - 1) >= 0) s = __fsub_rn(s, vo[u]);
+        }
+    }
+    for (; f < f_end; ++f) {
         s = __fadd_rn(s, vring[(size_t)(f % R) * N + k]);
         if (f == emit_frame) out[k] = s;
         const int fo = f - (L - 1);
@@ -173,7 +195,7 @@ void launch_scan_movsum(float *vring, int N, int R, int L, int f0, int n_frames,
                         float *out, hipStream_t s)
 {
     if (n_frames <= 0) return;
-    hipLaunchKernelGGL(movsum_kernel, dim3((N + 255) / 256), dim3(256), 0, s, vring, N, R, L, f0, n_frames,
+    hipLaunchKernelGGL(movsum_kernel, dim3((N + kMovThreads - 1) / kMovThreads), dim3(kMovThreads), 0, s, vring, N, R, L, f0, n_frames,
                        emit_frame, sum, out);
 }
 
