@@ -1,0 +1,63 @@
+"""End to end on the GPU through the reference's own API surface: a backend-style client asks
+`frontend_connector.create_channel(rate, freq)`, the front-end (receiver mirror on librcf) is fed
+wideband IQ, and the client-side stream equals what the reference's per-channel GNU Radio path would
+produce (oracle).  BASELINE configs[0] shape."""
+import types
+
+import numpy as np
+import pytest
+
+from oracle import cbind as OC
+from oracle import grspec as G
+from rcf import frontend_connector as FC
+from rcf import protocol, receiver, synth
+
+pytestmark = pytest.mark.gpu
+
+
+class OneChannelizer:
+    def get_channelizer_for_frequency(self, f):
+        return ("127.0.0.1", 0)
+
+
+def test_create_channel_feed_read_release(gpu_required):
+    x, meta = synth.cfg1(seconds=0.2)
+    cfg = types.SimpleNamespace(
+        sources={0: dict(type="synthetic", center_freq=meta["center_freq"], samp_rate=int(meta["fs"]))},
+        frontend_mode="xlat")
+    tb = receiver.receiver(cfg)
+    try:
+        srv = protocol.FrontendServer(tb)
+        fc = FC.frontend_connector("backend-uuid", OneChannelizer(), heartbeat=False,
+                                   transport_factory=lambda h, p: protocol.LoopbackTransport(srv))
+        cid, port = fc.create_channel(12500, meta["freq"])
+        assert cid and isinstance(port, str)
+        ch = tb.channels[cid]
+        assert ch.decim == 96 and ch.ntaps == 349 and ch.offset == meta["offset"]
+        half = len(x) // 2 + 1234
+        tb.feed(0, x[:half])
+        tb.feed(0, x[half:])
+        y = ch.read_iq()
+        fm = ch.read_fm(G.p25_fm_gain(25000.0))
+        D, taps = G.channel_params(meta["fs"], 12500)
+        ct, incr = OC.xlating_composite(taps, D, meta["offset"], meta["fs"])
+        yo, fo = OC.channel_bank(x, D, ct[None, :], np.array([incr]), gains=[G.p25_fm_gain(25000.0)])
+        assert len(y) == yo.shape[1]
+        assert np.sqrt(np.mean(np.abs(y - yo[0]) ** 2) / np.mean(np.abs(yo[0]) ** 2)) < 1e-5
+        assert np.sqrt(np.mean((fm - fo[0]) ** 2)) < 1e-4
+        # drift report > dead band retunes every channel's NCO (receiver.source_offset)
+        assert fc.report_offset(2.0) is True
+        assert tb.sources[0]["accumulated_offset"] == 100.0
+        tb.feed(0, x[:96 * 50])
+        y2 = ch.read_iq()
+        assert len(y2) == 50
+        assert fc.release_channel() == cid and not ch.in_use
+        # the idle channel is re-used for the next request of the same rate (receiver.py:311-319)
+        cid2, _ = fc.create_channel(12500, meta["freq"] + 25000)
+        assert cid2 == cid and ch.offset == meta["offset"] + 25000
+        # 10 s idle sweep destroys released channels
+        fc.release_channel()
+        assert tb.sweep_idle_channels(now=ch.channel_close_time + 11) == [cid]
+        assert tb.channels == {}
+    finally:
+        tb.close()
