@@ -156,6 +156,31 @@ def main():
     produced = fe.chan_produced(chans[0])
     assert produced > 0
 
+    # ---- "concurrent 12.5 kHz FM channels sustained": the reference-shaped bank (one 2909-tap xlating FIR
+    # /800 + discriminator per channel, GR-faithful) on this GPU, outside the timed region: how many such
+    # channels run in real time at 20 Msps -- directly comparable with cpu_baseline.realtime_channels
+    direct = None
+    if rank == 0:
+        nd, bd = 256, 1 << 22
+        fd = native.Frontend(FS, 0.0, device=local_rank, block_capacity=bd, hist_capacity=1 << 16,
+                             out_capacity=1 << 14)
+        for at in range(0, bd, len(tile)):
+            fd.ingest_write(tile[: min(len(tile), bd - at)], at)
+        ids = [fd.chan_open(12500, float(k * 12500 - nd // 2 * 12500)) for k in range(nd)]
+        fd.commit(bd)
+        fd.commit(bd)
+        fd.timing_enable(True)
+        fd.timing_read(native.T_FIR)
+        fd.timing_read(native.T_DISC)
+        for _ in range(3):
+            fd.commit(bd)
+        fms, fn = fd.timing_read(native.T_FIR)
+        dms, dn = fd.timing_read(native.T_DISC)
+        per_block_s = (fms / fn + dms / dn) * 1e-3
+        direct = {"channels_measured": nd, "block_samples": bd, "kernel_ms_per_block": per_block_s * 1e3,
+                  "realtime_channels_at_20Msps": nd * (bd / FS) / per_block_s}
+        fd.close()
+
     # ---- peak-list all-gather (BASELINE configs[4] collective), outside the timed region
     allgather_us = None
     if dist is not None:
@@ -226,9 +251,12 @@ def main():
         }
         if allgather_us is not None:
             out["peaks_allgather_us"] = allgather_us
+        out["channels"]["direct_bank"] = direct
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tile, meta["carriers"])
-            out["cpu_baseline"]["gpu_over_cpu_channels"] = None
+            if direct:
+                out["cpu_baseline"]["gpu_over_cpu_realtime_channels"] = (
+                    direct["realtime_channels_at_20Msps"] / out["cpu_baseline"]["realtime_channels_at_20Msps"])
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -329,3 +329,30 @@ def test_scan_1m_point_peaks_bit_exact(gpu_required):
     np.testing.assert_array_equal(lines_dev, l_want)
     assert len(l_want) == 12
     assert all(abs(int(a) - b) < 40 for a, b in zip(l_want, centres))
+
+
+def test_p25_prefilter_chain_on_channel_output(gpu_required):
+    """p25_control_demod.py:106-108,120-121 -- the channel stream goes through
+    freq_xlating_fir_filter_ccc(1, low_pass_2(1, 25000, 6250, 500, 30, WIN_BLACKMAN), 0, 25000) (69 taps)
+    and then quadrature_demod_cf(25000 / (2 pi 600)).  Here: a derived channel fed by a channel's ring."""
+    nat = gpu_required
+    x, meta = synth.cfg1(seconds=0.3, seed=1717)
+    pre = G.low_pass_2(1.0, 25000.0, 6250.0, 500.0, 30.0, G.WIN_BLACKMAN)
+    assert len(pre) == 69
+    np.testing.assert_allclose(nat.design_low_pass_2(1.0, 25000.0, 6250.0, 500.0, 30.0, nat.WIN_BLACKMAN), pre,
+                               rtol=0, atol=2e-9)
+    gain = G.p25_fm_gain(25000.0)
+    with nat.Frontend(meta["fs"]) as fe:
+        c1 = fe.chan_open(12500, meta["offset"])
+        c2 = fe.chan_open_taps(c1, 1, pre, 0.0)
+        assert fe.chan_info(c2)["out_rate"] == 25000.0 and fe.chan_info(c2)["ntaps"] == 69
+        for part in np.array_split(x, 7):                  # uneven blocks: the chain is block-cut invariant
+            fe.push(part)
+        y2 = fe.chan_read_iq(c2)
+        fm = fe.chan_read_fm(c2, gain)
+    yo, _ = oracle_channel(x, meta["fs"], 12500, meta["offset"], [])
+    y2o = G.xlating_fir_ccc(yo, 1, pre, 0.0, 25000.0)
+    fo = G.quadrature_demod_cf(y2o, gain)
+    assert len(y2) == len(y2o) == len(yo)
+    assert rel_rms(y2, y2o) < 1e-5
+    assert rms(fm, fo) < 1e-4
