@@ -234,6 +234,116 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel(PfbLaunch p, int frames_p
 }
 
 // ------------------------------------------------------------------------------------------------
+// Output-stationary variant (the default): one 16-frame chunk per workgroup, and instead of holding a
+// 16 + OS(P-1)-sample window in registers the thread keeps the 16 OUTPUT accumulators and streams the
+// input rows through them in groups of G (row j feeds output f with tap q = (HALO + f - j) / OS; the
+// schedule is fully unrolled, every index is a compile-time constant).  26+ fewer live VGPRs than the
+// sliding window => 4 workgroups per CU (the LDS limit) instead of 3, which is what this
+// latency-bound kernel responds to (measured: workgroups per CU, not instruction count, set its rate).
+template <int NB, int OS, int P, int MINW, int POL, bool ZH>
+__global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
+{
+    constexpr int D = NB / OS;
+    constexpr int HALO = OS * (P - 1);
+    constexpr int W = F + HALO;
+    constexpr int G = 8;
+    constexpr int RS = row_stride<NB>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+    cf *tw_lds = buf + F * RS;
+
+    const int tid = threadIdx.x;
+    int wg;
+    {
+        const int b = blockIdx.x, q = n_wg / 8, r = n_wg % 8, xcd = b % 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    }
+    const int fb0 = wg * F;
+    if (fb0 >= p.n_frames) return;
+    const int nf = min(F, p.n_frames - fb0);
+    const int64_t n0 = p.n_lo + fb0;
+
+    tw_lds[tid] = p.tw[tid];
+    float h[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) h[q] = p.ptaps[q * NB + tid];
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cf *>(p.src.base), 0, (int)(p.src_len * (int64_t)sizeof(cf)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.bins_ring, 0, (int)((int64_t)NB * p.ring_cap * (int64_t)sizeof(cf)), 0x00020000);
+    const int64_t m_min = (p.start_sample + tid + D - 1) / D;
+    const int64_t m0 = n0 - HALO;
+    const int vo_in = (int)((m0 * D - tid - p.src.origin) * (int64_t)sizeof(cf));
+
+    float ur[F], ui[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) ur[f] = ui[f] = 0.f;
+#pragma unroll
+    for (int j0 = 0; j0 < W; j0 += G) {
+        v2f x[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (j0 + g < W) {
+                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, vo_in, (j0 + g) * D * (int)sizeof(cf),
+                                                                     (POL & 1) ? 2 : 0);
+                x[g].x = __uint_as_float(r.x);
+                x[g].y = __uint_as_float(r.y);
+                if (ZH && m0 + j0 + g < m_min) x[g] = (v2f)(0.f);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int j = j0 + g;
+            if (j < W) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const int t = HALO + f - j;          // = OS * q
+                    if (t >= 0 && t % OS == 0 && t / OS < P) {
+                        ur[f] = fmaf(h[t / OS], x[g].x, ur[f]);
+                        ui[f] = fmaf(h[t / OS], x[g].y, ui[f]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) buf[f * RS + lds_pad(tid)] = make_float2(ur[f], ui[f]);
+    __syncthreads();
+    {
+        using PL = Plan<NB>;
+        pfb_pass<NB, PL::r[0], 1, (PL::n < 2 || PL::r[1] != PL::r[0])>(buf, tw_lds, tid);
+        if constexpr (PL::n >= 2)
+            pfb_pass<NB, PL::r[1], PL::r[0], (PL::n < 3 || PL::r[2] != PL::r[1])>(buf, tw_lds, tid);
+        if constexpr (PL::n >= 3) pfb_pass<NB, PL::r[2], PL::r[0] * PL::r[1], true>(buf, tw_lds, tid);
+    }
+    {
+        const int k0 = tid / F, f_lane = tid % F;
+        const int out_so_step = (int)((int64_t)(NB / F) * p.ring_cap * (int64_t)sizeof(cf));
+        const int64_t n = n0 + f_lane;
+        const int ridx = (int)((uint64_t)(n - p.n_abs0) & p.ring_mask);
+        const int vo = (int)(((int64_t)k0 * p.ring_cap + ridx) * (int64_t)sizeof(cf));
+        if (f_lane < nf) {
+#pragma unroll
+            for (int i = 0; i < F; ++i) {
+                const int k = k0 + i * (NB / F);
+                cf v = ((NB / F) % 16 == 0) ? buf[f_lane * RS + lds_pad(k0) + i * ((NB / F) + (NB / F) / 16)]
+                                            : buf[f_lane * RS + lds_pad(k)];
+                if (OS == 2) {
+                    if ((k & 1) && (n & 1)) v = make_float2(-v.x, -v.y);
+                }
+                u32x2 o;
+                o.x = __float_as_uint(v.x);
+                o.y = __float_as_uint(v.y);
+                __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, vo, i * out_so_step, (POL & 2) ? 2 : 0);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Role-split variant: a workgroup is 2*NB threads.  Waves [0, NB/64) are the FIR role (thread rho =
 // branch rho: global loads -> sliding-window FIR -> LDS chunk), waves [NB/64, 2NB/64) are the FFT role
 // (Stockham passes -> transposed non-temporal stores).  The roles work on the two halves of a
@@ -433,6 +543,16 @@ void launch_one(const PfbLaunch &p, hipStream_t s)
     else    hipLaunchKernelGGL((pfb_kernel<NB, OS, P, MINW, FB, POL, false, ABL>), dim3(n_wg), dim3(NB), lds, s, p, fpw, n_wg);
 }
 
+template <int NB, int OS, int P, int MINW, int POL>
+void launch_os(const PfbLaunch &p, hipStream_t s)
+{
+    const int n_wg = (p.n_frames + F - 1) / F;
+    const size_t lds = ((size_t)F * row_stride<NB>() + NB) * sizeof(cf);
+    const bool zh = (p.n_lo - (int64_t)OS * (P - 1)) * (NB / OS) - (NB - 1) < p.start_sample;
+    if (zh) hipLaunchKernelGGL((pfb_kernel_os<NB, OS, P, MINW, POL, true>), dim3(n_wg), dim3(NB), lds, s, p, n_wg);
+    else    hipLaunchKernelGGL((pfb_kernel_os<NB, OS, P, MINW, POL, false>), dim3(n_wg), dim3(NB), lds, s, p, n_wg);
+}
+
 int round_p(int P)
 {
     if (P <= 4) return 4;
@@ -446,9 +566,10 @@ bool dispatch_nb(const PfbLaunch &p, int OS, int P, bool probe, hipStream_t s)
     const int PR = round_p(P);
     if (PR == 0 || (OS != 1 && OS != 2)) return false;
     if (probe) return true;
-    constexpr int MW = NB >= 1024 ? 1 : 2;      // waves per SIMD the register allocator must allow
-    if (OS == 1) { if (PR == 4) launch_one<NB, 1, 4, MW, 16, 2>(p, s); else launch_one<NB, 1, 16, MW, 16, 2>(p, s); }
-    else         { if (PR == 4) launch_one<NB, 2, 4, MW, 16, 2>(p, s); else launch_one<NB, 2, 16, MW, 16, 2>(p, s); }
+    // waves per SIMD the register allocator must allow: 4 workgroups per CU is the LDS limit
+    constexpr int MW = NB >= 1024 ? 4 : (NB >= 512 ? 4 : 4 * NB / 256 > 0 ? (4 * NB / 256 > 8 ? 8 : (4 * NB / 256 < 1 ? 1 : 4 * NB / 256)) : 1);
+    if (OS == 1) { if (PR == 4) launch_os<NB, 1, 4, MW, 2>(p, s); else launch_os<NB, 1, 16, MW, 2>(p, s); }
+    else         { if (PR == 4) launch_os<NB, 2, 4, MW, 2>(p, s); else launch_os<NB, 2, 16, MW, 2>(p, s); }
     return true;
 }
 
@@ -467,7 +588,11 @@ bool dispatch(const PfbLaunch &p, bool probe, hipStream_t s)
                 case 5:  launch_one<256, 1, 14, 2, 16, 2, 1>(p, s); break;   // ablation: 1-tap FIR
                 case 6:  launch_one<256, 1, 14, 2, 16, 2, 2>(p, s); break;   // ablation: no FFT passes
                 case 7:  launch_one<256, 1, 14, 2, 16, 2, 3>(p, s); break;   // ablation: both
-                default: launch_one<256, 1, 14, 2, 16, 2>(p, s); break;
+                case 8:  launch_os<256, 1, 14, 4, 2>(p, s); break;
+                case 9:  launch_os<256, 1, 14, 3, 2>(p, s); break;
+                case 10: launch_os<256, 1, 14, 2, 2>(p, s); break;
+                case 11: launch_one<256, 1, 14, 2, 16, 2>(p, s); break;   // sliding-window kernel
+                default: launch_os<256, 1, 14, 4, 2>(p, s); break;
             }
         }
         return true;
