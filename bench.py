@@ -90,8 +90,17 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # RCF_BENCH_BACKEND=gloo + RCF_BENCH_DEVICE=0 lets two ranks share ONE GPU to exercise this code
+        # path on a single-GPU box; the driver's multi-GPU runs use the defaults (nccl == RCCL, one GPU each)
+        backend = os.environ.get("RCF_BENCH_BACKEND", "nccl")
+        if "RCF_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["RCF_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = "cuda" if (world <= 1 or os.environ.get("RCF_BENCH_BACKEND", "nccl") == "nccl") else "cpu"
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
@@ -141,7 +150,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     barrier()
@@ -187,10 +196,10 @@ def main():
         fe.scan_start(16384, 8, 4)
         fe.commit(B)
         idx, _, _ = fe.scan_find_peaks(cap=1024)
-        mine = torch.full((1025,), -1, dtype=torch.int64, device="cuda")
+        mine = torch.full((1025,), -1, dtype=torch.int64, device=coll_dev)
         mine[0] = len(idx)
         if len(idx):
-            mine[1:1 + len(idx)] = torch.from_numpy(idx).to("cuda")
+            mine[1:1 + len(idx)] = torch.from_numpy(idx).to(coll_dev)
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)                      # warm-up (RCCL ring setup)
         torch.cuda.synchronize()
