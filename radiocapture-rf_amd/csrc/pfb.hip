@@ -34,6 +34,7 @@ namespace {
 constexpr int F = 16;   // frames per LDS chunk
 int env_int(const char *name, int dflt);
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int NB> struct Plan;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel(PfbLaunch p, int frames_p
 // schedule is fully unrolled, every index is a compile-time constant).  26+ fewer live VGPRs than the
 // sliding window => 4 workgroups per CU (the LDS limit) instead of 3, which is what this
 // latency-bound kernel responds to (measured: workgroups per CU, not instruction count, set its rate).
-template <int NB, int OS, int P, int MINW, int POL, bool ZH>
+template <int NB, int OS, int P, int MINW, int POL, bool ZH, int ABL = 0>
 __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
 {
     constexpr int D = NB / OS;
@@ -254,7 +255,9 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
 
     const int tid = threadIdx.x;
     int wg;
-    {
+    if (n_wg < 0) {
+        wg = blockIdx.x;                                   // probe: no XCD remap
+    } else {
         const int b = blockIdx.x, q = n_wg / 8, r = n_wg % 8, xcd = b % 8;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
     }
@@ -284,7 +287,8 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
         v2f x[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            if (j0 + g < W) {
+            x[g] = (v2f)(0.f);
+            if (j0 + g < W && !((ABL & 1) && j0 + g < HALO)) {
                 const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, vo_in, (j0 + g) * D * (int)sizeof(cf),
                                                                      (POL & 1) ? 2 : 0);
                 x[g].x = __uint_as_float(r.x);
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
 #pragma unroll
                 for (int f = 0; f < F; ++f) {
                     const int t = HALO + f - j;          // = OS * q
-                    if (t >= 0 && t % OS == 0 && t / OS < P) {
+                    if (t >= 0 && t % OS == 0 && t / OS < ((ABL & 4) ? 1 : P)) {
                         ur[f] = fmaf(h[t / OS], x[g].x, ur[f]);
                         ui[f] = fmaf(h[t / OS], x[g].y, ui[f]);
                     }
@@ -312,14 +316,40 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
 #pragma unroll
     for (int f = 0; f < F; ++f) buf[f * RS + lds_pad(tid)] = make_float2(ur[f], ui[f]);
     __syncthreads();
-    {
+    if (!(ABL & 2)) {
         using PL = Plan<NB>;
         pfb_pass<NB, PL::r[0], 1, (PL::n < 2 || PL::r[1] != PL::r[0])>(buf, tw_lds, tid);
         if constexpr (PL::n >= 2)
             pfb_pass<NB, PL::r[1], PL::r[0], (PL::n < 3 || PL::r[2] != PL::r[1])>(buf, tw_lds, tid);
         if constexpr (PL::n >= 3) pfb_pass<NB, PL::r[2], PL::r[0] * PL::r[1], true>(buf, tw_lds, tid);
     }
-    {
+    // Wide epilogue (POL & 4): a lane stores TWO consecutive frames of a bin as one 16-byte access -- half
+    // the store instructions for the same bytes.  Needs a full chunk and an even ring index (16-byte
+    // alignment, no wrap inside the pair); otherwise the 8-byte form below runs.
+    if ((POL & 4) && nf == F && (((n0 - p.n_abs0) & 1) == 0)) {
+        constexpr int KQ = NB / (F / 2);                       // bins covered by one store instruction
+        const int kq = tid / (F / 2), fp = tid % (F / 2);
+        const int64_t n = n0 + 2 * fp;
+        const int ridx = (int)((uint64_t)(n - p.n_abs0) & p.ring_mask);
+        const int vo = (int)(((int64_t)kq * p.ring_cap + ridx) * (int64_t)sizeof(cf));
+        const int so_step = (int)((int64_t)KQ * p.ring_cap * (int64_t)sizeof(cf));
+#pragma unroll
+        for (int i = 0; i < F / 2; ++i) {
+            const int k = kq + i * KQ;
+            const int col = (KQ % 16 == 0) ? lds_pad(kq) + i * (KQ + KQ / 16) : lds_pad(k);
+            cf a = buf[(2 * fp) * RS + col];
+            cf b = buf[(2 * fp + 1) * RS + col];
+            if (OS == 2) {
+                if (k & 1) b = make_float2(-b.x, -b.y);         // n even, n + 1 odd
+            }
+            u32x4 o;
+            o.x = __float_as_uint(a.x);
+            o.y = __float_as_uint(a.y);
+            o.z = __float_as_uint(b.x);
+            o.w = __float_as_uint(b.y);
+            __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, vo, i * so_step, (POL & 2) ? 2 : 0);
+        }
+    } else {
         const int k0 = tid / F, f_lane = tid % F;
         const int out_so_step = (int)((int64_t)(NB / F) * p.ring_cap * (int64_t)sizeof(cf));
         const int64_t n = n0 + f_lane;
@@ -543,14 +573,16 @@ void launch_one(const PfbLaunch &p, hipStream_t s)
     else    hipLaunchKernelGGL((pfb_kernel<NB, OS, P, MINW, FB, POL, false, ABL>), dim3(n_wg), dim3(NB), lds, s, p, fpw, n_wg);
 }
 
-template <int NB, int OS, int P, int MINW, int POL>
+template <int NB, int OS, int P, int MINW, int POL, int ABL = 0>
 void launch_os(const PfbLaunch &p, hipStream_t s)
 {
     const int n_wg = (p.n_frames + F - 1) / F;
+    static const int no_remap = env_int("RCF_PFB_NOREMAP", 0);
+    const int arg = no_remap ? -n_wg : n_wg;
     const size_t lds = ((size_t)F * row_stride<NB>() + NB) * sizeof(cf);
     const bool zh = (p.n_lo - (int64_t)OS * (P - 1)) * (NB / OS) - (NB - 1) < p.start_sample;
-    if (zh) hipLaunchKernelGGL((pfb_kernel_os<NB, OS, P, MINW, POL, true>), dim3(n_wg), dim3(NB), lds, s, p, n_wg);
-    else    hipLaunchKernelGGL((pfb_kernel_os<NB, OS, P, MINW, POL, false>), dim3(n_wg), dim3(NB), lds, s, p, n_wg);
+    if (zh) hipLaunchKernelGGL((pfb_kernel_os<NB, OS, P, MINW, POL, true, ABL>), dim3(n_wg), dim3(NB), lds, s, p, arg);
+    else    hipLaunchKernelGGL((pfb_kernel_os<NB, OS, P, MINW, POL, false, ABL>), dim3(n_wg), dim3(NB), lds, s, p, arg);
 }
 
 int round_p(int P)
@@ -592,6 +624,11 @@ bool dispatch(const PfbLaunch &p, bool probe, hipStream_t s)
                 case 9:  launch_os<256, 1, 14, 3, 2>(p, s); break;
                 case 10: launch_os<256, 1, 14, 2, 2>(p, s); break;
                 case 11: launch_one<256, 1, 14, 2, 16, 2>(p, s); break;   // sliding-window kernel
+                case 12: launch_os<256, 1, 14, 4, 6>(p, s); break;       // 16-byte stores
+                case 14: launch_os<256, 1, 14, 4, 2, 1>(p, s); break;    // ablation: no halo loads
+                case 15: launch_os<256, 1, 14, 4, 2, 6>(p, s); break;    // ablation: no FIR math, no FFT
+                case 16: launch_os<256, 1, 14, 4, 2, 7>(p, s); break;    // ablation: all three
+                case 13: launch_os<256, 1, 14, 4, 4>(p, s); break;       // 16-byte stores, default cache policy
                 default: launch_os<256, 1, 14, 4, 2>(p, s); break;
             }
         }

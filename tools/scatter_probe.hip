@@ -40,6 +40,61 @@ __global__ __launch_bounds__(256) void copy_scatter(const float2* __restrict__ i
     }
 }
 
+
+template <int SEG, int LDSPAD>
+__global__ __launch_bounds__(256) void copy_scatter_buf(const float2* __restrict__ in, float2* __restrict__ out,
+                                                       int n_frames, int fpw, long pitch, long in_len) {
+    extern __shared__ float2 dbuf[];
+    constexpr int RS = 256 + LDSPAD;
+    const int tid = threadIdx.x;
+    const long f0 = (long)blockIdx.x * fpw;
+    __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(in_len * 8), 0x00020000);
+    __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)(256 * pitch * 8), 0x00020000);
+    for (int ch = 0; ch < fpw; ch += SEG) {
+        const int vo = (int)(((f0 + ch + 1) * 256 - tid) * 8);
+        u32x2 r[SEG];
+#pragma unroll
+        for (int f = 0; f < SEG; ++f) r[f] = __builtin_amdgcn_raw_buffer_load_b64(ir, vo, f * 2048, 0);
+#pragma unroll
+        for (int f = 0; f < SEG; ++f) dbuf[f * RS + tid + (LDSPAD ? (tid >> 4) : 0)] = make_float2(__uint_as_float(r[f].x), __uint_as_float(r[f].y));
+        __syncthreads();
+        const int fl = tid % SEG, k0 = tid / SEG;
+        const int so = (int)((long)(256 / SEG) * pitch * 8);
+        const int vo2 = (int)(((long)k0 * pitch + (f0 + ch + fl)) * 8);
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+            const int k = k0 + i * (256 / SEG);
+            float2 v = dbuf[fl * RS + k + (LDSPAD ? (k >> 4) : 0)];
+            u32x2 o; o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y);
+            __builtin_amdgcn_raw_buffer_store_b64(o, orr, vo2, i * so, 2);
+        }
+        __syncthreads();
+    }
+}
+template <int SEG, int LDSPAD>
+float run_buf(const float2* in, float2* out, int n_frames, int fpw, long pitch, long in_len, int reps) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    dim3 g(n_frames / fpw);
+    size_t lds = (size_t)SEG * (256 + LDSPAD) * 8 + 2048;
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((copy_scatter_buf<SEG, LDSPAD>), g, dim3(256), lds, 0, in, out, n_frames, fpw, pitch, in_len);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((copy_scatter_buf<SEG, LDSPAD>), g, dim3(256), lds, 0, in, out, n_frames, fpw, pitch, in_len);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / reps;
+}
+
+template <int SEG, int LDSPAD>
+float run_buf_rot(float2** ins, float2** outs, int nset, int n_frames, int fpw, long pitch, long in_len, int reps) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    dim3 g(n_frames / fpw);
+    size_t lds = (size_t)SEG * (256 + LDSPAD) * 8 + 2048;
+    for (int i = 0; i < nset; ++i) hipLaunchKernelGGL((copy_scatter_buf<SEG, LDSPAD>), g, dim3(256), lds, 0, ins[i], outs[i], n_frames, fpw, pitch, in_len);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((copy_scatter_buf<SEG, LDSPAD>), g, dim3(256), lds, 0, ins[i % nset], outs[i % nset], n_frames, fpw, pitch, in_len);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / reps;
+}
+
 template <int SEG, int NT, int REV>
 float run_scatter(const float2* in, float2* out, int n_frames, int fpw, long pitch, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -55,7 +110,14 @@ int main() {
     const size_t n = 1ull << 25; const int n_frames = n / 256; const long cap = 1 << 18;
     float2 *in, *out;
     CK(hipMalloc(&in, n * 8 + 4096)); CK(hipMalloc(&out, (size_t)256 * (cap + 1040) * 8));
-    CK(hipMemset(in, 1, n * 8));
+    if (getenv("RANDOM_INPUT")) {
+        float *hbuf = (float *)malloc(n * 8);
+        unsigned st = 12345u;
+        for (size_t i = 0; i < 2 * n; ++i) { st = st * 1664525u + 1013904223u; hbuf[i] = (float)(int)(st >> 8) * (1.0f / 8388608.0f) - 1.0f; }
+        CK(hipMemcpy(in, hbuf, n * 8, hipMemcpyHostToDevice));
+        free(hbuf);
+        printf("random input\n");
+    } else CK(hipMemset(in, 1, n * 8));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(copy_lin, dim3(4096), dim3(256), 0, 0, in, out, n);
     CK(hipEventRecord(a));
@@ -65,10 +127,24 @@ int main() {
     printf("linear copy 8B/lane          : %.4f ms  %.0f GB/s\n", ms, 16.0 * n / ms / 1e6);
     {
         float t; const long pitch = cap + 80;
-        t = run_scatter<16, 1, 0>(in, out, n_frames, 32, pitch, 10); printf("scatter seg=16 nt aligned ascending   : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
-        t = run_scatter<16, 1, 1>(in, out, n_frames, 32, pitch, 10); printf("scatter seg=16 nt x[mD - tid] (PFB)   : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
-        t = run_scatter<16, 1, 2>(in, out, n_frames, 32, pitch, 10); printf("scatter seg=16 nt ascending + stray   : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
-        t = run_scatter<16, 0, 0>(in, out, n_frames, 32, pitch, 10); printf("scatter seg=16 plain stores aligned   : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
+        for (int fpw : {16, 32, 64, 128}) {
+            t = run_scatter<16, 1, 1>(in, out, n_frames, fpw, pitch, 10);
+            printf("scatter seg=16 nt x[mD - tid] frames/WG=%d : %.4f ms  %.0f GB/s\n", fpw, t, 16.0 * n / t / 1e6);
+        }
+    }
+    {
+        float t; const long pitch = cap + 80;
+        t = run_buf<16, 0>(in, out, n_frames, 16, pitch, (long)n + 512, 10); printf("buffer ops, LDS stride 256, fpw16   : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
+        t = run_buf<16, 18>(in, out, n_frames, 16, pitch, (long)n + 512, 10); printf("buffer ops, LDS stride 274 padded     : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
+        t = run_buf<16, 18>(in, out, n_frames, 32, pitch, (long)n + 512, 10); printf("buffer ops, LDS stride 274, fpw32     : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
+    }
+    {
+        const int NSET = 4; float2 *ins[NSET], *outs[NSET]; const long pitch = cap + 80;
+        for (int i = 0; i < NSET; ++i) { CK(hipMalloc(&ins[i], n * 8 + 4096)); CK(hipMemset(ins[i], i + 1, n * 8)); CK(hipMalloc(&outs[i], (size_t)256 * (cap + 1040) * 8)); }
+        float t = run_buf_rot<16, 18>(ins, outs, NSET, n_frames, 16, pitch, (long)n + 512, 12);
+        printf("buffer ops, padded LDS, fpw16, rotating over %d x (256 MiB in, 512 MiB out) : %.4f ms  %.0f GB/s\n", NSET, t, 16.0 * n / t / 1e6);
+        t = run_buf_rot<16, 18>(ins, outs, NSET, n_frames, 32, pitch, (long)n + 512, 12);
+        printf("same, fpw32 : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
     }
     return 0;
 }
