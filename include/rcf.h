@@ -109,6 +109,15 @@ int rcf_ingest_ptr(rcf_t *h, float **dev_ptr, size_t *max_samples);
  * for drivers that deliver a block in pieces, and for pre-loading resident data */
 int rcf_ingest_write(rcf_t *h, const float *iq_interleaved, size_t n_samples, size_t at);
 int rcf_commit(rcf_t *h, size_t n_samples);
+/* Wire-format ingest: the host hands over the SDR's native samples (2 or 4 bytes per complex sample
+ * instead of 8 over PCIe) and the conversion the reference leaves to gr-osmosdr / gr-uhd on the host
+ * (rc_frontend/receiver.py:74-98,170-191) runs on the GPU: x = (float(raw) - offset) * scale per
+ * component, then the block is processed like rcf_push_iq.  rtl-sdr: RCF_FMT_U8, offset 127.4,
+ * scale 1/128; sc16 (USRP wire, bladeRF Q11): RCF_FMT_S16, offset 0, scale 1/32768 or 1/2048. */
+#define RCF_FMT_U8   1   /* unsigned 8-bit I,Q interleaved */
+#define RCF_FMT_S8   2   /* signed 8-bit I,Q interleaved */
+#define RCF_FMT_S16  3   /* signed 16-bit little-endian I,Q interleaved */
+int rcf_push_raw(rcf_t *h, const void *iq_raw, size_t n_samples, int fmt, float scale, float offset);
 /* total samples ingested so far */
 int64_t rcf_samples_in(rcf_t *h);
 

@@ -1,0 +1,79 @@
+// ingest.hip -- on-device conversion of the SDR wire formats to cf32.
+//
+// The reference receives cf32 because gr-osmosdr / gr-uhd convert the hardware's samples on the host
+// (/root/reference/rc_frontend/receiver.py:74-98,170-191: rtl-sdr delivers unsigned 8-bit I/Q, USRP /
+// bladeRF signed 16-bit).  Converting here instead moves 2 or 4 bytes per sample over PCIe rather
+// than 8 -- the host link (63 GB/s), not HBM, is the real end-to-end bottleneck of this path.
+//   x = (float(raw) - offset) * scale     (float32, unfused: the drivers' lookup-table semantics)
+// Bound: HBM, 2|4 B read + 8 B written per sample; 16 bytes stored per lane.
+#include <algorithm>
+
+#include "rcf_internal.h"
+
+namespace rcfx {
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ float conv1(T r, float scale, float offset)
+{
+    return __fmul_rn(__fsub_rn((float)r, offset), scale);
+}
+
+// one thread = two complex samples = four raw values = one 16-byte store (grid-stride)
+template <typename T>
+__global__ __launch_bounds__(256) void convert_kernel(const T *__restrict__ raw, float4 *__restrict__ out,
+                                                      size_t n_pairs, float scale, float offset)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n_pairs; i += stride) {
+        const T *r = raw + 4 * i;
+        out[i] = make_float4(conv1(r[0], scale, offset), conv1(r[1], scale, offset), conv1(r[2], scale, offset),
+                             conv1(r[3], scale, offset));
+    }
+}
+
+template <typename T>
+__global__ void convert_tail(const T *__restrict__ raw, float2 *__restrict__ out, float scale, float offset)
+{
+    if (threadIdx.x == 0) *out = make_float2(conv1(raw[0], scale, offset), conv1(raw[1], scale, offset));
+}
+
+template <typename T>
+void launch_t(const void *raw, float2 *out, size_t n, float scale, float offset, hipStream_t s)
+{
+    const T *r = static_cast<const T *>(raw);
+    const size_t n_pairs = n / 2;
+    if (n_pairs) {
+        const int grid = (int)std::min<size_t>((n_pairs + 255) / 256, 256 * 8);
+        hipLaunchKernelGGL((convert_kernel<T>), dim3(grid), dim3(256), 0, s, r, reinterpret_cast<float4 *>(out),
+                           n_pairs, scale, offset);
+    }
+    if (n & 1)
+        hipLaunchKernelGGL((convert_tail<T>), dim3(1), dim3(64), 0, s, r + 2 * (n - 1), out + (n - 1), scale, offset);
+}
+
+}  // namespace
+
+size_t raw_sample_bytes(int fmt)
+{
+    switch (fmt) {
+        case RCF_FMT_U8:
+        case RCF_FMT_S8:  return 2;
+        case RCF_FMT_S16: return 4;
+        default:          return 0;
+    }
+}
+
+void launch_convert(int fmt, const void *d_raw, float2 *d_out, size_t n, float scale, float offset, hipStream_t s)
+{
+    switch (fmt) {
+        case RCF_FMT_U8:  launch_t<uint8_t>(d_raw, d_out, n, scale, offset, s); break;
+        case RCF_FMT_S8:  launch_t<int8_t>(d_raw, d_out, n, scale, offset, s); break;
+        case RCF_FMT_S16: launch_t<int16_t>(d_raw, d_out, n, scale, offset, s); break;
+        default: break;
+    }
+}
+
+}  // namespace rcfx

@@ -112,6 +112,7 @@ struct rcf {
     int64_t total_in = 0;
     double shift_hz = 0;          // accumulated rcf_source_shift
     float *d_atan = nullptr;
+    void *d_raw = nullptr;        // wire-format staging (rcf_push_raw), block_cap * 4 bytes, lazily allocated
     // launch-parameter arenas (pinned host + device), double buffered
     static constexpr size_t kArena = 8u << 20;
     unsigned char *h_arena[2] = {nullptr, nullptr};
@@ -631,6 +632,7 @@ int rcf_close(rcf_t *h)
     bury(h, s.d_window); bury(h, s.d_vring); bury(h, s.d_sum); bury(h, s.d_out); bury(h, s.d_tw);
     bury(h, s.d_scratch); bury(h, s.d_peaks); bury(h, s.d_peak_ws);
     bury(h, h->d_atan);
+    bury(h, h->d_raw);
     for (int i = 0; i < 2; ++i) {
         bury(h, h->d_buf[i]);
         bury(h, h->d_arena[i]);
@@ -698,6 +700,26 @@ int rcf_push_iq(rcf_t *h, const float *iq, size_t n)
     RCF_HIP(hipEventRecord(ev, h->stream));
     int rc = process_block(h, n);
     (void)hipEventSynchronize(ev);
+    (void)hipEventDestroy(ev);
+    return rc;
+}
+
+int rcf_push_raw(rcf_t *h, const void *iq_raw, size_t n, int fmt, float scale, float offset)
+{
+    const size_t bps = raw_sample_bytes(fmt);
+    if (!h || (!iq_raw && n) || bps == 0) { set_error("bad raw push arguments"); return RCF_EINVAL; }
+    if (n == 0) return RCF_OK;
+    if (n > h->block_cap) { set_error("push of %zu samples exceeds block capacity %zu", n, h->block_cap); return RCF_ECAP; }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    if (!h->d_raw) RCF_HIP(hipMalloc(&h->d_raw, h->block_cap * 4));       // staging for the widest format
+    RCF_HIP(hipMemcpyAsync(h->d_raw, iq_raw, n * bps, hipMemcpyHostToDevice, h->stream));
+    hipEvent_t ev;
+    RCF_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    RCF_HIP(hipEventRecord(ev, h->stream));
+    launch_convert(fmt, h->d_raw, h->d_buf[h->cur] + h->hist_cap, n, scale, offset, h->stream);
+    int rc = process_block(h, n);
+    (void)hipEventSynchronize(ev);      // the caller may reuse its buffer once the H2D copy has been read
     (void)hipEventDestroy(ev);
     return rc;
 }

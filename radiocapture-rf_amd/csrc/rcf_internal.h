@@ -116,6 +116,10 @@ size_t peaks_workspace_bytes(int n);
 void launch_find_peaks(const float *d_spec, int n, double min_w, double max_w, double prominence, void *ws,
                        int64_t *d_out, int cap, int **d_count_out, double **d_mean_out, hipStream_t s);
 
+// wire-format ingest (ingest.hip)
+size_t raw_sample_bytes(int fmt);
+void launch_convert(int fmt, const void *d_raw, float2 *d_out, size_t n, float scale, float offset, hipStream_t s);
+
 const float *atan_table_host();   // 257 floats: atan(i/255), i = 0..255, + pi/4
 
 }  // namespace rcfx

@@ -29,8 +29,9 @@ SYMBOLS = [
     "rcf_pfb_produced", "rcf_pfb_read_bin", "rcf_pfb_rings", "rcf_pfb_chan_open", "rcf_scan_start",
     "rcf_scan_result", "rcf_scan_frames_done", "rcf_scan_result_device", "rcf_find_peaks",
     "rcf_peak_frequency", "rcf_scan_find_peaks", "rcf_timing_enable", "rcf_timing_read",
-    "rcf_ingest_write",
+    "rcf_ingest_write", "rcf_push_raw",
 ]
+FMT_U8, FMT_S8, FMT_S16 = 1, 2, 3
 T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY = range(7)
 
 
@@ -67,6 +68,7 @@ def lib():
         "rcf_ingest_ptr": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "rcf_commit": (C.c_int, [vp, sz]),
         "rcf_ingest_write": (C.c_int, [vp, fp, sz, sz]),
+        "rcf_push_raw": (C.c_int, [vp, vp, sz, C.c_int, C.c_float, C.c_float]),
         "rcf_samples_in": (i64, [vp]),
         "rcf_chan_open": (C.c_int, [vp, C.c_int, C.c_double, ip]),
         "rcf_chan_open_taps": (C.c_int, [vp, C.c_int, C.c_int, fp, C.c_int, C.c_double, ip]),
@@ -211,6 +213,13 @@ class Frontend:
         p, n = C.c_void_p(), C.c_size_t()
         _check(lib().rcf_ingest_ptr(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def push_raw(self, raw: np.ndarray, fmt, scale, offset=0.0):
+        """raw: interleaved I,Q in the SDR's wire type (uint8 / int8 / int16), 2 values per sample."""
+        dt = {FMT_U8: np.uint8, FMT_S8: np.int8, FMT_S16: np.int16}[fmt]
+        raw = np.ascontiguousarray(raw, dtype=dt)
+        _check(lib().rcf_push_raw(self._h, raw.ctypes.data_as(C.c_void_p), raw.size // 2, int(fmt),
+                                  float(scale), float(offset)))
 
     def ingest_write(self, iq: np.ndarray, at=0):
         iq = np.ascontiguousarray(iq, dtype=np.complex64)

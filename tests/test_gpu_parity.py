@@ -356,3 +356,31 @@ def test_p25_prefilter_chain_on_channel_output(gpu_required):
     assert len(y2) == len(y2o) == len(yo)
     assert rel_rms(y2, y2o) < 1e-5
     assert rms(fm, fo) < 1e-4
+
+
+@pytest.mark.parametrize("fmt_name,dtype,scale,offset", [
+    ("FMT_U8", np.uint8, 1.0 / 128.0, 127.4),          # rtl-sdr wire format
+    ("FMT_S16", np.int16, 1.0 / 2048.0, 0.0),          # bladeRF sc16 Q11
+    ("FMT_S8", np.int8, 1.0 / 128.0, 0.0),
+])
+def test_wire_format_ingest_equals_host_conversion(gpu_required, fmt_name, dtype, scale, offset):
+    """converting the SDR's native samples on the GPU gives bit-identical cf32 to the
+    host conversion (float(raw) - offset) * scale, hence identical channel output."""
+    nat = gpu_required
+    rng = np.random.default_rng(44)
+    info = np.iinfo(dtype)
+    n = 96 * 300 + 1                                          # odd length: exercises the tail path
+    raw = rng.integers(info.min, info.max + 1, size=2 * n).astype(dtype)
+    x = ((raw.astype(np.float32) - np.float32(offset)) * np.float32(scale)).view(np.complex64)
+    with nat.Frontend(2.4e6) as fe:
+        cid = fe.chan_open(12500, 200000.0)
+        fe.push_raw(raw[: 2 * 7001], getattr(nat, fmt_name), scale, offset)
+        fe.push_raw(raw[2 * 7001:], getattr(nat, fmt_name), scale, offset)
+        y_raw = fe.chan_read_iq(cid)
+    with nat.Frontend(2.4e6) as fe:
+        cid = fe.chan_open(12500, 200000.0)
+        fe.push(x)
+        y_ref = fe.chan_read_iq(cid)
+    np.testing.assert_array_equal(y_raw.view(np.float32), y_ref.view(np.float32))
+    yo, _ = oracle_channel(x, 2.4e6, 12500, 200000.0, [])
+    assert rel_rms(y_raw, yo) < 1e-5
