@@ -150,6 +150,16 @@ int64_t rcf_chan_produced(rcf_t *h, int chan_id);
  * samples (as a PUB socket at its HWM does). */
 int64_t rcf_chan_read_iq(rcf_t *h, int chan_id, float *out_interleaved, size_t max_samples);
 int64_t rcf_chan_read_fm(rcf_t *h, int chan_id, float gain, float *out, size_t max_samples);
+/* P25 C4FM front half after the discriminator (p25_control_demod.py:129-133, logging_receiver.py:240-244):
+ * filter.fir_filter_fff(1, taps) over quadrature_demod_cf(gain) -- e.g. the 5-tap boxcar symbol filter
+ * (1/sps,)*sps.  Enabled per channel; applies from the next block on; output read with rcf_chan_read_sym
+ * at the channel's rate (the sequential symbol-timing loop, op25 fsk4_demod_ff, stays on the host). */
+int rcf_chan_fm_filter(rcf_t *h, int chan_id, float gain, const float *taps, int ntaps);
+int64_t rcf_chan_read_sym(rcf_t *h, int chan_id, float *out, size_t max_samples);
+/* drift probe of p25_control_demod.py:123-127: moving_average_ff(window, 1) * (1/window) of the
+ * discriminator output (window = 10000 there) == mean of gain*fm over the last `window` samples; this is
+ * the value demod_watcher hands to frontend_connector.report_offset */
+int rcf_chan_fm_level(rcf_t *h, int chan_id, float gain, int window, float *level);
 /* device pointers of the channel's rings (cf32 iq ring, f32 unit-gain discriminator ring) and their
  * power-of-two capacity: sample k lives at index k & (capacity-1) */
 int rcf_chan_rings(rcf_t *h, int chan_id, void **iq_ring, void **fm_ring, size_t *capacity);

@@ -249,7 +249,56 @@ __global__ __launch_bounds__(kThreads) void disc_kernel(const DiscLaunch *__rest
     it.fm_ring[(uint64_t)n & ring_mask] = fast_atan2f_gr(ti, tr, tab);
 }
 
+// P25 symbol filter and friends: a short real FIR over gain * fm (float32, taps in order)
+__global__ __launch_bounds__(kThreads) void fm_fir_kernel(const FmFirLaunch *__restrict__ items, uint64_t ring_mask)
+{
+    const FmFirLaunch it = items[blockIdx.y];
+    const int j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= it.n_k) return;
+    const int64_t n = it.n_lo + j;
+    float acc = 0.f;
+    for (int i = 0; i < it.ntaps; ++i) {
+        const int64_t m = n - i;
+        const float v = m >= it.n_first ? __fmul_rn(it.gain, it.fm_ring[(uint64_t)m & ring_mask]) : 0.f;
+        acc = fmaf(it.taps[i], v, acc);
+    }
+    it.sym_ring[(uint64_t)n & ring_mask] = acc;
+}
+
+// drift probe: mean of gain * fm over a window (p25_control_demod.py:123-127 computes it as a 10000-sample
+// moving sum times 1e-4); float64 accumulation, one workgroup
+__global__ __launch_bounds__(kThreads) void fm_level_kernel(const float *__restrict__ fm_ring, int64_t n_end, int window,
+                                                            float gain, uint64_t ring_mask, float *out)
+{
+    __shared__ double red[kThreads];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < window; i += kThreads) {
+        const int64_t m = n_end - 1 - i;
+        if (m >= 0) s += (double)__fmul_rn(gain, fm_ring[(uint64_t)m & ring_mask]);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = kThreads / 2; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = (float)(red[0] / (double)window);
+}
+
 }  // namespace
+
+void launch_fm_fir(const FmFirLaunch *d_items, int n_items, int max_n_k, uint64_t ring_mask, hipStream_t s)
+{
+    if (n_items <= 0 || max_n_k <= 0) return;
+    hipLaunchKernelGGL(fm_fir_kernel, dim3((max_n_k + kThreads - 1) / kThreads, n_items), dim3(kThreads), 0, s,
+                       d_items, ring_mask);
+}
+
+void launch_fm_level(const float *fm_ring, int64_t n_end, int window, float gain, uint64_t ring_mask, float *d_out,
+                     hipStream_t s)
+{
+    hipLaunchKernelGGL(fm_level_kernel, dim3(1), dim3(kThreads), 0, s, fm_ring, n_end, window, gain, ring_mask, d_out);
+}
 
 void launch_fir_bank(const ChanLaunch *d_chans, const FirLaunchDims &dims, hipStream_t s)
 {

@@ -66,6 +66,12 @@ struct Chan {
     int64_t k_abs0 = 0;
     int64_t produced = 0;         // relative output count
     int64_t rd_iq = 0, rd_fm = 0;
+    // optional real FIR over gain * fm (P25 symbol filter)
+    float *d_sym = nullptr, *d_symtaps = nullptr;
+    int sym_ntaps = 0;
+    float sym_gain = 1.f;
+    int64_t sym_from = 0;         // first relative output index the filter is defined for
+    int64_t rd_sym = 0;
     // rotator model
     double dangle = 0, dlogmag = 0;
     long double angle0 = 0;
@@ -112,6 +118,7 @@ struct rcf {
     int64_t total_in = 0;
     double shift_hz = 0;          // accumulated rcf_source_shift
     float *d_atan = nullptr;
+    float *d_level = nullptr;     // rcf_chan_fm_level result
     void *d_raw = nullptr;        // wire-format staging (rcf_push_raw), block_cap * 4 bytes, lazily allocated
     // launch-parameter arenas (pinned host + device), double buffered
     static constexpr size_t kArena = 8u << 20;
@@ -281,6 +288,10 @@ void free_channel(rcf_t *h, Chan *c)
     bury(h, c->d_ctaps);
     bury(h, c->d_iq);
     bury(h, c->d_fm);
+    bury(h, c->d_sym);
+    bury(h, c->d_symtaps);
+    c->d_sym = nullptr;
+    c->d_symtaps = nullptr;
     c->d_ctaps = nullptr;
     c->d_iq = nullptr;
     c->d_fm = nullptr;
@@ -327,6 +338,8 @@ int process_block(rcf_t *h, size_t n)
     struct DiscJob { const DiscLaunch *dev; int n; int max_n; };
     std::vector<std::vector<FirJob>> fir_by_depth;
     std::vector<DiscJob> disc_jobs;
+    std::vector<FmFirLaunch> symf;     // symbol filters, all channels in one launch
+    int symf_max_n = 0;
 
     // ---- PFB bookkeeping first (derived channels need its new range)
     PfbLaunch pl{};
@@ -415,6 +428,19 @@ int process_block(rcf_t *h, size_t n)
                 dl.n_k = (int32_t)cnt;
                 discs.push_back(dl);
                 max_n = std::max(max_n, (int)cnt);
+                if (c->d_sym) {
+                    FmFirLaunch fl{};
+                    fl.fm_ring = c->d_fm;
+                    fl.sym_ring = c->d_sym;
+                    fl.taps = c->d_symtaps;
+                    fl.gain = c->sym_gain;
+                    fl.ntaps = c->sym_ntaps;
+                    fl.n_lo = std::max(dl.n_lo, c->sym_from);
+                    fl.n_first = c->sym_from;
+                    fl.n_k = (int32_t)(dl.n_lo + dl.n_k - fl.n_lo);
+                    if (fl.n_k > 0) symf.push_back(fl);
+                    symf_max_n = std::max(symf_max_n, (int)cnt);
+                }
                 // advance channel state: rebase the rotator model at the next output index
                 const int64_t n_next = k_hi - c->k_abs0 + 1;
                 const int64_t r512 = n_next & ~(int64_t)511;
@@ -442,6 +468,9 @@ int process_block(rcf_t *h, size_t n)
         }
     }
 
+    const FmFirLaunch *d_symf = nullptr;
+    if (!symf.empty() && !ar.put(symf, &d_symf)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+
     // ---- upload all launch parameters in one copy, then launch in dependency order
     if (ar.used) {
         RCF_HIP(hipMemcpyAsync(ar.d, ar.h, ar.used, hipMemcpyHostToDevice, st));
@@ -457,6 +486,10 @@ int process_block(rcf_t *h, size_t n)
     for (auto &dj : disc_jobs) {
         Timed t(h, RCF_T_DISC);
         launch_discriminator(dj.dev, dj.n, dj.max_n, h->ring_mask, h->d_atan, st);
+    }
+    if (d_symf) {
+        Timed t(h, RCF_T_DISC);
+        launch_fm_fir(d_symf, (int)symf.size(), symf_max_n, h->ring_mask, st);
     }
 
     // ---- scan
@@ -633,6 +666,7 @@ int rcf_close(rcf_t *h)
     bury(h, s.d_scratch); bury(h, s.d_peaks); bury(h, s.d_peak_ws);
     bury(h, h->d_atan);
     bury(h, h->d_raw);
+    bury(h, h->d_level);
     for (int i = 0; i < 2; ++i) {
         bury(h, h->d_buf[i]);
         bury(h, h->d_arena[i]);
@@ -859,6 +893,53 @@ int64_t rcf_chan_read_fm(rcf_t *h, int chan_id, float gain, float *out, size_t m
     // quadrature_demod_cf: out = gain * fast_atan2f(...), one float32 multiply per sample
     for (int64_t i = 0; i < n; ++i) out[i] = gain * out[i];
     return n;
+}
+
+int rcf_chan_fm_filter(rcf_t *h, int chan_id, float gain, const float *taps, int ntaps)
+{
+    if (!h || !taps || ntaps < 1 || ntaps > 4096) { set_error("bad fm filter arguments"); return RCF_EINVAL; }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    FIND_CHAN(h, chan_id, c);
+    if ((size_t)ntaps * 2 > h->out_cap) { set_error("ring too small for %d taps", ntaps); return RCF_ECAP; }
+    float *fresh = nullptr;
+    RCF_HIP(hipMalloc(&fresh, sizeof(float) * (size_t)ntaps));
+    RCF_HIP(hipMemcpy(fresh, taps, sizeof(float) * (size_t)ntaps, hipMemcpyHostToDevice));
+    bury(h, c->d_symtaps);
+    c->d_symtaps = fresh;
+    c->sym_ntaps = ntaps;
+    c->sym_gain = gain;
+    if (!c->d_sym) {
+        RCF_HIP(hipMalloc(&c->d_sym, sizeof(float) * h->out_cap));
+        RCF_HIP(hipMemsetAsync(c->d_sym, 0, sizeof(float) * h->out_cap, h->stream));
+        c->sym_from = c->produced;      // a new GR block starts with zero history
+        c->rd_sym = c->produced;
+    }
+    return RCF_OK;
+}
+
+int64_t rcf_chan_read_sym(rcf_t *h, int chan_id, float *out, size_t max_samples)
+{
+    if (!h || !out) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    FIND_CHAN(h, chan_id, c);
+    if (!c->d_sym) { set_error("channel %d has no fm filter", chan_id); return RCF_ESTATE; }
+    return ring_read(h, c->d_sym, sizeof(float), c->produced, &c->rd_sym, out, max_samples);
+}
+
+int rcf_chan_fm_level(rcf_t *h, int chan_id, float gain, int window, float *level)
+{
+    if (!h || !level || window < 1) { set_error("bad fm level arguments"); return RCF_EINVAL; }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    FIND_CHAN(h, chan_id, c);
+    if ((size_t)window > h->out_cap) { set_error("window %d exceeds the ring", window); return RCF_ECAP; }
+    if (!h->d_level) RCF_HIP(hipMalloc(&h->d_level, sizeof(float)));
+    launch_fm_level(c->d_fm, c->produced, window, gain, h->ring_mask, h->d_level, h->stream);
+    RCF_HIP(hipMemcpyAsync(level, h->d_level, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    RCF_HIP(hipStreamSynchronize(h->stream));
+    return RCF_OK;
 }
 
 int rcf_chan_rings(rcf_t *h, int chan_id, void **iq_ring, void **fm_ring, size_t *capacity)

@@ -74,6 +74,24 @@ struct DiscLaunch {
 void launch_discriminator(const DiscLaunch *d_items, int n_items, int max_n_k, uint64_t ring_mask,
                           const float *d_atan_table, hipStream_t s);
 
+// real FIR on the (gain-scaled) discriminator stream: sym[n] = sum_i taps[i] * (gain * fm[n - i])
+// (the P25 symbol filter fir_filter_fff(1, (1/sps,)*sps), p25_control_demod.py:129-133)
+struct FmFirLaunch {
+    const float *fm_ring;
+    float *sym_ring;
+    const float *taps;
+    float gain;
+    int32_t ntaps;
+    int64_t n_lo;
+    int64_t n_first;         // samples before this index count as zero (the filter's start)
+    int32_t n_k;
+    int32_t pad_;
+};
+void launch_fm_fir(const FmFirLaunch *d_items, int n_items, int max_n_k, uint64_t ring_mask, hipStream_t s);
+// mean of gain * fm over the last `window` samples ending at n_end (exclusive), one workgroup
+void launch_fm_level(const float *fm_ring, int64_t n_end, int window, float gain, uint64_t ring_mask, float *d_out,
+                     hipStream_t s);
+
 // ---------------------------------------------------------------- polyphase filterbank
 struct PfbLaunch {
     StreamView src;

@@ -29,7 +29,7 @@ SYMBOLS = [
     "rcf_pfb_produced", "rcf_pfb_read_bin", "rcf_pfb_rings", "rcf_pfb_chan_open", "rcf_scan_start",
     "rcf_scan_result", "rcf_scan_frames_done", "rcf_scan_result_device", "rcf_find_peaks",
     "rcf_peak_frequency", "rcf_scan_find_peaks", "rcf_timing_enable", "rcf_timing_read",
-    "rcf_ingest_write", "rcf_push_raw",
+    "rcf_ingest_write", "rcf_push_raw", "rcf_chan_fm_filter", "rcf_chan_read_sym", "rcf_chan_fm_level",
 ]
 FMT_U8, FMT_S8, FMT_S16 = 1, 2, 3
 T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY = range(7)
@@ -69,6 +69,9 @@ def lib():
         "rcf_commit": (C.c_int, [vp, sz]),
         "rcf_ingest_write": (C.c_int, [vp, fp, sz, sz]),
         "rcf_push_raw": (C.c_int, [vp, vp, sz, C.c_int, C.c_float, C.c_float]),
+        "rcf_chan_fm_filter": (C.c_int, [vp, C.c_int, C.c_float, fp, C.c_int]),
+        "rcf_chan_read_sym": (i64, [vp, C.c_int, fp, sz]),
+        "rcf_chan_fm_level": (C.c_int, [vp, C.c_int, C.c_float, C.c_int, fp]),
         "rcf_samples_in": (i64, [vp]),
         "rcf_chan_open": (C.c_int, [vp, C.c_int, C.c_double, ip]),
         "rcf_chan_open_taps": (C.c_int, [vp, C.c_int, C.c_int, fp, C.c_int, C.c_double, ip]),
@@ -269,6 +272,20 @@ class Frontend:
         out = np.empty(max_samples, dtype=np.float32)
         n = _check(lib().rcf_chan_read_fm(self._h, cid, float(gain), _fp(out), max_samples))
         return out[:n].copy()
+
+    def chan_fm_filter(self, cid, gain, taps):
+        taps = np.ascontiguousarray(taps, dtype=np.float32)
+        _check(lib().rcf_chan_fm_filter(self._h, cid, float(gain), _fp(taps), len(taps)))
+
+    def chan_read_sym(self, cid, max_samples=1 << 20) -> np.ndarray:
+        out = np.empty(max_samples, dtype=np.float32)
+        n = _check(lib().rcf_chan_read_sym(self._h, cid, _fp(out), max_samples))
+        return out[:n].copy()
+
+    def chan_fm_level(self, cid, gain, window=10000) -> float:
+        v = C.c_float()
+        _check(lib().rcf_chan_fm_level(self._h, cid, float(gain), int(window), C.byref(v)))
+        return v.value
 
     def source_shift(self, delta_hz):
         _check(lib().rcf_source_shift(self._h, float(delta_hz)))

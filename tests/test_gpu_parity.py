@@ -384,3 +384,33 @@ def test_wire_format_ingest_equals_host_conversion(gpu_required, fmt_name, dtype
     np.testing.assert_array_equal(y_raw.view(np.float32), y_ref.view(np.float32))
     yo, _ = oracle_channel(x, 2.4e6, 12500, 200000.0, [])
     assert rel_rms(y_raw, yo) < 1e-5
+
+
+def test_p25_c4fm_front_half_symbol_filter_and_drift_probe(gpu_required):
+    """pre-filter -> quadrature_demod_cf(gain) -> fir_filter_fff(1, (1/5,)*5)
+    (p25_control_demod.py:106-133), plus the 10000-sample drift probe (:123-127)."""
+    nat = gpu_required
+    x, meta = synth.cfg1(seconds=0.6, seed=2121)
+    pre = G.low_pass_2(1.0, 25000.0, 6250.0, 500.0, 30.0, G.WIN_BLACKMAN)
+    gain = G.p25_fm_gain(25000.0)
+    sps = 25000 // 4800
+    coeffs = np.full(sps, 1.0 / sps, dtype=np.float32)
+    with nat.Frontend(meta["fs"]) as fe:
+        c1 = fe.chan_open(12500, meta["offset"] + 40.0)          # 40 Hz off: a visible DC term in fm
+        c2 = fe.chan_open_taps(c1, 1, pre, 0.0)
+        fe.chan_fm_filter(c2, gain, coeffs)
+        for part in np.array_split(x, 5):
+            fe.push(part)
+        sym = fe.chan_read_sym(c2)
+        fm = fe.chan_read_fm(c2, gain)
+        level = fe.chan_fm_level(c2, gain, 10000)
+    yo, _ = oracle_channel(x, meta["fs"], 12500, meta["offset"] + 40.0, [])
+    y2o = G.xlating_fir_ccc(yo, 1, pre, 0.0, 25000.0)
+    fo = G.quadrature_demod_cf(y2o, gain)
+    so = np.convolve(fo.astype(np.float64), coeffs.astype(np.float64))[: len(fo)].astype(np.float32)
+    assert len(sym) == len(so) == len(fm)
+    assert rms(fm, fo) < 1e-4
+    assert rms(sym, so) < 1e-4
+    want_level = float(np.mean(fo[-10000:].astype(np.float64)))
+    assert abs(level - want_level) < 1e-4
+    assert abs(want_level - gain * 2 * math.pi * (-40.0) / 25000.0) < 0.02     # discriminator DC of a -40 Hz offset
