@@ -1,0 +1,82 @@
+"""Narrowband egress: what /root/reference/rc_frontend/channel.py:36 does with
+`zeromq.pub_sink(gr.sizeof_gr_complex, 1, 'tcp://0.0.0.0:<port>')` -- bare cf32 bytes on a ZMQ PUB socket,
+no framing, lossy at the HWM -- fed from the channel rings of librcf instead of a GNU Radio flowgraph.
+
+One pump thread per receiver: every `period` seconds it drains each in-use channel's ring
+(`rcf_chan_read_iq`) and publishes the bytes on that channel's socket.  Backends keep using
+`zeromq.sub_source('tcp://<connector.host>:<port>')` unchanged (p25_control_demod.py:244,
+logging_receiver.py:98-99).  The socket factory is injectable; with pyzmq installed the default binds
+real PUB sockets.  A second, optional socket per channel carries `quadrature_demod_cf(gain)` output
+for consumers that want the discriminator done on the GPU.
+"""
+from __future__ import annotations
+
+import threading
+import time
+
+
+def zmq_pub_factory():
+    import zmq
+    ctx = zmq.Context.instance()
+
+    def make(port):
+        s = ctx.socket(zmq.PUB)
+        s.bind("tcp://0.0.0.0:%s" % port)
+        return s
+    return make
+
+
+class EgressPump:
+    def __init__(self, tb, socket_factory=None, period=0.01, fm_gain=None, fm_port_offset=1):
+        """tb: rcf.receiver.receiver.  socket_factory(port) -> object with send(bytes) / close()."""
+        self.tb = tb
+        self.make = socket_factory or zmq_pub_factory()
+        self.period = period
+        self.fm_gain = fm_gain
+        self.fm_port_offset = fm_port_offset
+        self.socks = {}
+        self.fm_socks = {}
+        self.continue_running = True
+        self.bytes_out = 0
+        self._thread = None
+
+    def pump_once(self):
+        with self.tb.access_lock:
+            chans = dict(self.tb.channels)
+        for block_id, ch in chans.items():
+            if ch.chan_id is None:
+                continue
+            if block_id not in self.socks:
+                self.socks[block_id] = self.make(ch.port)
+                if self.fm_gain is not None:
+                    self.fm_socks[block_id] = self.make(ch.port + self.fm_port_offset)
+            iq = ch.read_iq()
+            if len(iq):
+                payload = iq.tobytes()                   # raw gr_complex items, arbitrary chunking
+                self.socks[block_id].send(payload)
+                self.bytes_out += len(payload)
+            if block_id in self.fm_socks:
+                fm = ch.read_fm(self.fm_gain)
+                if len(fm):
+                    self.fm_socks[block_id].send(fm.tobytes())
+        for block_id in [b for b in self.socks if b not in chans]:   # destroyed channels
+            for table in (self.socks, self.fm_socks):
+                s = table.pop(block_id, None)
+                if s is not None:
+                    s.close()
+
+    def run(self):
+        while self.continue_running:
+            self.pump_once()
+            time.sleep(self.period)
+
+    def start(self):
+        self._thread = threading.Thread(target=self.run, name="egress_pump")
+        self._thread.daemon = True
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self.continue_running = False
+        if self._thread is not None:
+            self._thread.join(timeout=2)

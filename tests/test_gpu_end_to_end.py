@@ -61,3 +61,47 @@ def test_create_channel_feed_read_release(gpu_required):
         assert tb.channels == {}
     finally:
         tb.close()
+
+
+def test_egress_pump_publishes_bare_cf32_bytes(gpu_required):
+    """Surface (2) of SURVEY 8(b): per-channel PUB of raw cf32 items (rc_frontend/channel.py:36)."""
+    from rcf import egress
+    x, meta = synth.cfg1(seconds=0.05, seed=31)
+    cfg = types.SimpleNamespace(
+        sources={0: dict(type="synthetic", center_freq=meta["center_freq"], samp_rate=int(meta["fs"]))},
+        frontend_mode="xlat")
+    tb = receiver.receiver(cfg)
+
+    class FakePub:
+        made = {}
+
+        def __init__(self, port):
+            self.port, self.chunks = port, []
+            FakePub.made[port] = self
+
+        def send(self, b):
+            self.chunks.append(b)
+
+        def close(self):
+            self.closed = True
+    try:
+        bid, port = tb.connect_channel(12500, meta["freq"])
+        pump = egress.EgressPump(tb, socket_factory=FakePub, fm_gain=5.0)
+        tb.feed(0, x[: len(x) // 2])
+        pump.pump_once()
+        tb.feed(0, x[len(x) // 2:])
+        pump.pump_once()
+        iq = np.frombuffer(b"".join(FakePub.made[port].chunks), dtype=np.complex64)
+        fm = np.frombuffer(b"".join(FakePub.made[port + 1].chunks), dtype=np.float32)
+        D, taps = G.channel_params(meta["fs"], 12500)
+        ct, incr = OC.xlating_composite(taps, D, meta["offset"], meta["fs"])
+        yo, fo = OC.channel_bank(x, D, ct[None, :], np.array([incr]), gains=[5.0])
+        assert len(iq) == yo.shape[1] and len(fm) == len(iq)
+        assert np.sqrt(np.mean(np.abs(iq - yo[0]) ** 2) / np.mean(np.abs(yo[0]) ** 2)) < 1e-5
+        assert np.sqrt(np.mean((fm - fo[0]) ** 2)) < 1e-4
+        tb.release_channel(bid)
+        tb.sweep_idle_channels(now=tb.channels[bid].channel_close_time + 11)
+        pump.pump_once()
+        assert FakePub.made[port].closed and pump.socks == {}
+    finally:
+        tb.close()
