@@ -118,14 +118,22 @@ __global__ __launch_bounds__(scan_threads<N>()) void scan_fft_kernel(ScanLaunch 
 // One thread per bin; the add/subtract chain is inherently sequential in float32 (that IS the
 // specified result), but the loads are not: U frames' newest/oldest values are fetched up front so the
 // chain runs on registers.  64-thread workgroups so that a 16384-bin spectrum still spreads over all CUs.
+// Four-step frames (n1 > 0) sit in the ring in row order p = k1 * n2 + k2 (frequency k = k1 + n1 * k2, not
+// yet fft-shifted): the running sum does not care about the order of bins, so the un-permute and the
+// fftshift are applied only to the ONE emitted vector.
 constexpr int kMovThreads = 64;
 __global__ __launch_bounds__(kMovThreads) void movsum_kernel(const float *__restrict__ vring, int N, int R, int L, int f0,
                                                             int n_frames, int emit_frame, float *__restrict__ sum,
-                                                            float *__restrict__ out)
+                                                            float *__restrict__ out_base, int n1, int n2)
 {
     constexpr int U = 8;
     const int k = blockIdx.x * kMovThreads + threadIdx.x;
     if (k >= N) return;
+    float *out = out_base;
+    if (n1 > 0) {
+        const int k1 = k / n2, k2 = k - k1 * n2;
+        out = out_base + (((k1 + n1 * k2) + N / 2) & (N - 1)) - k;      // so that out[k] lands on the shifted bin
+    }
     float s = sum[k];
     int f = f0;
     const int f_end = f0 + n_frames;
@@ -151,6 +159,54 @@ __global__ __launch_bounds__(kMovThreads) void movsum_kernel(const float *__rest
         if (fo >= 0) s = __fsub_rn(s, vring[(size_t)(fo % R) * N + k]);
     }
     sum[k] = s;
+}
+
+// Four-step, second half: length-N2 FFTs along the CONTIGUOUS rows of the scratch matrix [N1][N2] the
+// column kernel (scan4.hip) produced, then |X|^2 -> log10 -> +1.  Output stays in row order
+// (p = k1 * N2 + k2): fully coalesced float stores, no transpose -- movsum_kernel un-permutes the one
+// emitted vector.  grid = (N1 / FPW, frames).
+template <int N2>
+__global__ __launch_bounds__(scan_threads<N2>()) void scan4_rows_kernel(ScanLaunch p, const cf *__restrict__ tw2, int N1)
+{
+    constexpr int NT = scan_threads<N2>();
+    constexpr int FPW = scan_fpw<N2>();                  // rows per workgroup
+    constexpr int RS = scan_rs<N2>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * FPW;
+    const int fl = blockIdx.y;
+    const cf *scr = p.scratch + (size_t)fl * p.N + (size_t)r0 * N2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + i * NT;
+        const int r = e / N2, idx = e % N2;
+        buf[r * RS + lds_pad(idx)] = scr[(size_t)r * N2 + idx];
+    }
+    __syncthreads();
+    scan_pass<N2, NT, SPlan<N2>::r[0], 1>(buf, tw2, tid);
+    if constexpr (SPlan<N2>::n >= 2) scan_pass<N2, NT, SPlan<N2>::r[1], SPlan<N2>::r[0]>(buf, tw2, tid);
+    if constexpr (SPlan<N2>::n >= 3)
+        scan_pass<N2, NT, SPlan<N2>::r[2], SPlan<N2>::r[0] * SPlan<N2>::r[1]>(buf, tw2, tid);
+    if constexpr (SPlan<N2>::n >= 4)
+        scan_pass<N2, NT, SPlan<N2>::r[3], SPlan<N2>::r[0] * SPlan<N2>::r[1] * SPlan<N2>::r[2]>(buf, tw2, tid);
+    const int f = p.f0 + fl;
+    float *dst = p.vring + (size_t)(f % p.R) * p.N + (size_t)r0 * N2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + i * NT;
+        const int r = e / N2, k2 = e % N2;
+        dst[(size_t)r * N2 + k2] = logmag_gr(buf[r * RS + lds_pad(k2)]);
+    }
+    (void)N1;
+}
+
+template <int N2>
+void launch_rows(const ScanLaunch &p, const cf *tw2, int N1, hipStream_t s)
+{
+    constexpr int FPW = scan_fpw<N2>();
+    const size_t lds = (size_t)FPW * scan_rs<N2>() * sizeof(cf);
+    hipLaunchKernelGGL((scan4_rows_kernel<N2>), dim3(N1 / FPW, p.n_frames), dim3(scan_threads<N2>()), lds, s, p, tw2, N1);
 }
 
 template <int N>
@@ -195,8 +251,23 @@ void launch_scan_movsum(float *vring, int N, int R, int L, int f0, int n_frames,
                         float *out, hipStream_t s)
 {
     if (n_frames <= 0) return;
+    int n1 = 0, n2 = 0;
+    if (N > 16384 && !scan4_split(N, &n1, &n2)) return;
     hipLaunchKernelGGL(movsum_kernel, dim3((N + kMovThreads - 1) / kMovThreads), dim3(kMovThreads), 0, s, vring, N, R, L, f0, n_frames,
-                       emit_frame, sum, out);
+                       emit_frame, sum, out, n1, n2);
+}
+
+// rows of the four-step transform (called from scan4.hip after the column kernel)
+void launch_scan4_rows(const ScanLaunch &p, const cf *tw2, int N1, int N2, hipStream_t s)
+{
+    switch (N2) {
+        case 256:  launch_rows<256>(p, tw2, N1, s); break;
+        case 512:  launch_rows<512>(p, tw2, N1, s); break;
+        case 1024: launch_rows<1024>(p, tw2, N1, s); break;
+        case 2048: launch_rows<2048>(p, tw2, N1, s); break;
+        case 4096: launch_rows<4096>(p, tw2, N1, s); break;
+        default: break;
+    }
 }
 
 }  // namespace rcfx

@@ -3,12 +3,14 @@
 //
 // With n = N2 n1 + n2 and k = k1 + N1 k2:
 //   X[k1 + N1 k2] = sum_{n2} W_N2^{n2 k2} * ( W_N^{n2 k1} * sum_{n1} W_N1^{n1 k1} x[N2 n1 + n2] )
-// Kernel A (columns): a workgroup takes 16 consecutive columns n2 (16 x 8 B = one 128-byte line per
+// N1 is kept SMALL (256; 128 for N = 2^15) so that the column kernel's LDS tile is 35 KB and four
+// workgroups share a CU (load / FFT / store phases of different tiles overlap); the long dimension N2
+// (up to 4096) runs along contiguous rows in scan.hip's single-pass FFT machinery.
+// Kernel A (here, columns): a workgroup takes 16 consecutive columns n2 (16 x 8 B = one 128-byte line per
 //   row), applies the Blackman-Harris window on load, runs 16 length-N1 FFTs in LDS, multiplies by
-//   W_N^{n2 k1} (two 1024-entry tables: W_N^{1024 j} * W_N^{i}) and writes scratch[k1][n2] in 128-byte runs.
-// Kernel B (rows): a workgroup takes 16 consecutive rows k1, runs 16 length-N2 FFTs in LDS and emits
-//   |X|^2 -> log10 -> +1 -> fftshift through a transposed LDS read so that 16 lanes write 16
-//   consecutive output bins (64-byte runs of the float32 spectrum).
+//   W_N^{n2 k1} (two tables: W_N^{1024 j} * W_N^{i}) and writes scratch[k1][n2] in 128-byte runs.
+// Kernel B (scan.hip, rows): length-N2 FFTs along contiguous rows, log-magnitude stored in row order
+//   (fully coalesced); the un-permute k = k1 + N1 k2 and the fftshift happen once, on the emitted vector.
 // HBM traffic per sample: 8 (read) + 8 (scratch write) + 8 (scratch read) + 4 (write) = 28 B against
 // 12 B algorithmic -- the four-step ceiling stated in SURVEY.md 8(d) (~43 % of the algorithmic roofline).
 #include "fft_core.hpp"
@@ -16,15 +18,15 @@
 
 namespace rcfx {
 
+void launch_scan4_rows(const ScanLaunch &p, const cf *tw2, int N1, int N2, hipStream_t s);   // scan.hip
+
 namespace {
 
-constexpr int CW = 16;   // columns (kernel A) / rows (kernel B) per workgroup
+constexpr int CW = 16;   // columns per workgroup
 
 template <int N> struct P4;
-template <> struct P4<128>  { static constexpr int n = 2; static constexpr int r[3] = {16, 8, 1}; };
-template <> struct P4<256>  { static constexpr int n = 2; static constexpr int r[3] = {16, 16, 1}; };
-template <> struct P4<512>  { static constexpr int n = 3; static constexpr int r[3] = {16, 16, 2}; };
-template <> struct P4<1024> { static constexpr int n = 3; static constexpr int r[3] = {16, 16, 4}; };
+template <> struct P4<128> { static constexpr int n = 2; static constexpr int r[2] = {16, 8}; };
+template <> struct P4<256> { static constexpr int n = 2; static constexpr int r[2] = {16, 16}; };
 
 template <int N> constexpr int rs4() { return lds_padded_len(N) + 1; }   // odd: transposed accesses spread
 
@@ -63,20 +65,10 @@ __device__ __forceinline__ void pass4(cf *buf, const cf *tw_lds, int tid)
     __syncthreads();
 }
 
-template <int N>
-__device__ __forceinline__ void fft16(cf *buf, const cf *tw_lds, int tid)
-{
-    using PL = P4<N>;
-    pass4<N, PL::r[0], 1>(buf, tw_lds, tid);
-    if constexpr (PL::n >= 2) pass4<N, PL::r[1], PL::r[0]>(buf, tw_lds, tid);
-    if constexpr (PL::n >= 3) pass4<N, PL::r[2], PL::r[0] * PL::r[1]>(buf, tw_lds, tid);
-}
-
 struct Scan4Args {
     ScanLaunch p;
     int N1, N2;
     const cf *tw1;      // e^{-2 pi i n / N1}
-    const cf *tw2;      // e^{-2 pi i n / N2}
     const cf *tlo;      // W_N^{i},        i < 1024
     const cf *thi;      // W_N^{1024 j},   j < N / 1024
 };
@@ -96,7 +88,7 @@ __global__ __launch_bounds__(N1) void scan4_cols(Scan4Args a)
     tw_lds[tid] = a.tw1[tid];
     const int64_t s0 = a.p.s0 + (int64_t)fl * N;
     // load: lane -> (column c = e % 16, row n1 = e / 16): 16 lanes read one 128-byte line
-#pragma unroll 4
+#pragma unroll
     for (int i = 0; i < CW; ++i) {
         const int e = tid + i * N1;
         const int c = e % CW, n1 = e / CW;
@@ -106,9 +98,10 @@ __global__ __launch_bounds__(N1) void scan4_cols(Scan4Args a)
         buf[c * RS + lds_pad(n1)] = make_float2(__fmul_rn(x.x, w), __fmul_rn(x.y, w));
     }
     __syncthreads();
-    fft16<N1>(buf, tw_lds, tid);
+    pass4<N1, P4<N1>::r[0], 1>(buf, tw_lds, tid);
+    pass4<N1, P4<N1>::r[1], P4<N1>::r[0]>(buf, tw_lds, tid);
     cf *scr = a.p.scratch + (size_t)fl * N;
-#pragma unroll 4
+#pragma unroll
     for (int i = 0; i < CW; ++i) {
         const int e = tid + i * N1;
         const int c = e % CW, k1 = e / CW;
@@ -118,71 +111,11 @@ __global__ __launch_bounds__(N1) void scan4_cols(Scan4Args a)
     }
 }
 
-__device__ __forceinline__ float logmag4(cf X)
-{
-    const float p = __fadd_rn(__fmul_rn(X.x, X.x), __fmul_rn(X.y, X.y));
-    float l2 = log2f(p);
-    if (isinf(l2)) l2 = copysignf(127.0f, l2);
-    return __fadd_rn(__fmul_rn(l2, 0.30102999566398120f), 1.0f);
-}
-
-// grid: (N1 / CW, frames)
-template <int N2>
-__global__ __launch_bounds__(N2) void scan4_rows(Scan4Args a)
-{
-    constexpr int RS = rs4<N2>();
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf *buf = reinterpret_cast<cf *>(smem_raw);
-    cf *tw_lds = buf + CW * RS;
-    const int tid = threadIdx.x;
-    const int N1 = a.N1, N = a.p.N;
-    const int r0 = blockIdx.x * CW;
-    const int fl = blockIdx.y;
-    tw_lds[tid] = a.tw2[tid];
-    const cf *scr = a.p.scratch + (size_t)fl * N;
-#pragma unroll 4
-    for (int i = 0; i < CW; ++i) {
-        const int e = tid + i * N2;
-        const int r = e / N2, n2 = e % N2;                   // coalesced along the row
-        buf[r * RS + lds_pad(n2)] = scr[(size_t)(r0 + r) * N2 + n2];
-    }
-    __syncthreads();
-    fft16<N2>(buf, tw_lds, tid);
-    const int f = a.p.f0 + fl;
-    float *dst = a.p.vring + (size_t)(f % a.p.R) * N;
-#pragma unroll 4
-    for (int i = 0; i < CW; ++i) {
-        const int e = tid + i * N2;
-        const int r = e % CW, k2 = e / CW;
-        const int k = (r0 + r) + N1 * k2;
-        dst[(k + N / 2) & (N - 1)] = logmag4(buf[r * RS + lds_pad(k2)]);
-    }
-}
-
 template <int N1>
 void launch_cols(const Scan4Args &a, hipStream_t s)
 {
     const size_t lds = ((size_t)CW * rs4<N1>() + N1) * sizeof(cf);
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scan4_cols<N1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
     hipLaunchKernelGGL((scan4_cols<N1>), dim3(a.N2 / CW, a.p.n_frames), dim3(N1), lds, s, a);
-}
-
-template <int N2>
-void launch_rows(const Scan4Args &a, hipStream_t s)
-{
-    const size_t lds = ((size_t)CW * rs4<N2>() + N2) * sizeof(cf);
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scan4_rows<N2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
-    hipLaunchKernelGGL((scan4_rows<N2>), dim3(a.N1 / CW, a.p.n_frames), dim3(N2), lds, s, a);
 }
 
 }  // namespace
@@ -190,9 +123,7 @@ void launch_rows(const Scan4Args &a, hipStream_t s)
 bool scan4_split(int N, int *N1, int *N2)
 {
     if (N < (1 << 15) || N > (1 << 20) || (N & (N - 1))) return false;
-    int m = 0;
-    while ((1 << m) < N) ++m;
-    *N1 = 1 << (m / 2);
+    *N1 = N >= (1 << 16) ? 256 : 128;
     *N2 = N / *N1;
     return true;
 }
@@ -210,22 +141,12 @@ void launch_scan4_fft(const ScanLaunch &p, hipStream_t s)
     a.p = p;
     if (!scan4_split(p.N, &a.N1, &a.N2)) return;
     a.tw1 = p.tw;
-    a.tw2 = p.tw + a.N1;
-    a.tlo = a.tw2 + a.N2;
+    const cf *tw2 = p.tw + a.N1;
+    a.tlo = tw2 + a.N2;
     a.thi = a.tlo + 1024;
-    switch (a.N1) {
-        case 128:  launch_cols<128>(a, s); break;
-        case 256:  launch_cols<256>(a, s); break;
-        case 512:  launch_cols<512>(a, s); break;
-        case 1024: launch_cols<1024>(a, s); break;
-        default: return;
-    }
-    switch (a.N2) {
-        case 256:  launch_rows<256>(a, s); break;
-        case 512:  launch_rows<512>(a, s); break;
-        case 1024: launch_rows<1024>(a, s); break;
-        default: return;
-    }
+    if (a.N1 == 128) launch_cols<128>(a, s);
+    else             launch_cols<256>(a, s);
+    launch_scan4_rows(p, tw2, a.N1, a.N2, s);
 }
 
 }  // namespace rcfx
