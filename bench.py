@@ -180,13 +180,18 @@ def main():
         fd.commit(bd)
         fd.timing_enable(True)
         fd.timing_read(native.T_FIR)
+        fd.timing_read(native.T_FIR_MFMA)
         fd.timing_read(native.T_DISC)
         for _ in range(3):
             fd.commit(bd)
         fms, fn = fd.timing_read(native.T_FIR)
+        mms, mn = fd.timing_read(native.T_FIR_MFMA)
+        fms, fn = fms + mms, max(fn, mn)
         dms, dn = fd.timing_read(native.T_DISC)
         per_block_s = (fms / fn + dms / dn) * 1e-3
         direct = {"channels_measured": nd, "block_samples": bd, "kernel_ms_per_block": per_block_s * 1e3,
+                  "kernel": "fp32 matrix-core" if mn else "vector",
+                  "tflops_fp32": 8.0 * 2909 * (bd // 800) * nd / (fms / fn * 1e-3) / 1e12,
                   "realtime_channels_at_20Msps": nd * (bd / FS) / per_block_s}
         fd.close()
 

@@ -83,14 +83,15 @@ int rcf_device(rcf_t *h);
 /* ------------------------------------------------------------------ measurement */
 /* Per-kernel-class timing with HIP events recorded on the handle's own stream around each launch
  * (torch.cuda.Event would only see torch's stream).  Used by bench.py for roofline.achieved. */
-#define RCF_T_FIR          0   /* direct xlating-FIR bank on the wideband stream */
+#define RCF_T_FIR          0   /* direct xlating-FIR bank on the wideband stream, vector-FMA kernel */
 #define RCF_T_PFB          1   /* polyphase filterbank kernel */
 #define RCF_T_FIR_DERIVED  2   /* stage-2 / pre-filter FIRs on narrowband rings */
 #define RCF_T_DISC         3   /* discriminator */
 #define RCF_T_SCAN_FFT     4   /* scan FFT + log-magnitude */
 #define RCF_T_SCAN_MOVSUM  5   /* scan running sum */
 #define RCF_T_HISTORY      6   /* history carry-over copy */
-#define RCF_T_COUNT        7
+#define RCF_T_FIR_MFMA     7   /* the same bank on the FP32 matrix cores (>= 8 channels on one source) */
+#define RCF_T_COUNT        8
 int rcf_timing_enable(rcf_t *h, int on);
 /* accumulated milliseconds and launch count of one class since the last reset (syncs the stream) */
 int rcf_timing_read(rcf_t *h, int what, double *total_ms, int64_t *launches, int reset);

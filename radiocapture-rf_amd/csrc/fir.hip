@@ -201,6 +201,219 @@ __global__ __launch_bounds__(kThreads) void fir_bank_kernel(const ChanLaunch *__
     }
 }
 
+// ---------------------------------------------------------------- matrix-core bank
+// For >= 8 channels on one source the bank is a dense real contraction
+//   [Re y_c ; Im y_c][k] = sum_tap [ cr  -ci ; ci  cr ]_c[tap] . [Re x ; Im x][k D - tap]
+// and runs on the FP32 matrix cores (v_mfma_f32_16x16x4_f32: a sequential float32 FMA chain, i.e. the same
+// arithmetic as the vector kernel above, without one LDS read and four VALU issues per complex MAC):
+//   M = 16 rows   = 8 channels x {Re y, Im y}
+//   N = 16 cols   = 16 consecutive outputs k
+//   K = 4 per op  = 2 taps x {Re x, Im x}
+// A (taps) streams from the launch's bank matrix (rcf_internal.h), stored in MFMA lane order with the
+// [cr -ci; ci cr] signs applied: one fully coalesced 16-byte buffer load per lane covers four ops.  B (samples) is one ds_read_b32 per op from the LDS tile, whose rows of D
+// samples are skewed by one sample when D is even so that the 16 columns (stride D) fall in 16 different banks.
+// The 16-output tile is (15 D + T) samples = 119 KB at D = 800, T = 2909, so ONE workgroup owns a CU.  It runs
+// 8 waves: wave w takes channels 32 (w & 3) .. +32 (MT = 4 M-tiles x one N-tile, two accumulator sets per tile
+// to cover the MFMA latency) and HALF of the taps (w >> 2) -- a wave's own VALU / LDS / VMEM issue does not
+// overlap its MFMAs (measured: additive), the second wave on each SIMD is what fills the matrix pipe meanwhile.
+// The two halves swap partial sums through the (by then dead) tile memory and each finishes two M-tiles: a lane
+// holds complete (Re, Im) pairs of two channels for one output, so the rotator and the ring store need no
+// cross-lane step.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const v4f __attribute__((address_space(1))) *gv4;
+constexpr int MT = 4;
+constexpr int kThreadsM = 512;
+constexpr int kMfmaExchangeBytes = (kThreadsM / kWave) * 2 * 4 * kWave * 4;   // 16 KB
+
+__global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *__restrict__ chans, FirLaunchDims d)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *xf = reinterpret_cast<float *>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = blockIdx.y * d.chans_per_wg;
+    const int nc = min(d.chans_per_wg, d.n_chans - c0);
+    const ChanLaunch &L0 = chans[c0];
+    const int tile = blockIdx.x;
+    if ((int64_t)tile * 16 >= L0.n_k) return;
+    const int kt_n = min(16, L0.n_k - tile * 16);
+    const int64_t kt0 = L0.k_lo + (int64_t)tile * 16;
+    const int64_t s_tile0 = kt0 * d.D - (d.T - 1);
+    const int len = (kt_n - 1) * d.D + d.T;
+    const int delta = (d.D & 1) ? 0 : 1;
+    const int Dp = d.D + delta;
+
+    // tile load, 8 independent 8-byte loads in flight per thread (one workgroup per CU: nothing else hides HBM)
+    const StreamView sv = L0.src;
+    constexpr int LU = 8;
+    for (int p0 = tid; p0 < len; p0 += kThreadsM * LU) {
+        float2 v[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int p = p0 + u * kThreadsM;
+            const uint64_t idx = (uint64_t)(s_tile0 + (p < len ? p : len - 1) - sv.origin) & sv.mask;
+            v[u] = sv.base[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int p = p0 + u * kThreadsM;
+            if (p < len) reinterpret_cast<float2 *>(xf)[p + (p / d.D) * delta] = v[u];
+        }
+    }
+    __syncthreads();
+
+    const int j = lane & 15, kap = lane >> 4;
+    const int q = kap & 1, tp = kap >> 1;
+    const int jj = j < kt_n ? j : kt_n - 1;
+    const int lbase = jj * Dp * 2 + q;
+    const int n_steps = bank_steps(d.T);
+    const int item = wave & 3, half = wave >> 2;
+    const int cw0 = c0 + item * 8 * MT;
+    const bool active = item * 8 * MT < nc;
+
+    v4f acc[MT][2];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t][0] = acc[t][1] = (v4f){0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const int step0 = half * (n_steps >> 1), step1 = step0 + (n_steps >> 1);
+        // A operand: one buffer descriptor over the bank matrix, lane offset in a VGPR, (tile, step) offset in an
+        // SGPR -- no vector arithmetic per load
+        const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(d.bank), 0, (int)(bank_floats(d.n_chans, d.T) * sizeof(float)), 0x00020000);
+        int gbase[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            int g = (cw0 >> 3) + t;
+            if (g * 8 >= d.n_chans) g = (d.n_chans - 1) >> 3;   // dead tiles: computed, never stored
+            gbase[t] = g * n_steps;
+        }
+        const int a_voff = lane * 16;
+        // B operand: x[k D - tap] sits at LDS sample position rr + floor(rr / D) delta, rr = (T-1-tp) - 2 op.
+        // Per step (4 ops, rr spans top-7 .. top with top = T-1-8 step) the quotient is one wave-uniform value
+        // except in the few steps that straddle a multiple of D: track top's quotient / remainder in scalars.
+        const int lconst = (lbase + 2 * (d.T - 1 - tp)) * 4;
+        int top = d.T - 1 - 8 * step0;
+        int topq = top >= 0 ? top / d.D : 0;
+        int toprem = top >= 0 ? top - topq * d.D : 0;
+        auto fetch_b = [&](float (&b)[4]) {
+            if (top >= 7 && toprem >= 7) {                     // clean step: one add, four reads at fixed offsets
+                const float *pb = reinterpret_cast<const float *>(
+                    smem_raw + (lconst + 8 * (topq * delta + top - (d.T - 1)) - 48));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) b[u] = pb[(48 - 16 * u) / 4];
+            } else if (top < 0) {                              // padding taps only (zero coefficients)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) b[u] = xf[lbase];
+            } else {                                           // straddles a multiple of D, or runs into padding
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = top - tp - 2 * u;
+                    const int qd = rr >= topq * d.D ? topq : topq - 1;
+                    b[u] = xf[lbase + 2 * (rr < 0 ? 0 : rr + qd * delta)];
+                }
+            }
+            top -= 8;
+            toprem -= 8;
+            if (toprem < 0) { toprem += d.D; topq -= 1; }      // D >= 8 (mfma_tile_bytes)
+        };
+        // Four steps per trip.  A sets rotate through four register groups and are requested three steps before
+        // use, B comes from LDS one step ahead.  sched_barrier pins the issue order so the counter waits land on
+        // the first use and not on the issue.  Everything that is not an MFMA costs its issue slot on this SIMD
+        // (measured: VALU time adds to matrix time, also across the two waves of a SIMD), hence the effort above
+        // to keep a step at 16 MFMAs + 4 loads + 4 LDS reads + one add.
+        v4f a0[MT], a1[MT], a2[MT], a3[MT];
+        float b0[4], b1[4];
+        auto fetch_a = [&](v4f (&a)[MT], int step) {
+            const int sidx = step < n_steps ? step : n_steps - 1;   // past the end: harmless repeat, never used
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                a[t] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(bank_rsrc, a_voff,
+                                                                                     (gbase[t] + sidx) * 1024, 0));
+        };
+        auto mac = [&](const v4f (&a)[MT], const float (&b)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    acc[t][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][u], b[u], acc[t][u & 1], 0, 0, 0);
+        };
+        __builtin_amdgcn_sched_barrier(0);            // same issue order as the loop body, or the loop-top waits
+        fetch_a(a0, step0);                           // are sized for the worse of the two predecessors
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_a(a1, step0 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_a(a2, step0 + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_b(b0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int m4 = step0; m4 < step1; m4 += 4) {   // n_steps / 2 is a multiple of 4 (bank_steps pads to 32 ops)
+            fetch_a(a3, m4 + 3); fetch_b(b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_a(a0, m4 + 4); fetch_b(b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_a(a1, m4 + 5); fetch_b(b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(a2, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_a(a2, m4 + 6); fetch_b(b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(a3, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // the tap halves swap partial sums: half 0 finishes M-tiles 0 and 1, half 1 finishes 2 and 3
+    __syncthreads();                                  // every wave is done with the sample tile
+    v4f sum[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) sum[t] = acc[t][0] + acc[t][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const v4f give = half ? sum[i] : sum[2 + i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xf[((wave * 2 + i) * 4 + e) * kWave + lane] = give[e];
+    }
+    __syncthreads();
+    if (!active || j >= kt_n) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        v4f keep = half ? sum[2 + i] : sum[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep[e] += xf[(((wave ^ 4) * 2 + i) * 4 + e) * kWave + lane];
+        const int t = half * 2 + i;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int ci = cw0 + t * 8 + 2 * kap + hh;
+            if (ci < c0 + nc) rotate_store(chans[ci], kt0 + j, keep[2 * hh], keep[2 * hh + 1], d.ring_mask);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void fir_pack_kernel(const ChanLaunch *__restrict__ chans, int n_chans, int T,
+                                                            int n_steps, float *__restrict__ bank)
+{
+    const size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= bank_floats(n_chans, T)) return;
+    const int mm = e & 3, lane = (e >> 2) & 63;
+    const size_t gs = e >> 8;
+    const int step = (int)(gs % n_steps), g = (int)(gs / n_steps);
+    const int j = lane & 15, kap = lane >> 4;
+    const int c = j >> 1, r = j & 1, tp = kap >> 1, q = kap & 1;
+    const int tap = 2 * (4 * step + mm) + tp, ci = g * 8 + c;
+    float v = 0.f;
+    if (ci < n_chans && tap < T) {
+        const float2 ct = chans[ci].ctaps[tap];
+        v = (r == q) ? ct.x : (r == 0 ? -ct.y : ct.y);       // [cr -ci; ci cr]
+    }
+    bank[e] = v;
+}
+
 // ---------------------------------------------------------------- discriminator
 // gr::fast_atan2f: 255-interval table + linear interpolation, octant fix-up (gr-runtime fast_atan2f.cc)
 __device__ __forceinline__ float fast_atan2f_gr(float y, float x, const float *tab)
@@ -300,12 +513,33 @@ void launch_fm_level(const float *fm_ring, int64_t n_end, int window, float gain
     hipLaunchKernelGGL(fm_level_kernel, dim3(1), dim3(kThreads), 0, s, fm_ring, n_end, window, gain, ring_mask, d_out);
 }
 
+void launch_fir_pack(const ChanLaunch *d_chans, int n_chans, int T, float *bank, hipStream_t s)
+{
+    const size_t n = bank_floats(n_chans, T);
+    hipLaunchKernelGGL(fir_pack_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, d_chans,
+                       n_chans, T, bank_steps(T), bank);
+}
+
 void launch_fir_bank(const ChanLaunch *d_chans, const FirLaunchDims &dims, hipStream_t s)
 {
     if (dims.n_chans <= 0 || dims.max_n_k <= 0) return;
     if (dims.T <= 96 && dims.chans_per_wg == 1) {
         hipLaunchKernelGGL(fir_small_kernel, dim3((dims.max_n_k + kThreads - 1) / kThreads, dims.n_chans),
                            dim3(kThreads), 0, s, d_chans, dims.D, dims.T, dims.ring_mask);
+        return;
+    }
+    if (dims.mfma) {
+        static size_t attr_lds = 0;
+        size_t lds = mfma_tile_bytes(dims.D, dims.T);
+        if (lds < (size_t)kMfmaExchangeBytes) lds = kMfmaExchangeBytes;
+        if (lds > attr_lds) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fir_mfma_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_lds = lds;
+        }
+        const int groups = (dims.n_chans + dims.chans_per_wg - 1) / dims.chans_per_wg;
+        hipLaunchKernelGGL(fir_mfma_kernel, dim3((dims.max_n_k + 15) / 16, groups), dim3(kThreadsM), lds, s, d_chans,
+                           dims);
         return;
     }
     const int tiles = (dims.max_n_k + dims.KT - 1) / dims.KT;

@@ -60,6 +60,7 @@ struct Chan {
     double src_rate = 0, offset_hz = 0;
     std::vector<float> proto;     // prototype taps (host)
     float2 *d_ctaps = nullptr;
+    uint64_t taps_version = 0;    // bumped whenever d_ctaps changes (bank-matrix cache key)
     float2 *d_iq = nullptr;
     float *d_fm = nullptr;
     int64_t start_sample = 0;     // in source index space
@@ -131,9 +132,14 @@ struct rcf {
     int next_id = 1;
     Pfb pfb;
     Scan scan;
+    // bank matrices of the matrix-core FIR path, one per (D, T) class, rebuilt when membership or taps change
+    struct BankCache { std::vector<std::pair<int, uint64_t>> key; float *d = nullptr; size_t cap = 0; };
+    std::map<std::pair<int, int>, BankCache> banks;
+    uint64_t taps_clock = 0;
     std::vector<void *> graveyard;   // device buffers to free once the stream is idle
     // optional per-kernel-class HIP-event timing (rcf_timing_*)
     bool timing = false;
+    bool no_mfma = false;         // RCF_FIR_NOMFMA=1: keep the vector-FMA bank kernel (A/B measurements)
     struct TimeRec { int what; hipEvent_t a, b; };
     std::vector<TimeRec> time_pending;
     std::vector<hipEvent_t> time_pool;
@@ -237,6 +243,7 @@ int upload_composite(rcf_t *h, Chan *c)
     RCF_HIP(hipMemcpy(fresh, ct.data(), sizeof(float2) * (size_t)c->T, hipMemcpyHostToDevice));
     bury(h, c->d_ctaps);
     c->d_ctaps = fresh;
+    c->taps_version = ++h->taps_clock;
     // GR iterates phase *= incr in float32; model it by the increment's actual angle and magnitude
     c->dangle = std::atan2((double)incr[1], (double)incr[0]);
     c->dlogmag = std::log(std::hypot((double)incr[0], (double)incr[1]));
@@ -334,7 +341,7 @@ int process_block(rcf_t *h, size_t n)
     if (h->arena_used[a]) RCF_HIP(hipEventSynchronize(h->arena_ev[a]));
     Arena ar{h->h_arena[a], h->d_arena[a], 0, rcf::kArena};
 
-    struct FirJob { FirLaunchDims dims; const ChanLaunch *dev; };
+    struct FirJob { FirLaunchDims dims; const ChanLaunch *dev; bool repack; };
     struct DiscJob { const DiscLaunch *dev; int n; int max_n; };
     std::vector<std::vector<FirJob>> fir_by_depth;
     std::vector<DiscJob> disc_jobs;
@@ -383,6 +390,7 @@ int process_block(rcf_t *h, size_t n)
         for (auto &cls : classes) {
             const int D = cls.first.first, T = cls.first.second;
             std::vector<ChanLaunch> launches;
+            std::vector<Chan *> launched;
             std::vector<DiscLaunch> discs;
             int max_n = 0;
             bool shared_src = true;
@@ -421,6 +429,7 @@ int process_block(rcf_t *h, size_t n)
                 L.dlogmag = c->dlogmag;
                 L.n_k = (int32_t)cnt;
                 launches.push_back(L);
+                launched.push_back(c);
                 DiscLaunch dl{};
                 dl.iq_ring = c->d_iq;
                 dl.fm_ring = c->d_fm;
@@ -457,6 +466,32 @@ int process_block(rcf_t *h, size_t n)
             job.dims.D = D; job.dims.T = T; job.dims.KT = choose_kt(D, T);
             job.dims.n_chans = (int)launches.size();
             job.dims.chans_per_wg = shared_src ? 16 : 1;
+            // matrix-core path: one shared source, one common output range, no zero-history taps in range
+            bool mfma = shared_src && depth == 0 && launches.size() >= 8 && mfma_tile_bytes(D, T) != 0 && !h->no_mfma &&
+                        bank_floats((int)launches.size(), T) * sizeof(float) < (size_t(1) << 31);
+            for (auto &L : launches)
+                mfma = mfma && L.k_lo == launches[0].k_lo && L.n_k == launches[0].n_k &&
+                       L.k_lo * D - L.start_sample >= (int64_t)(T - 1);
+            if (mfma) {
+                rcf::BankCache &bc = h->banks[cls.first];
+                std::vector<std::pair<int, uint64_t>> key;
+                for (Chan *c : launched) key.push_back({c->id, c->taps_version});
+                job.repack = key != bc.key;
+                if (job.repack) {
+                    const size_t need = bank_floats((int)launches.size(), T);
+                    if (need > bc.cap) {
+                        bury(h, bc.d);
+                        bc.d = nullptr;
+                        bc.cap = 0;
+                        RCF_HIP(hipMalloc(&bc.d, sizeof(float) * need));
+                        bc.cap = need;
+                    }
+                    bc.key = key;
+                }
+                job.dims.mfma = 1;
+                job.dims.chans_per_wg = 128;
+                job.dims.bank = bc.d;
+            }
             job.dims.max_n_k = max_n;
             job.dims.ring_mask = h->ring_mask;
             if (!ar.put(launches, &job.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
@@ -479,7 +514,11 @@ int process_block(rcf_t *h, size_t n)
         h->arena_cur ^= 1;
     }
     if (!fir_by_depth.empty())
-        for (auto &j : fir_by_depth[0]) { Timed t(h, RCF_T_FIR); launch_fir_bank(j.dev, j.dims, st); }
+        for (auto &j : fir_by_depth[0]) {
+            if (j.repack) launch_fir_pack(j.dev, j.dims.n_chans, j.dims.T, const_cast<float *>(j.dims.bank), st);
+            Timed t(h, j.dims.mfma ? RCF_T_FIR_MFMA : RCF_T_FIR);
+            launch_fir_bank(j.dev, j.dims, st);
+        }
     if (run_pfb) { Timed t(h, RCF_T_PFB); launch_pfb(pl, st); }
     for (size_t d = 1; d < fir_by_depth.size(); ++d)
         for (auto &j : fir_by_depth[d]) { Timed t(h, RCF_T_FIR_DERIVED); launch_fir_bank(j.dev, j.dims, st); }
@@ -632,6 +671,7 @@ int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_c
     h->out_cap = pow2_at_least(out_capacity ? out_capacity : (size_t(1) << 16));
     h->ring_mask = (uint64_t)h->out_cap - 1;
     {
+        if (const char *nm = getenv("RCF_FIR_NOMFMA")) h->no_mfma = atoi(nm) != 0;
         const char *e = getenv("RCF_PFB_PITCH_PAD");
         h->bin_pitch = h->out_cap + (e ? (size_t)atol(e) : 80);
     }
@@ -664,6 +704,8 @@ int rcf_close(rcf_t *h)
     Scan &s = h->scan;
     bury(h, s.d_window); bury(h, s.d_vring); bury(h, s.d_sum); bury(h, s.d_out); bury(h, s.d_tw);
     bury(h, s.d_scratch); bury(h, s.d_peaks); bury(h, s.d_peak_ws);
+    for (auto &kv : h->banks) bury(h, kv.second.d);
+    h->banks.clear();
     bury(h, h->d_atan);
     bury(h, h->d_raw);
     bury(h, h->d_level);

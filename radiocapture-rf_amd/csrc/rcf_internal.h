@@ -53,15 +53,37 @@ struct ChanLaunch {
     int32_t pad_;
 };
 
+// Matrix-core bank operand ("bank matrix"): the composite taps of a launch's channels as the MFMA A operand,
+// in lane order, signs applied.  Group g = 8 consecutive channels of the launch (M-tile rows 2c + r, r = 0 Re y,
+// 1 Im y); step = 4 MFMA ops = 8 taps; op m covers taps 2m, 2m+1 with k-slot kap = 2 (tap & 1) + q (q = 0 times
+// Re x, 1 times Im x); lane = 16 kap + 2 c + r:
+//   bank[((g * n_steps + step) * 64 + lane) * 4 + (m & 3)] = [cr -ci; ci cr][r][q] of channel 8g + c, tap 2m + (kap >> 1)
+// zero past tap T-1 and for channels past the end of the launch.
+__host__ __device__ inline int bank_steps(int T) { return ((((T + 1) / 2) + 31) & ~31) >> 2; }
+__host__ __device__ inline size_t bank_floats(int n_chans, int T) { return (size_t)((n_chans + 7) / 8) * bank_steps(T) * 256; }
+
+// LDS bytes of the matrix-core kernel's skewed 16-output tile; 0 when that path does not apply
+inline size_t mfma_tile_bytes(int D, int T)
+{
+    if (D < 8 || T < 64) return 0;
+    const int len = 15 * D + T;
+    const size_t b = (size_t)(len + len / D + 2) * sizeof(float2);
+    return b <= 160 * 1024 ? b : 0;
+}
+
 struct FirLaunchDims {
     int D, T, KT;            // decimation, taps, outputs per workgroup tile
     int n_chans;             // entries in the ChanLaunch array
     int chans_per_wg;        // >1 only when every channel of the launch shares one source view
     int max_n_k;             // max over channels of n_k
     uint64_t ring_mask;
+    int mfma;                // 1: every channel shares source, k_lo and n_k, and no zero-history masking is needed
+    const float *bank;       // mfma: the launch's bank matrix (bank_floats(n_chans, T) floats)
 };
 
 void launch_fir_bank(const ChanLaunch *d_chans, const FirLaunchDims &dims, hipStream_t s);
+// (re)build a bank matrix from the channels' composite taps
+void launch_fir_pack(const ChanLaunch *d_chans, int n_chans, int T, float *bank, hipStream_t s);
 
 // discriminator: fm[n] = fast_atan2f(imag(y[n] conj(y[n-1])), real(.)) (unit gain), n relative index
 struct DiscLaunch {

@@ -32,7 +32,7 @@ SYMBOLS = [
     "rcf_ingest_write", "rcf_push_raw", "rcf_chan_fm_filter", "rcf_chan_read_sym", "rcf_chan_fm_level",
 ]
 FMT_U8, FMT_S8, FMT_S16 = 1, 2, 3
-T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY = range(7)
+T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY, T_FIR_MFMA = range(8)
 
 
 class RcfError(RuntimeError):

@@ -115,6 +115,40 @@ def test_multichannel_bank_gr_faithful(gpu_required, fs, cr, offsets):
         assert rms(fm, fo) < 1e-4, f
 
 
+@pytest.mark.parametrize("fs,cr,nch,D_override", [(2.4e6, 12500, 37, None), (20e6, 12500, 12, None),
+                                                  (2.4e6, 12500, 9, 75)])
+def test_matrix_core_bank_equals_oracle(gpu_required, fs, cr, nch, D_override):
+    """>= 8 channels on one source run on the FP32 matrix cores once their history is real (fir.hip
+    fir_mfma_kernel): same GR-faithful result as the oracle, including a channel count that leaves dead MFMA
+    rows (37, 12, 9), the reference's 2909-tap / 800 shape, and an odd decimation (no LDS skew)."""
+    nat = gpu_required
+    rng = np.random.default_rng(nch)
+    D, taps = G.channel_params(fs, cr)
+    if D_override:
+        D = D_override
+    T = len(taps)
+    n1 = T + 5 * D + 13                      # first block: zero-history outputs -> vector kernel
+    n_out = 150 if T > 1000 else 400
+    n = n1 + D * n_out + 7
+    x = (synth.awgn(rng, n) + synth.nbfm_carrier(n, fs, 31000.0, 700.0, 2500.0, 0.5)).astype(np.complex64)
+    offs = [float(np.round(o / 6250) * 6250) for o in np.linspace(-0.4, 0.4, nch) * fs]
+    with nat.Frontend(fs) as fe:
+        ids = [fe.chan_open_taps(-1, D, taps, f) for f in offs]
+        fe.timing_enable(True)
+        fe.push(x[:n1])
+        assert fe.timing_read(nat.T_FIR_MFMA)[1] == 0
+        fe.push(x[n1:])
+        assert fe.timing_read(nat.T_FIR_MFMA)[1] == 1      # the path under test actually ran
+        ys = [fe.chan_read_iq(c) for c in ids]
+    for f, y in zip(offs, ys):
+        ct, incr = OC.xlating_composite(taps, D, f, fs)
+        v = G.fir_decim_cc(x, ct, D)
+        ph, _, _ = G.rotator_phases(incr, len(v))
+        yo = (v * ph).astype(np.complex64)
+        assert len(y) == len(yo)
+        assert rel_rms(y, yo) < 1e-5, f
+
+
 def test_channel_opened_mid_stream_has_zero_history(gpu_required):
     nat = gpu_required
     fs, cr = 2.4e6, 12500

@@ -21,12 +21,13 @@ for _ in range(2):
 offs = np.linspace(-0.45, 0.45, C_) * fs
 ids = [fe.chan_open(cr, float(np.round(o / 6250) * 6250)) for o in offs]
 for _ in range(2): fe.commit(B)
-fe.timing_enable(True); fe.timing_read(native.T_FIR); fe.timing_read(native.T_DISC)
+fe.timing_enable(True); fe.timing_read(native.T_FIR); fe.timing_read(native.T_FIR_MFMA); fe.timing_read(native.T_DISC)
 for _ in range(steps): fe.commit(B)
-ms, n = fe.timing_read(native.T_FIR); dms, dn = fe.timing_read(native.T_DISC)
-ms /= n
+ms, n = fe.timing_read(native.T_FIR); mms, mn = fe.timing_read(native.T_FIR_MFMA); dms, dn = fe.timing_read(native.T_DISC)
+kind = 'matrix-core' if mn else 'vector'
+ms = (ms + mms) / max(n, mn)
 n_out = B // D
 flop = 8.0 * T * n_out * C_
-print("C=%d fs=%.0f D=%d T=%d block=%d: fir %.3f ms (%.1f TFLOP/s, %.1f%% of 157 TF), disc %.3f ms; "
+print(kind, "C=%d fs=%.0f D=%d T=%d block=%d: fir %.3f ms (%.1f TFLOP/s, %.1f%% of 157 TF), disc %.3f ms; "
       "real-time channels at this fs: %.0f" % (C_, fs, D, T, B, ms, flop / (ms * 1e-3) / 1e12,
       flop / (ms * 1e-3) / 157.3e12 * 100, dms / max(dn, 1), C_ * (B / fs) / (ms * 1e-3)))
