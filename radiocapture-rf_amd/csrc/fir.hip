@@ -34,6 +34,39 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// sin / cos of a float64 angle of moderate size (|a| < 1e6 rad) to ~1e-16: Cody-Waite reduction by pi/2 and the
+// Taylor polynomials on |x| <= pi/4.  The library sincos() carries a Payne-Hanek path and costs ~10x as much;
+// with eight of them per lane it was a tenth of the matrix-core bank's time.
+__device__ __forceinline__ void sincos_fast(double a, double &sn, double &cs)
+{
+    const double k = rint(a * 0.63661977236758134308);
+    double x = fma(-k, 1.57079632679489655800e+00, a);
+    x = fma(-k, 6.12323399573676603587e-17, x);
+    const double x2 = x * x;
+    double ps = -1.0 / 1307674368000.0;
+    ps = fma(ps, x2, 1.0 / 6227020800.0);
+    ps = fma(ps, x2, -1.0 / 39916800.0);
+    ps = fma(ps, x2, 1.0 / 362880.0);
+    ps = fma(ps, x2, -1.0 / 5040.0);
+    ps = fma(ps, x2, 1.0 / 120.0);
+    ps = fma(ps, x2, -1.0 / 6.0);
+    const double S = fma(x * x2, ps, x);
+    double pc = 1.0 / 20922789888000.0;
+    pc = fma(pc, x2, -1.0 / 87178291200.0);
+    pc = fma(pc, x2, 1.0 / 479001600.0);
+    pc = fma(pc, x2, -1.0 / 3628800.0);
+    pc = fma(pc, x2, 1.0 / 40320.0);
+    pc = fma(pc, x2, -1.0 / 720.0);
+    pc = fma(pc, x2, 1.0 / 24.0);
+    pc = fma(pc, x2, -0.5);
+    const double Cc = fma(x2, pc, 1.0);
+    const int nq = (int)k & 3;
+    sn = (nq & 1) ? Cc : S;
+    cs = (nq & 1) ? S : Cc;
+    if (nq == 1 || nq == 2) cs = -cs;
+    if (nq >= 2) sn = -sn;
+}
+
 // GNU Radio's rotator (phase *= incr in float32, renormalised every 512 calls) in closed form: the
 // float32 increment's true angle and magnitude drive a float64 model, rebased by the host every block.
 __device__ __forceinline__ void rotate_store(const ChanLaunch &L, int64_t k, float vr, float vi, uint64_t ring_mask)
@@ -45,8 +78,9 @@ __device__ __forceinline__ void rotate_store(const ChanLaunch &L, int64_t k, flo
     const double ang = L.angle0 + (double)dk * L.dangle;
     const double lm = (r512 > L.n_seg0) ? (double)(n - r512) * L.dlogmag : L.logmag0 + (double)dk * L.dlogmag;
     double sn, cs;
-    sincos(ang, &sn, &cs);
-    const double mag = exp(lm);
+    sincos_fast(ang, sn, cs);
+    // |lm| is a few hundred times log|incr| ~ 1e-7: four series terms are exact to double rounding
+    const double mag = fabs(lm) < 1e-3 ? 1.0 + lm * (1.0 + lm * (0.5 + lm * (1.0 / 6.0))) : exp(lm);
     const float pr = (float)(mag * cs), pi = (float)(mag * sn);
     // rotator::rotate(): z = in * phase, float32 complex multiply, unfused
     float2 y;
@@ -247,6 +281,7 @@ __global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *_
 
     // tile load, 8 independent 8-byte loads in flight per thread (one workgroup per CU: nothing else hides HBM)
     const StreamView sv = L0.src;
+    const unsigned magic = 0xffffffffu / (unsigned)d.D + 1;   // floor(p / D) = umulhi(p, magic) for p D < 2^32 / D
     constexpr int LU = 8;
     for (int p0 = tid; p0 < len; p0 += kThreadsM * LU) {
         float2 v[LU];
@@ -259,7 +294,7 @@ __global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *_
 #pragma unroll
         for (int u = 0; u < LU; ++u) {
             const int p = p0 + u * kThreadsM;
-            if (p < len) reinterpret_cast<float2 *>(xf)[p + (p / d.D) * delta] = v[u];
+            if (p < len) reinterpret_cast<float2 *>(xf)[p + (int)__umulhi((unsigned)p, magic) * delta] = v[u];
         }
     }
     __syncthreads();
@@ -282,12 +317,12 @@ __global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *_
         // SGPR -- no vector arithmetic per load
         const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(d.bank), 0, (int)(bank_floats(d.n_chans, d.T) * sizeof(float)), 0x00020000);
-        int gbase[MT];
+        int a_soff[MT];                                // byte offset of (tile, next step to fetch)
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             int g = (cw0 >> 3) + t;
             if (g * 8 >= d.n_chans) g = (d.n_chans - 1) >> 3;   // dead tiles: computed, never stored
-            gbase[t] = g * n_steps;
+            a_soff[t] = (g * n_steps + step0) * 1024;
         }
         const int a_voff = lane * 16;
         // B operand: x[k D - tap] sits at LDS sample position rr + floor(rr / D) delta, rr = (T-1-tp) - 2 op.
@@ -325,12 +360,12 @@ __global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *_
         // to keep a step at 16 MFMAs + 4 loads + 4 LDS reads + one add.
         v4f a0[MT], a1[MT], a2[MT], a3[MT];
         float b0[4], b1[4];
-        auto fetch_a = [&](v4f (&a)[MT], int step) {
-            const int sidx = step < n_steps ? step : n_steps - 1;   // past the end: harmless repeat, never used
+        auto fetch_a = [&](v4f (&a)[MT]) {               // fetches past the end of the bank return zeros (descriptor)
 #pragma unroll
-            for (int t = 0; t < MT; ++t)
-                a[t] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(bank_rsrc, a_voff,
-                                                                                     (gbase[t] + sidx) * 1024, 0));
+            for (int t = 0; t < MT; ++t) {
+                a[t] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(bank_rsrc, a_voff, a_soff[t], 0));
+                a_soff[t] += 1024;
+            }
         };
         auto mac = [&](const v4f (&a)[MT], const float (&b)[4]) {
 #pragma unroll
@@ -340,28 +375,28 @@ __global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *_
                     acc[t][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][u], b[u], acc[t][u & 1], 0, 0, 0);
         };
         __builtin_amdgcn_sched_barrier(0);            // same issue order as the loop body, or the loop-top waits
-        fetch_a(a0, step0);                           // are sized for the worse of the two predecessors
+        fetch_a(a0);                                  // are sized for the worse of the two predecessors
         __builtin_amdgcn_sched_barrier(0);
-        fetch_a(a1, step0 + 1);
+        fetch_a(a1);
         __builtin_amdgcn_sched_barrier(0);
-        fetch_a(a2, step0 + 2);
+        fetch_a(a2);
         __builtin_amdgcn_sched_barrier(0);
         fetch_b(b0);
         __builtin_amdgcn_sched_barrier(0);
         for (int m4 = step0; m4 < step1; m4 += 4) {   // n_steps / 2 is a multiple of 4 (bank_steps pads to 32 ops)
-            fetch_a(a3, m4 + 3); fetch_b(b1);
+            fetch_a(a3); fetch_b(b1);
             __builtin_amdgcn_sched_barrier(0);
             mac(a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            fetch_a(a0, m4 + 4); fetch_b(b0);
+            fetch_a(a0); fetch_b(b0);
             __builtin_amdgcn_sched_barrier(0);
             mac(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
-            fetch_a(a1, m4 + 5); fetch_b(b1);
+            fetch_a(a1); fetch_b(b1);
             __builtin_amdgcn_sched_barrier(0);
             mac(a2, b0);
             __builtin_amdgcn_sched_barrier(0);
-            fetch_a(a2, m4 + 6); fetch_b(b0);
+            fetch_a(a2); fetch_b(b0);
             __builtin_amdgcn_sched_barrier(0);
             mac(a3, b1);
             __builtin_amdgcn_sched_barrier(0);
