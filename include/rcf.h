@@ -218,7 +218,8 @@ int rcf_find_peaks(const float *spectrum, int64_t n, double min_w, double max_w,
 int64_t rcf_peak_frequency(int64_t line, double samp_rate, int64_t fft_len, double center_freq);
 /* same detection run on the device-resident result of the last scan (HIP kernels: local maxima,
  * block-skipping prominence/width walks); indices land in a device int64 buffer and are also copied to
- * idx (host) when idx != NULL. */
+ * idx (host) when idx != NULL.  At most min(cap, 4096) indices are kept (the device sort's size); *count
+ * still reports how many survived. */
 int rcf_scan_find_peaks(rcf_t *h, double prominence, int64_t *idx, int64_t cap, int64_t *count,
                         double *mean_out, void **dev_idx);
 
