@@ -11,8 +11,10 @@ import time
 
 
 class channel:
-    def __init__(self, frontend, port, channel_rate, samp_rate, offset):
-        """frontend: rcf.native.Frontend (the HBM-resident source that replaces `parent_zmq_address`)."""
+    def __init__(self, frontend, port, channel_rate, samp_rate, offset, parent_chan=None):
+        """frontend: rcf.native.Frontend (the HBM-resident source that replaces `parent_zmq_address`).
+        parent_chan: channel id of a receiver_split2 half-band source (receiver.py:205-237) this channel
+        reads instead of the wideband stream; samp_rate is then that half's rate."""
         self.frontend = frontend
         self.samp_rate = samp_rate
         self.channel_rate = channel_rate
@@ -23,7 +25,14 @@ class channel:
         self.block_id = None
         # rc_frontend/channel.py:31-35: decim = int(fs/cr)/2, low_pass_2(1.0, fs, cr/2, cr/2, 20, HAMMING);
         # the C ABI derives both (rcf_chan_open) and rejects non-integral decimations
-        self.chan_id = frontend.chan_open(channel_rate, offset)
+        if parent_chan is None:
+            self.chan_id = frontend.chan_open(channel_rate, offset)
+        else:
+            from . import native
+            decim, ntaps = native.channel_params(samp_rate, channel_rate)
+            taps = native.design_low_pass_2(1.0, samp_rate, channel_rate / 2, channel_rate / 2, 20.0)
+            assert len(taps) == ntaps
+            self.chan_id = frontend.chan_open_taps(parent_chan, decim, taps, offset)
         info = frontend.chan_info(self.chan_id)
         self.decim = info["decim"]
         self.ntaps = info["ntaps"]

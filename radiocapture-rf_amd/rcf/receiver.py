@@ -48,6 +48,22 @@ class receiver:
         for source in sorted(self.realsources):
             src = self.realsources[source]
             fe = frontend_factory(float(src["samp_rate"]), float(src["center_freq"]), device)
+            if getattr(config, "receiver_split2", False):
+                # receiver.py:205-237: each source becomes two half-rate sources, centre -/+ fs/4, through
+                # freq_xlating_fir_filter_ccc(2, firdes.low_pass(1, fs, fs/4, fs/8), -/+fs/4, fs).
+                # firdes.low_pass(...) == low_pass_2(..., 53 dB, HAMMING): same body, and compute_ntaps uses
+                # window::max_attenuation(HAMMING) = 53 where low_pass_2 takes the attenuation argument.
+                from . import native
+                fs = float(src["samp_rate"])
+                taps = native.design_low_pass_2(1.0, fs, fs / 4, fs / 8, 53.0)
+                for sign in (-1.0, +1.0):
+                    half = fe.chan_open_taps(-1, 2, taps, sign * fs / 4)
+                    self.sources[numsources] = {
+                        "center_freq": src["center_freq"] + sign * fs / 4, "samp_rate": src["samp_rate"] / 2,
+                        "block": fe, "source_id": source, "offset": src.get("offset", 0), "parent_chan": half,
+                    }
+                    numsources += 1
+                continue
             self.sources[numsources] = {
                 "center_freq": src["center_freq"], "samp_rate": src["samp_rate"],
                 "block": fe, "source_id": source, "offset": src.get("offset", 0),
@@ -61,8 +77,17 @@ class receiver:
 
     # ------------------------------------------------------------------ data plane
     def feed(self, source_id, iq):
-        """Deliver wideband cf32 samples for one source (replaces source -> pub_sink, receiver.py:201)."""
-        self.sources[source_id]["block"].push(iq)
+        """Deliver wideband cf32 samples for one source (replaces source -> pub_sink, receiver.py:201).
+        With receiver_split2 both halves of a real source share one front-end: feed either, once."""
+        src = self.sources[source_id]
+        if "parent_chan" in src:
+            # the half-band channel writes n/2 samples per push into a ring of the front-end's out_capacity
+            # (default 2^16): deliver in pieces that fit, block cuts do not change the result
+            step = src.get("feed_chunk", 1 << 16)
+            for at in range(0, len(iq), step):
+                src["block"].push(iq[at:at + step])
+            return
+        src["block"].push(iq)
 
     # ------------------------------------------------------------------ control plane
     def connect_channel(self, channel_rate, freq):
@@ -106,7 +131,8 @@ class receiver:
                     break
             if block is None:
                 port = random.randint(10000, 60000)         # receiver.py:323 (kept: the egress pump binds it)
-                block = channel_mod.channel(frontend, port, channel_rate, source_samp_rate, offset)
+                block = channel_mod.channel(frontend, port, channel_rate, source_samp_rate, offset,
+                                            parent_chan=self.sources[source_id].get("parent_chan"))
                 block.source_id = source_id
                 block.block_id = "%s" % uuid.uuid4()
                 self.channels[block.block_id] = block
@@ -176,5 +202,5 @@ class receiver:
             for c in list(self.channels):
                 self.channels[c].destroy()
             self.channels.clear()
-            for s in self.sources.values():
-                s["block"].close()
+            for fe in {id(s["block"]): s["block"] for s in self.sources.values()}.values():
+                fe.close()

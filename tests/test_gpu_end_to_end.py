@@ -105,3 +105,40 @@ def test_egress_pump_publishes_bare_cf32_bytes(gpu_required):
         assert FakePub.made[port].closed and pump.socks == {}
     finally:
         tb.close()
+
+
+def test_receiver_split2_chain_equals_two_stage_oracle(gpu_required):
+    """receiver_split2 (receiver.py:205-237): source -> /2 half-band xlating FIR at -/+fs/4 -> the channel's
+    own xlating FIR at the half rate.  The chained device path equals the two GNU Radio blocks in series."""
+    x, meta = synth.cfg1(seconds=0.1)
+    fs = meta["fs"]
+    cfg = types.SimpleNamespace(
+        sources={0: dict(type="synthetic", center_freq=meta["center_freq"], samp_rate=int(fs))},
+        frontend_mode="xlat", receiver_split2=True)
+    tb = receiver.receiver(cfg)
+    try:
+        bid, _ = tb.connect_channel(12500, meta["freq"])
+        ch = tb.channels[bid]
+        src = tb.sources[ch.source_id]
+        sign = -1.0 if src["center_freq"] < meta["center_freq"] else 1.0
+        assert src["samp_rate"] == fs / 2 and ch.decim == 48
+        cut = len(x) // 3 + 77
+        tb.feed(ch.source_id, x[:cut])
+        tb.feed(ch.source_id, x[cut:])
+        y = ch.read_iq()
+    finally:
+        tb.close()
+    t1 = G.low_pass_2(1.0, fs, fs / 4, fs / 8, 53.0)
+    assert len(t1) == 19
+    ct1, incr1 = OC.xlating_composite(t1, 2, sign * fs / 4, fs)
+    v1 = G.fir_decim_cc(x, ct1, 2)
+    ph1, _, _ = G.rotator_phases(incr1, len(v1))
+    h = (v1 * ph1).astype(np.complex64)
+    D2, t2 = G.channel_params(fs / 2, 12500)
+    ct2, incr2 = OC.xlating_composite(t2, D2, ch.offset, fs / 2)
+    v2 = G.fir_decim_cc(h, ct2, D2)
+    ph2, _, _ = G.rotator_phases(incr2, len(v2))
+    yo = (v2 * ph2).astype(np.complex64)
+    assert len(y) == len(yo) > 100
+    err = np.sqrt(np.mean(np.abs(y - yo) ** 2)) / np.sqrt(np.mean(np.abs(yo) ** 2))
+    assert err < 2e-5

@@ -205,6 +205,76 @@ def test_retune_keeps_phase_and_history(gpu_required):
     assert rel_rms(y, yo) < 1e-5
 
 
+def test_matrix_core_bank_survives_retune_close_and_open(gpu_required):
+    """The matrix-core path caches a per-class bank matrix keyed by (channel ids, tap versions): a retune
+    must repack it, a closed channel must leave it, a newly opened channel sends the class through the
+    vector kernel while its history is zero and joins the matrix afterwards."""
+    nat = gpu_required
+    fs, cr = 2.4e6, 12500
+    rng = np.random.default_rng(77)
+    D, taps = G.channel_params(fs, cr)
+    T = len(taps)
+    seg = [T + 3 * D + 5, 200 * D, 150 * D + 11, 8 * D + 3, 170 * D]          # warm-up, A, B, C (new channel warms), E
+    cuts = np.cumsum([0] + seg)
+    x = synth.awgn(rng, int(cuts[-1]))
+    offs = [float(np.round(o / 6250) * 6250) for o in np.linspace(-0.4, 0.4, 11) * fs]
+    f_new, f_retune = 193750.0, -506250.0
+    with nat.Frontend(fs) as fe:
+        ids = [fe.chan_open(cr, f) for f in offs]
+        fe.timing_enable(True)
+        fe.push(x[cuts[0]:cuts[1]])
+        fe.push(x[cuts[1]:cuts[2]])                                  # A: matrix-core
+        assert fe.timing_read(nat.T_FIR_MFMA, reset=False)[1] == 1
+        fe.chan_set_offset(ids[3], f_retune)
+        fe.chan_close(ids[5])
+        fe.push(x[cuts[2]:cuts[3]])                                  # B: matrix-core, repacked (10 channels)
+        assert fe.timing_read(nat.T_FIR_MFMA, reset=False)[1] == 2
+        late = fe.chan_open(cr, f_new)
+        fe.push(x[cuts[3]:cuts[4]])                                  # C: new channel has zero history -> vector
+        assert fe.timing_read(nat.T_FIR_MFMA, reset=False)[1] == 2
+        fe.push(x[cuts[4]:cuts[5]])                                  # E: matrix-core again, 11 channels
+        assert fe.timing_read(nat.T_FIR_MFMA, reset=False)[1] == 3
+        ys = {c: fe.chan_read_iq(c) for c in ids if c != ids[5]}
+        y_late = fe.chan_read_iq(late)
+
+    def bank(xs, f, k0=0):
+        ct, incr = OC.xlating_composite(taps, D, f, fs)
+        v = G.fir_decim_cc(xs, ct, D)[k0:]
+        ph, _, _ = G.rotator_phases(incr, len(v))
+        return (v * ph).astype(np.complex64)
+
+    for c, f in zip(ids, offs):
+        if c in (ids[3], ids[5]):
+            continue
+        yo = bank(x, f)
+        assert len(ys[c]) == len(yo) and rel_rms(ys[c], yo) < 1e-5, f
+    # the late channel: zero history before its start, outputs on the absolute decimation grid
+    start = int(cuts[3])
+    xz = x.copy()
+    xz[:start] = 0
+    yo = bank(xz, f_new, -(-start // D))
+    assert len(y_late) == len(yo) and rel_rms(y_late, yo) < 1e-5
+    # the retuned channel: rotator phase carried across the retune (oracle's stateful C path)
+    import ctypes as C
+    L = OC.lib()
+    st = OC.RotState(1.0, 0.0, 0)
+    xp = np.concatenate([np.zeros(T - 1, np.complex64), x])
+    base = xp.view(np.float32)[2 * (T - 1):]
+    fp = C.POINTER(C.c_float)
+    n_tot = (len(x) - 1) // D + 1
+    k_cut = -(-int(cuts[2]) // D)
+    yo = np.empty(n_tot, dtype=np.complex64)
+    for (f, k0, k1) in ((offs[3], 0, k_cut), (f_retune, k_cut, n_tot)):
+        ct, incr = OC.xlating_composite(taps, D, f, fs)
+        inc = np.array([incr], dtype=np.complex64)
+        sg = np.empty(k1 - k0, dtype=np.complex64)
+        L.ro_xlating_fir_ccc(base.ctypes.data_as(fp), k0, k1 - k0, D, ct.view(np.float32).ctypes.data_as(fp),
+                             T, inc.view(np.float32).ctypes.data_as(fp), C.byref(st),
+                             sg.view(np.float32).ctypes.data_as(fp), 1)
+        yo[k0:k1] = sg
+    assert len(ys[ids[3]]) == n_tot and rel_rms(ys[ids[3]], yo) < 1e-5
+
+
 def _pfb_proto(fs, nb):
     # SURVEY 8(d) cfg2 prototype: low_pass_2 rule, fc = bin/2.5, tw = bin/5, 60 dB, Blackman-Harris
     bw = fs / nb

@@ -79,9 +79,15 @@ class StubFrontend:
         self.chans[cid] = dict(cr=cr, off=off, D=q // 2)
         return cid
 
+    def chan_open_taps(self, src, decim, taps, off):
+        cid = self.next
+        self.next += 1
+        self.chans[cid] = dict(cr=None, off=off, D=int(decim), src=src, ntaps=len(taps))
+        return cid
+
     def chan_info(self, cid):
         c = self.chans[cid]
-        return dict(decim=c["D"], ntaps=1, out_rate=self.samp_rate / c["D"], offset_hz=c["off"])
+        return dict(decim=c["D"], ntaps=c.get("ntaps", 1), out_rate=self.samp_rate / c["D"], offset_hz=c["off"])
 
     def chan_set_offset(self, cid, off):
         self.chans[cid]["off"] = off
@@ -213,3 +219,30 @@ def test_registry_publish_and_expiry():
     pub.publish_once(now=200.0)
     other.poll_once(now=200.5)
     assert other.channelizers == {}                      # index filter (redis_channelizer_manager.py:94)
+
+
+def test_receiver_split2_makes_two_half_rate_sources_per_real_source():
+    """receiver.py:205-237: centre -/+ fs/4, rate fs/2, through a /2 xlating FIR with firdes.low_pass taps;
+    channels of a half are chained behind it with channel.py's rule at the HALF rate."""
+    cfg = types.SimpleNamespace(
+        sources={0: dict(type="synthetic", center_freq=855000000, samp_rate=2400000)},
+        frontend_mode="xlat", scan_mode=False, receiver_split2=True)
+    StubFrontend.instances = []
+    tb = receiver.receiver(cfg, frontend_factory=StubFrontend)
+    assert len(StubFrontend.instances) == 1 and len(tb.sources) == 2
+    fe = StubFrontend.instances[0]
+    lo, hi = tb.sources[0], tb.sources[1]
+    assert (lo["center_freq"], lo["samp_rate"]) == (855000000 - 600000, 1200000)
+    assert (hi["center_freq"], hi["samp_rate"]) == (855000000 + 600000, 1200000)
+    halves = [fe.chans[lo["parent_chan"]], fe.chans[hi["parent_chan"]]]
+    assert [h["off"] for h in halves] == [-600000.0, 600000.0]
+    assert all(h["D"] == 2 and h["src"] == -1 for h in halves)
+    # firdes.low_pass(1, fs, fs/4, fs/8): int(53 fs / (22 fs/8)) = 19 taps (odd already)
+    assert halves[0]["ntaps"] == 19
+    bid, port = tb.connect_channel(12500, 855000000 + 500000)      # nearest centre: the upper half
+    ch = tb.channels[bid]
+    assert ch.source_id == 1 and ch.offset == 500000 - 600000
+    c = fe.chans[ch.chan_id]
+    assert c["src"] == hi["parent_chan"] and c["D"] == 48          # int(1.2e6 / 12500) / 2
+    tb.close()
+    assert fe.closed
