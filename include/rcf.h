@@ -40,6 +40,7 @@ typedef struct rcf rcf_t;
 /* window types: numeric values follow gnuradio.filter.firdes.WIN_* */
 #define RCF_WIN_HAMMING          0
 #define RCF_WIN_BLACKMAN         2
+#define RCF_WIN_KAISER           4   /* takes beta */
 #define RCF_WIN_BLACKMAN_HARRIS  5
 
 /* ------------------------------------------------------------------ library / device */
@@ -56,6 +57,20 @@ int rcf_design_low_pass_2(double gain, double fs, double fc, double tw, double a
                           float *taps, int cap);
 /* gnuradio.fft.window.{hamming,blackman,blackmanharris}(n) (fft_vector.py:38) */
 int rcf_design_window(int window, int n, float *w);
+/* firdes.low_pass / firdes.high_pass (gain, fs, cutoff, transition, window, beta): tap count from the window's
+ * max_attenuation (Hamming 53, Blackman 74, Blackman-harris 92, Kaiser beta/0.1102+8.7).  Used by the analog
+ * voice chain: firdes.high_pass(1, rate, 300, 30, WIN_HAMMING, 6.76) (logging_receiver.py:215) and the
+ * rational resampler's Kaiser low-pass.  Same return convention as rcf_design_low_pass_2. */
+#define RCF_FIR_LOW_PASS   0
+#define RCF_FIR_HIGH_PASS  1
+int rcf_design_firdes(int kind, double gain, double fs, double fc, double tw, int window, double beta,
+                      float *taps, int cap);
+/* analog.fm_deemph(fs, tau) (gr-analog fm_emph.py): bilinear 1-pole/1-zero section -> iir_filter_ffd taps */
+int rcf_design_fm_deemph(double fs, double tau, double btaps[2], double ataps[2]);
+/* rational_resampler_fff(interpolation, decimation, taps=None, fractional_bw=None) (logging_receiver.py:216-221):
+ * reduces by the gcd and designs firdes.low_pass(I, I, mid, width, WIN_KAISER, 7.0) with fractional_bw 0.4.
+ * Writes the reduced ratio; same return convention for the taps. */
+int rcf_design_resampler(int interpolation, int decimation, int *interp_out, int *decim_out, float *taps, int cap);
 /* rc_frontend/channel.py:31-33: decim = int(fs/cr)/2 (must be integral -> else RCF_ERANGE) and the
  * tap count of low_pass_2(1.0, fs, cr/2, cr/2, 20.0, WIN_HAMMING). */
 int rcf_channel_params(double samp_rate, int channel_rate, int *decim, int *ntaps);
@@ -91,7 +106,8 @@ int rcf_device(rcf_t *h);
 #define RCF_T_SCAN_MOVSUM  5   /* scan running sum */
 #define RCF_T_HISTORY      6   /* history carry-over copy */
 #define RCF_T_FIR_MFMA     7   /* the same bank on the FP32 matrix cores (>= 8 channels on one source) */
-#define RCF_T_COUNT        8
+#define RCF_T_AUDIO        8   /* analog voice chain (squelch/demod/de-emphasis walk, FIRs, resampler) */
+#define RCF_T_COUNT        9
 int rcf_timing_enable(rcf_t *h, int on);
 /* accumulated milliseconds and launch count of one class since the last reset (syncs the stream) */
 int rcf_timing_read(rcf_t *h, int what, double *total_ms, int64_t *launches, int reset);
@@ -161,6 +177,37 @@ int64_t rcf_chan_read_sym(rcf_t *h, int chan_id, float *out, size_t max_samples)
  * discriminator output (window = 10000 there) == mean of gain*fm over the last `window` samples; this is
  * the value demod_watcher hands to frontend_connector.report_offset */
 int rcf_chan_fm_level(rcf_t *h, int chan_id, float gain, int window, float *level);
+/* Analog NBFM voice chain behind a channel (logging_receiver.py:211-222, file_to_wav.py:109-122):
+ *   analog.pwr_squelch_cc(db, alpha, 0, True)           gates (drops) samples while the smoothed power is low
+ *   analog.fm_demod_cf(...) = quadrature_demod_cf(k) -> fm_deemph(rate, tau) -> fir_filter_fff(1, audio_taps)
+ *   filter.fir_filter_fff(1, firdes.high_pass(...))
+ *   filter.rational_resampler_fff(8000, rate)
+ * The chain starts, with zero state, at the channel's next output.  The squelch and the de-emphasis IIR are
+ * sequential per channel (one lane per channel walks the new samples); the FIRs and the resampler run one
+ * thread per output.  Taps are the caller's (rcf/audio.py derives them as the reference's calls do). */
+typedef struct rcf_audio_params {
+    double squelch_db;        /* pwr_squelch_cc threshold, dB */
+    double squelch_alpha;     /* its single-pole power filter */
+    float quad_gain;          /* quadrature_demod_cf gain k = rate / (2 pi deviation) */
+    int reserved_;
+    double deemph_b[2];       /* iir_filter_ffd(btaps, ataps, False); {1,0},{1,0} = no de-emphasis */
+    double deemph_a[2];
+    const float *lpf_taps;    /* audio low-pass, fir_filter_fff(1, taps) */
+    int n_lpf;
+    int n_hpf;
+    const float *hpf_taps;    /* 300 Hz high-pass */
+    const float *rs_taps;     /* rational_resampler_base_fff(interpolation, decimation, taps) */
+    int n_rs;
+    int interpolation;
+    int decimation;
+    int reserved2_;
+} rcf_audio_params_t;
+int rcf_chan_audio_open(rcf_t *h, int chan_id, const rcf_audio_params_t *p);
+int rcf_chan_audio_close(rcf_t *h, int chan_id);
+/* audio samples (resampler outputs) produced so far / samples that passed the squelch (syncs the stream) */
+int rcf_chan_audio_produced(rcf_t *h, int chan_id, int64_t *n_audio, int64_t *n_ungated);
+/* unread audio samples, oldest first; returns the count or a negative error */
+int64_t rcf_chan_read_audio(rcf_t *h, int chan_id, float *out, size_t max_samples);
 /* device pointers of the channel's rings (cf32 iq ring, f32 unit-gain discriminator ring) and their
  * power-of-two capacity: sample k lives at index k & (capacity-1) */
 int rcf_chan_rings(rcf_t *h, int chan_id, void **iq_ring, void **fm_ring, size_t *capacity);

@@ -73,6 +73,18 @@ struct Chan {
     float sym_gain = 1.f;
     int64_t sym_from = 0;         // first relative output index the filter is defined for
     int64_t rd_sym = 0;
+    // analog voice chain (rcf_chan_audio_open)
+    struct Audio {
+        AudioState *d_state = nullptr;
+        float *d_rings = nullptr;       // a | l | h | o, out_cap floats each
+        float *d_taps = nullptr;        // lpf | hpf | rs (padded)
+        int n_lpf = 0, n_hpf = 0, nt_rs = 0, interp = 1, decim = 1;
+        float gain = 1.f;
+        double thr = 0, alpha = 0, b0 = 1, b1 = 0, fb1 = 0;
+        int64_t from = 0;               // first relative channel output the chain consumes
+        int64_t rd = 0;                 // audio samples handed to the reader
+    };
+    std::unique_ptr<Audio> audio;
     // rotator model
     double dangle = 0, dlogmag = 0;
     long double angle0 = 0;
@@ -297,6 +309,7 @@ void free_channel(rcf_t *h, Chan *c)
     bury(h, c->d_fm);
     bury(h, c->d_sym);
     bury(h, c->d_symtaps);
+    if (c->audio) { bury(h, c->audio->d_state); bury(h, c->audio->d_rings); bury(h, c->audio->d_taps); c->audio.reset(); }
     c->d_sym = nullptr;
     c->d_symtaps = nullptr;
     c->d_ctaps = nullptr;
@@ -347,6 +360,10 @@ int process_block(rcf_t *h, size_t n)
     std::vector<DiscJob> disc_jobs;
     std::vector<FmFirLaunch> symf;     // symbol filters, all channels in one launch
     int symf_max_n = 0;
+    std::vector<AudioLaunch> audf;     // analog voice chains, all channels in one set of launches
+    int audf_max_n = 0;
+    double audf_ratio = 0;
+    int audf_num = 1, audf_den = 1;
 
     // ---- PFB bookkeeping first (derived channels need its new range)
     PfbLaunch pl{};
@@ -450,6 +467,37 @@ int process_block(rcf_t *h, size_t n)
                     if (fl.n_k > 0) symf.push_back(fl);
                     symf_max_n = std::max(symf_max_n, (int)cnt);
                 }
+                if (c->audio) {
+                    Chan::Audio &au = *c->audio;
+                    AudioLaunch al{};
+                    al.iq_ring = c->d_iq;
+                    al.st = au.d_state;
+                    al.a_ring = au.d_rings;
+                    al.l_ring = au.d_rings + h->out_cap;
+                    al.h_ring = au.d_rings + 2 * h->out_cap;
+                    al.o_ring = au.d_rings + 3 * h->out_cap;
+                    al.lpf = au.d_taps;
+                    al.hpf = au.d_taps + au.n_lpf;
+                    al.rs = au.d_taps + au.n_lpf + au.n_hpf;
+                    al.n_lo = std::max(dl.n_lo, au.from);
+                    al.n_k = (int32_t)(dl.n_lo + dl.n_k - al.n_lo);
+                    al.n_lpf = au.n_lpf; al.n_hpf = au.n_hpf; al.nt_rs = au.nt_rs;
+                    al.interp = au.interp; al.decim = au.decim;
+                    al.gain = au.gain;
+                    al.thr = au.thr; al.alpha = au.alpha; al.b0 = au.b0; al.b1 = au.b1; al.fb1 = au.fb1;
+                    if (al.n_k > 0) {
+                        const size_t reach = (size_t)std::max(std::max(au.n_lpf, au.n_hpf), au.nt_rs);
+                        if ((size_t)al.n_k + reach > h->out_cap) {
+                            set_error("block yields %d channel samples: audio rings of %zu too small", al.n_k, h->out_cap);
+                            return RCF_ECAP;
+                        }
+                        audf.push_back(al);
+                        audf_max_n = std::max(audf_max_n, (int)al.n_k);
+                        if ((double)au.interp / au.decim > audf_ratio) {
+                            audf_ratio = (double)au.interp / au.decim; audf_num = au.interp; audf_den = au.decim;
+                        }
+                    }
+                }
                 // advance channel state: rebase the rotator model at the next output index
                 const int64_t n_next = k_hi - c->k_abs0 + 1;
                 const int64_t r512 = n_next & ~(int64_t)511;
@@ -505,6 +553,8 @@ int process_block(rcf_t *h, size_t n)
 
     const FmFirLaunch *d_symf = nullptr;
     if (!symf.empty() && !ar.put(symf, &d_symf)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+    const AudioLaunch *d_audf = nullptr;
+    if (!audf.empty() && !ar.put(audf, &d_audf)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
 
     // ---- upload all launch parameters in one copy, then launch in dependency order
     if (ar.used) {
@@ -529,6 +579,10 @@ int process_block(rcf_t *h, size_t n)
     if (d_symf) {
         Timed t(h, RCF_T_DISC);
         launch_fm_fir(d_symf, (int)symf.size(), symf_max_n, h->ring_mask, st);
+    }
+    if (d_audf) {
+        Timed t(h, RCF_T_AUDIO);
+        launch_audio(d_audf, (int)audf.size(), audf_max_n, audf_num, audf_den, h->ring_mask, h->d_atan, st);
     }
 
     // ---- scan
@@ -968,6 +1022,132 @@ int64_t rcf_chan_read_sym(rcf_t *h, int chan_id, float *out, size_t max_samples)
     FIND_CHAN(h, chan_id, c);
     if (!c->d_sym) { set_error("channel %d has no fm filter", chan_id); return RCF_ESTATE; }
     return ring_read(h, c->d_sym, sizeof(float), c->produced, &c->rd_sym, out, max_samples);
+}
+
+int rcf_chan_audio_open(rcf_t *h, int chan_id, const rcf_audio_params_t *p)
+{
+    if (!h || !p || !p->lpf_taps || !p->hpf_taps || !p->rs_taps || p->n_lpf < 1 || p->n_hpf < 1 || p->n_rs < 1 ||
+        p->interpolation < 1 || p->decimation < 1 || p->deemph_a[0] == 0.0) {
+        set_error("bad audio chain arguments");
+        return RCF_EINVAL;
+    }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    FIND_CHAN(h, chan_id, c);
+    const int I = p->interpolation;
+    const int n_rs_pad = (p->n_rs + I - 1) / I * I;              // rational_resampler_base: pad to a multiple of I
+    const size_t reach = (size_t)std::max(std::max(p->n_lpf, p->n_hpf), n_rs_pad / I);
+    if (reach * 2 > h->out_cap) { set_error("ring of %zu too small for %zu-tap audio filters", h->out_cap, reach); return RCF_ECAP; }
+    std::unique_ptr<Chan::Audio> au(new Chan::Audio);
+    au->n_lpf = p->n_lpf; au->n_hpf = p->n_hpf; au->nt_rs = n_rs_pad / I;
+    au->interp = I; au->decim = p->decimation;
+    au->gain = p->quad_gain;
+    au->thr = std::pow(10.0, p->squelch_db / 10);                // pwr_squelch_cc::set_threshold
+    au->alpha = p->squelch_alpha;
+    // iir_filter(fftaps, fbtaps, oldstyle = false): feedback taps are negated, a[0] must be 1
+    au->b0 = p->deemph_b[0]; au->b1 = p->deemph_b[1]; au->fb1 = -p->deemph_a[1];
+    std::vector<float> taps((size_t)p->n_lpf + p->n_hpf + n_rs_pad, 0.0f);
+    std::memcpy(taps.data(), p->lpf_taps, sizeof(float) * (size_t)p->n_lpf);
+    std::memcpy(taps.data() + p->n_lpf, p->hpf_taps, sizeof(float) * (size_t)p->n_hpf);
+    std::memcpy(taps.data() + p->n_lpf + p->n_hpf, p->rs_taps, sizeof(float) * (size_t)p->n_rs);
+    RCF_HIP(hipMalloc(&au->d_taps, sizeof(float) * taps.size()));
+    RCF_HIP(hipMemcpy(au->d_taps, taps.data(), sizeof(float) * taps.size(), hipMemcpyHostToDevice));
+    RCF_HIP(hipMalloc(&au->d_rings, sizeof(float) * 4 * h->out_cap));
+    RCF_HIP(hipMemsetAsync(au->d_rings, 0, sizeof(float) * 4 * h->out_cap, h->stream));
+    AudioState st0{};
+    st0.muted = 1;                                               // squelch_base_cc starts in ST_MUTED
+    RCF_HIP(hipMalloc(&au->d_state, sizeof(AudioState)));
+    RCF_HIP(hipMemcpy(au->d_state, &st0, sizeof(st0), hipMemcpyHostToDevice));
+    au->from = c->produced;                                      // a new flowgraph: zero state from here on
+    if (c->audio) { bury(h, c->audio->d_state); bury(h, c->audio->d_rings); bury(h, c->audio->d_taps); }
+    c->audio = std::move(au);
+    return RCF_OK;
+}
+
+int rcf_chan_audio_close(rcf_t *h, int chan_id)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    FIND_CHAN(h, chan_id, c);
+    if (c->audio) { bury(h, c->audio->d_state); bury(h, c->audio->d_rings); bury(h, c->audio->d_taps); c->audio.reset(); }
+    return RCF_OK;
+}
+
+static int audio_counts(rcf_t *h, Chan *c, int64_t *n_audio, int64_t *n_ungated)
+{
+    AudioState st{};
+    RCF_HIP(hipMemcpyAsync(&st, c->audio->d_state, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    RCF_HIP(hipStreamSynchronize(h->stream));
+    const int64_t I = c->audio->interp, D = c->audio->decim;
+    *n_ungated = st.n_a;
+    *n_audio = (st.n_a * I + D - 1) / D;
+    return RCF_OK;
+}
+
+int rcf_chan_audio_produced(rcf_t *h, int chan_id, int64_t *n_audio, int64_t *n_ungated)
+{
+    if (!h || !n_audio) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    FIND_CHAN(h, chan_id, c);
+    if (!c->audio) { set_error("channel %d has no audio chain", chan_id); return RCF_ESTATE; }
+    int64_t a = 0, u = 0;
+    const int rc = audio_counts(h, c, &a, &u);
+    if (rc != RCF_OK) return rc;
+    *n_audio = a;
+    if (n_ungated) *n_ungated = u;
+    return RCF_OK;
+}
+
+int64_t rcf_chan_read_audio(rcf_t *h, int chan_id, float *out, size_t max_samples)
+{
+    if (!h || !out) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    FIND_CHAN(h, chan_id, c);
+    if (!c->audio) { set_error("channel %d has no audio chain", chan_id); return RCF_ESTATE; }
+    int64_t a = 0, u = 0;
+    const int rc = audio_counts(h, c, &a, &u);
+    if (rc != RCF_OK) return rc;
+    return ring_read(h, c->audio->d_rings + 3 * h->out_cap, sizeof(float), a, &c->audio->rd, out, max_samples);
+}
+
+int rcf_design_firdes(int kind, double gain, double fs, double fc, double tw, int window, double beta, float *taps,
+                      int cap)
+{
+    if (fs <= 0 || tw <= 0 || (kind != RCF_FIR_LOW_PASS && kind != RCF_FIR_HIGH_PASS) ||
+        design_max_attenuation(window, beta) <= 0) {
+        set_error("bad design arguments");
+        return RCF_EINVAL;
+    }
+    const int n = design_ntaps(fs, tw, design_max_attenuation(window, beta));
+    if (!taps || cap < n) return -n;
+    std::vector<float> t = design_firdes(kind, gain, fs, fc, tw, window, beta);
+    std::memcpy(taps, t.data(), sizeof(float) * (size_t)n);
+    return n;
+}
+
+int rcf_design_fm_deemph(double fs, double tau, double btaps[2], double ataps[2])
+{
+    if (fs <= 0 || tau <= 0 || !btaps || !ataps) { set_error("bad de-emphasis arguments"); return RCF_EINVAL; }
+    design_fm_deemph(fs, tau, btaps, ataps);
+    return RCF_OK;
+}
+
+int rcf_design_resampler(int interpolation, int decimation, int *interp_out, int *decim_out, float *taps, int cap)
+{
+    if (interpolation < 1 || decimation < 1) { set_error("bad resampler ratio"); return RCF_EINVAL; }
+    int a = interpolation, b = decimation;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const int I = interpolation / a, D = decimation / a;
+    if (interp_out) *interp_out = I;
+    if (decim_out) *decim_out = D;
+    std::vector<float> t = design_resampler(I, D);
+    const int n = (int)t.size();
+    if (!taps || cap < n) return -n;
+    std::memcpy(taps, t.data(), sizeof(float) * (size_t)n);
+    return n;
 }
 
 int rcf_chan_fm_level(rcf_t *h, int chan_id, float gain, int window, float *level)

@@ -11,7 +11,11 @@
 namespace rcfx {
 
 // ---------------------------------------------------------------- host design helpers (rcf_design.cpp)
-void design_window(int type, int n, float *w);
+void design_window(int type, int n, float *w, double beta = 6.76);
+double design_max_attenuation(int window, double beta);
+std::vector<float> design_firdes(int kind, double gain, double fs, double fc, double tw, int window, double beta);
+void design_fm_deemph(double fs, double tau, double b[2], double a[2]);
+std::vector<float> design_resampler(int interpolation, int decimation);
 int design_ntaps(double fs, double tw, double att_db);
 std::vector<float> design_low_pass_2(double gain, double fs, double fc, double tw, double att_db, int window);
 void design_composite(const float *taps, int T, int D, double f0, double fs,
@@ -113,6 +117,33 @@ void launch_fm_fir(const FmFirLaunch *d_items, int n_items, int max_n_k, uint64_
 // mean of gain * fm over the last `window` samples ending at n_end (exclusive), one workgroup
 void launch_fm_level(const float *fm_ring, int64_t n_end, int window, float gain, uint64_t ring_mask, float *d_out,
                      hipStream_t s);
+
+// ---------------------------------------------------------------- analog voice chain (audio.hip)
+// per-channel running state, device resident, owned by audio_front_kernel
+struct AudioState {
+    double pwr;              // pwr_squelch_cc's single_pole_iir<double> output
+    double iir_px, iir_py;   // iir_filter_ffd history: previous input, previous (double) output
+    float2 prev;             // previous sample that passed the squelch (quadrature_demod history)
+    int32_t muted;           // squelch_base state: 1 = ST_MUTED
+    int32_t pad_;
+    int64_t n_a;             // samples that passed the squelch so far == outputs of demod / de-emphasis
+    int64_t n_prev;          // n_a before the current block (the later stages work on [n_prev, n_a))
+};
+struct AudioLaunch {
+    const float2 *iq_ring;
+    AudioState *st;
+    float *a_ring, *l_ring, *h_ring, *o_ring;   // de-emphasised fm, after audio LPF, after HPF, 8 kHz audio
+    const float *lpf, *hpf, *rs;                // rs: rational_resampler taps zero-padded to a multiple of interp
+    int64_t n_lo;            // first relative channel output index to consume
+    int32_t n_k;             // channel outputs to consume
+    int32_t n_lpf, n_hpf, nt_rs;                // nt_rs = taps per polyphase arm
+    int32_t interp, decim;
+    float gain;
+    int32_t pad_;
+    double thr, alpha, b0, b1, fb1;
+};
+void launch_audio(const AudioLaunch *d_items, int n_items, int max_n_k, int max_interp_over_decim_num,
+                  int max_interp_over_decim_den, uint64_t ring_mask, const float *d_atan_table, hipStream_t s);
 
 // ---------------------------------------------------------------- polyphase filterbank
 struct PfbLaunch {

@@ -81,6 +81,16 @@ class channel:
     def read_iq(self, max_samples=1 << 20):
         return self.frontend.chan_read_iq(self.chan_id, max_samples)
 
+    def attach_analog_voice(self, **kw):
+        """Run the reference's analog voice chain (logging_receiver.py:211-222: pwr_squelch_cc -> fm_demod_cf ->
+        300 Hz high-pass -> rational_resampler to 8 kHz) on this channel's stream on the GPU; the consumer then
+        reads finished 8 kHz float audio instead of 2 x channel_rate complex samples."""
+        from . import audio
+        audio.open_analog_voice(self.frontend, self.chan_id, self.out_rate, **kw)
+
+    def read_audio(self, max_samples=1 << 20):
+        return self.frontend.chan_read_audio(self.chan_id, max_samples)
+
     def read_fm(self, gain, max_samples=1 << 20):
         """analog.quadrature_demod_cf(gain) of the channel stream (p25_control_demod.py:120-121)."""
         return self.frontend.chan_read_fm(self.chan_id, gain, max_samples)

@@ -16,7 +16,8 @@ _lib = None
 
 RCF_OK, RCF_EINVAL, RCF_ENOMEM, RCF_EHIP, RCF_ENOCHAN = 0, -1, -2, -3, -4
 RCF_ECAP, RCF_ESTATE, RCF_EAGAIN, RCF_ERANGE = -5, -6, -7, -8
-WIN_HAMMING, WIN_BLACKMAN, WIN_BLACKMAN_HARRIS = 0, 2, 5
+WIN_HAMMING, WIN_BLACKMAN, WIN_KAISER, WIN_BLACKMAN_HARRIS = 0, 2, 4, 5
+FIR_LOW_PASS, FIR_HIGH_PASS = 0, 1
 SRC_PFB_BIN0 = 0x40000000
 
 # every symbol include/rcf.h declares (tests check the library exports all of them)
@@ -30,9 +31,20 @@ SYMBOLS = [
     "rcf_scan_result", "rcf_scan_frames_done", "rcf_scan_result_device", "rcf_find_peaks",
     "rcf_peak_frequency", "rcf_scan_find_peaks", "rcf_timing_enable", "rcf_timing_read",
     "rcf_ingest_write", "rcf_push_raw", "rcf_chan_fm_filter", "rcf_chan_read_sym", "rcf_chan_fm_level",
+    "rcf_design_firdes", "rcf_design_fm_deemph", "rcf_design_resampler", "rcf_chan_audio_open",
+    "rcf_chan_audio_close", "rcf_chan_audio_produced", "rcf_chan_read_audio",
 ]
 FMT_U8, FMT_S8, FMT_S16 = 1, 2, 3
-T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY, T_FIR_MFMA = range(8)
+T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY, T_FIR_MFMA, T_AUDIO = range(9)
+
+
+class AudioParams(C.Structure):
+    """rcf_audio_params_t (include/rcf.h)"""
+    _fields_ = [("squelch_db", C.c_double), ("squelch_alpha", C.c_double), ("quad_gain", C.c_float),
+                ("reserved_", C.c_int), ("deemph_b", C.c_double * 2), ("deemph_a", C.c_double * 2),
+                ("lpf_taps", C.POINTER(C.c_float)), ("n_lpf", C.c_int), ("n_hpf", C.c_int),
+                ("hpf_taps", C.POINTER(C.c_float)), ("rs_taps", C.POINTER(C.c_float)), ("n_rs", C.c_int),
+                ("interpolation", C.c_int), ("decimation", C.c_int), ("reserved2_", C.c_int)]
 
 
 class RcfError(RuntimeError):
@@ -72,6 +84,13 @@ def lib():
         "rcf_chan_fm_filter": (C.c_int, [vp, C.c_int, C.c_float, fp, C.c_int]),
         "rcf_chan_read_sym": (i64, [vp, C.c_int, fp, sz]),
         "rcf_chan_fm_level": (C.c_int, [vp, C.c_int, C.c_float, C.c_int, fp]),
+        "rcf_design_firdes": (C.c_int, [C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_double, fp, C.c_int]),
+        "rcf_design_fm_deemph": (C.c_int, [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "rcf_design_resampler": (C.c_int, [C.c_int, C.c_int, ip, ip, fp, C.c_int]),
+        "rcf_chan_audio_open": (C.c_int, [vp, C.c_int, C.POINTER(AudioParams)]),
+        "rcf_chan_audio_close": (C.c_int, [vp, C.c_int]),
+        "rcf_chan_audio_produced": (C.c_int, [vp, C.c_int, C.POINTER(i64), C.POINTER(i64)]),
+        "rcf_chan_read_audio": (i64, [vp, C.c_int, fp, sz]),
         "rcf_samples_in": (i64, [vp]),
         "rcf_chan_open": (C.c_int, [vp, C.c_int, C.c_double, ip]),
         "rcf_chan_open_taps": (C.c_int, [vp, C.c_int, C.c_int, fp, C.c_int, C.c_double, ip]),
@@ -131,6 +150,35 @@ def design_low_pass_2(gain, fs, fc, tw, att_db, window=WIN_HAMMING) -> np.ndarra
     taps = np.empty(n, dtype=np.float32)
     _check(L.rcf_design_low_pass_2(gain, fs, fc, tw, att_db, window, _fp(taps), n))
     return taps
+
+
+def design_firdes(kind, gain, fs, fc, tw, window=WIN_HAMMING, beta=6.76) -> np.ndarray:
+    """firdes.low_pass / firdes.high_pass(gain, fs, fc, tw, window, beta)"""
+    L = lib()
+    n = -L.rcf_design_firdes(kind, gain, fs, fc, tw, window, beta, None, 0)
+    if n <= 0:
+        _check(-n if n else RCF_EINVAL)
+    taps = np.empty(n, dtype=np.float32)
+    _check(L.rcf_design_firdes(kind, gain, fs, fc, tw, window, beta, _fp(taps), n))
+    return taps
+
+
+def design_fm_deemph(fs, tau=75e-6):
+    b, a = (C.c_double * 2)(), (C.c_double * 2)()
+    _check(lib().rcf_design_fm_deemph(fs, tau, b, a))
+    return [b[0], b[1]], [a[0], a[1]]
+
+
+def design_resampler(interpolation, decimation):
+    """-> (interp, decim, taps) of rational_resampler_fff(interpolation, decimation) with default taps"""
+    L = lib()
+    i, d = C.c_int(), C.c_int()
+    n = -L.rcf_design_resampler(int(interpolation), int(decimation), C.byref(i), C.byref(d), None, 0)
+    if n <= 0:
+        _check(-n if n else RCF_EINVAL)
+    taps = np.empty(n, dtype=np.float32)
+    _check(L.rcf_design_resampler(int(interpolation), int(decimation), C.byref(i), C.byref(d), _fp(taps), n))
+    return i.value, d.value, taps
 
 
 def design_window(window, n) -> np.ndarray:
@@ -286,6 +334,36 @@ class Frontend:
         v = C.c_float()
         _check(lib().rcf_chan_fm_level(self._h, cid, float(gain), int(window), C.byref(v)))
         return v.value
+
+    def chan_audio_open(self, cid, squelch_db, squelch_alpha, quad_gain, deemph_b, deemph_a, lpf_taps, hpf_taps,
+                        interpolation, decimation, rs_taps):
+        """analog voice chain behind a channel (rcf_chan_audio_open); rcf.audio.analog_chain_params builds the
+        arguments the way the reference's GNU Radio calls do"""
+        lpf = np.ascontiguousarray(lpf_taps, dtype=np.float32)
+        hpf = np.ascontiguousarray(hpf_taps, dtype=np.float32)
+        rs = np.ascontiguousarray(rs_taps, dtype=np.float32)
+        p = AudioParams()
+        p.squelch_db, p.squelch_alpha, p.quad_gain = float(squelch_db), float(squelch_alpha), float(quad_gain)
+        p.deemph_b[0], p.deemph_b[1] = float(deemph_b[0]), float(deemph_b[1])
+        p.deemph_a[0], p.deemph_a[1] = float(deemph_a[0]), float(deemph_a[1])
+        p.lpf_taps, p.n_lpf = _fp(lpf), len(lpf)
+        p.hpf_taps, p.n_hpf = _fp(hpf), len(hpf)
+        p.rs_taps, p.n_rs = _fp(rs), len(rs)
+        p.interpolation, p.decimation = int(interpolation), int(decimation)
+        _check(lib().rcf_chan_audio_open(self._h, cid, C.byref(p)))
+
+    def chan_audio_close(self, cid):
+        _check(lib().rcf_chan_audio_close(self._h, cid))
+
+    def chan_audio_produced(self, cid):
+        a, u = C.c_int64(), C.c_int64()
+        _check(lib().rcf_chan_audio_produced(self._h, cid, C.byref(a), C.byref(u)))
+        return a.value, u.value
+
+    def chan_read_audio(self, cid, max_samples=1 << 20) -> np.ndarray:
+        out = np.empty(max_samples, dtype=np.float32)
+        n = _check(lib().rcf_chan_read_audio(self._h, cid, _fp(out), max_samples))
+        return out[:n].copy()
 
     def source_shift(self, delta_hz):
         _check(lib().rcf_source_shift(self._h, float(delta_hz)))
