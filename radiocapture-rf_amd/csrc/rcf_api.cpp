@@ -76,7 +76,7 @@ struct Chan {
     // analog voice chain (rcf_chan_audio_open)
     struct Audio {
         AudioState *d_state = nullptr;
-        float *d_rings = nullptr;       // a | l | h | o, out_cap floats each
+        float *d_rings = nullptr;       // a | l | h | o | c (cf32), out_cap samples each
         float *d_taps = nullptr;        // lpf | hpf | rs (padded)
         int n_lpf = 0, n_hpf = 0, nt_rs = 0, interp = 1, decim = 1;
         float gain = 1.f;
@@ -476,6 +476,7 @@ int process_block(rcf_t *h, size_t n)
                     al.l_ring = au.d_rings + h->out_cap;
                     al.h_ring = au.d_rings + 2 * h->out_cap;
                     al.o_ring = au.d_rings + 3 * h->out_cap;
+                    al.c_ring = reinterpret_cast<float2 *>(au.d_rings + 4 * h->out_cap);
                     al.lpf = au.d_taps;
                     al.hpf = au.d_taps + au.n_lpf;
                     al.rs = au.d_taps + au.n_lpf + au.n_hpf;
@@ -1052,8 +1053,8 @@ int rcf_chan_audio_open(rcf_t *h, int chan_id, const rcf_audio_params_t *p)
     std::memcpy(taps.data() + p->n_lpf + p->n_hpf, p->rs_taps, sizeof(float) * (size_t)p->n_rs);
     RCF_HIP(hipMalloc(&au->d_taps, sizeof(float) * taps.size()));
     RCF_HIP(hipMemcpy(au->d_taps, taps.data(), sizeof(float) * taps.size(), hipMemcpyHostToDevice));
-    RCF_HIP(hipMalloc(&au->d_rings, sizeof(float) * 4 * h->out_cap));
-    RCF_HIP(hipMemsetAsync(au->d_rings, 0, sizeof(float) * 4 * h->out_cap, h->stream));
+    RCF_HIP(hipMalloc(&au->d_rings, sizeof(float) * 6 * h->out_cap));
+    RCF_HIP(hipMemsetAsync(au->d_rings, 0, sizeof(float) * 6 * h->out_cap, h->stream));
     AudioState st0{};
     st0.muted = 1;                                               // squelch_base_cc starts in ST_MUTED
     RCF_HIP(hipMalloc(&au->d_state, sizeof(AudioState)));

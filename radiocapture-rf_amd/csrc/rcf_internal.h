@@ -123,7 +123,6 @@ void launch_fm_level(const float *fm_ring, int64_t n_end, int window, float gain
 struct AudioState {
     double pwr;              // pwr_squelch_cc's single_pole_iir<double> output
     double iir_px, iir_py;   // iir_filter_ffd history: previous input, previous (double) output
-    float2 prev;             // previous sample that passed the squelch (quadrature_demod history)
     int32_t muted;           // squelch_base state: 1 = ST_MUTED
     int32_t pad_;
     int64_t n_a;             // samples that passed the squelch so far == outputs of demod / de-emphasis
@@ -132,6 +131,7 @@ struct AudioState {
 struct AudioLaunch {
     const float2 *iq_ring;
     AudioState *st;
+    float2 *c_ring;                             // samples that passed the squelch, compacted
     float *a_ring, *l_ring, *h_ring, *o_ring;   // de-emphasised fm, after audio LPF, after HPF, 8 kHz audio
     const float *lpf, *hpf, *rs;                // rs: rational_resampler taps zero-padded to a multiple of interp
     int64_t n_lo;            // first relative channel output index to consume

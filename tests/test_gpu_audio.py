@@ -43,6 +43,7 @@ def test_analog_voice_chain_equals_oracle(gpu_required):
     st = A.analog_chain(y, 25000.0, stages=True)
     assert n_ungated == len(st["gated"]) == len(y)                         # noise keeps the squelch open
     assert len(audio) == n_audio == len(st["audio"]) == (len(y) * 8 + 24) // 25
+    print("audio rms error vs oracle: %.3e (signal rms %.3f)" % (rms(audio, st["audio"]), rms(audio, 0 * audio)))
     assert rms(audio, st["audio"]) < 1e-4
     # and it is the 1 kHz tone (deviation 2.5 kHz -> 8 * 2500 / 15000 = 1.33 before de-emphasis)
     seg = audio[1500:].astype(np.float64)
