@@ -69,10 +69,8 @@ __device__ __forceinline__ void sincos_fast(double a, double &sn, double &cs)
 
 // GNU Radio's rotator (phase *= incr in float32, renormalised every 512 calls) in closed form: the
 // float32 increment's true angle and magnitude drive a float64 model, rebased by the host every block.
-__device__ __forceinline__ void rotate_store(const ChanLaunch &L, int64_t k, float vr, float vi, uint64_t ring_mask)
+__device__ __forceinline__ float2 rotate_value(const ChanLaunch &L, int64_t n, float vr, float vi)
 {
-    if (k < L.k_lo || k >= L.k_lo + L.n_k || k < L.k_abs0) return;
-    const int64_t n = k - L.k_abs0;
     const int64_t dk = n - L.n_seg0;
     const int64_t r512 = n & ~(int64_t)511;
     const double ang = L.angle0 + (double)dk * L.dangle;
@@ -86,7 +84,43 @@ __device__ __forceinline__ void rotate_store(const ChanLaunch &L, int64_t k, flo
     float2 y;
     y.x = __fsub_rn(__fmul_rn(vr, pr), __fmul_rn(vi, pi));
     y.y = __fadd_rn(__fmul_rn(vr, pi), __fmul_rn(vi, pr));
-    L.iq_ring[(uint64_t)n & ring_mask] = y;
+    return y;
+}
+
+__device__ __forceinline__ void rotate_store(const ChanLaunch &L, int64_t k, float vr, float vi, uint64_t ring_mask)
+{
+    if (k < L.k_lo || k >= L.k_lo + L.n_k || k < L.k_abs0) return;
+    const int64_t n = k - L.k_abs0;
+    L.iq_ring[(uint64_t)n & ring_mask] = rotate_value(L, n, vr, vi);
+}
+
+// gr::fast_atan2f: 255-interval table + linear interpolation, octant fix-up (gr-runtime fast_atan2f.cc)
+__device__ __forceinline__ float fast_atan2f_gr(float y, float x, const float *tab)
+{
+    const float TAN_MAP_RES = 0.003921569f;
+    const float PI = 3.14159265358979323846f, PI_2 = 1.57079632679489661923f;
+    const float ya = fabsf(y), xa = fabsf(x);
+    if (!((ya > 0.0f) || (xa > 0.0f))) return 0.0f;
+    const float z = (ya < xa) ? __fdiv_rn(ya, xa) : __fdiv_rn(xa, ya);
+    float base;
+    if (z < TAN_MAP_RES) {
+        base = z;
+    } else {
+        float alpha = __fmul_rn(z, 255.0f);
+        const int index = ((int)alpha) & 0xff;
+        alpha = __fsub_rn(alpha, (float)index);
+        const float t0 = tab[index], t1 = tab[index + 1];
+        base = __fadd_rn(t0, __fmul_rn(__fsub_rn(t1, t0), alpha));
+    }
+    float angle;
+    if (xa > ya) {
+        if (x >= 0.0f) angle = (y >= 0.0f) ? base : -base;
+        else           angle = (y >= 0.0f) ? __fsub_rn(PI, base) : __fsub_rn(base, PI);
+    } else {
+        if (y >= 0.0f) angle = (x >= 0.0f) ? __fsub_rn(PI_2, base) : __fadd_rn(PI_2, base);
+        else           angle = (x >= 0.0f) ? __fadd_rn(-PI_2, base) : __fsub_rn(-PI_2, base);
+    }
+    return angle;
 }
 
 template <bool MASK>
@@ -164,30 +198,64 @@ __device__ __forceinline__ void fir_item(const float2 *xs, const ChanLaunch *__r
     }
 }
 
-// Small-T path (stage-2 FIRs on narrowband rings, e.g. D = 3, T = 11; the P25 69-tap pre-filter):
-// one thread per output, taps broadcast from the scalar cache, the few overlapping input reads served
-// by L1.  The lanes-over-taps kernel above would idle 53 of 64 lanes at T = 11.
-__global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *__restrict__ chans, int D, int T,
-                                                             uint64_t ring_mask)
+// Small-T path (stage-2 FIRs on narrowband rings, e.g. D = 3, T = 11; the P25 69-tap pre-filter): one thread per
+// output (the lanes-over-taps kernel above would idle 53 of 64 lanes at T = 11).  A workgroup stages the
+// KB D + T input samples of its KB outputs (plus the output just before them) in LDS with coalesced loads,
+// taps come from the scalar cache, and the FM discriminator is fused in: outputs meet their predecessor in LDS,
+// thread 0 recomputes the one that belongs to the previous workgroup.  One launch and one pass over the channel
+// stream instead of two (the stage-2 FIR + discriminator pair was 22 % of the bench step).
+__global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *__restrict__ chans, int D, int T, int KB,
+                                                             uint64_t ring_mask, const float *__restrict__ atan_tab)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *xs = reinterpret_cast<float2 *>(smem_raw);          // KB D + T samples
+    float2 *ys = xs + (size_t)KB * D + T;                        // KB + 1 outputs: ys[t] = y[k0 - 1 + t]
+    float2 *cts = ys + KB + 1;                                   // T composite taps
+    float *tab = reinterpret_cast<float *>(cts + T);             // 257 + pad
     const ChanLaunch &L = chans[blockIdx.y];
-    const int j = blockIdx.x * kThreads + threadIdx.x;
-    if (j >= L.n_k) return;
-    const int64_t k = L.k_lo + j;
-    const int64_t s0 = k * (int64_t)D;
-    const int64_t lim = s0 - L.start_sample;             // taps i <= lim see real samples
-    const int tmax = lim + 1 < (int64_t)T ? (int)(lim + 1) : T;
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * KB;
+    if (j0 >= L.n_k) return;
+    const int nj = min(KB, L.n_k - j0);
+    for (int i = tid; i < 257; i += kThreads) tab[i] = atan_tab[i];
+    for (int i = tid; i < T; i += kThreads) cts[i] = L.ctaps[i];
+    // samples (k0 - 1) D - (T - 1) .. (k0 + nj - 1) D, zero before the channel's start (GR zero history)
+    const int64_t k0 = L.k_lo + j0;
+    const int64_t s_first = (k0 - 1) * (int64_t)D - (T - 1);
+    const int len = nj * D + T;
     const StreamView sv = L.src;
-    float ar = 0.f, ai = 0.f;
-    for (int i = 0; i < tmax; ++i) {
-        const float2 t = L.ctaps[i];
-        const float2 xv = sv.base[(uint64_t)(s0 - i - sv.origin) & sv.mask];
-        ar = fmaf(t.x, xv.x, ar);
-        ar = fmaf(-t.y, xv.y, ar);
-        ai = fmaf(t.x, xv.y, ai);
-        ai = fmaf(t.y, xv.x, ai);
+    for (int p = tid; p < len; p += kThreads) {
+        const int64_t sidx = s_first + p;
+        xs[p] = sidx >= L.start_sample ? sv.base[(uint64_t)(sidx - sv.origin) & sv.mask] : make_float2(0.f, 0.f);
     }
-    rotate_store(L, k, ar, ai, ring_mask);
+    __syncthreads();
+    // thread t computes y[k0 - 1 + t]: t = 0 is the predecessor the discriminator needs (it belongs to the previous
+    // workgroup or launch and is only recomputed, not stored), t = 1 .. nj are this workgroup's outputs (KB <= 255)
+    const int64_t n = k0 - 1 + tid - L.k_abs0;                  // relative output index
+    float2 y = make_float2(0.f, 0.f);
+    if (tid <= nj && n >= 0) {
+        const float2 *w = xs + (size_t)tid * D + (T - 1);       // x[(k0 - 1 + tid) D - i] = w[-i]
+        float ar = 0.f, ai = 0.f;
+        for (int i = 0; i < T; ++i) {
+            const float2 c = cts[i];
+            const float2 xv = w[-i];
+            ar = fmaf(c.x, xv.x, ar);
+            ar = fmaf(-c.y, xv.y, ar);
+            ai = fmaf(c.x, xv.y, ai);
+            ai = fmaf(c.y, xv.x, ai);
+        }
+        y = rotate_value(L, n, ar, ai);
+        if (tid >= 1) L.iq_ring[(uint64_t)n & ring_mask] = y;
+    }
+    if (tid <= nj) ys[tid] = y;                                  // n < 0: quadrature_demod's zero history
+    __syncthreads();
+    if (tid >= 1 && tid <= nj) {
+        const float2 b = ys[tid - 1];
+        // volk_32fc_x2_multiply_conjugate_32fc: a * conj(b), unfused
+        const float tr = __fadd_rn(__fmul_rn(y.x, b.x), __fmul_rn(y.y, b.y));
+        const float ti = __fsub_rn(__fmul_rn(y.y, b.x), __fmul_rn(y.x, b.y));
+        L.fm_ring[(uint64_t)n & ring_mask] = fast_atan2f_gr(ti, tr, tab);
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void fir_bank_kernel(const ChanLaunch *__restrict__ chans, FirLaunchDims d)
@@ -450,35 +518,6 @@ __global__ __launch_bounds__(kThreads) void fir_pack_kernel(const ChanLaunch *__
 }
 
 // ---------------------------------------------------------------- discriminator
-// gr::fast_atan2f: 255-interval table + linear interpolation, octant fix-up (gr-runtime fast_atan2f.cc)
-__device__ __forceinline__ float fast_atan2f_gr(float y, float x, const float *tab)
-{
-    const float TAN_MAP_RES = 0.003921569f;
-    const float PI = 3.14159265358979323846f, PI_2 = 1.57079632679489661923f;
-    const float ya = fabsf(y), xa = fabsf(x);
-    if (!((ya > 0.0f) || (xa > 0.0f))) return 0.0f;
-    const float z = (ya < xa) ? __fdiv_rn(ya, xa) : __fdiv_rn(xa, ya);
-    float base;
-    if (z < TAN_MAP_RES) {
-        base = z;
-    } else {
-        float alpha = __fmul_rn(z, 255.0f);
-        const int index = ((int)alpha) & 0xff;
-        alpha = __fsub_rn(alpha, (float)index);
-        const float t0 = tab[index], t1 = tab[index + 1];
-        base = __fadd_rn(t0, __fmul_rn(__fsub_rn(t1, t0), alpha));
-    }
-    float angle;
-    if (xa > ya) {
-        if (x >= 0.0f) angle = (y >= 0.0f) ? base : -base;
-        else           angle = (y >= 0.0f) ? __fsub_rn(PI, base) : __fsub_rn(base, PI);
-    } else {
-        if (y >= 0.0f) angle = (x >= 0.0f) ? __fsub_rn(PI_2, base) : __fadd_rn(PI_2, base);
-        else           angle = (x >= 0.0f) ? __fadd_rn(-PI_2, base) : __fsub_rn(-PI_2, base);
-    }
-    return angle;
-}
-
 __global__ __launch_bounds__(kThreads) void disc_kernel(const DiscLaunch *__restrict__ items, uint64_t ring_mask,
                                                         const float *__restrict__ atan_tab)
 {
@@ -558,9 +597,11 @@ void launch_fir_pack(const ChanLaunch *d_chans, int n_chans, int T, float *bank,
 void launch_fir_bank(const ChanLaunch *d_chans, const FirLaunchDims &dims, hipStream_t s)
 {
     if (dims.n_chans <= 0 || dims.max_n_k <= 0) return;
-    if (dims.T <= 96 && dims.chans_per_wg == 1) {
-        hipLaunchKernelGGL(fir_small_kernel, dim3((dims.max_n_k + kThreads - 1) / kThreads, dims.n_chans),
-                           dim3(kThreads), 0, s, d_chans, dims.D, dims.T, dims.ring_mask);
+    if (dims.small) {
+        const int KB = fir_small_outputs(dims.D, dims.T);
+        const size_t lds = ((size_t)KB * dims.D + 2 * dims.T + KB + 1) * sizeof(float2) + 264 * sizeof(float);
+        hipLaunchKernelGGL(fir_small_kernel, dim3((dims.max_n_k + KB - 1) / KB, dims.n_chans), dim3(kThreads), lds, s,
+                           d_chans, dims.D, dims.T, KB, dims.ring_mask, dims.atan_tab);
         return;
     }
     if (dims.mfma) {

@@ -151,6 +151,7 @@ struct rcf {
     std::vector<void *> graveyard;   // device buffers to free once the stream is idle
     // optional per-kernel-class HIP-event timing (rcf_timing_*)
     bool timing = false;
+    unsigned timing_mask = ~0u;
     bool no_mfma = false;         // RCF_FIR_NOMFMA=1: keep the vector-FMA bank kernel (A/B measurements)
     struct TimeRec { int what; hipEvent_t a, b; };
     std::vector<TimeRec> time_pending;
@@ -193,7 +194,7 @@ struct Timed {   // RAII: brackets the launches issued in its scope with two eve
     rcf_t *h; int what; hipEvent_t a = nullptr;
     Timed(rcf_t *h_, int what_) : h(h_), what(what_)
     {
-        if (h->timing) { a = time_event(h); (void)hipEventRecord(a, h->stream); }
+        if (h->timing && (h->timing_mask >> what & 1u)) { a = time_event(h); (void)hipEventRecord(a, h->stream); }
     }
     ~Timed()
     {
@@ -434,6 +435,7 @@ int process_block(rcf_t *h, size_t n)
                 if ((size_t)cnt > h->out_cap) { set_error("block yields %lld outputs > ring capacity", (long long)cnt); return RCF_ECAP; }
                 ChanLaunch L{};
                 L.ctaps = c->d_ctaps;
+                L.fm_ring = c->d_fm;
                 L.iq_ring = c->d_iq;
                 L.src = sr.view;
                 L.k_lo = k_lo;
@@ -544,11 +546,15 @@ int process_block(rcf_t *h, size_t n)
             job.dims.max_n_k = max_n;
             job.dims.ring_mask = h->ring_mask;
             if (!ar.put(launches, &job.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+            job.dims.small = (!shared_src && fir_small_outputs(D, T) > 0) ? 1 : 0;
+            job.dims.atan_tab = h->d_atan;
             fir_by_depth[depth].push_back(job);
-            DiscJob dj{};
-            dj.n = (int)discs.size(); dj.max_n = max_n;
-            if (!ar.put(discs, &dj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
-            disc_jobs.push_back(dj);
+            if (!job.dims.small) {                  // the small-T kernel writes the discriminator ring itself
+                DiscJob dj{};
+                dj.n = (int)discs.size(); dj.max_n = max_n;
+                if (!ar.put(discs, &dj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+                disc_jobs.push_back(dj);
+            }
         }
     }
 
@@ -796,6 +802,7 @@ int rcf_timing_enable(rcf_t *h, int on)
     RCF_HIP(hipStreamSynchronize(h->stream));
     time_collect(h);
     h->timing = on != 0;
+    h->timing_mask = on == 1 ? ~0u : (unsigned)on >> 1;      // 1 = every class, else bit (class + 1)
     return RCF_OK;
 }
 

@@ -55,6 +55,7 @@ struct ChanLaunch {
     double logmag0, dlogmag; // rotator magnitude model (log |phase|)
     int32_t n_k;             // outputs to produce
     int32_t pad_;
+    float *fm_ring;          // discriminator ring (written by the fused small-T kernel only)
 };
 
 // Matrix-core bank operand ("bank matrix"): the composite taps of a launch's channels as the MFMA A operand,
@@ -75,6 +76,15 @@ inline size_t mfma_tile_bytes(int D, int T)
     return b <= 160 * 1024 ? b : 0;
 }
 
+// outputs per workgroup of the small-T kernel (tile of KB D + T samples within ~48 KB of LDS); 0 = not applicable
+inline int fir_small_outputs(int D, int T)
+{
+    if (T > 96) return 0;
+    int kb = (6000 - T) / D;
+    if (kb > 255) kb = 255;          // 256 threads: one recomputes the predecessor output for the discriminator
+    return kb >= 32 ? kb : 0;
+}
+
 struct FirLaunchDims {
     int D, T, KT;            // decimation, taps, outputs per workgroup tile
     int n_chans;             // entries in the ChanLaunch array
@@ -83,6 +93,8 @@ struct FirLaunchDims {
     uint64_t ring_mask;
     int mfma;                // 1: every channel shares source, k_lo and n_k, and no zero-history masking is needed
     const float *bank;       // mfma: the launch's bank matrix (bank_floats(n_chans, T) floats)
+    int small;               // 1: one-thread-per-output kernel with the discriminator fused in (no DiscLaunch)
+    const float *atan_tab;   // small: gr::fast_atan2f table
 };
 
 void launch_fir_bank(const ChanLaunch *d_chans, const FirLaunchDims &dims, hipStream_t s);

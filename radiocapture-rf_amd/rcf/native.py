@@ -247,8 +247,14 @@ class Frontend:
         return lib().rcf_samples_in(self._h)
 
     # -- measurement
-    def timing_enable(self, on=True):
-        _check(lib().rcf_timing_enable(self._h, 1 if on else 0))
+    def timing_enable(self, on=True, classes=None):
+        """classes: iterable of T_* to time only those (each timed launch costs two event records)"""
+        v = 1 if on else 0
+        if on and classes is not None:
+            v = 0
+            for c in classes:
+                v |= 1 << (int(c) + 1)
+        _check(lib().rcf_timing_enable(self._h, v))
 
     def timing_read(self, what, reset=True):
         ms, n = C.c_double(), C.c_int64()
