@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void copy_scatter(const float2* __restrict__ i
 }
 
 
-template <int SEG, int LDSPAD>
+template <int SEG, int LDSPAD, int TILED = 0>
 __global__ __launch_bounds__(256) void copy_scatter_buf(const float2* __restrict__ in, float2* __restrict__ out,
                                                        int n_frames, int fpw, long pitch, long in_len) {
     extern __shared__ float2 dbuf[];
@@ -59,8 +59,9 @@ __global__ __launch_bounds__(256) void copy_scatter_buf(const float2* __restrict
         for (int f = 0; f < SEG; ++f) dbuf[f * RS + tid + (LDSPAD ? (tid >> 4) : 0)] = make_float2(__uint_as_float(r[f].x), __uint_as_float(r[f].y));
         __syncthreads();
         const int fl = tid % SEG, k0 = tid / SEG;
-        const int so = (int)((long)(256 / SEG) * pitch * 8);
-        const int vo2 = (int)(((long)k0 * pitch + (f0 + ch + fl)) * 8);
+        // TILED: [chunk][bin][SEG frames] -- one contiguous 256 * SEG * 8 bytes per chunk
+        const int so = TILED ? (256 / SEG) * SEG * 8 : (int)((long)(256 / SEG) * pitch * 8);
+        const int vo2 = TILED ? (int)((((f0 + ch) / SEG) * 256 + k0) * SEG * 8 + fl * 8) : (int)(((long)k0 * pitch + (f0 + ch + fl)) * 8);
 #pragma unroll
         for (int i = 0; i < SEG; ++i) {
             const int k = k0 + i * (256 / SEG);
@@ -83,14 +84,14 @@ float run_buf(const float2* in, float2* out, int n_frames, int fpw, long pitch, 
     float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / reps;
 }
 
-template <int SEG, int LDSPAD>
+template <int SEG, int LDSPAD, int TILED = 0>
 float run_buf_rot(float2** ins, float2** outs, int nset, int n_frames, int fpw, long pitch, long in_len, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     dim3 g(n_frames / fpw);
     size_t lds = (size_t)SEG * (256 + LDSPAD) * 8 + 2048;
-    for (int i = 0; i < nset; ++i) hipLaunchKernelGGL((copy_scatter_buf<SEG, LDSPAD>), g, dim3(256), lds, 0, ins[i], outs[i], n_frames, fpw, pitch, in_len);
+    for (int i = 0; i < nset; ++i) hipLaunchKernelGGL((copy_scatter_buf<SEG, LDSPAD, TILED>), g, dim3(256), lds, 0, ins[i], outs[i], n_frames, fpw, pitch, in_len);
     CK(hipEventRecord(a));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((copy_scatter_buf<SEG, LDSPAD>), g, dim3(256), lds, 0, ins[i % nset], outs[i % nset], n_frames, fpw, pitch, in_len);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((copy_scatter_buf<SEG, LDSPAD, TILED>), g, dim3(256), lds, 0, ins[i % nset], outs[i % nset], n_frames, fpw, pitch, in_len);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / reps;
 }
@@ -145,6 +146,15 @@ int main() {
         printf("buffer ops, padded LDS, fpw16, rotating over %d x (256 MiB in, 512 MiB out) : %.4f ms  %.0f GB/s\n", NSET, t, 16.0 * n / t / 1e6);
         t = run_buf_rot<16, 18>(ins, outs, NSET, n_frames, 32, pitch, (long)n + 512, 12);
         printf("same, fpw32 : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
+        t = run_buf_rot<16, 18, 1>(ins, outs, NSET, n_frames, 16, pitch, (long)n + 512, 12);
+        printf("TILED output [chunk][bin][16], fpw16, rotating : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
+        t = run_buf_rot<16, 18, 1>(ins, outs, NSET, n_frames, 32, pitch, (long)n + 512, 12);
+        printf("TILED, fpw32, rotating : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
+        CK(hipEventRecord(a));
+        for (int i = 0; i < 12; ++i) hipLaunchKernelGGL(copy_lin, dim3(4096), dim3(256), 0, 0, ins[i % NSET], outs[i % NSET], n);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        CK(hipEventElapsedTime(&t, a, b)); t /= 12;
+        printf("linear copy, rotating : %.4f ms  %.0f GB/s\n", t, 16.0 * n / t / 1e6);
     }
     return 0;
 }
