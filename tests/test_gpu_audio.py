@@ -93,3 +93,24 @@ def test_audio_chain_opened_mid_stream_starts_from_zero_state(gpu_required):
     y = oracle_channel(x, fs, 12500, meta["offset"])
     ref = A.analog_chain(y[k0:], 25000.0)                                  # a flowgraph started at that sample
     assert len(audio) == len(ref) and rms(audio, ref) < 1e-4
+
+
+def test_audio_rings_wrap_and_incremental_reads(gpu_required):
+    """small rings (out_capacity 4096 < stream length): every stage's ring wraps several times, audio is read
+    after each push -- the concatenation equals the one-shot oracle"""
+    nat = gpu_required
+    x, meta = synth.cfg1(seconds=0.8)
+    fs = meta["fs"]
+    got = []
+    with nat.Frontend(fs, meta["center_freq"], out_capacity=4096) as fe:
+        cid = fe.chan_open(12500, meta["offset"])
+        host_audio.open_analog_voice(fe, cid, 25000)
+        step = 96 * 1500 + 31                                              # 1500 channel samples per push
+        for at in range(0, len(x), step):
+            fe.push(x[at:at + step])
+            got.append(fe.chan_read_audio(cid))
+    audio = np.concatenate(got)
+    y = oracle_channel(x, fs, 12500, meta["offset"])
+    assert len(y) > 4 * 4096
+    ref = A.analog_chain(y, 25000.0)
+    assert len(audio) == len(ref) and rms(audio, ref) < 1e-4

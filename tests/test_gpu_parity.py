@@ -205,6 +205,33 @@ def test_retune_keeps_phase_and_history(gpu_required):
     assert rel_rms(y, yo) < 1e-5
 
 
+def test_matrix_core_bank_ring_wrap_and_empty_push(gpu_required):
+    """output rings shorter than the stream (wrap inside and between launches), a zero-length push in between"""
+    nat = gpu_required
+    fs, cr = 2.4e6, 12500
+    rng = np.random.default_rng(5)
+    D, taps = G.channel_params(fs, cr)
+    n = D * 2600 + 5
+    x = synth.awgn(rng, n)
+    offs = [float(np.round(o / 6250) * 6250) for o in np.linspace(-0.35, 0.35, 9) * fs]
+    got = {f: [] for f in offs}
+    with nat.Frontend(fs, out_capacity=1024) as fe:
+        ids = [fe.chan_open(cr, f) for f in offs]
+        step = D * 700 + 13                                  # 700 outputs per push into rings of 1024
+        for at in range(0, n, step):
+            fe.push(x[at:at + step])
+            fe.push(x[:0])                                   # empty block: a no-op
+            for f, c in zip(offs, ids):
+                got[f].append(fe.chan_read_iq(c))
+    for f in offs:
+        ct, incr = OC.xlating_composite(taps, D, f, fs)
+        v = G.fir_decim_cc(x, ct, D)
+        ph, _, _ = G.rotator_phases(incr, len(v))
+        yo = (v * ph).astype(np.complex64)
+        y = np.concatenate(got[f])
+        assert len(y) == len(yo) and rel_rms(y, yo) < 1e-5, f
+
+
 def test_matrix_core_bank_survives_retune_close_and_open(gpu_required):
     """The matrix-core path caches a per-class bank matrix keyed by (channel ids, tap versions): a retune
     must repack it, a closed channel must leave it, a newly opened channel sends the class through the
