@@ -218,9 +218,13 @@ void launch_os(const PfbLaunch &p, hipStream_t s)
     else    hipLaunchKernelGGL((pfb_kernel_os<NB, OS, P, MINW, false>), dim3(n_wg), dim3(NB), lds, s, p, arg);
 }
 
-int round_p(int P)
+// taps per branch the kernels are instantiated for.  14 is what the reference's own low_pass_2 rule with a
+// Blackman-Harris window gives a critically sampled bank of ANY size (transition 0.2 bin, 60 dB -> 13.6 taps
+// per branch), so that case gets its exact row count instead of 16.
+int round_p(int P, int OS)
 {
     if (P <= 4) return 4;
+    if (OS == 1 && P > 8 && P <= 14) return 14;
     if (P <= 16) return 16;
     return 0;
 }
@@ -228,12 +232,16 @@ int round_p(int P)
 template <int NB>
 bool dispatch_nb(const PfbLaunch &p, int OS, int P, bool probe, hipStream_t s)
 {
-    const int PR = round_p(P);
+    const int PR = round_p(P, OS);
     if (PR == 0 || (OS != 1 && OS != 2)) return false;
     if (probe) return true;
     // waves per SIMD the register allocator must allow: 4 workgroups per CU is the LDS limit
     constexpr int MW = NB >= 1024 ? 4 : (NB >= 512 ? 4 : 4 * NB / 256 > 0 ? (4 * NB / 256 > 8 ? 8 : (4 * NB / 256 < 1 ? 1 : 4 * NB / 256)) : 1);
-    if (OS == 1) { if (PR == 4) launch_os<NB, 1, 4, MW>(p, s); else launch_os<NB, 1, 16, MW>(p, s); }
+    if (OS == 1) {
+        if (PR == 4) launch_os<NB, 1, 4, MW>(p, s);
+        else if (PR == 14) launch_os<NB, 1, 14, MW>(p, s);
+        else launch_os<NB, 1, 16, MW>(p, s);
+    }
     else         { if (PR == 4) launch_os<NB, 2, 4, MW>(p, s); else launch_os<NB, 2, 16, MW>(p, s); }
     return true;
 }
@@ -242,10 +250,6 @@ bool dispatch(const PfbLaunch &p, bool probe, hipStream_t s)
 {
     if (p.D <= 0 || p.NB % p.D) return false;
     const int OS = p.NB / p.D;
-    if (p.NB == 256 && OS == 1 && p.P > 8 && p.P <= 14) {          // BASELINE config 2 shape: exact tap rows
-        if (!probe) launch_os<256, 1, 14, 4>(p, s);
-        return true;
-    }
     switch (p.NB) {
         case 64:   return dispatch_nb<64>(p, OS, p.P, probe, s);
         case 128:  return dispatch_nb<128>(p, OS, p.P, probe, s);
@@ -268,8 +272,7 @@ bool pfb_supported(int NB, int D, int P)
 
 int pfb_padded_p(int NB, int D, int P)
 {
-    if (NB == 256 && D == 256 && P > 8 && P <= 14) return 14;
-    return round_p(P);
+    return round_p(P, D > 0 ? NB / D : 1);
 }
 
 void launch_pfb(const PfbLaunch &p, hipStream_t s)
