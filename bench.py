@@ -261,7 +261,7 @@ def main():
             "channels": {"pfb_bins_total": NB * n_gpus, "fm_demod_total": N_ACTIVE * n_gpus,
                          "realtime_factor_at_20Msps": value / n_gpus / (FS / 1e6)},
             "roofline": {
-                "bound": "hbm", "kernel": "pfb_kernel_os<256,1,14,4,2,false,0>",
+                "bound": "hbm", "kernel": "pfb_kernel_os<256,1,14,4,false>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,

@@ -2,12 +2,13 @@
 """Copy what tools/make_profiles.sh left under gpurun_out/ into profiles/ (run where gpurun_out/ was merged):
    python tools/collect_profiles.py r01"""
 import shutil, os, re
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 R = sys.argv[1]
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     v = []
-    for f in glob.glob("gpurun_out/%s_pmc_%s/**/*counter_collection.csv" % (R, c), recursive=True):
+    for f in sorted(glob.glob("gpurun_out/%s_pmc_%s/**/*counter_collection.csv" % (R, c), recursive=True),
+                    key=os.path.getmtime)[-1:]:                            # newest run only
         for r in csv.DictReader(open(f)):
             if "pfb_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
                 v.append(float(r["Counter_Value"]))
@@ -36,5 +37,6 @@ for src, dst in (("gpurun_out/%s_bench.json" % R, "profiles/%s_bench.json" % R),
             lines = [l for l in f.read().splitlines() if l.startswith("{")]
         if lines:
             open(dst, "w").write(lines[-1] + "\n")
-for f in glob.glob("gpurun_out/%s_trace/**/*kernel_stats.csv" % R, recursive=True):
-    shutil.copy(f, "profiles/%s_bench_kernel_stats.csv" % R)
+fs = sorted(glob.glob("gpurun_out/%s_trace/**/*kernel_stats.csv" % R, recursive=True), key=os.path.getmtime)
+if fs:
+    shutil.copy(fs[-1], "profiles/%s_bench_kernel_stats.csv" % R)       # newest run
