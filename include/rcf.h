@@ -65,6 +65,11 @@ int rcf_design_window(int window, int n, float *w);
 #define RCF_FIR_HIGH_PASS  1
 int rcf_design_firdes(int kind, double gain, double fs, double fc, double tw, int window, double beta,
                       float *taps, int cap);
+/* gr-filter optfir.low_pass(gain, Fs, freq1, freq2, passband_ripple_db, stopband_atten_db): remezord() length
+ * estimate + Parks-McClellan exchange (pm_remez, grid density 16, 2 extra taps) -- the audio low-pass inside
+ * analog.fm_demod_cf (logging_receiver.py:214).  Same return convention as rcf_design_low_pass_2. */
+int rcf_design_optfir_low_pass(double gain, double fs, double freq1, double freq2, double passband_ripple_db,
+                               double stopband_atten_db, float *taps, int cap);
 /* analog.fm_deemph(fs, tau) (gr-analog fm_emph.py): bilinear 1-pole/1-zero section -> iir_filter_ffd taps */
 int rcf_design_fm_deemph(double fs, double tau, double btaps[2], double ataps[2]);
 /* rational_resampler_fff(interpolation, decimation, taps=None, fractional_bw=None) (logging_receiver.py:216-221):

@@ -1136,6 +1136,20 @@ int rcf_design_firdes(int kind, double gain, double fs, double fc, double tw, in
     return n;
 }
 
+int rcf_design_optfir_low_pass(double gain, double fs, double freq1, double freq2, double passband_ripple_db,
+                               double stopband_atten_db, float *taps, int cap)
+{
+    std::vector<float> t;
+    if (!design_optfir_low_pass(gain, fs, freq1, freq2, passband_ripple_db, stopband_atten_db, 2, t)) {
+        set_error("equiripple design failed (bad band edges, or the exchange did not find its extrema)");
+        return RCF_EINVAL;
+    }
+    const int n = (int)t.size();
+    if (!taps || cap < n) return -n;
+    std::memcpy(taps, t.data(), sizeof(float) * (size_t)n);
+    return n;
+}
+
 int rcf_design_fm_deemph(double fs, double tau, double btaps[2], double ataps[2])
 {
     if (fs <= 0 || tau <= 0 || !btaps || !ataps) { set_error("bad de-emphasis arguments"); return RCF_EINVAL; }

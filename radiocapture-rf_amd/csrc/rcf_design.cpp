@@ -169,3 +169,192 @@ void design_composite(const float *taps, int T, int D, double f0, double fs,
 }
 
 }  // namespace rcfx
+
+// ---------------------------------------------------------------- Parks-McClellan (equiripple) design
+// gr-filter's optfir.low_pass() = remezord() order estimate + pm_remez(order, bands, ampl, weights, "bandpass").
+// This is the classical exchange algorithm for symmetric (type I / II) linear-phase filters on a dense grid of
+// 16 points per extremum: barycentric Lagrange interpolation through the r + 1 trial extrema (Oppenheim &
+// Schafer 7.131-7.133), search for the new alternating extrema of the weighted error, stop when the extremal
+// errors agree to 1e-4, then frequency-sample the interpolant to get the taps.  All in double.
+namespace rcfx {
+namespace {
+
+struct PmState {
+    int r = 0;
+    std::vector<double> grid, D, W, E, x, y, ad;
+    std::vector<int> ext;
+};
+
+void pm_params(PmState &s)
+{
+    const int r = s.r;
+    for (int i = 0; i <= r; ++i) s.x[i] = std::cos(2.0 * kPi * s.grid[s.ext[i]]);
+    const int ld = (r - 1) / 15 + 1;                   // interleaved products keep the denominators in range
+    for (int i = 0; i <= r; ++i) {
+        double denom = 1.0;
+        const double xi = s.x[i];
+        for (int j = 0; j < ld; ++j)
+            for (int k = j; k <= r; k += ld)
+                if (k != i) denom *= 2.0 * (xi - s.x[k]);
+        if (std::fabs(denom) < 1e-5) denom = 1e-5;
+        s.ad[i] = 1.0 / denom;
+    }
+    double numer = 0, denom = 0, sign = 1;
+    for (int i = 0; i <= r; ++i) {
+        numer += s.ad[i] * s.D[s.ext[i]];
+        denom += sign * s.ad[i] / s.W[s.ext[i]];
+        sign = -sign;
+    }
+    const double delta = numer / denom;
+    sign = 1;
+    for (int i = 0; i <= r; ++i) {
+        s.y[i] = s.D[s.ext[i]] - sign * delta / s.W[s.ext[i]];
+        sign = -sign;
+    }
+}
+
+double pm_response(const PmState &s, double freq)
+{
+    double numer = 0, denom = 0;
+    const double xc = std::cos(2.0 * kPi * freq);
+    for (int i = 0; i <= s.r; ++i) {
+        double c = xc - s.x[i];
+        if (std::fabs(c) < 1e-7) return s.y[i];
+        c = s.ad[i] / c;
+        denom += c;
+        numer += c * s.y[i];
+    }
+    return numer / denom;
+}
+
+// new extremal set: local extrema of E on the grid, thinned to r + 1 alternating ones
+bool pm_search(PmState &s)
+{
+    const int r = s.r, n = (int)s.grid.size();
+    const std::vector<double> &E = s.E;
+    std::vector<int> found;
+    if ((E[0] > 0.0 && E[0] > E[1]) || (E[0] < 0.0 && E[0] < E[1])) found.push_back(0);
+    for (int i = 1; i < n - 1; ++i)
+        if ((E[i] >= E[i - 1] && E[i] > E[i + 1] && E[i] > 0.0) || (E[i] <= E[i - 1] && E[i] < E[i + 1] && E[i] < 0.0)) {
+            if ((int)found.size() >= 2 * r) return false;
+            found.push_back(i);
+        }
+    const int j = n - 1;
+    if ((E[j] > 0.0 && E[j] > E[j - 1]) || (E[j] < 0.0 && E[j] < E[j - 1])) {
+        if ((int)found.size() >= 2 * r) return false;
+        found.push_back(j);
+    }
+    if ((int)found.size() < r + 1) return false;
+    int extra = (int)found.size() - (r + 1);
+    while (extra > 0) {
+        const int k = (int)found.size();
+        bool up = E[found[0]] > 0.0, alt = true;
+        int l = 0;
+        for (int q = 1; q < k; ++q) {
+            if (std::fabs(E[found[q]]) < std::fabs(E[found[l]])) l = q;
+            if (up && E[found[q]] < 0.0) up = false;
+            else if (!up && E[found[q]] > 0.0) up = true;
+            else { alt = false; break; }               // two neighbours of one sign: drop the smallest seen so far
+        }
+        if (alt && extra == 1) l = std::fabs(E[found[k - 1]]) < std::fabs(E[found[0]]) ? k - 1 : 0;
+        found.erase(found.begin() + l);
+        --extra;
+    }
+    for (int i = 0; i <= r; ++i) s.ext[i] = found[i];
+    return true;
+}
+
+}  // namespace
+
+// bands: edges in cycles/sample (0 .. 0.5), two per band; des: desired amplitude per band; weight per band
+bool design_pm_remez(int numtaps, const std::vector<double> &bands, const std::vector<double> &des,
+                     const std::vector<double> &weight, std::vector<double> &h)
+{
+    const int nb = (int)des.size(), density = 16;
+    if (numtaps < 3 || nb < 1 || (int)bands.size() != 2 * nb || (int)weight.size() != nb) return false;
+    PmState s;
+    s.r = numtaps / 2 + (numtaps & 1);
+    const int r = s.r;
+    const double delf = 0.5 / (density * r);
+    for (int b = 0; b < nb; ++b) {
+        double lowf = bands[2 * b];
+        const double highf = bands[2 * b + 1];
+        const int k = (int)((highf - lowf) / delf + 0.5);
+        if (k < 1) return false;
+        for (int i = 0; i < k; ++i) {
+            s.grid.push_back(lowf);
+            s.D.push_back(des[b]);
+            s.W.push_back(weight[b]);
+            lowf += delf;
+        }
+        s.grid.back() = highf;
+    }
+    const int n = (int)s.grid.size();
+    if (n < r + 2) return false;
+    if ((numtaps & 1) == 0)                            // type II: A(w) = cos(w/2) P(w)
+        for (int i = 0; i < n; ++i) {
+            const double c = std::cos(kPi * s.grid[i]);
+            s.D[i] /= c;
+            s.W[i] *= c;
+        }
+    s.E.assign(n, 0.0);
+    s.x.assign(r + 1, 0.0); s.y.assign(r + 1, 0.0); s.ad.assign(r + 1, 0.0);
+    s.ext.resize(r + 1);
+    for (int i = 0; i <= r; ++i) s.ext[i] = i * (n - 1) / r;
+    for (int iter = 0; iter < 40; ++iter) {
+        pm_params(s);
+        for (int i = 0; i < n; ++i) s.E[i] = s.W[i] * (s.D[i] - pm_response(s, s.grid[i]));
+        if (!pm_search(s)) return false;
+        double mn = std::fabs(s.E[s.ext[0]]), mx = mn;
+        for (int i = 1; i <= r; ++i) {
+            const double v = std::fabs(s.E[s.ext[i]]);
+            mn = std::min(mn, v);
+            mx = std::max(mx, v);
+        }
+        if ((mx - mn) / mx < 0.0001) break;
+    }
+    pm_params(s);
+    // frequency sampling of the converged interpolant
+    std::vector<double> A(numtaps / 2 + 1);
+    for (int i = 0; i <= numtaps / 2; ++i) {
+        const double c = (numtaps & 1) ? 1.0 : std::cos(kPi * (double)i / numtaps);
+        A[i] = pm_response(s, (double)i / numtaps) * c;
+    }
+    h.assign(numtaps, 0.0);
+    const double M = (numtaps - 1) / 2.0;
+    const int kmax = (numtaps & 1) ? (int)M : numtaps / 2 - 1;
+    for (int t = 0; t < numtaps; ++t) {
+        double val = A[0];
+        const double xx = 2.0 * kPi * (t - M) / numtaps;
+        for (int k = 1; k <= kmax; ++k) val += 2.0 * A[k] * std::cos(xx * k);
+        h[t] = val / numtaps;
+    }
+    return true;
+}
+
+// gr-filter optfir.py: low_pass(gain, Fs, freq1, freq2, passband_ripple_db, stopband_atten_db, nextra_taps = 2)
+bool design_optfir_low_pass(double gain, double fs, double f1, double f2, double ripple_db, double atten_db,
+                            int nextra, std::vector<float> &taps)
+{
+    if (!(fs > 0) || !(f1 > 0) || !(f2 > f1) || !(f2 < fs / 2) || !(gain != 0)) return false;
+    const double rr = std::pow(10.0, ripple_db / 20.0);
+    const double dev_p = ((rr - 1.0) / (rr + 1.0)) / gain;       // remezord: deviation relative to the passband gain
+    const double dev_s = std::pow(10.0, -atten_db / 20.0);
+    const double c1 = f1 / fs, c2 = f2 / fs;
+    // lporder(): Herrmann / Rabiner / Chan length estimate
+    const double df = std::fabs(c2 - c1), ddp = std::log10(dev_p), dds = std::log10(dev_s);
+    const double a1 = 5.309e-3, a2 = 7.114e-2, a3 = -4.761e-1, a4 = -2.66e-3, a5 = -5.941e-1, a6 = -4.278e-1;
+    const double b1 = 11.01217, b2 = 0.5124401;
+    const double dinf = ((a1 * ddp * ddp + a2 * ddp + a3) * dds) + (a4 * ddp * ddp + a5 * ddp + a6);
+    const double ff = b1 + b2 * (ddp - dds);
+    const double l = dinf / df - ff * df + 1;
+    const int order = (int)std::ceil(l) - 1;
+    const double mx = std::max(dev_p, dev_s);
+    std::vector<double> h;
+    if (!design_pm_remez(order + nextra + 1, {0.0, c1, c2, 0.5}, {gain, 0.0}, {mx / dev_p, mx / dev_s}, h)) return false;
+    taps.resize(h.size());
+    for (size_t i = 0; i < h.size(); ++i) taps[i] = (float)h[i];
+    return true;
+}
+
+}  // namespace rcfx

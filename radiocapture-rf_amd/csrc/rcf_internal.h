@@ -16,6 +16,10 @@ double design_max_attenuation(int window, double beta);
 std::vector<float> design_firdes(int kind, double gain, double fs, double fc, double tw, int window, double beta);
 void design_fm_deemph(double fs, double tau, double b[2], double a[2]);
 std::vector<float> design_resampler(int interpolation, int decimation);
+bool design_pm_remez(int numtaps, const std::vector<double> &bands, const std::vector<double> &des,
+                     const std::vector<double> &weight, std::vector<double> &h);
+bool design_optfir_low_pass(double gain, double fs, double f1, double f2, double ripple_db, double atten_db,
+                            int nextra, std::vector<float> &taps);
 int design_ntaps(double fs, double tw, double att_db);
 std::vector<float> design_low_pass_2(double gain, double fs, double fc, double tw, double att_db, int window);
 void design_composite(const float *taps, int T, int D, double f0, double fs,

@@ -31,7 +31,7 @@ SYMBOLS = [
     "rcf_scan_result", "rcf_scan_frames_done", "rcf_scan_result_device", "rcf_find_peaks",
     "rcf_peak_frequency", "rcf_scan_find_peaks", "rcf_timing_enable", "rcf_timing_read",
     "rcf_ingest_write", "rcf_push_raw", "rcf_chan_fm_filter", "rcf_chan_read_sym", "rcf_chan_fm_level",
-    "rcf_design_firdes", "rcf_design_fm_deemph", "rcf_design_resampler", "rcf_chan_audio_open",
+    "rcf_design_firdes", "rcf_design_optfir_low_pass", "rcf_design_fm_deemph", "rcf_design_resampler", "rcf_chan_audio_open",
     "rcf_chan_audio_close", "rcf_chan_audio_produced", "rcf_chan_read_audio",
 ]
 FMT_U8, FMT_S8, FMT_S16 = 1, 2, 3
@@ -85,6 +85,7 @@ def lib():
         "rcf_chan_read_sym": (i64, [vp, C.c_int, fp, sz]),
         "rcf_chan_fm_level": (C.c_int, [vp, C.c_int, C.c_float, C.c_int, fp]),
         "rcf_design_firdes": (C.c_int, [C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_double, fp, C.c_int]),
+        "rcf_design_optfir_low_pass": (C.c_int, [C.c_double] * 6 + [fp, C.c_int]),
         "rcf_design_fm_deemph": (C.c_int, [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "rcf_design_resampler": (C.c_int, [C.c_int, C.c_int, ip, ip, fp, C.c_int]),
         "rcf_chan_audio_open": (C.c_int, [vp, C.c_int, C.POINTER(AudioParams)]),
@@ -160,6 +161,17 @@ def design_firdes(kind, gain, fs, fc, tw, window=WIN_HAMMING, beta=6.76) -> np.n
         _check(-n if n else RCF_EINVAL)
     taps = np.empty(n, dtype=np.float32)
     _check(L.rcf_design_firdes(kind, gain, fs, fc, tw, window, beta, _fp(taps), n))
+    return taps
+
+
+def design_optfir_low_pass(gain, fs, freq1, freq2, passband_ripple_db, stopband_atten_db) -> np.ndarray:
+    """gr-filter optfir.low_pass(): remezord + Parks-McClellan"""
+    L = lib()
+    n = -L.rcf_design_optfir_low_pass(gain, fs, freq1, freq2, passband_ripple_db, stopband_atten_db, None, 0)
+    if n <= 0:
+        _check(-n if n else RCF_EINVAL)
+    taps = np.empty(n, dtype=np.float32)
+    _check(L.rcf_design_optfir_low_pass(gain, fs, freq1, freq2, passband_ripple_db, stopband_atten_db, _fp(taps), n))
     return taps
 
 

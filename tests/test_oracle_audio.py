@@ -94,6 +94,18 @@ def test_library_designs_equal_the_oracle_bit_for_bit():
     assert np.array_equal(k, A.low_pass(8, 8, 0.144, 0.032, A.WIN_KAISER, 7.0))
 
 
+@pytest.mark.parametrize("args", [(8, 25000, 6250, 8250, 0.1, 60), (1, 48000, 3000, 4000, 0.5, 40),
+                                  (8, 12500, 3125, 5125, 0.1, 60), (2, 8000, 1000, 1300, 0.2, 50),
+                                  (1, 1.0, 0.1, 0.2, 1.0, 30)])
+def test_native_parks_mcclellan_equals_scipy_remez(args):
+    """librcf's own exchange (rcf_design_optfir_low_pass) against the live third-party one behind the oracle"""
+    mine = native.design_optfir_low_pass(*args)
+    ref = A.optfir_low_pass(*args)
+    assert len(mine) == len(ref)
+    assert np.abs(mine - ref).max() <= 1e-6 * np.abs(ref).max()
+    assert np.allclose(mine, mine[::-1], atol=1e-9)
+
+
 def test_analog_chain_recovers_the_tone():
     """whole oracle chain on a clean FM carrier at the channel rate: 1 kHz tone out, right amplitude"""
     rate, dev, fm = 25000.0, 2500.0, 1000.0
