@@ -26,6 +26,7 @@ constexpr int kWave = 64;
 constexpr int kThreads = 256;
 constexpr int CT = 2;   // channels per wave item
 constexpr int KR = 8;   // outputs per wave item
+constexpr int kSmallPerThread = 1;   // outputs per thread of the small-T kernel (fir_small_outputs <= 256 n - 1)
 
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -224,37 +225,61 @@ __global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *_
     const int64_t s_first = (k0 - 1) * (int64_t)D - (T - 1);
     const int len = nj * D + T;
     const StreamView sv = L.src;
-    for (int p = tid; p < len; p += kThreads) {
-        const int64_t sidx = s_first + p;
-        xs[p] = sidx >= L.start_sample ? sv.base[(uint64_t)(sidx - sv.origin) & sv.mask] : make_float2(0.f, 0.f);
-    }
-    __syncthreads();
-    // thread t computes y[k0 - 1 + t]: t = 0 is the predecessor the discriminator needs (it belongs to the previous
-    // workgroup or launch and is only recomputed, not stored), t = 1 .. nj are this workgroup's outputs (KB <= 255)
-    const int64_t n = k0 - 1 + tid - L.k_abs0;                  // relative output index
-    float2 y = make_float2(0.f, 0.f);
-    if (tid <= nj && n >= 0) {
-        const float2 *w = xs + (size_t)tid * D + (T - 1);       // x[(k0 - 1 + tid) D - i] = w[-i]
-        float ar = 0.f, ai = 0.f;
-        for (int i = 0; i < T; ++i) {
-            const float2 c = cts[i];
-            const float2 xv = w[-i];
-            ar = fmaf(c.x, xv.x, ar);
-            ar = fmaf(-c.y, xv.y, ar);
-            ai = fmaf(c.x, xv.y, ai);
-            ai = fmaf(c.y, xv.x, ai);
+    // all of a thread's tile loads are issued before the first LDS store: a load -> store loop exposes the full
+    // memory latency once per iteration (measured: that, not arithmetic, was this kernel's time)
+    constexpr int LU = 12;
+    for (int p0 = tid; p0 < len; p0 += kThreads * LU) {
+        float2 v[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int p = p0 + u * kThreads;
+            const int64_t sidx = s_first + (p < len ? p : len - 1);
+            v[u] = sidx >= L.start_sample ? sv.base[(uint64_t)(sidx - sv.origin) & sv.mask] : make_float2(0.f, 0.f);
         }
-        y = rotate_value(L, n, ar, ai);
-        if (tid >= 1) L.iq_ring[(uint64_t)n & ring_mask] = y;
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int p = p0 + u * kThreads;
+            if (p < len) xs[p] = v[u];
+        }
     }
-    if (tid <= nj) ys[tid] = y;                                  // n < 0: quadrature_demod's zero history
     __syncthreads();
-    if (tid >= 1 && tid <= nj) {
-        const float2 b = ys[tid - 1];
-        // volk_32fc_x2_multiply_conjugate_32fc: a * conj(b), unfused
-        const float tr = __fadd_rn(__fmul_rn(y.x, b.x), __fmul_rn(y.y, b.y));
-        const float ti = __fsub_rn(__fmul_rn(y.y, b.x), __fmul_rn(y.x, b.y));
-        L.fm_ring[(uint64_t)n & ring_mask] = fast_atan2f_gr(ti, tr, tab);
+    // slot j = tid + 256 o holds y[k0 - 1 + j]: j = 0 is the predecessor the discriminator needs (it belongs to the
+    // previous workgroup or launch and is only recomputed, not stored), j = 1 .. nj are this workgroup's outputs.
+    // Up to kSmallPerThread outputs per thread: the whole launch then fits the GPU in one or two waves of
+    // workgroups, and this latency-bound kernel costs about one load -> FIR -> store chain per wave.
+    float2 y[kSmallPerThread];
+#pragma unroll
+    for (int o = 0; o < kSmallPerThread; ++o) {
+        const int j = tid + o * kThreads;
+        const int64_t n = k0 - 1 + j - L.k_abs0;               // relative output index
+        y[o] = make_float2(0.f, 0.f);
+        if (j <= nj && n >= 0) {
+            const float2 *w = xs + (size_t)j * D + (T - 1);     // x[(k0 - 1 + j) D - i] = w[-i]
+            float ar = 0.f, ai = 0.f;
+            for (int i = 0; i < T; ++i) {
+                const float2 c = cts[i];
+                const float2 xv = w[-i];
+                ar = fmaf(c.x, xv.x, ar);
+                ar = fmaf(-c.y, xv.y, ar);
+                ai = fmaf(c.x, xv.y, ai);
+                ai = fmaf(c.y, xv.x, ai);
+            }
+            y[o] = rotate_value(L, n, ar, ai);
+            if (j >= 1) L.iq_ring[(uint64_t)n & ring_mask] = y[o];
+        }
+        if (j <= nj) ys[j] = y[o];                               // n < 0: quadrature_demod's zero history
+    }
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < kSmallPerThread; ++o) {
+        const int j = tid + o * kThreads;
+        if (j >= 1 && j <= nj) {
+            const float2 b = ys[j - 1];
+            // volk_32fc_x2_multiply_conjugate_32fc: a * conj(b), unfused
+            const float tr = __fadd_rn(__fmul_rn(y[o].x, b.x), __fmul_rn(y[o].y, b.y));
+            const float ti = __fsub_rn(__fmul_rn(y[o].y, b.x), __fmul_rn(y[o].x, b.y));
+            L.fm_ring[(uint64_t)(k0 - 1 + j - L.k_abs0) & ring_mask] = fast_atan2f_gr(ti, tr, tab);
+        }
     }
 }
 

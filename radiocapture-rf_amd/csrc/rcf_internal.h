@@ -80,12 +80,13 @@ inline size_t mfma_tile_bytes(int D, int T)
     return b <= 160 * 1024 ? b : 0;
 }
 
-// outputs per workgroup of the small-T kernel (tile of KB D + T samples within ~48 KB of LDS); 0 = not applicable
+// outputs per workgroup of the small-T kernel (tile of KB D + T samples within ~24 KB of LDS, one output per
+// thread minus the recomputed predecessor); 0 = not applicable
 inline int fir_small_outputs(int D, int T)
 {
     if (T > 96) return 0;
-    int kb = (6000 - T) / D;
-    if (kb > 255) kb = 255;          // 256 threads: one recomputes the predecessor output for the discriminator
+    int kb = (3000 - T) / D;
+    if (kb > 255) kb = 255;          // 256 slots: one is the predecessor output the discriminator needs
     return kb >= 32 ? kb : 0;
 }
 
