@@ -1,0 +1,89 @@
+"""-m gpu: BASELINE.json's full sizes.  The oracle still finishes the reference-shaped bank in seconds (C, OpenMP);
+for the 2^25-sample filterbank block the checks are size-independent properties: invariance to how the stream is
+cut, linearity, and where a bin-centred tone lands."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cbind as OC
+from oracle import grspec as G
+from rcf import synth
+
+pytestmark = pytest.mark.gpu
+FS = 20e6
+
+
+def _proto(nb=256):
+    bw = FS / nb
+    return G.low_pass_2(1.0, FS, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+
+
+def test_reference_shaped_bank_256_channels_at_20msps_equals_oracle(gpu_required):
+    """BASELINE configs[3] per-GPU shape on the GR-faithful path: 256 channels x (2909-tap xlating FIR / 800) over
+    a 2^22-sample block of a 20 Msps stream, every output of every channel against the oracle."""
+    nat = gpu_required
+    rng = np.random.default_rng(20)
+    D, taps = G.channel_params(FS, 12500)
+    assert (D, len(taps)) == (800, 2909)
+    n1, n2 = len(taps) + 2 * D + 3, 1 << 22
+    x = synth.awgn(rng, n1 + n2)
+    offs = [float(k * 12500 - 128 * 12500 + 6250) for k in range(256)]
+    with nat.Frontend(FS, block_capacity=1 << 22, out_capacity=1 << 14) as fe:
+        ids = [fe.chan_open(12500, f) for f in offs]
+        fe.timing_enable(True)
+        fe.push(x[:n1])                                        # history becomes real
+        fe.push(x[n1:])                                        # the full-size block: matrix-core kernel
+        assert fe.timing_read(nat.T_FIR_MFMA)[1] == 1
+        ys = np.stack([fe.chan_read_iq(c) for c in ids])
+    cts = np.stack([OC.xlating_composite(taps, D, f, FS)[0] for f in offs])
+    inc = np.array([OC.xlating_composite(taps, D, f, FS)[1] for f in offs], dtype=np.complex64)
+    yo, _ = OC.channel_bank(x, D, cts, inc, acc_double=True)
+    assert ys.shape == yo.shape and ys.shape[1] > 5200
+    err = np.sqrt(np.mean(np.abs(ys - yo) ** 2, axis=1)) / np.sqrt(np.mean(np.abs(yo) ** 2, axis=1))
+    assert err.max() < 1e-5, (int(err.argmax()), float(err.max()))
+
+
+def test_pfb_full_block_cut_invariance_linearity_and_tone_placement(gpu_required):
+    nat = gpu_required
+    nb, B = 256, 1 << 25
+    taps = _proto(nb)
+    rng = np.random.default_rng(21)
+    tile_a = synth.awgn(rng, 1 << 20)
+    tile_b = synth.awgn(rng, 1 << 20)
+    k_tone = 37
+    tone = (0.25 * np.exp(2j * math.pi * (k_tone / nb) * np.arange(1 << 20))).astype(np.complex64)   # periodic in 2^20
+    bins = [0, 1, k_tone, 128, 255]
+
+    def run(tile, cuts):
+        with nat.Frontend(FS, block_capacity=B, hist_capacity=1 << 16, out_capacity=1 << 18) as fe:
+            fe.pfb_open(nb, nb, taps)
+            at = 0
+            for n in cuts:
+                for o in range(0, n, 1 << 20):                 # fill the resident block from the 2^20 tile
+                    m = min(1 << 20, n - o)
+                    src = np.roll(tile, -((at + o) % (1 << 20)))[:m]
+                    fe.ingest_write(src, o)
+                fe.commit(n)
+                at += n
+            return {k: fe.pfb_read_bin(k) for k in bins}
+
+    one = run(tile_a, [B])
+    cut = run(tile_a, [(1 << 23) + 256 * 3, (1 << 24) - 256 * 1000, B - (1 << 23) - (1 << 24) + 256 * 997])
+    for k in bins:
+        assert len(one[k]) == B // nb
+        assert np.array_equal(one[k], cut[k]), k               # bit-identical however the stream is cut
+    # linearity: PFB(a + 2 b) = PFB(a) + 2 PFB(b) to float32 rounding
+    ob = run(tile_b, [B])
+    osum = run((tile_a + 2 * tile_b).astype(np.complex64), [B])
+    for k in bins:
+        ref = one[k] + 2 * ob[k]
+        assert np.sqrt(np.mean(np.abs(osum[k] - ref) ** 2)) < 2e-6 * np.sqrt(np.mean(np.abs(ref) ** 2)) + 1e-7
+    # a tone on bin 37's centre: all of it in bin 37 (DC gain 1 of the prototype), nothing (> -60 dB) elsewhere
+    ot = run(tone, [B])
+    settled = slice(64, None)
+    assert abs(np.mean(np.abs(ot[k_tone][settled])) - 0.25) < 1e-4
+    for k in bins:
+        if k != k_tone:
+            assert np.max(np.abs(ot[k][settled])) < 0.25 * 2e-3
