@@ -515,21 +515,44 @@ int process_block(rcf_t *h, size_t n)
             if (launches.empty()) continue;
             FirJob job{};
             job.dims.D = D; job.dims.T = T; job.dims.KT = choose_kt(D, T);
-            job.dims.n_chans = (int)launches.size();
             job.dims.chans_per_wg = shared_src ? 16 : 1;
-            // matrix-core path: one shared source, one common output range, no zero-history taps in range
-            bool mfma = shared_src && depth == 0 && launches.size() >= 8 && mfma_tile_bytes(D, T) != 0 && !h->no_mfma &&
-                        bank_floats((int)launches.size(), T) * sizeof(float) < (size_t(1) << 31);
-            for (auto &L : launches)
-                mfma = mfma && L.k_lo == launches[0].k_lo && L.n_k == launches[0].n_k &&
-                       L.k_lo * D - L.start_sample >= (int64_t)(T - 1);
-            if (mfma) {
+            job.dims.max_n_k = max_n;
+            job.dims.ring_mask = h->ring_mask;
+            job.dims.atan_tab = h->d_atan;
+            // Matrix-core path: channels on one shared source with one common output range and no zero-history taps
+            // in range.  Channels that do not qualify yet (just opened: their first outputs still see zero history,
+            // or start later in the block) go through the vector kernel in a launch of their own, so channel churn
+            // does not pull the whole class off the matrix cores.
+            std::vector<ChanLaunch> clean, rest;
+            std::vector<Chan *> clean_ch;
+            if (shared_src && depth == 0 && mfma_tile_bytes(D, T) != 0 && !h->no_mfma) {
+                int64_t k_common = -1;
+                int32_t n_common = 0;
+                for (auto &L : launches)                                   // the range most channels share: the earliest
+                    if (k_common < 0 || L.k_lo < k_common) { k_common = L.k_lo; n_common = L.n_k; }
+                for (size_t i = 0; i < launches.size(); ++i) {
+                    const ChanLaunch &L = launches[i];
+                    const bool ok = L.k_lo == k_common && L.n_k == n_common &&
+                                    L.k_lo * D - L.start_sample >= (int64_t)(T - 1);
+                    if (ok) { clean.push_back(L); clean_ch.push_back(launched[i]); }
+                    else rest.push_back(L);
+                }
+                if (clean.size() < 8 || bank_floats((int)clean.size(), T) * sizeof(float) >= (size_t(1) << 31)) {
+                    clean.clear();
+                    clean_ch.clear();
+                    rest = launches;
+                }
+            } else {
+                rest = launches;
+            }
+            if (!clean.empty()) {
+                FirJob mj = job;
                 rcf::BankCache &bc = h->banks[cls.first];
                 std::vector<std::pair<int, uint64_t>> key;
-                for (Chan *c : launched) key.push_back({c->id, c->taps_version});
-                job.repack = key != bc.key;
-                if (job.repack) {
-                    const size_t need = bank_floats((int)launches.size(), T);
+                for (Chan *c : clean_ch) key.push_back({c->id, c->taps_version});
+                mj.repack = key != bc.key;
+                if (mj.repack) {
+                    const size_t need = bank_floats((int)clean.size(), T);
                     if (need > bc.cap) {
                         bury(h, bc.d);
                         bc.d = nullptr;
@@ -539,17 +562,20 @@ int process_block(rcf_t *h, size_t n)
                     }
                     bc.key = key;
                 }
-                job.dims.mfma = 1;
-                job.dims.chans_per_wg = 128;
-                job.dims.bank = bc.d;
+                mj.dims.n_chans = (int)clean.size();
+                mj.dims.mfma = 1;
+                mj.dims.chans_per_wg = 128;
+                mj.dims.bank = bc.d;
+                if (!ar.put(clean, &mj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+                fir_by_depth[depth].push_back(mj);
             }
-            job.dims.max_n_k = max_n;
-            job.dims.ring_mask = h->ring_mask;
-            if (!ar.put(launches, &job.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
-            job.dims.small = (!shared_src && fir_small_outputs(D, T) > 0) ? 1 : 0;
-            job.dims.atan_tab = h->d_atan;
-            fir_by_depth[depth].push_back(job);
-            if (!job.dims.small) {                  // the small-T kernel writes the discriminator ring itself
+            if (!rest.empty()) {
+                job.dims.n_chans = (int)rest.size();
+                job.dims.small = (!shared_src && fir_small_outputs(D, T) > 0) ? 1 : 0;
+                if (!ar.put(rest, &job.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+                fir_by_depth[depth].push_back(job);
+            }
+            if (!(job.dims.small && clean.empty())) {   // the small-T kernel writes the discriminator ring itself
                 DiscJob dj{};
                 dj.n = (int)discs.size(); dj.max_n = max_n;
                 if (!ar.put(discs, &dj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }

@@ -234,8 +234,8 @@ def test_matrix_core_bank_ring_wrap_and_empty_push(gpu_required):
 
 def test_matrix_core_bank_survives_retune_close_and_open(gpu_required):
     """The matrix-core path caches a per-class bank matrix keyed by (channel ids, tap versions): a retune
-    must repack it, a closed channel must leave it, a newly opened channel sends the class through the
-    vector kernel while its history is zero and joins the matrix afterwards."""
+    must repack it, a closed channel must leave it, a newly opened channel runs through the vector kernel
+    on its own while its history is zero (the rest of the class stays on the matrix cores) and joins afterwards."""
     nat = gpu_required
     fs, cr = 2.4e6, 12500
     rng = np.random.default_rng(77)
@@ -257,10 +257,12 @@ def test_matrix_core_bank_survives_retune_close_and_open(gpu_required):
         fe.push(x[cuts[2]:cuts[3]])                                  # B: matrix-core, repacked (10 channels)
         assert fe.timing_read(nat.T_FIR_MFMA, reset=False)[1] == 2
         late = fe.chan_open(cr, f_new)
-        fe.push(x[cuts[3]:cuts[4]])                                  # C: new channel has zero history -> vector
-        assert fe.timing_read(nat.T_FIR_MFMA, reset=False)[1] == 2
-        fe.push(x[cuts[4]:cuts[5]])                                  # E: matrix-core again, 11 channels
-        assert fe.timing_read(nat.T_FIR_MFMA, reset=False)[1] == 3
+        fe.push(x[cuts[3]:cuts[4]])                                  # C: the new channel alone goes through the vector
+        assert fe.timing_read(nat.T_FIR_MFMA, reset=False)[1] == 3   #    kernel (zero history), the other 10 stay
+        assert fe.timing_read(nat.T_FIR, reset=False)[1] == 2        #    (block 0 and this one)
+        fe.push(x[cuts[4]:cuts[5]])                                  # E: all 11 on the matrix cores
+        assert fe.timing_read(nat.T_FIR_MFMA, reset=False)[1] == 4
+        assert fe.timing_read(nat.T_FIR, reset=False)[1] == 2
         ys = {c: fe.chan_read_iq(c) for c in ids if c != ids[5]}
         y_late = fe.chan_read_iq(late)
 
