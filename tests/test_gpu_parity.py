@@ -116,11 +116,12 @@ def test_multichannel_bank_gr_faithful(gpu_required, fs, cr, offsets):
 
 
 @pytest.mark.parametrize("fs,cr,nch,D_override", [(2.4e6, 12500, 37, None), (20e6, 12500, 12, None),
-                                                  (2.4e6, 12500, 9, 75)])
+                                                  (2.4e6, 12500, 9, 75), (25e6, 12500, 9, None)])
 def test_matrix_core_bank_equals_oracle(gpu_required, fs, cr, nch, D_override):
     """>= 8 channels on one source run on the FP32 matrix cores once their history is real (fir.hip
     fir_mfma_kernel): same GR-faithful result as the oracle, including a channel count that leaves dead MFMA
-    rows (37, 12, 9), the reference's 2909-tap / 800 shape, and an odd decimation (no LDS skew)."""
+    rows (37, 12, 9), the reference's 2909-tap / 800 shape, an odd decimation (no LDS skew), and the largest
+    shape of the SURVEY 8(a) a3 table that fits the matrix-core tile (25 Msps: D = 1000, T = 3637, 149 KB of LDS)."""
     nat = gpu_required
     rng = np.random.default_rng(nch)
     D, taps = G.channel_params(fs, cr)
@@ -147,6 +148,30 @@ def test_matrix_core_bank_equals_oracle(gpu_required, fs, cr, nch, D_override):
         yo = (v * ph).astype(np.complex64)
         assert len(y) == len(yo)
         assert rel_rms(y, yo) < 1e-5, f
+
+
+def test_largest_channel_shape_20msps_6k25(gpu_required):
+    """SURVEY 8(a) a3's biggest filter: 6.25 kHz channels at 20 Msps, D = 1600, T = 5819 (the sample tile no longer
+    fits the matrix-core kernel's LDS: vector kernel), chunked pushes."""
+    nat = gpu_required
+    fs, cr = 20e6, 6250
+    rng = np.random.default_rng(3)
+    D, taps = G.channel_params(fs, cr)
+    assert (D, len(taps)) == (1600, 5819)
+    n = D * 260 + 11
+    x = synth.awgn(rng, n)
+    offs = [-3.7e6 + k * 0.9e6 for k in range(9)]
+    with nat.Frontend(fs) as fe:
+        ids = [fe.chan_open(cr, f) for f in offs]
+        fe.push(x[: D * 90 + 7])
+        fe.push(x[D * 90 + 7:])
+        ys = [fe.chan_read_iq(c) for c in ids]
+    for f, y in zip(offs, ys):
+        ct, incr = OC.xlating_composite(taps, D, f, fs)
+        v = G.fir_decim_cc(x, ct, D)
+        ph, _, _ = G.rotator_phases(incr, len(v))
+        yo = (v * ph).astype(np.complex64)
+        assert len(y) == len(yo) and rel_rms(y, yo) < 1e-5, f
 
 
 def test_channel_opened_mid_stream_has_zero_history(gpu_required):
