@@ -364,9 +364,10 @@ __global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *_
     const int nc = min(d.chans_per_wg, d.n_chans - c0);
     const ChanLaunch &L0 = chans[c0];
     const int tile = blockIdx.x;
-    if ((int64_t)tile * 16 >= L0.n_k) return;
-    const int kt_n = min(16, L0.n_k - tile * 16);
-    const int64_t kt0 = L0.k_lo + (int64_t)tile * 16;
+    const int KTM = d.KT;                               // outputs per tile: 16, or 8 when 16 do not fit the LDS
+    if ((int64_t)tile * KTM >= L0.n_k) return;
+    const int kt_n = min(KTM, L0.n_k - tile * KTM);
+    const int64_t kt0 = L0.k_lo + (int64_t)tile * KTM;
     const int64_t s_tile0 = kt0 * d.D - (d.T - 1);
     const int len = (kt_n - 1) * d.D + d.T;
     const int delta = (d.D & 1) ? 0 : 1;
@@ -639,8 +640,10 @@ void launch_fir_bank(const ChanLaunch *d_chans, const FirLaunchDims &dims, hipSt
             attr_lds = lds;
         }
         const int groups = (dims.n_chans + dims.chans_per_wg - 1) / dims.chans_per_wg;
-        hipLaunchKernelGGL(fir_mfma_kernel, dim3((dims.max_n_k + 15) / 16, groups), dim3(kThreadsM), lds, s, d_chans,
-                           dims);
+        FirLaunchDims md = dims;
+        md.KT = mfma_tile_outputs(dims.D, dims.T);
+        hipLaunchKernelGGL(fir_mfma_kernel, dim3((dims.max_n_k + md.KT - 1) / md.KT, groups), dim3(kThreadsM), lds, s,
+                           d_chans, md);
         return;
     }
     const int tiles = (dims.max_n_k + dims.KT - 1) / dims.KT;

@@ -71,13 +71,24 @@ struct ChanLaunch {
 __host__ __device__ inline int bank_steps(int T) { return ((((T + 1) / 2) + 31) & ~31) >> 2; }
 __host__ __device__ inline size_t bank_floats(int n_chans, int T) { return (size_t)((n_chans + 7) / 8) * bank_steps(T) * 256; }
 
-// LDS bytes of the matrix-core kernel's skewed 16-output tile; 0 when that path does not apply
-inline size_t mfma_tile_bytes(int D, int T)
+// Outputs per matrix-core tile: 16 (all MFMA columns) when the skewed sample tile (kt - 1) D + T fits the CU's
+// LDS, else 8 (half of the columns idle -- still several times the vector kernel), else 0: path not applicable.
+inline size_t mfma_tile_bytes_kt(int D, int T, int kt)
+{
+    const int len = (kt - 1) * D + T;
+    return (size_t)(len + len / D + 2) * sizeof(float2);
+}
+inline int mfma_tile_outputs(int D, int T)
 {
     if (D < 8 || T < 64) return 0;
-    const int len = 15 * D + T;
-    const size_t b = (size_t)(len + len / D + 2) * sizeof(float2);
-    return b <= 160 * 1024 ? b : 0;
+    if (mfma_tile_bytes_kt(D, T, 16) <= 160 * 1024) return 16;
+    if (mfma_tile_bytes_kt(D, T, 8) <= 160 * 1024) return 8;
+    return 0;
+}
+inline size_t mfma_tile_bytes(int D, int T)
+{
+    const int kt = mfma_tile_outputs(D, T);
+    return kt ? mfma_tile_bytes_kt(D, T, kt) : 0;
 }
 
 // outputs per workgroup of the small-T kernel (tile of KB D + T samples within ~24 KB of LDS, one output per

@@ -151,8 +151,8 @@ def test_matrix_core_bank_equals_oracle(gpu_required, fs, cr, nch, D_override):
 
 
 def test_largest_channel_shape_20msps_6k25(gpu_required):
-    """SURVEY 8(a) a3's biggest filter: 6.25 kHz channels at 20 Msps, D = 1600, T = 5819 (the sample tile no longer
-    fits the matrix-core kernel's LDS: vector kernel), chunked pushes."""
+    """SURVEY 8(a) a3's biggest filter: 6.25 kHz channels at 20 Msps, D = 1600, T = 5819.  Sixteen outputs' worth of
+    samples no longer fit the LDS: the matrix-core kernel runs 8-output tiles (136 KB)."""
     nat = gpu_required
     fs, cr = 20e6, 6250
     rng = np.random.default_rng(3)
@@ -163,8 +163,10 @@ def test_largest_channel_shape_20msps_6k25(gpu_required):
     offs = [-3.7e6 + k * 0.9e6 for k in range(9)]
     with nat.Frontend(fs) as fe:
         ids = [fe.chan_open(cr, f) for f in offs]
+        fe.timing_enable(True)
         fe.push(x[: D * 90 + 7])
         fe.push(x[D * 90 + 7:])
+        assert fe.timing_read(nat.T_FIR_MFMA)[1] == 1
         ys = [fe.chan_read_iq(c) for c in ids]
     for f, y in zip(offs, ys):
         ct, incr = OC.xlating_composite(taps, D, f, fs)
