@@ -340,17 +340,17 @@ __global__ __launch_bounds__(kThreads) void fir_bank_kernel(const ChanLaunch *__
 // [cr -ci; ci cr] signs applied: one fully coalesced 16-byte buffer load per lane covers four ops.  B (samples) is one ds_read_b32 per op from the LDS tile, whose rows of D
 // samples are skewed by one sample when D is even so that the 16 columns (stride D) fall in 16 different banks.
 // The 16-output tile is (15 D + T) samples = 119 KB at D = 800, T = 2909, so ONE workgroup owns a CU.  It runs
-// 8 waves: wave w takes channels 32 (w & 3) .. +32 (MT = 4 M-tiles x one N-tile, two accumulator sets per tile
-// to cover the MFMA latency) and HALF of the taps (w >> 2) -- a wave's own VALU / LDS / VMEM issue does not
-// overlap its MFMAs (measured: additive), the second wave on each SIMD is what fills the matrix pipe meanwhile.
-// The two halves swap partial sums through the (by then dead) tile memory and each finishes two M-tiles: a lane
-// holds complete (Re, Im) pairs of two channels for one output, so the rotator and the ring store need no
-// cross-lane step.
+// 8 waves = (items of 32 channels: MT = 4 M-tiles x one N-tile, two accumulator sets per tile to cover the MFMA
+// latency) x (parts of the tap range): 4 x 2 for a full 128-channel workgroup, 1 x 8 for a bank of up to 32 channels.
+// A wave's own VALU / LDS / VMEM issue does not overlap its MFMAs (measured: additive), the second wave on each
+// SIMD is what fills the matrix pipe meanwhile.  The parts add their partial sums through the (by then dead) tile
+// memory; a lane holds complete (Re, Im) pairs of two channels for one output, so the rotator and the ring store
+// need no cross-lane step.
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const v4f __attribute__((address_space(1))) *gv4;
 constexpr int MT = 4;
 constexpr int kThreadsM = 512;
-constexpr int kMfmaExchangeBytes = (kThreadsM / kWave) * 2 * 4 * kWave * 4;   // 16 KB
+constexpr int kMfmaExchangeBytes = (kThreadsM / kWave) * MT * 4 * kWave * 4;   // 32 KB
 
 __global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *__restrict__ chans, FirLaunchDims d)
 {
@@ -398,7 +398,11 @@ __global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *_
     const int jj = j < kt_n ? j : kt_n - 1;
     const int lbase = jj * Dp * 2 + q;
     const int n_steps = bank_steps(d.T);
-    const int item = wave & 3, half = wave >> 2;
+    // 8 waves = (items of 32 channels) x (tap parts): 4 x 2 for 97+ channels, 2 x 4 for 33..64, 1 x 8 up to 32 --
+    // a small bank spreads its taps over all eight waves instead of leaving six of them idle
+    const int items_p2 = nc > 64 ? 4 : (nc > 32 ? 2 : 1);
+    const int n_parts = (kThreadsM / kWave) / items_p2;
+    const int item = wave % items_p2, part = wave / items_p2;
     const int cw0 = c0 + item * 8 * MT;
     const bool active = item * 8 * MT < nc;
 
@@ -406,7 +410,8 @@ __global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *_
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t][0] = acc[t][1] = (v4f){0.f, 0.f, 0.f, 0.f};
     if (active) {
-        const int step0 = half * (n_steps >> 1), step1 = step0 + (n_steps >> 1);
+        const int per = ((n_steps / 4 + n_parts - 1) / n_parts) * 4;     // steps per part, a multiple of the 4-step trip
+        const int step0 = min(part * per, n_steps), step1 = min(step0 + per, n_steps);
         // A operand: one buffer descriptor over the bank matrix, lane offset in a VGPR, (tile, step) offset in an
         // SGPR -- no vector arithmetic per load
         const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *_
         __builtin_amdgcn_sched_barrier(0);
         fetch_b(b0);
         __builtin_amdgcn_sched_barrier(0);
-        for (int m4 = step0; m4 < step1; m4 += 4) {   // n_steps / 2 is a multiple of 4 (bank_steps pads to 32 ops)
+        for (int m4 = step0; m4 < step1; m4 += 4) {   // every part's step count is a multiple of 4
             fetch_a(a3); fetch_b(b1);
             __builtin_amdgcn_sched_barrier(0);
             mac(a0, b0);
@@ -497,29 +502,29 @@ __global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *_
         }
     }
 
-    // the tap halves swap partial sums: half 0 finishes M-tiles 0 and 1, half 1 finishes 2 and 3
+    // every wave parks its partial sums (4 M-tiles x 4 accumulator registers) in the now dead sample tile; M-tile t of
+    // an item is finished by that item's tap part t % n_parts, which adds the parts in order 0 .. n_parts - 1
     __syncthreads();                                  // every wave is done with the sample tile
-    v4f sum[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) sum[t] = acc[t][0] + acc[t][1];
+    for (int t = 0; t < MT; ++t) {
+        const v4f sum = acc[t][0] + acc[t][1];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const v4f give = half ? sum[i] : sum[2 + i];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xf[((wave * 2 + i) * 4 + e) * kWave + lane] = give[e];
+        for (int e = 0; e < 4; ++e) xf[((wave * MT + t) * 4 + e) * kWave + lane] = sum[e];
     }
     __syncthreads();
     if (!active || j >= kt_n) return;
+    for (int t = part % MT; t < MT; t += n_parts) {
+        if (part >= MT) break;                        // 8 parts, 4 tiles: parts 4 .. 7 have nothing to finish
+        v4f tot = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int pp = 0; pp < n_parts; ++pp) {
+            const int w2 = pp * items_p2 + item;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        v4f keep = half ? sum[2 + i] : sum[i];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) keep[e] += xf[(((wave ^ 4) * 2 + i) * 4 + e) * kWave + lane];
-        const int t = half * 2 + i;
+            for (int e = 0; e < 4; ++e) tot[e] += xf[((w2 * MT + t) * 4 + e) * kWave + lane];
+        }
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int ci = cw0 + t * 8 + 2 * kap + hh;
-            if (ci < c0 + nc) rotate_store(chans[ci], kt0 + j, keep[2 * hh], keep[2 * hh + 1], d.ring_mask);
+            if (ci < c0 + nc) rotate_store(chans[ci], kt0 + j, tot[2 * hh], tot[2 * hh + 1], d.ring_mask);
         }
     }
 }

@@ -152,6 +152,7 @@ struct rcf {
     // optional per-kernel-class HIP-event timing (rcf_timing_*)
     bool timing = false;
     unsigned timing_mask = ~0u;
+    int mfma_min = 8;             // fewest channels of a class worth a matrix-core launch (RCF_FIR_MFMA_MIN)
     bool no_mfma = false;         // RCF_FIR_NOMFMA=1: keep the vector-FMA bank kernel (A/B measurements)
     struct TimeRec { int what; hipEvent_t a, b; };
     std::vector<TimeRec> time_pending;
@@ -537,7 +538,7 @@ int process_block(rcf_t *h, size_t n)
                     if (ok) { clean.push_back(L); clean_ch.push_back(launched[i]); }
                     else rest.push_back(L);
                 }
-                if (clean.size() < 8 || bank_floats((int)clean.size(), T) * sizeof(float) >= (size_t(1) << 31)) {
+                if ((int)clean.size() < h->mfma_min || bank_floats((int)clean.size(), T) * sizeof(float) >= (size_t(1) << 31)) {
                     clean.clear();
                     clean_ch.clear();
                     rest = launches;
@@ -759,6 +760,7 @@ int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_c
     h->ring_mask = (uint64_t)h->out_cap - 1;
     {
         if (const char *nm = getenv("RCF_FIR_NOMFMA")) h->no_mfma = atoi(nm) != 0;
+    if (const char *nm = getenv("RCF_FIR_MFMA_MIN")) h->mfma_min = std::max(1, atoi(nm));
         const char *e = getenv("RCF_PFB_PITCH_PAD");
         h->bin_pitch = h->out_cap + (e ? (size_t)atol(e) : 80);
     }

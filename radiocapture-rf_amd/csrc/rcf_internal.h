@@ -68,7 +68,7 @@ struct ChanLaunch {
 // Re x, 1 times Im x); lane = 16 kap + 2 c + r:
 //   bank[((g * n_steps + step) * 64 + lane) * 4 + (m & 3)] = [cr -ci; ci cr][r][q] of channel 8g + c, tap 2m + (kap >> 1)
 // zero past tap T-1 and for channels past the end of the launch.
-__host__ __device__ inline int bank_steps(int T) { return ((((T + 1) / 2) + 31) & ~31) >> 2; }
+__host__ __device__ inline int bank_steps(int T) { return ((((T + 1) / 2) + 15) & ~15) >> 2; }   // multiple of 4 steps
 __host__ __device__ inline size_t bank_floats(int n_chans, int T) { return (size_t)((n_chans + 7) / 8) * bank_steps(T) * 256; }
 
 // Outputs per matrix-core tile: 16 (all MFMA columns) when the skewed sample tile (kt - 1) D + T fits the CU's
