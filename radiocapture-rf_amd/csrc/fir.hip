@@ -340,8 +340,7 @@ __global__ __launch_bounds__(kThreads) void fir_bank_kernel(const ChanLaunch *__
 // [cr -ci; ci cr] signs applied: one fully coalesced 16-byte buffer load per lane covers four ops.  B (samples) is one ds_read_b32 per op from the LDS tile, whose rows of D
 // samples are skewed by one sample when D is even so that the 16 columns (stride D) fall in 16 different banks.
 // The 16-output tile is (15 D + T) samples = 119 KB at D = 800, T = 2909, so ONE workgroup owns a CU.  It runs
-// 8 waves = (items of 32 channels: MT = 4 M-tiles x one N-tile, two accumulator sets per tile to cover the MFMA
-// latency) x (parts of the tap range): 4 x 2 for a full 128-channel workgroup, 1 x 8 for a bank of up to 32 channels.
+// 8 waves = (items of 32 channels: MT = 4 M-tiles x one N-tile, four accumulator sets per tile) x (parts of the tap range): 4 x 2 for a full 128-channel workgroup, 1 x 8 for a bank of up to 32 channels.
 // A wave's own VALU / LDS / VMEM issue does not overlap its MFMAs (measured: additive), the second wave on each
 // SIMD is what fills the matrix pipe meanwhile.  The parts add their partial sums through the (by then dead) tile
 // memory; a lane holds complete (Re, Im) pairs of two channels for one output, so the rotator and the ring store
@@ -406,9 +405,11 @@ __global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *_
     const int cw0 = c0 + item * 8 * MT;
     const bool active = item * 8 * MT < nc;
 
-    v4f acc[MT][2];
+    // four accumulator sets per M-tile (one per op of a step): covers the MFMA latency and keeps each float32
+    // summation chain a quarter of the part's taps long (rounding noise ~ sqrt(chain length))
+    v4f acc[MT][4];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t][0] = acc[t][1] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MT; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = (v4f){0.f, 0.f, 0.f, 0.f};
     if (active) {
         const int per = ((n_steps / 4 + n_parts - 1) / n_parts) * 4;     // steps per part, a multiple of the 4-step trip
         const int step0 = min(part * per, n_steps), step1 = min(step0 + per, n_steps);
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *_
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
-                    acc[t][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][u], b[u], acc[t][u & 1], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][u], b[u], acc[t][u], 0, 0, 0);
         };
         __builtin_amdgcn_sched_barrier(0);            // same issue order as the loop body, or the loop-top waits
         fetch_a(a0);                                  // are sized for the worse of the two predecessors
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *_
     __syncthreads();                                  // every wave is done with the sample tile
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        const v4f sum = acc[t][0] + acc[t][1];
+        const v4f sum = (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) xf[((wave * MT + t) * 4 + e) * kWave + lane] = sum[e];
     }

@@ -35,13 +35,14 @@ def test_reference_shaped_bank_256_channels_at_20msps_equals_oracle(gpu_required
         fe.timing_enable(True)
         fe.push(x[:n1])                                        # history becomes real
         fe.push(x[n1:])                                        # the full-size block: matrix-core kernel
-        assert fe.timing_read(nat.T_FIR_MFMA)[1] == 1
+        assert fe.timing_read(nat.T_FIR_MFMA)[1] == (0 if os.environ.get("RCF_FIR_NOMFMA") else 1)
         ys = np.stack([fe.chan_read_iq(c) for c in ids])
     cts = np.stack([OC.xlating_composite(taps, D, f, FS)[0] for f in offs])
     inc = np.array([OC.xlating_composite(taps, D, f, FS)[1] for f in offs], dtype=np.complex64)
     yo, _ = OC.channel_bank(x, D, cts, inc, acc_double=True)
     assert ys.shape == yo.shape and ys.shape[1] > 5200
     err = np.sqrt(np.mean(np.abs(ys - yo) ** 2, axis=1)) / np.sqrt(np.mean(np.abs(yo) ** 2, axis=1))
+    print("256-channel bank vs oracle: worst channel rel-rms %.3e, median %.3e" % (err.max(), np.median(err)))
     assert err.max() < 1e-5, (int(err.argmax()), float(err.max()))
 
 
