@@ -25,8 +25,8 @@ namespace {
 constexpr int CW = 16;   // columns per workgroup
 
 template <int N> struct P4;
-template <> struct P4<128> { static constexpr int n = 2; static constexpr int r[2] = {16, 8}; };
-template <> struct P4<256> { static constexpr int n = 2; static constexpr int r[2] = {16, 16}; };
+template <> struct P4<128> { static constexpr int r[2] = {16, 8}; };
+template <> struct P4<256> { static constexpr int r[2] = {16, 16}; };
 
 template <int N> constexpr int rs4() { return lds_padded_len(N) + 1; }   // odd: transposed accesses spread
 
