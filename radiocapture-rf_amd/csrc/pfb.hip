@@ -174,20 +174,45 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
         pfb_pass<NB, PL::r[0], 1, (PL::n < 2 || PL::r[1] != PL::r[0])>(buf, tw_lds, tid);
         if constexpr (PL::n >= 2)
             pfb_pass<NB, PL::r[1], PL::r[0], (PL::n < 3 || PL::r[2] != PL::r[1])>(buf, tw_lds, tid);
-        if constexpr (PL::n >= 3) pfb_pass<NB, PL::r[2], PL::r[0] * PL::r[1], true>(buf, tw_lds, tid);
+        // a third pass (radix 2 for 512 bins, 4 for 1024) is NOT run over LDS: its butterfly j reads and writes
+        // the same R3 positions j + t NB/R3, and those are exactly the bins one epilogue lane handles (bins
+        // k0 + i NB/F), so it is done in registers on the way out -- one LDS round trip and two barriers less
     }
     {
+        using PL = Plan<NB>;
         const int k0 = tid / F, f_lane = tid % F;
         const int out_so_step = (int)((int64_t)(NB / F) * p.ring_cap * (int64_t)sizeof(cf));
         const int64_t n = n0 + f_lane;
         const int ridx = (int)((uint64_t)(n - p.n_abs0) & p.ring_mask);
         const int vo = (int)(((int64_t)k0 * p.ring_cap + ridx) * (int64_t)sizeof(cf));
         if (f_lane < nf) {
+            cf vv[F];
 #pragma unroll
             for (int i = 0; i < F; ++i) {
                 const int k = k0 + i * (NB / F);
-                cf v = ((NB / F) % 16 == 0) ? buf[f_lane * RS + lds_pad(k0) + i * ((NB / F) + (NB / F) / 16)]
-                                            : buf[f_lane * RS + lds_pad(k)];
+                vv[i] = ((NB / F) % 16 == 0) ? buf[f_lane * RS + lds_pad(k0) + i * ((NB / F) + (NB / F) / 16)]
+                                             : buf[f_lane * RS + lds_pad(k)];
+            }
+            if constexpr (PL::n >= 3) {
+                constexpr int R3 = PL::r[2];                 // bins j + t NB/R3 = registers i + t F/R3
+                static_assert(PL::r[0] * PL::r[1] * R3 == NB && F % R3 == 0, "final radix must divide the chunk");
+#pragma unroll
+                for (int i = 0; i < F / R3; ++i) {
+                    const int j = k0 + i * (NB / F);         // butterfly index, < NB / R3
+                    cf w[R3];
+#pragma unroll
+                    for (int t = 0; t < R3; ++t) w[t] = vv[i + t * (F / R3)];
+#pragma unroll
+                    for (int t = 1; t < R3; ++t) w[t] = cmul(w[t], tw_lds[(j * t) & (NB - 1)]);   // W_NB^{j t}, exact entry
+                    Dft<R3, +1>::run(w);
+#pragma unroll
+                    for (int f = 0; f < R3; ++f) vv[i + f * (F / R3)] = w[Dft<R3, +1>::reg_of(f)];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < F; ++i) {
+                const int k = k0 + i * (NB / F);
+                cf v = vv[i];
                 if (OS == 2) {
                     if ((k & 1) && (n & 1)) v = make_float2(-v.x, -v.y);
                 }
