@@ -9,7 +9,8 @@
 // on a data-dependent stream) and the de-emphasis IIR are recurrences in time: audio_gate_kernel and
 // audio_deemph_kernel give each channel one lane that walks the block's new samples in order -- parallel over
 // channels, exact in GNU Radio's operation order (double accumulators as in single_pole_iir<double> /
-// iir_filter<float,float,double,double>), a few dependent double operations per step and nothing else.
+// iir_filter<float,float,double,double>), a few dependent double operations per step; their ring traffic is
+// staged through LDS so that it stays coalesced.
 // Everything else is a pure function of index and runs one thread per output on [n_prev, n_a), the range the
 // gate published in device memory: the discriminator on the compacted stream, the two FIRs and the polyphase
 // resampler (the host never learns how many samples passed the gate until it reads audio back).
@@ -54,49 +55,107 @@ __device__ __forceinline__ float fast_atan2f_gr(float y, float x, const float *t
 }
 
 // Stage 1, one lane per channel: pwr_squelch_cc over the channel's new samples, in order.  Survivors are compacted
-// into c_ring; [n_prev, n_a) is published for the stages behind.  Samples are fetched 16 at a time so the walk
-// pays the ring's load latency once per 16 steps, not per step.
+// into c_ring; [n_prev, n_a) is published for the stages behind.
+// A wave owns 64 channels.  Ring traffic goes through an LDS tile so that it is coalesced: for a chunk of 64
+// samples the 64 lanes first fetch channel 0's 64 samples (one 512-byte run), then channel 1's, ... into
+// xs[channel][sample]; each lane then walks ITS channel's row, parking the survivors in the same row, and the rows
+// are written out channel by channel.  (A lane reading its own ring directly touches one cache line per lane per
+// load instruction: measured 5x slower.)
+constexpr int kSeqChunk = 64;
+constexpr int kSeqRow = kSeqChunk + 1;               // row stride in elements: spreads a column over the banks
+
+// broadcast lane `src`'s value (src wave-uniform) through the scalar unit
+__device__ __forceinline__ int rl32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ long long rl64(long long v, int src)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), src);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(64) void audio_gate_kernel(const AudioLaunch *__restrict__ items, int n_items,
                                                         uint64_t ring_mask)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= n_items) return;
-    const AudioLaunch it = items[c];
-    AudioState s = *it.st;
+    __shared__ float2 xs[64 * kSeqRow];
+    const int lane = threadIdx.x;
+    const int c0 = blockIdx.x * 64;
+    const int nc = min(64, n_items - c0);
+    const bool mine = lane < nc;
+    const AudioLaunch *it = items + c0 + (mine ? lane : 0);
+    AudioState s = *it->st;
+    const double alpha = it->alpha, one_minus_alpha = 1.0 - it->alpha, thr = it->thr;
+    const int my_nk = mine ? it->n_k : 0;
+    // each lane keeps its own channel's ring pointers; the per-channel loops below broadcast them lane by lane
+    const long long my_src = (long long)(uintptr_t)it->iq_ring, my_dst = (long long)(uintptr_t)it->c_ring;
+    const long long my_lo = it->n_lo;
     s.n_prev = s.n_a;
-    const double one_minus_alpha = 1.0 - it.alpha;
-    // Only two operations per sample sit on the recurrence (oma * pwr, + alpha * p); everything else -- the loads,
-    // |x|^2, alpha * p -- is done for 16 samples at once ahead of it.  With ramp = 0 squelch_base_cc's state machine
-    // collapses to "muted = mute()": MUTED leaves on !mute, UNMUTED leaves on mute.
-    for (int i0 = 0; i0 < it.n_k; i0 += 16) {
-        float2 xs[16];
-        double t[16];
+    int max_nk = 0;
+    for (int c = 0; c < nc; ++c) max_nk = max(max_nk, rl32(my_nk, c));
+    // the whole next chunk (one coalesced 512-byte load per channel) is in flight while the current one is walked:
+    // four waves carry a 256-channel launch, there is nothing else to hide the ring's latency behind
+    float2 pre[64];
+    auto prefetch = [&](int i0) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int i = i0 + u < it.n_k ? i0 + u : it.n_k - 1;
-            xs[u] = it.iq_ring[(uint64_t)(it.n_lo + i) & ring_mask];
+        for (int c = 0; c < 64; ++c) {
+            const int cc = c < nc ? c : nc - 1;
+            const float2 *src = reinterpret_cast<const float2 *>((uintptr_t)rl64(my_src, cc));
+            const int i = i0 + lane < rl32(my_nk, cc) ? i0 + lane : 0;
+            pre[c] = src[(uint64_t)(rl64(my_lo, cc) + i) & ring_mask];
         }
+    };
+    prefetch(0);
+    for (int i0 = 0; i0 < max_nk; i0 += kSeqChunk) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            // pwr_squelch_cc::update_state: float |x|^2, then single_pole_iir<double,double,double>
-            const float p = __fadd_rn(__fmul_rn(xs[u].x, xs[u].x), __fmul_rn(xs[u].y, xs[u].y));
-            t[u] = __dmul_rn(it.alpha, (double)p);
-        }
+        for (int c = 0; c < 64; ++c) xs[c * kSeqRow + lane] = pre[c];
+        wave_lds_sync();
+        if (i0 + kSeqChunk < max_nk) prefetch(i0 + kSeqChunk);
+        // Only two operations per sample sit on the recurrence (oma * pwr, + alpha * p); |x|^2 and alpha * p are done
+        // 16 samples at a time ahead of it.  With ramp = 0 squelch_base_cc's state machine collapses to
+        // "muted = mute()": MUTED leaves on !mute, UNMUTED leaves on mute.
+        int kept = 0;
+        const int n_here = min(kSeqChunk, my_nk - i0);
+        for (int u0 = 0; u0 < n_here; u0 += 16) {
+            float2 x[16];
+            double t[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const bool live = i0 + u < it.n_k;
-            const double pw = __dadd_rn(t[u], __dmul_rn(one_minus_alpha, s.pwr));
-            s.pwr = live ? pw : s.pwr;
-            const bool pass = live && !(pw < it.thr);               // gate = True: muted samples vanish
-            if (live) s.muted = (pw < it.thr) ? 1 : 0;
-            if (pass) it.c_ring[(uint64_t)s.n_a & ring_mask] = xs[u];   // in[i] * gr_complex(envelope = 1, 0)
-            s.n_a += pass ? 1 : 0;
+            for (int u = 0; u < 16; ++u) x[u] = xs[lane * kSeqRow + u0 + u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                // pwr_squelch_cc::update_state: float |x|^2, then single_pole_iir<double,double,double>
+                const float p = __fadd_rn(__fmul_rn(x[u].x, x[u].x), __fmul_rn(x[u].y, x[u].y));
+                t[u] = __dmul_rn(alpha, (double)p);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const bool live = u0 + u < n_here;
+                const double pw = __dadd_rn(t[u], __dmul_rn(one_minus_alpha, s.pwr));
+                s.pwr = live ? pw : s.pwr;
+                const bool pass = live && !(pw < thr);              // gate = True: muted samples vanish
+                if (live) s.muted = (pw < thr) ? 1 : 0;
+                if (pass) xs[lane * kSeqRow + kept] = x[u];         // kept <= u0 + u: never ahead of the reads
+                kept += pass ? 1 : 0;
+            }
         }
+        wave_lds_sync();
+        for (int c = 0; c < nc; ++c) {                          // coalesced write-back of the survivors
+            float2 *dst = reinterpret_cast<float2 *>((uintptr_t)rl64(my_dst, c));
+            if (lane < rl32(kept, c)) dst[(uint64_t)(rl64(s.n_a, c) + lane) & ring_mask] = xs[c * kSeqRow + lane];
+        }
+        s.n_a += kept;
+        wave_lds_sync();
     }
-    it.st->pwr = s.pwr;
-    it.st->muted = s.muted;
-    it.st->n_a = s.n_a;
-    it.st->n_prev = s.n_prev;
+    if (mine) {
+        it->st->pwr = s.pwr;
+        it->st->muted = s.muted;
+        it->st->n_a = s.n_a;
+        it->st->n_prev = s.n_prev;
+    }
 }
 
 // Stage 2, one thread per surviving sample: quadrature_demod_cf(gain) on the compacted stream
@@ -119,37 +178,71 @@ __global__ __launch_bounds__(kThreads) void audio_demod_kernel(const AudioLaunch
 }
 
 // Stage 3, one lane per channel: fm_deemph = iir_filter<float,float,double,double>, two feed-forward taps and
-// one feedback tap, in its operation order
+// one feedback tap, in its operation order; ring traffic staged through LDS like the gate's
 __global__ __launch_bounds__(64) void audio_deemph_kernel(const AudioLaunch *__restrict__ items, int n_items,
                                                           uint64_t ring_mask)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= n_items) return;
-    const AudioLaunch it = items[c];
-    const int64_t n0 = it.st->n_prev, n1 = it.st->n_a;
-    double px = it.st->iir_px, py = it.st->iir_py;
-    // acc = b0 x[n] + b1 x[n-1] + fb1 y[n-1] in that order: the first two terms do not depend on the recurrence
-    for (int64_t j0 = n0; j0 < n1; j0 += 16) {
-        float v[16];
-        double ff[16];
+    __shared__ float gs[64 * kSeqRow];
+    const int lane = threadIdx.x;
+    const int c0 = blockIdx.x * 64;
+    const int nc = min(64, n_items - c0);
+    const bool mine = lane < nc;
+    const AudioLaunch *it = items + c0 + (mine ? lane : 0);
+    const double b0 = it->b0, b1 = it->b1, fb1 = it->fb1;
+    double px = it->st->iir_px, py = it->st->iir_py;
+    const long long my_p0 = it->st->n_prev, my_p1 = mine ? (long long)it->st->n_a : my_p0;
+    const int my_n = (int)(my_p1 - my_p0);
+    const long long my_src = (long long)(uintptr_t)it->h_ring, my_dst = (long long)(uintptr_t)it->a_ring;
+    int max_n = 0;
+    for (int c = 0; c < nc; ++c) max_n = max(max_n, rl32(my_n, c));
+    float pre[64];
+    auto prefetch = [&](int i0) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = it.h_ring[(uint64_t)(j0 + u < n1 ? j0 + u : n1 - 1) & ring_mask];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const double xm1 = u ? (double)v[u - 1] : px;
-            ff[u] = __dadd_rn(__dmul_rn(it.b0, (double)v[u]), __dmul_rn(it.b1, xm1));
+        for (int c = 0; c < 64; ++c) {
+            const int cc = c < nc ? c : nc - 1;
+            const float *src = reinterpret_cast<const float *>((uintptr_t)rl64(my_src, cc));
+            const int i = i0 + lane < rl32(my_n, cc) ? i0 + lane : 0;
+            pre[c] = src[(uint64_t)(rl64(my_p0, cc) + i) & ring_mask];
         }
+    };
+    prefetch(0);
+    for (int i0 = 0; i0 < max_n; i0 += kSeqChunk) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const bool live = j0 + u < n1;
-            const double acc = __dadd_rn(ff[u], __dmul_rn(it.fb1, py));
-            py = live ? acc : py;
-            px = live ? (double)v[u] : px;
-            if (live) it.a_ring[(uint64_t)(j0 + u) & ring_mask] = (float)acc;
+        for (int c = 0; c < 64; ++c) gs[c * kSeqRow + lane] = pre[c];
+        wave_lds_sync();
+        if (i0 + kSeqChunk < max_n) prefetch(i0 + kSeqChunk);
+        // acc = b0 x[n] + b1 x[n-1] + fb1 y[n-1] in that order; only the last product and sum wait for y[n-1]
+        const int n_here = min(kSeqChunk, my_n - i0);
+        for (int u0 = 0; u0 < n_here; u0 += 16) {
+            float v[16];
+            double ff[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = gs[lane * kSeqRow + u0 + u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const double xm1 = u ? (double)v[u - 1] : px;
+                ff[u] = __dadd_rn(__dmul_rn(b0, (double)v[u]), __dmul_rn(b1, xm1));
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const bool live = u0 + u < n_here;
+                const double acc = __dadd_rn(ff[u], __dmul_rn(fb1, py));
+                py = live ? acc : py;
+                px = live ? (double)v[u] : px;
+                if (live) gs[lane * kSeqRow + u0 + u] = (float)acc;
+            }
         }
+        wave_lds_sync();
+        for (int c = 0; c < nc; ++c) {
+            float *dst = reinterpret_cast<float *>((uintptr_t)rl64(my_dst, c));
+            if (i0 + lane < rl32(my_n, c)) dst[(uint64_t)(rl64(my_p0, c) + i0 + lane) & ring_mask] = gs[c * kSeqRow + lane];
+        }
+        wave_lds_sync();
     }
-    it.st->iir_px = px;
-    it.st->iir_py = py;
+    if (mine) {
+        it->st->iir_px = px;
+        it->st->iir_py = py;
+    }
 }
 
 // fir_filter_fff(1, taps) on [n_prev, n_a): which = 0 a_ring -> l_ring (audio low-pass), 1 l_ring -> h_ring
