@@ -35,6 +35,17 @@ def analog_chain_params(rate, deviation=15000.0, gain=8.0, tau=75e-6, squelch_db
         interpolation=interp, decimation=decim, rs_taps=rs)
 
 
+def dsd_feed_params(rate, fm_demod_gain, out_rate=48000):
+    """logging_receiver.py:333-349 ('provoice' gain 0.6, 'dsd_p25' gain 0.4): quadrature_demod_cf(gain) ->
+    rational_resampler_fff(48000, rate) -- the float stream the dsd vocoder block consumes.  Expressed with the same
+    chain: squelch threshold -inf dB (power is never below 0: nothing is gated), identity de-emphasis and
+    one-tap unit filters, the reference's default resampler taps."""
+    interp, decim, rs = native.design_resampler(int(out_rate), int(rate))
+    return dict(squelch_db=float("-inf"), squelch_alpha=0.0, quad_gain=float(fm_demod_gain),
+                deemph_b=[1.0, 0.0], deemph_a=[1.0, 0.0], lpf_taps=[1.0], hpf_taps=[1.0],
+                interpolation=interp, decimation=decim, rs_taps=rs)
+
+
 def open_analog_voice(frontend, chan_id, rate, **kw):
     """attach the reference's analog chain to a channel; read 8 kHz float audio with frontend.chan_read_audio"""
     frontend.chan_audio_open(chan_id, **analog_chain_params(rate, **kw))

@@ -114,3 +114,23 @@ def test_audio_rings_wrap_and_incremental_reads(gpu_required):
     assert len(y) > 4 * 4096
     ref = A.analog_chain(y, 25000.0)
     assert len(audio) == len(ref) and rms(audio, ref) < 1e-4
+
+
+def test_dsd_feed_chain_demod_plus_48k_resampler(gpu_required):
+    """logging_receiver.py 'provoice' / 'dsd_p25' front half: quadrature_demod_cf(0.4) -> rational_resampler_fff(48000,
+    rate), the stream dsd.block_ff consumes; same device chain with the squelch, de-emphasis and filters neutral"""
+    nat = gpu_required
+    x, meta = synth.cfg1(seconds=0.3)
+    fs = meta["fs"]
+    with nat.Frontend(fs, meta["center_freq"]) as fe:
+        cid = fe.chan_open(12500, meta["offset"])
+        fe.chan_audio_open(cid, **host_audio.dsd_feed_params(25000, 0.4))
+        fe.push(x[:300001])
+        fe.push(x[300001:])
+        n_out, n_ungated = fe.chan_audio_produced(cid)
+        out = fe.chan_read_audio(cid)
+    y = oracle_channel(x, fs, 12500, meta["offset"])
+    fm = G.quadrature_demod_cf(y, np.float32(0.4))
+    ref = A.rational_resampler_fff(fm, 48000, 25000)
+    assert n_ungated == len(y) and len(out) == n_out == len(ref) == (len(y) * 48 + 24) // 25
+    assert rms(out, ref) < 1e-4
