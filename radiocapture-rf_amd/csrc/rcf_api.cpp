@@ -175,12 +175,18 @@ void bury(rcf_t *h, void *p)
     if (p) h->graveyard.push_back(p);
 }
 
+// the stream is known to be idle (the caller just synchronised it): buried buffers can go
+void free_graveyard_idle(rcf_t *h)
+{
+    for (void *p : h->graveyard) (void)hipFree(p);
+    h->graveyard.clear();
+}
+
 void drain_graveyard(rcf_t *h)
 {
     if (h->graveyard.empty()) return;
     (void)hipStreamSynchronize(h->stream);
-    for (void *p : h->graveyard) (void)hipFree(p);
-    h->graveyard.clear();
+    free_graveyard_idle(h);
 }
 
 hipEvent_t time_event(rcf_t *h)
@@ -350,6 +356,7 @@ int process_block(rcf_t *h, size_t n)
 {
     const int64_t S0 = h->total_in, S1 = S0 + (int64_t)n;
     hipStream_t st = h->stream;
+    if (h->graveyard.size() > 512) drain_graveyard(h);     // bounded even if nobody ever syncs or reads
 
     // arena for this commit
     const int a = h->arena_cur;
@@ -685,6 +692,7 @@ int64_t ring_read(rcf_t *h, const void *ring, size_t elem, int64_t produced, int
         return RCF_EHIP;
     }
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("stream sync failed"); return RCF_EHIP; }
+    free_graveyard_idle(h);       // retuned / closed channels' old buffers: every read is a chance to release them
     *cursor += n;
     return n;
 }

@@ -259,6 +259,39 @@ def test_matrix_core_bank_ring_wrap_and_empty_push(gpu_required):
         assert len(y) == len(yo) and rel_rms(y, yo) < 1e-5, f
 
 
+def test_long_churn_retunes_opens_closes(gpu_required):
+    """600 small pushes with a retune every push and an open / close every few: deferred frees, the bank-matrix cache
+    and the launch arenas keep up, and a channel nobody touched still equals the oracle over the whole stream"""
+    nat = gpu_required
+    fs, cr = 2.4e6, 12500
+    rng = np.random.default_rng(99)
+    D, taps = G.channel_params(fs, cr)
+    step = D * 12 + 5
+    n = step * 600
+    x = synth.awgn(rng, n)
+    offs = [float(np.round(o / 6250) * 6250) for o in np.linspace(-0.42, 0.42, 10) * fs]
+    got = []
+    with nat.Frontend(fs) as fe:
+        ids = [fe.chan_open(cr, f) for f in offs]
+        extra = []
+        for it in range(600):
+            fe.chan_set_offset(ids[1 + it % 8], offs[1 + it % 8] + 6250.0 * ((it // 8) % 5))
+            if it % 7 == 0:
+                extra.append(fe.chan_open(cr, 100000.0 + 12500.0 * (it % 11)))
+            if it % 7 == 3 and extra:
+                fe.chan_close(extra.pop(0))
+            fe.push(x[it * step:(it + 1) * step])
+            if it % 50 == 49:
+                got.append(fe.chan_read_iq(ids[0]))
+        got.append(fe.chan_read_iq(ids[0]))
+    y = np.concatenate(got)
+    ct, incr = OC.xlating_composite(taps, D, offs[0], fs)
+    v = G.fir_decim_cc(x, ct, D)
+    ph, _, _ = G.rotator_phases(incr, len(v))
+    yo = (v * ph).astype(np.complex64)
+    assert len(y) == len(yo) and rel_rms(y, yo) < 1e-5
+
+
 def test_matrix_core_bank_survives_retune_close_and_open(gpu_required):
     """The matrix-core path caches a per-class bank matrix keyed by (channel ids, tap versions): a retune
     must repack it, a closed channel must leave it, a newly opened channel runs through the vector kernel
