@@ -259,6 +259,33 @@ def test_matrix_core_bank_ring_wrap_and_empty_push(gpu_required):
         assert len(y) == len(yo) and rel_rms(y, yo) < 1e-5, f
 
 
+def test_lagging_reader_gets_the_newest_ring_full(gpu_required):
+    """a consumer slower than the ring (ZMQ PUB at its high-water mark drops the same way): reads return the newest
+    out_capacity samples, oldest first -- channel IQ, discriminator and a filterbank bin"""
+    nat = gpu_required
+    fs, cr, nb = 2.4e6, 12500, 64
+    rng = np.random.default_rng(17)
+    D, taps = G.channel_params(fs, cr)
+    x = synth.awgn(rng, D * 3000 + 9)
+    proto = G.low_pass_2(1.0, fs, fs / nb * 0.4, fs / nb * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+    cap = 1024
+    with nat.Frontend(fs, out_capacity=cap) as fe:
+        cid = fe.chan_open(cr, 250000.0)
+        fe.pfb_open(nb, nb, proto)
+        for at in range(0, len(x), D * 500):                 # 500 channel outputs / 750 frames per push, never read
+            fe.push(x[at:at + D * 500])
+        y = fe.chan_read_iq(cid)
+        fm = fe.chan_read_fm(cid, 1.0)
+        b = fe.pfb_read_bin(5)
+        assert len(fe.chan_read_iq(cid)) == 0               # drained
+    yo, (fo,) = oracle_channel(x, fs, cr, 250000.0, [1.0])
+    assert len(y) == len(fm) == cap and len(yo) > 2 * cap
+    assert rel_rms(y, yo[-cap:]) < 1e-5
+    assert rms(fm, fo[-cap:]) < 1e-4
+    want = G.xlating_fir_exact(x, nb, proto, 5 * fs / nb, fs).astype(np.complex64)
+    assert len(b) == cap and rel_rms(b, want[-cap:]) < 2e-5
+
+
 def test_long_churn_retunes_opens_closes(gpu_required):
     """600 small pushes with a retune every push and an open / close every few: deferred frees, the bank-matrix cache
     and the launch arenas keep up, and a channel nobody touched still equals the oracle over the whole stream"""
