@@ -8,9 +8,12 @@ PARITY UNPINNED.  GNU Radio 3.8 / VOLK / FFTW are third-party dependencies of th
 are neither vendored under /root/reference nor installable here, and the reference ships no tests,
 golden vectors or fixtures for this path.  Every function below is a
 restatement of the published GR 3.8 block semantics ("[GR-spec]" in SURVEY.md section 8(c)) and is
-validated only by analytic known-answer tests (tests/test_oracle_kat.py) and by agreement with the
-independent C restatement in oracle/rcf_oracle.c.  The one live third-party oracle is
-``scipy.signal.find_peaks`` (see oracle/peaks.py).
+validated by analytic known-answer tests (tests/test_oracle_kat.py), by agreement with the
+independent C restatement in oracle/rcf_oracle.c, and -- for every formula that has a public twin --
+against third-party implementations of the same mathematics (scipy.signal.firwin / windows / bilinear /
+lfilter, numpy FFT: tests/test_oracle_thirdparty.py).  GNU Radio's float32 operation ORDER (tap-phase
+rounding, rotator iteration, VOLK summation) has no such twin and stays unpinned.  The live third-party
+oracles are ``scipy.signal.find_peaks`` (oracle/peaks.py) and ``scipy.signal.remez`` (oracle/audio.py).
 
 Reference call sites each function follows (paths relative to /root/reference):
   * low_pass_2 / windows      rc_frontend/channel.py:33, p25_control_demod.py:106-108
