@@ -12,6 +12,7 @@ from oracle import grspec as G
 from oracle import peaks as P
 
 V = np.load(os.path.join(os.path.dirname(__file__), "golden", "dsp_vectors.npz"))
+VA = np.load(os.path.join(os.path.dirname(__file__), "golden", "audio_vectors.npz"))
 
 
 def rel(a, b):
@@ -46,6 +47,36 @@ def test_oracles_reproduce_scan_vectors():
     l3, f3 = scan.peak_detect(V["scan_spec"], 2.4e6, 855.05e6)          # product host picker (librcf)
     np.testing.assert_array_equal(l3, V["scan_lines"])
     assert f3 == list(V["scan_freqs"])
+
+
+def test_oracle_and_library_reproduce_audio_vectors():
+    from oracle import audio as A
+    from rcf import audio as host_audio
+    st = A.analog_chain(VA["iq"], 25000.0, stages=True)
+    assert len(st["gated"]) == int(VA["gated_len"]) < len(VA["iq"])          # the silence was gated
+    np.testing.assert_array_equal(st["audio"], VA["audio"])
+    p = host_audio.analog_chain_params(25000)                                # librcf's designs (no oracle, no scipy)
+    np.testing.assert_array_equal(p["lpf_taps"], VA["lpf_taps"])
+    np.testing.assert_array_equal(p["hpf_taps"], VA["hpf_taps"])
+    np.testing.assert_array_equal(p["rs_taps"], VA["rs_taps"])
+    assert list(VA["deemph_b"]) == p["deemph_b"] and list(VA["deemph_a"]) == p["deemph_a"]
+
+
+@pytest.mark.gpu
+def test_hip_audio_chain_reproduces_golden_vectors(gpu_required):
+    """the committed channel-rate stream goes in through a pass-through channel (decimation 1, one unit tap), the
+    analog voice chain behind it must give the committed 8 kHz audio, gated silence included"""
+    nat = gpu_required
+    from rcf import audio as host_audio
+    with nat.Frontend(25000.0) as fe:
+        cid = fe.chan_open_taps(-1, 1, np.ones(1, dtype=np.float32), 0.0)
+        host_audio.open_analog_voice(fe, cid, 25000)
+        fe.push(VA["iq"][:1700])
+        fe.push(VA["iq"][1700:])
+        n_audio, n_ungated = fe.chan_audio_produced(cid)
+        audio = fe.chan_read_audio(cid)
+    assert n_ungated == int(VA["gated_len"]) and len(audio) == n_audio == len(VA["audio"])
+    assert np.sqrt(np.mean((audio - VA["audio"]) ** 2)) < 1e-4
 
 
 @pytest.mark.gpu
