@@ -16,6 +16,9 @@
 // butterfly shuffles.  The rotator is evaluated in closed form in float64 from the float32
 // increment GNU Radio would iterate (angle and the |incr|^n drift between its every-512 renormal-
 // isations), so outputs do not depend on how the stream is cut into blocks.
+#include <cstdlib>
+#include <mutex>
+
 #include "rcf_internal.h"
 
 namespace rcfx {
@@ -336,217 +339,176 @@ __global__ __launch_bounds__(kThreads) void fir_bank_kernel(const ChanLaunch *__
 //   M = 16 rows   = 8 channels x {Re y, Im y}
 //   N = 16 cols   = 16 consecutive outputs k
 //   K = 4 per op  = 2 taps x {Re x, Im x}
-// A (taps) streams from the launch's bank matrix (rcf_internal.h), stored in MFMA lane order with the
-// [cr -ci; ci cr] signs applied: one fully coalesced 16-byte buffer load per lane covers four ops.  B (samples) is one ds_read_b32 per op from the LDS tile, whose rows of D
-// samples are skewed by one sample when D is even so that the 16 columns (stride D) fall in 16 different banks.
-// The 16-output tile is (15 D + T) samples = 119 KB at D = 800, T = 2909, so ONE workgroup owns a CU.  It runs
-// 8 waves = (items of 32 channels: MT = 4 M-tiles x one N-tile, four accumulator sets per tile) x (parts of the tap range): 4 x 2 for a full 128-channel workgroup, 1 x 8 for a bank of up to 32 channels.
-// A wave's own VALU / LDS / VMEM issue does not overlap its MFMAs (measured: additive), the second wave on each
-// SIMD is what fills the matrix pipe meanwhile.  The parts add their partial sums through the (by then dead) tile
-// memory; a lane holds complete (Re, Im) pairs of two channels for one output, so the rotator and the ring store
-// need no cross-lane step.
+// Operand plan (rcf_internal.h, "bank2"):
+//   * workgroup = 4 waves = ONE group of 32 channels x (4 x NT) tiles of 16 consecutive outputs; two workgroups
+//     per CU (64 KB of LDS each), so one's prologue / epilogue / barrier waits are covered by the other's MFMAs;
+//   * the group's taps (A operand) stream through LDS in 32 KB chunks of 8 steps (64 taps), double buffered,
+//     fetched ONE chunk ahead with coalesced 16-byte loads and shared by the four waves: 32 B of L2 traffic per
+//     MFMA instead of 256;
+//   * the samples (B operand) come straight from the wideband buffer (L2 / Infinity Cache): lane (kap, j) needs
+//     x[(k0 + j) D - 2q], x[.. + 1] for pair q -- ONE 16-byte load feeds its four ops of a step, the four kap lanes
+//     of an output read one 64-byte run, a step later the next 64 bytes.  Steps run from the highest taps down so
+//     the addresses ascend and a chunk's eight steps are immediate offsets of one VGPR.
+//   * a wave keeps 4 x NT accumulator tiles (32 channels x 16 NT outputs): each A register feeds NT MFMAs, each B
+//     register four -- 6 operand registers per 32 MFMAs at NT = 2.
+// There is no sample tile in LDS: no D-dependent LDS limit (6.25 kHz channels at 20 Msps run full 16-wide tiles),
+// no serial tile-load phase, and no cross-wave reduction.  (The first version of this kernel kept a 16-output
+// sample tile in LDS -- 119 KB at D = 800, T = 2909, one workgroup per CU -- and streamed the taps from L2 into
+// registers: 256 B of L2 traffic per MFMA and a serial tile load + reduction per workgroup; 113 TF at 4096
+// channels against 128 here.)
 typedef float v4f __attribute__((ext_vector_type(4)));
-typedef const v4f __attribute__((address_space(1))) *gv4;
 constexpr int MT = 4;
-constexpr int kThreadsM = 512;
-constexpr int kMfmaExchangeBytes = (kThreadsM / kWave) * MT * 4 * kWave * 4;   // 32 KB
+constexpr int kM2Threads = 256;
 
-__global__ __launch_bounds__(kThreadsM) void fir_mfma_kernel(const ChanLaunch *__restrict__ chans, FirLaunchDims d)
+struct MfmaArgs {
+    const float *bank;
+    int64_t src_len;
+    uint64_t ring_mask;
+    int D, T, n_chans, n_groups, n_wt;
+};
+
+template <int NT, int PD>
+__global__ __launch_bounds__(kM2Threads, 2) void fir_mfma_kernel(const ChanLaunch *__restrict__ chans, MfmaArgs d)
 {
+    constexpr int CS = kM2ChunkSteps;
+    constexpr int kM2ChunkBytes = CS * 4096;
+    constexpr int NLD = CS * 4096 / (kM2Threads * 16);      // 16-byte loads per thread per chunk
+    constexpr int NB = PD + 1;                              // B register stages: loads run PD steps ahead
+    static_assert(CS % NB == 0, "stage rotation must close over a chunk");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float *xf = reinterpret_cast<float *>(smem_raw);
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c0 = blockIdx.y * d.chans_per_wg;
-    const int nc = min(d.chans_per_wg, d.n_chans - c0);
-    const ChanLaunch &L0 = chans[c0];
-    const int tile = blockIdx.x;
-    const int KTM = d.KT;                               // outputs per tile: 16, or 8 when 16 do not fit the LDS
-    if ((int64_t)tile * KTM >= L0.n_k) return;
-    const int kt_n = min(KTM, L0.n_k - tile * KTM);
-    const int64_t kt0 = L0.k_lo + (int64_t)tile * KTM;
-    const int64_t s_tile0 = kt0 * d.D - (d.T - 1);
-    const int len = (kt_n - 1) * d.D + d.T;
-    const int delta = (d.D & 1) ? 0 : 1;
-    const int Dp = d.D + delta;
-
-    // tile load, 8 independent 8-byte loads in flight per thread (one workgroup per CU: nothing else hides HBM)
-    const StreamView sv = L0.src;
-    const unsigned magic = 0xffffffffu / (unsigned)d.D + 1;   // floor(p / D) = umulhi(p, magic) for p D < 2^32 / D
-    constexpr int LU = 8;
-    for (int p0 = tid; p0 < len; p0 += kThreadsM * LU) {
-        float2 v[LU];
-#pragma unroll
-        for (int u = 0; u < LU; ++u) {
-            const int p = p0 + u * kThreadsM;
-            const uint64_t idx = (uint64_t)(s_tile0 + (p < len ? p : len - 1) - sv.origin) & sv.mask;
-            v[u] = sv.base[idx];
-        }
-#pragma unroll
-        for (int u = 0; u < LU; ++u) {
-            const int p = p0 + u * kThreadsM;
-            if (p < len) reinterpret_cast<float2 *>(xf)[p + (int)__umulhi((unsigned)p, magic) * delta] = v[u];
-        }
-    }
-    __syncthreads();
-
+    // groups fastest: the workgroups resident together mostly share their output tiles, i.e. their samples, through
+    // L2 (each streams its own taps once) -- measured 2-4 % better than tiles fastest
+    const int g = blockIdx.x % d.n_groups, wt = blockIdx.x / d.n_groups;
+    const ChanLaunch &L0 = chans[g * kM2Group];
+    const int n_k = L0.n_k;
+    const int k_rel0 = (wt * (kM2Threads / kWave) + wave) * (NT * 16);
     const int j = lane & 15, kap = lane >> 4;
-    const int q = kap & 1, tp = kap >> 1;
-    const int jj = j < kt_n ? j : kt_n - 1;
-    const int lbase = jj * Dp * 2 + q;
-    const int n_steps = bank_steps(d.T);
-    // 8 waves = (items of 32 channels) x (tap parts): 4 x 2 for 97+ channels, 2 x 4 for 33..64, 1 x 8 up to 32 --
-    // a small bank spreads its taps over all eight waves instead of leaving six of them idle
-    const int items_p2 = nc > 64 ? 4 : (nc > 32 ? 2 : 1);
-    const int n_parts = (kThreadsM / kWave) / items_p2;
-    const int item = wave % items_p2, part = wave / items_p2;
-    const int cw0 = c0 + item * 8 * MT;
-    const bool active = item * 8 * MT < nc;
+    const int NS = bank2_steps(d.T);
+    const int NC = NS / CS;
 
-    // four accumulator sets per M-tile (one per op of a step): covers the MFMA latency and keeps each float32
-    // summation chain a quarter of the part's taps long (rounding noise ~ sqrt(chain length))
-    v4f acc[MT][4];
+    const StreamView sv = L0.src;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float2 *>(sv.base), 0, (int)(d.src_len * (int64_t)sizeof(float2)), 0x00020000);
+    int voff[NT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = (v4f){0.f, 0.f, 0.f, 0.f};
-    if (active) {
-        const int per = ((n_steps / 4 + n_parts - 1) / n_parts) * 4;     // steps per part, a multiple of the 4-step trip
-        const int step0 = min(part * per, n_steps), step1 = min(step0 + per, n_steps);
-        // A operand: one buffer descriptor over the bank matrix, lane offset in a VGPR, (tile, step) offset in an
-        // SGPR -- no vector arithmetic per load
-        const __amdgpu_buffer_rsrc_t bank_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(d.bank), 0, (int)(bank_floats(d.n_chans, d.T) * sizeof(float)), 0x00020000);
-        int a_soff[MT];                                // byte offset of (tile, next step to fetch)
+    for (int n = 0; n < NT; ++n) {
+        int kr = k_rel0 + n * 16 + j;
+        if (kr > n_k - 1) kr = n_k - 1;                     // past the block: recompute the last output, never stored
+        if (kr < 0) kr = 0;
+        const int64_t sidx = (L0.k_lo + kr) * (int64_t)d.D - sv.origin - 8 * (NS - 1) - 2 * kap;
+        voff[n] = (int)(sidx * (int64_t)sizeof(float2));
+    }
+    const float *bank_g = d.bank + (size_t)g * bank2_group_floats(d.T);
+
+    v4f acc[MT][NT];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            int g = (cw0 >> 3) + t;
-            if (g * 8 >= d.n_chans) g = (d.n_chans - 1) >> 3;   // dead tiles: computed, never stored
-            a_soff[t] = (g * n_steps + step0) * 1024;
-        }
-        const int a_voff = lane * 16;
-        // B operand: x[k D - tap] sits at LDS sample position rr + floor(rr / D) delta, rr = (T-1-tp) - 2 op.
-        // Per step (4 ops, rr spans top-7 .. top with top = T-1-8 step) the quotient is one wave-uniform value
-        // except in the few steps that straddle a multiple of D: track top's quotient / remainder in scalars.
-        const int lconst = (lbase + 2 * (d.T - 1 - tp)) * 4;
-        int top = d.T - 1 - 8 * step0;
-        int topq = top >= 0 ? top / d.D : 0;
-        int toprem = top >= 0 ? top - topq * d.D : 0;
-        auto fetch_b = [&](float (&b)[4]) {
-            if (top >= 7 && toprem >= 7) {                     // clean step: one add, four reads at fixed offsets
-                const float *pb = reinterpret_cast<const float *>(
-                    smem_raw + (lconst + 8 * (topq * delta + top - (d.T - 1)) - 48));
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) b[u] = pb[(48 - 16 * u) / 4];
-            } else if (top < 0) {                              // padding taps only (zero coefficients)
+        for (int n = 0; n < NT; ++n) acc[t][n] = (v4f){0.f, 0.f, 0.f, 0.f};
+    v4f a[2][MT], b[NB][NT], stg[NLD];
+
+    auto ldA = [&](int c) {                                  // chunk c: 32 KB, 8 coalesced 16-byte loads per thread
+        const v4f *src = reinterpret_cast<const v4f *>(bank_g + (size_t)c * (kM2ChunkBytes / 4)) + tid;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) b[u] = xf[lbase];
-            } else {                                           // straddles a multiple of D, or runs into padding
+        for (int r = 0; r < NLD; ++r) stg[r] = src[r * kM2Threads];
+    };
+    auto stA = [&](int buf) {
+        v4f *dst = reinterpret_cast<v4f *>(smem_raw + buf * kM2ChunkBytes) + tid;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int rr = top - tp - 2 * u;
-                    const int qd = rr >= topq * d.D ? topq : topq - 1;
-                    b[u] = xf[lbase + 2 * (rr < 0 ? 0 : rr + qd * delta)];
-                }
-            }
-            top -= 8;
-            toprem -= 8;
-            if (toprem < 0) { toprem += d.D; topq -= 1; }      // D >= 8 (mfma_tile_bytes)
-        };
-        // Four steps per trip.  A sets rotate through four register groups and are requested three steps before
-        // use, B comes from LDS one step ahead.  sched_barrier pins the issue order so the counter waits land on
-        // the first use and not on the issue.  Everything that is not an MFMA costs its issue slot on this SIMD
-        // (measured: VALU time adds to matrix time, also across the two waves of a SIMD), hence the effort above
-        // to keep a step at 16 MFMAs + 4 loads + 4 LDS reads + one add.
-        v4f a0[MT], a1[MT], a2[MT], a3[MT];
-        float b0[4], b1[4];
-        auto fetch_a = [&](v4f (&a)[MT]) {               // fetches past the end of the bank return zeros (descriptor)
+        for (int r = 0; r < NLD; ++r) dst[r * kM2Threads] = stg[r];
+    };
+    auto rdA = [&](int buf, int i, v4f (&dst)[MT]) {
+        const v4f *src = reinterpret_cast<const v4f *>(smem_raw + buf * kM2ChunkBytes + i * 4096) + lane;
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                a[t] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(bank_rsrc, a_voff, a_soff[t], 0));
-                a_soff[t] += 1024;
-            }
-        };
-        auto mac = [&](const v4f (&a)[MT], const float (&b)[4]) {
+        for (int t = 0; t < MT; ++t) dst[t] = src[t * kWave];
+    };
+    // step i of the current chunk (i >= CS: the next chunk's step i - CS -- the addresses simply continue)
+    auto ldB = [&](int i, v4f (&dst)[NT]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+        for (int n = 0; n < NT; ++n)
+            dst[n] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, voff[n] + 64 * i, 0, 0));
+    };
+    auto mac = [&](const v4f (&aa)[MT], const v4f (&bb)[NT]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][u], b[u], acc[t][u], 0, 0, 0);
-        };
-        __builtin_amdgcn_sched_barrier(0);            // same issue order as the loop body, or the loop-top waits
-        fetch_a(a0);                                  // are sized for the worse of the two predecessors
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[t][u], bb[n][u], acc[t][n], 0, 0, 0);
+    };
+
+    // Pipeline.  Samples: PD steps ahead (they come from L2 / Infinity Cache / HBM -- a miss under load is several
+    // thousand cycles, a step is ~1000-2000).  Taps: chunk c + 1 is requested at the top of chunk c, parked in
+    // LDS at step CS - 3 (the other buffer: everybody left it at the previous chunk's barrier), published by ONE
+    // barrier after step CS - 2, so that step CS - 1 prefetches its first operands like any other step.  The memory
+    // counter is in order: a wave waiting for a step's samples also waits for every older load, so the tap loads'
+    // latency is covered by the same PD steps.
+    ldA(0);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) ldB(i, b[i]);
+    stA(0);
+    __syncthreads();
+    rdA(0, 0, a[0]);
+    for (int c = 0; c < NC; ++c) {
+        const int buf = c & 1;
         __builtin_amdgcn_sched_barrier(0);
-        fetch_a(a1);
+        ldA(c + 1);                       // past the last chunk: one chunk of slack behind the bank, never used
         __builtin_amdgcn_sched_barrier(0);
-        fetch_a(a2);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch_b(b0);
-        __builtin_amdgcn_sched_barrier(0);
-        for (int m4 = step0; m4 < step1; m4 += 4) {   // every part's step count is a multiple of 4
-            fetch_a(a3); fetch_b(b1);
+#pragma unroll
+        for (int i = 0; i < CS; ++i) {
+            ldB(i + PD, b[(i + PD) % NB]);   // past the last chunk: in range or zero (buffer descriptor), never used
+            if (i + 1 < CS) rdA(buf, i + 1, a[(i + 1) & 1]);
+            else            rdA(buf ^ 1, 0, a[0]);
+            if (i == CS - 3) stA(buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            mac(a0, b0);
+            mac(a[i & 1], b[i % NB]);
             __builtin_amdgcn_sched_barrier(0);
-            fetch_a(a0); fetch_b(b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mac(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch_a(a1); fetch_b(b1);
-            __builtin_amdgcn_sched_barrier(0);
-            mac(a2, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch_a(a2); fetch_b(b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mac(a3, b1);
-            __builtin_amdgcn_sched_barrier(0);
+            if (i == CS - 2) __syncthreads();
         }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) voff[n] += 64 * CS;
     }
 
-    // every wave parks its partial sums (4 M-tiles x 4 accumulator registers) in the now dead sample tile; M-tile t of
-    // an item is finished by that item's tap part t % n_parts, which adds the parts in order 0 .. n_parts - 1
-    __syncthreads();                                  // every wave is done with the sample tile
+    // C/D layout: lane (kap, j) holds rows 4 kap .. 4 kap + 3 = (Re, Im) of channels 2 kap, 2 kap + 1 for output j
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        const v4f sum = (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+    for (int n = 0; n < NT; ++n) {
+        const int kr = k_rel0 + n * 16 + j;
+        if (kr >= n_k) continue;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xf[((wave * MT + t) * 4 + e) * kWave + lane] = sum[e];
-    }
-    __syncthreads();
-    if (!active || j >= kt_n) return;
-    for (int t = part % MT; t < MT; t += n_parts) {
-        if (part >= MT) break;                        // 8 parts, 4 tiles: parts 4 .. 7 have nothing to finish
-        v4f tot = (v4f){0.f, 0.f, 0.f, 0.f};
-        for (int pp = 0; pp < n_parts; ++pp) {
-            const int w2 = pp * items_p2 + item;
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) tot[e] += xf[((w2 * MT + t) * 4 + e) * kWave + lane];
-        }
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int ci = cw0 + t * 8 + 2 * kap + hh;
-            if (ci < c0 + nc) rotate_store(chans[ci], kt0 + j, tot[2 * hh], tot[2 * hh + 1], d.ring_mask);
-        }
+            for (int hh = 0; hh < 2; ++hh) {
+                const int ci = g * kM2Group + t * 8 + 2 * kap + hh;
+                if (ci < d.n_chans) rotate_store(chans[ci], L0.k_lo + kr, acc[t][n][2 * hh], acc[t][n][2 * hh + 1], d.ring_mask);
+            }
     }
 }
 
 __global__ __launch_bounds__(kThreads) void fir_pack_kernel(const ChanLaunch *__restrict__ chans, int n_chans, int T,
-                                                            int n_steps, float *__restrict__ bank)
+                                                             int NS, float *__restrict__ bank,
+                                                             const unsigned char *__restrict__ dirty)
 {
+    const int g = blockIdx.y;
+    if (dirty && !dirty[g]) return;
     const size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x;
-    if (e >= bank_floats(n_chans, T)) return;
-    const int mm = e & 3, lane = (e >> 2) & 63;
-    const size_t gs = e >> 8;
-    const int step = (int)(gs % n_steps), g = (int)(gs / n_steps);
-    const int j = lane & 15, kap = lane >> 4;
-    const int c = j >> 1, r = j & 1, tp = kap >> 1, q = kap & 1;
-    const int tap = 2 * (4 * step + mm) + tp, ci = g * 8 + c;
+    if (e >= (size_t)NS * 1024) return;
+    const int u = e & 3, lane = (e >> 2) & 63, t = (e >> 8) & 3;
+    const int p = (int)(e >> 10);
+    const int kap = lane >> 4, row = lane & 15, c = row >> 1, r = row & 1;
+    const int q = 4 * (NS - 1 - p) + kap;
+    const int tap = (u < 2) ? 2 * q : 2 * q - 1, im = u & 1;
+    const int ci = g * kM2Group + t * 8 + c;
     float v = 0.f;
-    if (ci < n_chans && tap < T) {
+    if (ci < n_chans && tap >= 0 && tap < T) {
         const float2 ct = chans[ci].ctaps[tap];
-        v = (r == q) ? ct.x : (r == 0 ? -ct.y : ct.y);       // [cr -ci; ci cr]
+        v = im ? (r == 0 ? -ct.y : ct.x) : (r == 0 ? ct.x : ct.y);     // [cr -ci; ci cr][r][re|im]
     }
-    bank[e] = v;
+    bank[(size_t)g * NS * 1024 + e] = v;
 }
 
 // ---------------------------------------------------------------- discriminator
@@ -619,37 +581,65 @@ void launch_fm_level(const float *fm_ring, int64_t n_end, int window, float gain
     hipLaunchKernelGGL(fm_level_kernel, dim3(1), dim3(kThreads), 0, s, fm_ring, n_end, window, gain, ring_mask, d_out);
 }
 
-void launch_fir_pack(const ChanLaunch *d_chans, int n_chans, int T, float *bank, hipStream_t s)
+void launch_fir_pack(const ChanLaunch *d_chans, int n_chans, int T, float *bank, const unsigned char *dirty,
+                      hipStream_t s)
 {
-    const size_t n = bank_floats(n_chans, T);
-    hipLaunchKernelGGL(fir_pack_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, d_chans,
-                       n_chans, T, bank_steps(T), bank);
+    const int NS = bank2_steps(T);
+    const int groups = (n_chans + kM2Group - 1) / kM2Group;
+    hipLaunchKernelGGL(fir_pack_kernel, dim3((unsigned)((NS * 1024 + kThreads - 1) / kThreads), groups), dim3(kThreads),
+                       0, s, d_chans, n_chans, T, NS, bank, dirty);
+}
+
+template <int NT, int PD>
+static void launch_mfma_t(const ChanLaunch *d_chans, MfmaArgs a, int max_n_k, hipStream_t s)
+{
+    // 64 KB of dynamic LDS needs the attribute on every device the process uses (it is per function per device)
+    static std::mutex mu;
+    static bool attr_set[64] = {false};
+    const size_t lds = 2 * kM2ChunkSteps * 4096;
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> g(mu);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fir_mfma_kernel<NT, PD>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set[dev] = true;
+        }
+    }
+    a.n_wt = (max_n_k + 64 * NT - 1) / (64 * NT);
+    hipLaunchKernelGGL((fir_mfma_kernel<NT, PD>), dim3((unsigned)(a.n_wt * a.n_groups)), dim3(kM2Threads), lds, s,
+                       d_chans, a);
+}
+
+static void launch_mfma(const ChanLaunch *d_chans, const FirLaunchDims &dims, hipStream_t s)
+{
+    MfmaArgs a{};
+    a.bank = dims.bank;
+    a.src_len = dims.src_len;
+    a.ring_mask = dims.ring_mask;
+    a.D = dims.D; a.T = dims.T; a.n_chans = dims.n_chans;
+    a.n_groups = (dims.n_chans + kM2Group - 1) / kM2Group;
+    // outputs per workgroup: 4 waves x NT x 16.  NT = 2 halves the A-operand LDS reads and the tap traffic per
+    // MFMA; NT = 1 halves the work unit, which is what matters while the launch is only a round or two of workgroups
+    // (512 resident: two per CU)
+    static const int force_nt = [] { const char *e = getenv("RCF_FIR_MFMA_NT"); return e ? atoi(e) : 0; }();
+    const int wt2 = (dims.max_n_k + 127) / 128;
+    int nt = ((int64_t)a.n_groups * wt2 >= 1024) ? 2 : 1;
+    if (force_nt == 1 || force_nt == 2) nt = force_nt;
+    if (nt == 2) launch_mfma_t<2, 3>(d_chans, a, dims.max_n_k, s);
+    else         launch_mfma_t<1, 3>(d_chans, a, dims.max_n_k, s);
 }
 
 void launch_fir_bank(const ChanLaunch *d_chans, const FirLaunchDims &dims, hipStream_t s)
 {
     if (dims.n_chans <= 0 || dims.max_n_k <= 0) return;
+    if (dims.mfma) { launch_mfma(d_chans, dims, s); return; }
     if (dims.small) {
         const int KB = fir_small_outputs(dims.D, dims.T);
         const size_t lds = ((size_t)KB * dims.D + 2 * dims.T + KB + 1) * sizeof(float2) + 264 * sizeof(float);
         hipLaunchKernelGGL(fir_small_kernel, dim3((dims.max_n_k + KB - 1) / KB, dims.n_chans), dim3(kThreads), lds, s,
                            d_chans, dims.D, dims.T, KB, dims.ring_mask, dims.atan_tab);
-        return;
-    }
-    if (dims.mfma) {
-        static size_t attr_lds = 0;
-        size_t lds = mfma_tile_bytes(dims.D, dims.T);
-        if (lds < (size_t)kMfmaExchangeBytes) lds = kMfmaExchangeBytes;
-        if (lds > attr_lds) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fir_mfma_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_lds = lds;
-        }
-        const int groups = (dims.n_chans + dims.chans_per_wg - 1) / dims.chans_per_wg;
-        FirLaunchDims md = dims;
-        md.KT = mfma_tile_outputs(dims.D, dims.T);
-        hipLaunchKernelGGL(fir_mfma_kernel, dim3((dims.max_n_k + md.KT - 1) / md.KT, groups), dim3(kThreadsM), lds, s,
-                           d_chans, md);
         return;
     }
     const int tiles = (dims.max_n_k + dims.KT - 1) / dims.KT;

@@ -134,7 +134,7 @@ struct rcf {
     float *d_level = nullptr;     // rcf_chan_fm_level result
     void *d_raw = nullptr;        // wire-format staging (rcf_push_raw), block_cap * 4 bytes, lazily allocated
     // launch-parameter arenas (pinned host + device), double buffered
-    static constexpr size_t kArena = 8u << 20;
+    size_t arena_cap = 8u << 20;
     unsigned char *h_arena[2] = {nullptr, nullptr};
     unsigned char *d_arena[2] = {nullptr, nullptr};
     hipEvent_t arena_ev[2] = {nullptr, nullptr};
@@ -358,12 +358,43 @@ int process_block(rcf_t *h, size_t n)
     hipStream_t st = h->stream;
     if (h->graveyard.size() > 512) drain_graveyard(h);     // bounded even if nobody ever syncs or reads
 
-    // arena for this commit
+    // arena for this commit: sized for every channel's launch records before anything is scheduled, so the
+    // schedule below cannot run out half way (it mutates channel state as it goes)
+    {
+        size_t need = 4096;
+        for (auto &kv : h->chans) {
+            need += sizeof(ChanLaunch) + sizeof(DiscLaunch) + 2 + 128;
+            if (kv.second->d_sym) need += sizeof(FmFirLaunch);
+            if (kv.second->audio) need += sizeof(AudioLaunch);
+        }
+        need += 64 * (h->chans.size() / 4 + 64);              // per-class alignment slack
+        if (need > h->arena_cap) {
+            RCF_HIP(hipStreamSynchronize(h->stream));
+            size_t cap = h->arena_cap;
+            while (cap < need) cap *= 2;
+            for (int i = 0; i < 2; ++i) {
+                unsigned char *nh = nullptr, *nd = nullptr;
+                RCF_HIP(hipHostMalloc(&nh, cap, hipHostMallocDefault));
+                RCF_HIP(hipMalloc(&nd, cap));
+                (void)hipHostFree(h->h_arena[i]);
+                (void)hipFree(h->d_arena[i]);
+                h->h_arena[i] = nh;
+                h->d_arena[i] = nd;
+                h->arena_used[i] = false;
+            }
+            h->arena_cap = cap;
+        }
+    }
     const int a = h->arena_cur;
     if (h->arena_used[a]) RCF_HIP(hipEventSynchronize(h->arena_ev[a]));
-    Arena ar{h->h_arena[a], h->d_arena[a], 0, rcf::kArena};
+    Arena ar{h->h_arena[a], h->d_arena[a], 0, h->arena_cap};
 
-    struct FirJob { FirLaunchDims dims; const ChanLaunch *dev; bool repack; };
+    struct FirJob {
+        FirLaunchDims dims; const ChanLaunch *dev; bool repack; const unsigned char *dirty;
+        // bank-matrix cache entry to mark current once the pack launch has been queued (not before: an error
+        // return in between must not leave a key that claims a matrix nobody built)
+        rcf::BankCache *bc; std::vector<std::pair<int, uint64_t>> key;
+    };
     struct DiscJob { const DiscLaunch *dev; int n; int max_n; };
     std::vector<std::vector<FirJob>> fir_by_depth;
     std::vector<DiscJob> disc_jobs;
@@ -533,11 +564,13 @@ int process_block(rcf_t *h, size_t n)
             // does not pull the whole class off the matrix cores.
             std::vector<ChanLaunch> clean, rest;
             std::vector<Chan *> clean_ch;
-            if (shared_src && depth == 0 && mfma_tile_bytes(D, T) != 0 && !h->no_mfma) {
+            int n_common_of_clean = max_n;
+            if (shared_src && depth == 0 && mfma2_applicable(D, T, h->hist_cap) && !h->no_mfma) {
                 int64_t k_common = -1;
                 int32_t n_common = 0;
                 for (auto &L : launches)                                   // the range most channels share: the earliest
                     if (k_common < 0 || L.k_lo < k_common) { k_common = L.k_lo; n_common = L.n_k; }
+                n_common_of_clean = n_common;
                 for (size_t i = 0; i < launches.size(); ++i) {
                     const ChanLaunch &L = launches[i];
                     const bool ok = L.k_lo == k_common && L.n_k == n_common &&
@@ -545,7 +578,8 @@ int process_block(rcf_t *h, size_t n)
                     if (ok) { clean.push_back(L); clean_ch.push_back(launched[i]); }
                     else rest.push_back(L);
                 }
-                if ((int)clean.size() < h->mfma_min || bank_floats((int)clean.size(), T) * sizeof(float) >= (size_t(1) << 31)) {
+                // (no size limit on a class: every group of 32 channels has its own tap slab)
+                if ((int)clean.size() < h->mfma_min) {
                     clean.clear();
                     clean_ch.clear();
                     rest = launches;
@@ -555,25 +589,47 @@ int process_block(rcf_t *h, size_t n)
             }
             if (!clean.empty()) {
                 FirJob mj = job;
+                mj.bc = nullptr;
                 rcf::BankCache &bc = h->banks[cls.first];
                 std::vector<std::pair<int, uint64_t>> key;
                 for (Chan *c : clean_ch) key.push_back({c->id, c->taps_version});
                 mj.repack = key != bc.key;
+                mj.dirty = nullptr;
                 if (mj.repack) {
-                    const size_t need = bank_floats((int)clean.size(), T);
+                    // + one chunk of slack: the kernel prefetches one chunk past a group's last
+                    const size_t need = (size_t)((clean.size() + kM2Group - 1) / kM2Group) * bank2_group_floats(T) +
+                                        (size_t)kM2ChunkSteps * 1024;
+                    bool fresh = false;
                     if (need > bc.cap) {
+                        // grow with headroom: a class that gains channels one by one must not reallocate each time
+                        const size_t want = std::max(need, bc.cap + bc.cap / 2);
+                        float *nd = nullptr;
+                        RCF_HIP(hipMalloc(&nd, sizeof(float) * want));
                         bury(h, bc.d);
-                        bc.d = nullptr;
-                        bc.cap = 0;
-                        RCF_HIP(hipMalloc(&bc.d, sizeof(float) * need));
-                        bc.cap = need;
+                        bc.d = nd;
+                        bc.cap = want;
+                        fresh = true;
                     }
-                    bc.key = key;
+                    if (!fresh) {
+                        // rebuild only the groups of 32 whose membership or taps changed
+                        const size_t ng = (clean.size() + kM2Group - 1) / kM2Group;
+                        std::vector<unsigned char> dirty(ng, 0);
+                        for (size_t i = 0; i < key.size(); ++i)
+                            if (i >= bc.key.size() || bc.key[i] != key[i]) dirty[i / kM2Group] = 1;
+                        if (bc.key.size() > key.size())                      // the class shrank: its last group lost rows
+                            dirty[ng - 1] = 1;
+                        if (!ar.put(dirty, &mj.dirty)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+                    }
+                    bc.key.clear();                           // stale until the pack launch below is queued
+                    mj.bc = &bc;
+                    mj.key = key;
                 }
                 mj.dims.n_chans = (int)clean.size();
                 mj.dims.mfma = 1;
                 mj.dims.chans_per_wg = 128;
                 mj.dims.bank = bc.d;
+                mj.dims.max_n_k = n_common_of_clean;
+                mj.dims.src_len = (int64_t)(h->hist_cap + n);
                 if (!ar.put(clean, &mj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
                 fir_by_depth[depth].push_back(mj);
             }
@@ -606,7 +662,10 @@ int process_block(rcf_t *h, size_t n)
     }
     if (!fir_by_depth.empty())
         for (auto &j : fir_by_depth[0]) {
-            if (j.repack) launch_fir_pack(j.dev, j.dims.n_chans, j.dims.T, const_cast<float *>(j.dims.bank), st);
+            if (j.repack) {
+                launch_fir_pack(j.dev, j.dims.n_chans, j.dims.T, const_cast<float *>(j.dims.bank), j.dirty, st);
+                if (j.bc) j.bc->key = std::move(j.key);
+            }
             Timed t(h, j.dims.mfma ? RCF_T_FIR_MFMA : RCF_T_FIR);
             launch_fir_bank(j.dev, j.dims, st);
         }
@@ -778,8 +837,8 @@ int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_c
     for (int i = 0; i < 2; ++i) {
         RCF_HIP(hipMalloc(&h->d_buf[i], sizeof(float2) * buf_samples));
         RCF_HIP(hipMemsetAsync(h->d_buf[i], 0, sizeof(float2) * buf_samples, h->stream));
-        RCF_HIP(hipHostMalloc(&h->h_arena[i], rcf::kArena, hipHostMallocDefault));
-        RCF_HIP(hipMalloc(&h->d_arena[i], rcf::kArena));
+        RCF_HIP(hipHostMalloc(&h->h_arena[i], h->arena_cap, hipHostMallocDefault));
+        RCF_HIP(hipMalloc(&h->d_arena[i], h->arena_cap));
         RCF_HIP(hipEventCreateWithFlags(&h->arena_ev[i], hipEventDisableTiming));
     }
     RCF_HIP(hipMalloc(&h->d_atan, sizeof(float) * 257));

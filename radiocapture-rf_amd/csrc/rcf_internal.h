@@ -62,35 +62,6 @@ struct ChanLaunch {
     float *fm_ring;          // discriminator ring (written by the fused small-T kernel only)
 };
 
-// Matrix-core bank operand ("bank matrix"): the composite taps of a launch's channels as the MFMA A operand,
-// in lane order, signs applied.  Group g = 8 consecutive channels of the launch (M-tile rows 2c + r, r = 0 Re y,
-// 1 Im y); step = 4 MFMA ops = 8 taps; op m covers taps 2m, 2m+1 with k-slot kap = 2 (tap & 1) + q (q = 0 times
-// Re x, 1 times Im x); lane = 16 kap + 2 c + r:
-//   bank[((g * n_steps + step) * 64 + lane) * 4 + (m & 3)] = [cr -ci; ci cr][r][q] of channel 8g + c, tap 2m + (kap >> 1)
-// zero past tap T-1 and for channels past the end of the launch.
-__host__ __device__ inline int bank_steps(int T) { return ((((T + 1) / 2) + 15) & ~15) >> 2; }   // multiple of 4 steps
-__host__ __device__ inline size_t bank_floats(int n_chans, int T) { return (size_t)((n_chans + 7) / 8) * bank_steps(T) * 256; }
-
-// Outputs per matrix-core tile: 16 (all MFMA columns) when the skewed sample tile (kt - 1) D + T fits the CU's
-// LDS, else 8 (half of the columns idle -- still several times the vector kernel), else 0: path not applicable.
-inline size_t mfma_tile_bytes_kt(int D, int T, int kt)
-{
-    const int len = (kt - 1) * D + T;
-    return (size_t)(len + len / D + 2) * sizeof(float2);
-}
-inline int mfma_tile_outputs(int D, int T)
-{
-    if (D < 8 || T < 64) return 0;
-    if (mfma_tile_bytes_kt(D, T, 16) <= 160 * 1024) return 16;
-    if (mfma_tile_bytes_kt(D, T, 8) <= 160 * 1024) return 8;
-    return 0;
-}
-inline size_t mfma_tile_bytes(int D, int T)
-{
-    const int kt = mfma_tile_outputs(D, T);
-    return kt ? mfma_tile_bytes_kt(D, T, kt) : 0;
-}
-
 // outputs per workgroup of the small-T kernel (tile of KB D + T samples within ~24 KB of LDS, one output per
 // thread minus the recomputed predecessor); 0 = not applicable
 inline int fir_small_outputs(int D, int T)
@@ -101,6 +72,26 @@ inline int fir_small_outputs(int D, int T)
     return kb >= 32 ? kb : 0;
 }
 
+// Matrix-core bank operand (fir_mfma_kernel, fir.hip): groups of 32 channels; the taps of a group are stored in
+// PROCESSING order -- step p = 0 .. NS-1 handles tap pairs q = 4 (NS-1-p) + kap, pair q = taps (2q, 2q-1), i.e.
+// the two samples x[kD-2q], x[kD-2q+1] one 16-byte load covers -- as four M-tiles of MFMA A operands:
+//   bank2[((g * NS + p) * 4 + t) * 256 + lane * 4 + u],  lane = 16 kap + 2 c + r  (channel 32 g + 8 t + c, r: Re/Im y)
+//   u = 0: x[kD-2q].re  1: x[kD-2q].im  2: x[kD-2q+1].re  3: x[kD-2q+1].im   times  [cr -ci; ci cr][r][re|im]
+// zero for taps outside [0, T) and channels past the end.  Each group is its own slab (64-bit base), so a class
+// has no size limit.
+constexpr int kM2Group = 32;      // channels per group (4 M-tiles of 8)
+constexpr int kM2ChunkSteps = 8;  // steps per LDS chunk (32 KB)
+__host__ __device__ inline int bank2_steps(int T)
+{
+    const int s = ((T / 2 + 1) + 3) / 4;
+    return (s + kM2ChunkSteps - 1) / kM2ChunkSteps * kM2ChunkSteps;
+}
+__host__ __device__ inline size_t bank2_group_floats(int T) { return (size_t)bank2_steps(T) * 1024; }
+inline bool mfma2_applicable(int D, int T, size_t hist_cap)
+{
+    return D >= 1 && T >= 64 && (size_t)(8 * bank2_steps(T) + 8 + D) <= hist_cap;
+}
+
 struct FirLaunchDims {
     int D, T, KT;            // decimation, taps, outputs per workgroup tile
     int n_chans;             // entries in the ChanLaunch array
@@ -108,14 +99,17 @@ struct FirLaunchDims {
     int max_n_k;             // max over channels of n_k
     uint64_t ring_mask;
     int mfma;                // 1: every channel shares source, k_lo and n_k, and no zero-history masking is needed
-    const float *bank;       // mfma: the launch's bank matrix (bank_floats(n_chans, T) floats)
+    const float *bank;       // mfma: the class's tap slabs (bank2 layout above)
+    int64_t src_len;         // mfma: samples addressable from the source view's base (buffer descriptor range)
     int small;               // 1: one-thread-per-output kernel with the discriminator fused in (no DiscLaunch)
     const float *atan_tab;   // small: gr::fast_atan2f table
 };
 
 void launch_fir_bank(const ChanLaunch *d_chans, const FirLaunchDims &dims, hipStream_t s);
 // (re)build a bank matrix from the channels' composite taps
-void launch_fir_pack(const ChanLaunch *d_chans, int n_chans, int T, float *bank, hipStream_t s);
+// dirty: device array of one byte per group of 32 (nullptr: every group), only flagged groups are rebuilt
+void launch_fir_pack(const ChanLaunch *d_chans, int n_chans, int T, float *bank, const unsigned char *dirty,
+                     hipStream_t s);
 
 // discriminator: fm[n] = fast_atan2f(imag(y[n] conj(y[n-1])), real(.)) (unit gain), n relative index
 struct DiscLaunch {
