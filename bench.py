@@ -4,18 +4,31 @@
   256-channel polyphase filterbank over one 20 Msps synthetic IQ stream per MI355X, stage-2 xlating
   FIR (/3) + FM discriminator on 32 active bins.
 
-One "step" = one commit of a BLOCK-sample batch that is already resident in HBM: PFB kernel (all 256
-bins written), 32 stage-2 FIRs with their discriminators fused in, history carry-over.  value = input IQ Msamples/s
-over all ranks.  N > 1: one independent 20 Msps front-end per GPU (config_denver_massive_p25-style,
-BASELINE configs[3]); weak scaling; no data-path collective -- the only RCCL traffic is the
-all-gather of detected-peak lists after the timed region (reported as peaks_allgather_us).
+One "step" = one commit of a BLOCK-sample batch that is already resident in HBM: PFB kernel (all 256 bins
+written), 32 stage-2 FIRs with their discriminators fused in, history carry-over.  value = input IQ Msamples/s
+over all ranks.  N > 1: one independent 20 Msps front-end per GPU (config_denver_massive_p25-style, BASELINE
+configs[3]); weak scaling; no data-path collective -- the only RCCL traffic is the all-gather of detected-peak
+lists (ncclAllGather through librcf's C ABI) after the timed region, reported as peaks_allgather_us.
+
+No PyTorch: device work goes through librcf's C ABI (ctypes), ranks meet over rcf.multigpu.HostGroup (TCP next
+to MASTER_PORT), the barrier on both sides of the timed region is `rcf_allreduce_max` (stream sync + one
+ncclAllReduce), which also yields the max-over-ranks time.
+
+Outside the timed region, rank 0 at N = 1 also reports:
+  channels.direct_bank   the reference-shaped bank (one 2909-tap xlating FIR /800 + discriminator per channel)
+                         actually opened and run at 256 .. 131072 (--sweep-max) channels, kernel ms per block
+                         and TFLOP/s at each point
+  scan                   BASELINE configs[2]: 1M-point FFT x 1000 frames / 100-frame average + peak pick
+  end_to_end             PCIe-inclusive ingest (pinned cf32 rcf_push_iq, u8 rcf_push_raw), copy overlapped
+  control_plane          100 x create / release through the frontend_connector protocol
+  cpu_baseline           the oracle's C port of the reference path on the host cores (+ the parity check of the
+                         timed configuration's FM outputs against the oracle)
 
 Launch: python bench.py [--gpus 1 --steps K --warmup W]   or, for N > 1,
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -31,6 +44,7 @@ FS = 20e6
 NB = 256
 N_ACTIVE = 32
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+FP32_MATRIX_PEAK_TF = 157.3    # MI355X_MICROARCH.md: FP32 matrix = FP32 vector peak
 
 
 def proto_taps(native):
@@ -40,18 +54,25 @@ def proto_taps(native):
     return native.design_low_pass_2(1.0, FS, 0.4 * bw, 0.2 * bw, 60.0, native.WIN_BLACKMAN_HARRIS)
 
 
-def cpu_baseline(tile, carriers, seconds=0.5, reps=3):
-    """The reference's structure on the host cores: one 2909-tap xlating FIR (D=800) + discriminator
-    per channel over the whole 20 Msps stream (rc_frontend/channel.py:31-38), all cores, oracle C."""
+# ------------------------------------------------------------------------------------------- CPU baseline leg
+def cpu_baseline(tile, carriers, fm_check=None, seconds=0.5, reps=3):
+    """The reference's structure on the host cores: one 2909-tap xlating FIR (D=800) + discriminator per
+    channel over the whole 20 Msps stream (rc_frontend/channel.py:31-38), oracle C port.  This leg is the only
+    place bench.py touches oracle/: as the timed CPU baseline and as the checker of the GPU's FM outputs."""
     from oracle import cbind as OC
     from oracle import grspec as G
     n = int(FS * seconds)
     x = np.tile(tile, (n + len(tile) - 1) // len(tile))[:n]
     D, taps = G.channel_params(FS, 12500)
-    cores = OC.max_threads()
-    # one channel per host thread, so that every core the baseline claims is actually busy (the bank is
+    threads = OC.max_threads()
+    try:
+        phys = len({(l.split(":")[1].strip()) for l in open("/proc/cpuinfo") if l.startswith("core id")}) * \
+            max(1, len({(l.split(":")[1].strip()) for l in open("/proc/cpuinfo") if l.startswith("physical id")}))
+    except Exception:
+        phys = None
+    # (ii) one channel per host thread, so that every thread the baseline claims is actually busy (the bank is
     # parallel over channels): the 32 bench carriers, repeated on a 12.5 kHz raster
-    offs = [carriers[i % len(carriers)]["f_off"] + 12500.0 * (i // len(carriers)) for i in range(max(cores, 1))]
+    offs = [carriers[i % len(carriers)]["f_off"] + 12500.0 * (i // len(carriers)) for i in range(max(threads, 1))]
     ct = np.stack([OC.xlating_composite(taps, D, f, FS)[0] for f in offs])
     inc = np.array([OC.xlating_composite(taps, D, f, FS)[1] for f in offs], dtype=np.complex64)
     gains = np.full(len(offs), G.p25_fm_gain(25000.0), dtype=np.float32)
@@ -62,10 +83,19 @@ def cpu_baseline(tile, carriers, seconds=0.5, reps=3):
         OC.channel_bank(x, D, ct, inc, gains, acc_double=False)
         times.append(time.perf_counter() - t0)
     t = sorted(times)[len(times) // 2]
-    return {
+    # (i) a single channel on one core == one of the reference's per-channel GNU Radio flowgraphs
+    t1s = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        OC.channel_bank(x, D, ct[:1], inc[:1], gains[:1], acc_double=False, nthreads=1)
+        t1s.append(time.perf_counter() - t0)
+    t1 = sorted(t1s)[len(t1s) // 2]
+    out = {
         "value": n / t / 1e6,
         "unit": "Msamples/s",
-        "cores": min(cores, len(offs)),
+        "cores": min(threads, len(offs)),
+        "cores_are": "hardware threads (OpenMP max threads of the box%s)" % (
+            "; %d physical cores" % phys if phys else ""),
         "kind": "port",
         "sample": "%.2f s of the same 20 Msps synthetic stream, %d concurrent 12.5 kHz channels "
                   "(2909-tap xlating FIR /800 + discriminator each, one per host thread), median of %d, OpenMP over channels; "
@@ -73,9 +103,226 @@ def cpu_baseline(tile, carriers, seconds=0.5, reps=3):
                   % (seconds, len(offs), reps),
         "channels": len(offs),
         "realtime_channels_at_20Msps": len(offs) * seconds / t,
+        "single_channel_one_core": {"seconds_per_second_of_signal": t1 / seconds,
+                                    "Msamples_per_s": n / t1 / 1e6,
+                                    "realtime_channels_per_core_at_20Msps": seconds / t1},
     }
+    if fm_check is not None:
+        out["gpu_fm_parity_vs_oracle"] = fm_parity(G, tile, fm_check)
+    return out
 
 
+def fm_parity(G, tile, chk):
+    """The timed configuration's own outputs against the oracle: the last ~300 discriminator samples of each of the
+    32 FM channels after the timed loop vs PFB bin (float64 exact-phase bank) -> stage-2 xlating FIR /3 ->
+    quadrature_demod on the same tail of the stream.  The resident block is the 2^20-sample tile repeated, so
+    the tail is reproducible on the host."""
+    taps, L = chk["taps"], 1 << 18
+    x = np.tile(tile, 2)[-L:] if L <= 2 * len(tile) else None
+    n_frames = L // NB
+    f_end = chk["total_in"] // NB                 # PFB frames produced so far; the tail is frames [f_end - n_frames, f_end)
+    f0 = f_end - n_frames
+    warm = (len(taps) + NB - 1) // NB + 1          # frames that still see the tail's zero history
+    j0 = warm + (-(f0 + warm)) % 3                 # first clean frame on the stage-2 decimation grid (frame % 3 == 0)
+    bin_rate = FS / NB
+    D2, taps2 = G.channel_params(bin_rate, 12500)
+    worst, rows = 0.0, 0
+    for c, fm in zip(chk["carriers"], chk["fm"]):
+        stage1 = G.xlating_fir_exact(x, NB, taps, c["bin"] * FS / NB, FS).astype(np.complex64)
+        yo = G.xlating_fir_ccc(stage1[j0:], D2, taps2, c["delta"], bin_rate)
+        fo = G.quadrature_demod_cf(yo, 1.0)
+        k_last = (f_end - 1) // 3                  # absolute stage-2 index of the newest output
+        k_first = (f0 + j0) // 3                   # absolute index of fo[0]
+        n_cmp = min(300, len(fo) - 8)
+        ref = fo[k_last - k_first - n_cmp + 1: k_last - k_first + 1]
+        got = fm[-n_cmp:]
+        e = float(np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2)))
+        worst = max(worst, e)
+        rows += 1
+    return {"channels_checked": rows, "samples_per_channel": 300, "worst_fm_rms_error": worst,
+            "tolerance": 1e-4, "ok": bool(worst < 1e-4)}
+
+
+# ------------------------------------------------------------------------------------------- GPU legs (untimed)
+def direct_bank_sweep(native, tile, device, counts, block=1 << 22):
+    """The reference-shaped bank on this GPU: C channels of rcf_chan_open(12500, f) == channel.py:31-38 each
+    (D = 800, T = 2909, GR-faithful float32 phases), opened for real, three blocks timed per point."""
+    D, T = native.channel_params(FS, 12500)
+    fd = native.Frontend(FS, 0.0, device=device, block_capacity=block, hist_capacity=1 << 16, out_capacity=1 << 13)
+    for at in range(0, block, len(tile)):
+        fd.ingest_write(tile[: min(len(tile), block - at)], at)
+    fd.commit(block)
+    ids, points = [], []
+    block_s = block / FS
+    for C_ in counts:
+        t0 = time.perf_counter()
+        while len(ids) < C_:
+            k = len(ids)
+            # 6.25 kHz raster across +-9.9 MHz, wrapped: distinct NCO phases, all inside the band
+            f = ((k * 6250.0 + 9.9e6) % 19.8e6) - 9.9e6
+            ids.append(fd.chan_open(12500, f))
+        open_s = time.perf_counter() - t0
+        fd.commit(block)                            # first block after opening: zero-history launch + bank pack
+        fd.commit(block)
+        fd.sync()
+        fd.timing_enable(True, classes=[native.T_FIR, native.T_FIR_MFMA, native.T_DISC])
+        for w in (native.T_FIR, native.T_FIR_MFMA, native.T_DISC):
+            fd.timing_read(w)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fd.commit(block)
+        fd.sync()
+        wall = (time.perf_counter() - t0) / 3
+        fms, fn = fd.timing_read(native.T_FIR)
+        mms, mn = fd.timing_read(native.T_FIR_MFMA)
+        dms, dn = fd.timing_read(native.T_DISC)
+        fd.timing_enable(False)
+        fir_ms = (fms + mms) / max(fn, mn, 1)
+        per_block_s = (fir_ms + dms / max(dn, 1)) * 1e-3
+        n_out = block // D
+        tf = 8.0 * T * n_out * C_ / (fir_ms * 1e-3) / 1e12
+        points.append({
+            "channels": C_, "kernel_ms_per_block": per_block_s * 1e3, "fir_ms": fir_ms,
+            "wall_ms_per_block": wall * 1e3, "block_ms_of_signal": block_s * 1e3,
+            "real_time": bool(wall < block_s and per_block_s < block_s),
+            "kernel": "fir_mfma_kernel (fp32 matrix cores)" if mn else "fir_bank_kernel (vector)",
+            "tflops_fp32": tf, "frac_of_fp32_matrix_peak": tf / FP32_MATRIX_PEAK_TF,
+            "realtime_channels_at_20Msps_extrapolated": C_ * block_s / per_block_s,
+            "open_ms_per_channel": open_s * 1e3 / max(1, C_ - (points[-1]["channels"] if points else 0)),
+        })
+    fd.close()
+    rt = [p["channels"] for p in points if p["real_time"]]
+    return {"block_samples": block, "points": points,
+            "channels_run_in_real_time": max(rt) if rt else 0,
+            "note": "every count was opened and run (no extrapolation); flop = 8 T per output per channel; "
+                    "peak 157.3 TF (datasheet) -- a bare v_mfma_f32_16x16x4_f32 loop with non-zero operands "
+                    "sustains ~140 TF on this chip (tools/mfma_peak_probe.hip)"}
+
+
+def scan_leg(native, synth, device):
+    """BASELINE configs[2]: 1M-point FFT, 1000 frames, 100-frame average (fft_vector.py:31-60) at 100 Msps from a
+    16-frame periodic resident buffer, then the device peak pick (fft_peak_detection.py:38-73)."""
+    N, F, L, fs = 1 << 20, 1000, 100, 100e6
+    rng = np.random.default_rng(3003)                # SURVEY 8(d) cfg3: 12 carriers, bin centres >= 5000 bins apart
+    centres = [40000 + 80000 * i + int(rng.integers(-3000, 3000)) for i in range(12)]
+    carriers = [(c, float(rng.uniform(4000, 9000)), 45.0) for c in centres]
+    x = synth.scan_stream(fs, N, 16, carriers, seed=3003)
+    B = 16 * N
+    fe = native.Frontend(fs, 0.0, device=device, block_capacity=B, hist_capacity=N, out_capacity=1 << 10)
+    for _ in range(2):
+        fe.ingest_write(x, 0)
+        fe.commit(B)
+    fe.sync()
+    res = {}
+    for rep in range(2):                            # second pass: buffers warm
+        fe.timing_enable(True, classes=[native.T_SCAN_FFT, native.T_SCAN_MOVSUM])
+        fe.timing_read(native.T_SCAN_FFT)
+        fe.timing_read(native.T_SCAN_MOVSUM)
+        fe.scan_start(N, F, L)
+        t0 = time.perf_counter()
+        while fe.scan_frames_done() < F:
+            fe.commit(B)
+        fe.sync()
+        wall = time.perf_counter() - t0
+        fft_ms, _ = fe.timing_read(native.T_SCAN_FFT)
+        mov_ms, _ = fe.timing_read(native.T_SCAN_MOVSUM)
+        fe.timing_enable(False)
+        t0 = time.perf_counter()
+        idx, mean, _ = fe.scan_find_peaks(cap=1024)
+        pick_ms = (time.perf_counter() - t0) * 1e3
+        samples = float(N) * F
+        res = {
+            "workload": "BASELINE configs[2]: N=2^20, 1000 frames, 100-frame average, 100 Msps, 12 carriers",
+            "fft_logmag_ms": fft_ms, "moving_sum_ms": mov_ms, "peak_pick_ms_incl_readback": pick_ms,
+            "wall_ms": wall * 1e3, "peaks_found": int(len(idx)),
+            "input_Msamples_per_s": samples / ((fft_ms + mov_ms) * 1e-3) / 1e6,
+            "realtime_factor_at_100Msps": samples / fs / ((fft_ms + mov_ms) * 1e-3),
+            "roofline": {"bound": "hbm", "algorithmic_bytes": 12.0 * samples,
+                         "achieved": 12.0 * samples / ((fft_ms + mov_ms) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s",
+                         "frac": 12.0 * samples / ((fft_ms + mov_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "ceiling_note": "a 1M-point FFT cannot live in LDS: the four-step form moves 28 B/sample "
+                                         "against 12 B algorithmic, so its ceiling is 12/28 = 0.43 of the HBM peak"},
+        }
+    fe.close()
+    return res
+
+
+def end_to_end_leg(native, tile, device, B=1 << 24):
+    """PCIe-inclusive ingest with the filterbank and the FM channels running: pinned host buffers handed to
+    rcf_push_iq (cf32, 8 B/sample) and rcf_push_raw (u8, 2 B/sample); block n+1 is copied while block n runs."""
+    fe = native.Frontend(FS, 0.0, device=device, block_capacity=B, hist_capacity=1 << 16, out_capacity=1 << 18)
+    fe.pfb_open(NB, NB, proto_taps(native))
+    out = {"block_samples": B}
+    pin = native.PinnedArray(B, np.complex64)
+    pin.array[:] = np.tile(tile, B // len(tile))
+    for _ in range(2):
+        fe.push(pin.array)
+    fe.sync()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        fe.push(pin.array)
+    fe.sync()
+    out["pinned_cf32_push_iq_Msps"] = 8 * B / (time.perf_counter() - t0) / 1e6
+    pin.free()
+    raw = native.PinnedArray(2 * B, np.uint8)
+    raw.array[:] = np.tile((np.clip(np.round(tile.view(np.float32) * 32 + 127.4), 0, 255)).astype(np.uint8),
+                           B // len(tile))
+    for _ in range(2):
+        fe.push_raw(raw.array, native.FMT_U8, 1.0 / 128, 127.4)
+    fe.sync()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        fe.push_raw(raw.array, native.FMT_U8, 1.0 / 128, 127.4)
+    fe.sync()
+    out["pinned_u8_push_raw_Msps"] = 8 * B / (time.perf_counter() - t0) / 1e6
+    raw.free()
+    fe.close()
+    out["note"] = "host -> HBM over PCIe Gen5 x16 (63 GB/s spec) + 256-bin PFB per block; never `value`"
+    return out
+
+
+def control_plane_leg(device):
+    """100 x create / release through the reference's client (frontend_connector.py:242-251 times exactly this)."""
+    import types
+    from rcf import frontend_connector as FC, protocol, receiver
+
+    class OneChannelizer:
+        def get_channelizer_for_frequency(self, f):
+            return ("127.0.0.1", 0)
+
+    cfg = types.SimpleNamespace(sources={0: dict(type="synthetic", center_freq=855000000, samp_rate=20000000)},
+                                frontend_mode="xlat")
+    tb = receiver.receiver(cfg, device=device)
+    srv = protocol.FrontendServer(tb)
+    fc = FC.frontend_connector("bench", OneChannelizer(), heartbeat=False,
+                               transport_factory=lambda h, p: protocol.LoopbackTransport(srv))
+    t_create, t_release = [], []
+    for i in range(100):
+        t0 = time.perf_counter()
+        cid, port = fc.create_channel(12500, int(855e6 + 12500 * (i - 50)))
+        t1 = time.perf_counter()
+        assert cid, "create_channel failed"
+        fc.release_channel()
+        t2 = time.perf_counter()
+        t_create.append(t1 - t0)
+        t_release.append(t2 - t1)
+    # and 100 distinct channels held at once (no idle reuse): what a busy trunked system asks for
+    t0 = time.perf_counter()
+    held = [tb.connect_channel(12500, int(855e6 + 12500 * (i - 50)))[0] for i in range(100)]
+    t_hold = (time.perf_counter() - t0) / 100
+    for b in held:
+        tb.release_channel(b)
+    tb.sweep_idle_channels(now=time.time() + 60)
+    tb.close()
+    return {"n": 100, "create_ms_median": sorted(t_create)[50] * 1e3, "create_ms_max": max(t_create) * 1e3,
+            "release_ms_median": sorted(t_release)[50] * 1e3,
+            "connect_channel_new_ms_mean": t_hold * 1e3,
+            "note": "create = connect_channel (reuses an idle channel after the first, as receiver.py:311-319 does) "
+                    "+ protocol; channel buffers come from the handle's slab pool"}
+
+
+# ------------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,31 +330,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--block", type=int, default=1 << 25, help="samples per step (resident batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs (sweep, scan, end-to-end, ...)")
+    ap.add_argument("--sweep-max", type=int, default=131072, help="largest direct-bank channel count to open")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        # RCF_BENCH_BACKEND=gloo + RCF_BENCH_DEVICE=0 lets two ranks share ONE GPU to exercise this code
-        # path on a single-GPU box; the driver's multi-GPU runs use the defaults (nccl == RCCL, one GPU each)
-        backend = os.environ.get("RCF_BENCH_BACKEND", "nccl")
-        if "RCF_BENCH_DEVICE" in os.environ:
-            local_rank = int(os.environ["RCF_BENCH_DEVICE"])
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    coll_dev = "cuda" if (world <= 1 or os.environ.get("RCF_BENCH_BACKEND", "nccl") == "nccl") else "cpu"
+    if "RCF_BENCH_DEVICE" in os.environ:             # two ranks on ONE GPU: exercises the N > 1 code on a 1-GPU box
+        local_rank = int(os.environ["RCF_BENCH_DEVICE"])
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
 
-    from rcf import native, synth
+    from rcf import multigpu, native, synth
     if native.device_count() < 1:
         raise RuntimeError("bench.py needs an MI355X (no HIP device visible)")
 
@@ -119,6 +355,13 @@ def main():
         out_cap <<= 1
     fe = native.Frontend(FS, 0.0, device=local_rank, block_capacity=B, hist_capacity=1 << 16,
                          out_capacity=out_cap)
+    group = None
+    use_rccl = os.environ.get("RCF_BENCH_TRANSPORT", "rccl") == "rccl"
+    if world > 1:
+        group = multigpu.HostGroup(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                   int(os.environ.get("MASTER_PORT", "29500")) + 101)
+        if use_rccl:
+            multigpu.init_comm(fe, group)            # ncclCommInitRank on this rank's GPU
     taps = proto_taps(native)
     fe.pfb_open(NB, NB, taps)
     tile, meta = synth.cfg2(n=1 << 20, seed=2002 if n_gpus == 1 else 4000 + rank, n_bins=NB,
@@ -132,11 +375,12 @@ def main():
         fe.commit(B)
     fe.sync()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def barrier_max(v=0.0):
+        """barrier + device sync on every rank, max of v over ranks"""
         fe.sync()
+        if group is None:
+            return v
+        return fe.allreduce_max(v) if use_rccl else group.max(v)
 
     for _ in range(args.warmup):
         fe.commit(B)
@@ -145,83 +389,48 @@ def main():
     fe.timing_enable(True, classes=[native.T_PFB])
     for w in range(native.T_HISTORY + 1):
         fe.timing_read(w, reset=True)
-    barrier()
+    barrier_max()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fe.commit(B)
     fe.sync()
-    torch.cuda.synchronize()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    barrier()
+    elapsed = barrier_max(t1 - t0)
 
     pfb_ms, pfb_n = fe.timing_read(native.T_PFB)
+    # the FM channels' newest outputs, for the parity check against the oracle (done in the cpu_baseline leg)
+    fm_check = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        fm_check = {"taps": taps, "total_in": fe.samples_in, "carriers": meta["carriers"],
+                    "fm": [fe.chan_read_fm(c, 1.0, max_samples=out_cap) for c in chans]}
     # per-kernel breakdown of the other launches: a few extra, untimed steps with every class instrumented
     fe.timing_enable(True)
-    for _ in range(min(args.steps, 5)):
+    n_extra = min(args.steps, 5)
+    for _ in range(n_extra):
         fe.commit(B)
     fe.sync()
     fe.timing_read(native.T_PFB)
-    fir2_ms, fir2_n = fe.timing_read(native.T_FIR_DERIVED)
-    disc_ms, disc_n = fe.timing_read(native.T_DISC)
-    hist_ms, hist_n = fe.timing_read(native.T_HISTORY)
+    fir2_ms, _ = fe.timing_read(native.T_FIR_DERIVED)
+    disc_ms, _ = fe.timing_read(native.T_DISC)
+    hist_ms, _ = fe.timing_read(native.T_HISTORY)
     fe.timing_enable(False)
-
-    # sanity: the FM channels really produced output during the timed steps
-    produced = fe.chan_produced(chans[0])
-    assert produced > 0
-
-    # ---- "concurrent 12.5 kHz FM channels sustained": the reference-shaped bank (one 2909-tap xlating FIR
-    # /800 + discriminator per channel, GR-faithful) on this GPU, outside the timed region: how many such
-    # channels run in real time at 20 Msps -- directly comparable with cpu_baseline.realtime_channels
-    direct = None
-    if rank == 0:
-        nd, bd = 256, 1 << 22
-        fd = native.Frontend(FS, 0.0, device=local_rank, block_capacity=bd, hist_capacity=1 << 16,
-                             out_capacity=1 << 14)
-        for at in range(0, bd, len(tile)):
-            fd.ingest_write(tile[: min(len(tile), bd - at)], at)
-        ids = [fd.chan_open(12500, float(k * 12500 - nd // 2 * 12500)) for k in range(nd)]
-        fd.commit(bd)
-        fd.commit(bd)
-        fd.timing_enable(True)
-        fd.timing_read(native.T_FIR)
-        fd.timing_read(native.T_FIR_MFMA)
-        fd.timing_read(native.T_DISC)
-        for _ in range(3):
-            fd.commit(bd)
-        fms, fn = fd.timing_read(native.T_FIR)
-        mms, mn = fd.timing_read(native.T_FIR_MFMA)
-        fms, fn = fms + mms, max(fn, mn)
-        dms, dn = fd.timing_read(native.T_DISC)
-        per_block_s = (fms / fn + dms / dn) * 1e-3
-        direct = {"channels_measured": nd, "block_samples": bd, "kernel_ms_per_block": per_block_s * 1e3,
-                  "kernel": "fp32 matrix-core" if mn else "vector",
-                  "tflops_fp32": 8.0 * 2909 * (bd // 800) * nd / (fms / fn * 1e-3) / 1e12,
-                  "realtime_channels_at_20Msps": nd * (bd / FS) / per_block_s}
-        fd.close()
+    assert fe.chan_produced(chans[0]) > 0            # the FM channels really produced output
 
     # ---- peak-list all-gather (BASELINE configs[4] collective), outside the timed region
-    allgather_us = None
-    if dist is not None:
+    allgather_us, gathered_n = None, None
+    if group is not None:
         fe.scan_start(16384, 8, 4)
         fe.commit(B)
         idx, _, _ = fe.scan_find_peaks(cap=1024)
-        mine = torch.full((1025,), -1, dtype=torch.int64, device=coll_dev)
-        mine[0] = len(idx)
-        if len(idx):
-            mine[1:1 + len(idx)] = torch.from_numpy(idx).to(coll_dev)
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)                      # warm-up (RCCL ring setup)
-        torch.cuda.synchronize()
+        freqs = [native.peak_frequency(int(i), FS, 16384, 851e6 + 25e6 * rank) for i in idx]
+        gather = (lambda: multigpu.allgather_peaks(fe, freqs)) if use_rccl else \
+                 (lambda: multigpu.allgather_peaks_host(group, freqs))
+        gather()                                     # warm-up (RCCL ring setup)
+        barrier_max()
         ta = time.perf_counter()
-        dist.all_gather(gathered, mine)
-        torch.cuda.synchronize()
-        allgather_us = (time.perf_counter() - ta) * 1e6
+        everyone = gather()
+        allgather_us = barrier_max((time.perf_counter() - ta) * 1e6)
+        gathered_n = len(everyone)
 
     if rank == 0:
         total_samples = float(B) * args.steps * n_gpus
@@ -270,25 +479,37 @@ def main():
             },
             "kernel_ms_per_step": {
                 "pfb": pfb_ms / max(pfb_n, 1),
-                "stage2_fir_with_fused_discriminator": fir2_ms / max(min(args.steps, 5), 1),
-                "separate_discriminator_launches": disc_ms / max(min(args.steps, 5), 1),
-                "history_copy": hist_ms / max(min(args.steps, 5), 1),
+                "stage2_fir_with_fused_discriminator": fir2_ms / max(n_extra, 1),
+                "separate_discriminator_launches": disc_ms / max(n_extra, 1),
+                "history_copy": hist_ms / max(n_extra, 1),
             },
         }
         if allgather_us is not None:
             out["peaks_allgather_us"] = allgather_us
-        out["channels"]["direct_bank"] = direct
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tile, meta["carriers"])
-            if direct:
-                out["cpu_baseline"]["gpu_over_cpu_realtime_channels"] = (
-                    direct["realtime_channels_at_20Msps"] / out["cpu_baseline"]["realtime_channels_at_20Msps"])
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
+            out["peaks_allgather"] = {"transport": "ncclAllGather via rcf_allgather_peaks" if use_rccl else "host TCP",
+                                      "values_gathered": gathered_n, "ranks": world}
     fe.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    if group is not None:
+        group.close()
+    if rank != 0:
+        return
+
+    extras = n_gpus == 1 and not args.no_extras
+    if extras:
+        counts = [c for c in (256, 1024, 4096, 16384, 65536, 131072, 196608) if c <= args.sweep_max]
+        out["channels"]["direct_bank"] = direct_bank_sweep(native, tile, local_rank, counts)
+        out["scan"] = scan_leg(native, synth, local_rank)
+        out["end_to_end"] = end_to_end_leg(native, tile, local_rank)
+        out["control_plane"] = control_plane_leg(local_rank)
+    if n_gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(tile, meta["carriers"], fm_check)
+        db = out["channels"].get("direct_bank")
+        if db:
+            out["cpu_baseline"]["gpu_channels_run_in_real_time_over_cpu_realtime_channels"] = (
+                db["channels_run_in_real_time"] / out["cpu_baseline"]["realtime_channels_at_20Msps"])
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

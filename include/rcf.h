@@ -144,6 +144,11 @@ int rcf_commit(rcf_t *h, size_t n_samples);
 int rcf_push_raw(rcf_t *h, const void *iq_raw, size_t n_samples, int fmt, float scale, float offset);
 /* total samples ingested so far */
 int64_t rcf_samples_in(rcf_t *h);
+/* Page-locked host memory for push buffers: a pinned buffer is DMA'd in place, and rcf_push_iq / rcf_push_raw copy
+ * block n+1 on a separate stream while block n's kernels run (the reference's SDR driver thread filling the next
+ * buffer while GNU Radio's scheduler works on the current one).  Pageable buffers work too, staged by the runtime. */
+void *rcf_host_alloc(size_t bytes);
+void rcf_host_free(void *p);
 
 /* ------------------------------------------------------------------ direct ("xlat") channels */
 /*
@@ -276,6 +281,27 @@ int64_t rcf_peak_frequency(int64_t line, double samp_rate, int64_t fft_len, doub
  * still reports how many survived. */
 int rcf_scan_find_peaks(rcf_t *h, double prominence, int64_t *idx, int64_t cap, int64_t *count,
                         double *mean_out, void **dev_idx);
+
+/* ------------------------------------------------------------------ multi-GPU: peak-list exchange */
+/*
+ * One process (one rcf_t) per GPU, one SDR front-end / spectrum slice each -- the reference already runs one
+ * channelizer process per SDR (systemd/radiocapture-channelizer@.service, rc_frontend/receiver.py:67-70) and the
+ * only thing its fft_based_scan.sh instances have in common is the list of detected frequencies.  These calls
+ * give every rank the lists of all ranks with ONE ncclAllGather over xGMI (librccl, loaded on first use):
+ *   rank 0: rcf_comm_unique_id(id) -> the host passes the 128 bytes to the other ranks (any transport)
+ *   every rank: rcf_comm_init(h, rank, n_ranks, id)      (ncclCommInitRank on the handle's device; collective)
+ *   after a scan: rcf_allgather_peaks(h, mine, n, all, cap, counts): all[w * cap + i], i < counts[w], is rank w's
+ *   i-th value (at most cap per rank are exchanged; fixed records, 8 (cap + 1) bytes per rank -- latency-bound).
+ * Without rcf_comm_init (or with n_ranks = 1 and id128 = NULL) the gather is a local copy; n_ranks = 1 WITH an id
+ * builds a real one-rank communicator (same RCCL calls, one GPU).  rcf_allreduce_max is the barrier +
+ * max-over-ranks the benchmark needs (syncs the handle's stream, then one ncclAllReduce on a double).
+ */
+int rcf_comm_unique_id(void *id128);
+int rcf_comm_init(rcf_t *h, int rank, int n_ranks, const void *id128);
+int rcf_comm_destroy(rcf_t *h);
+int rcf_comm_size(rcf_t *h);
+int rcf_allgather_peaks(rcf_t *h, const int64_t *mine, int n, int64_t *all, int cap, int *counts);
+int rcf_allreduce_max(rcf_t *h, double *value);
 
 #ifdef __cplusplus
 }

@@ -338,3 +338,22 @@ def scan_chain(x: np.ndarray, N: int = 16384, n_frames: int = 1000, avg_len: int
             s = (s - ring[i - (avg_len - 1)]).astype(f32)
             ring[i - (avg_len - 1)] = None
     return out
+
+
+def scan_chain_periodic(frame_logspec, n_frames: int = 1000, avg_len: int = 100):
+    """fft_vector.py's moving_average_ff -> head(n_frames) -> skiphead(n_frames - 1) over a stream whose frames
+    repeat with period U = len(frame_logspec): the float32 running sum in GNU Radio's operation order (add the
+    newest frame, emit, subtract the frame avg_len - 1 back), frame f being frame_logspec[f % U].  Lets a test run
+    the reference's own lengths (1000 frames, 100-frame average) at N = 2^20 without 8 GB of input: the caller
+    computes the U distinct log-magnitude frames (cbind.scan_chain(x_u, N, 1, 1)) once."""
+    v = [np.asarray(a, dtype=f32) for a in frame_logspec]
+    U = len(v)
+    s = np.zeros_like(v[0], dtype=f32)
+    out = None
+    for f in range(n_frames):
+        s = (s + v[f % U]).astype(f32)
+        if f == n_frames - 1:
+            out = s.copy()
+        if f - (avg_len - 1) >= 0:
+            s = (s - v[(f - (avg_len - 1)) % U]).astype(f32)
+    return out

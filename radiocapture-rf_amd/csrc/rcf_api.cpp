@@ -9,6 +9,7 @@
 // linearly (no wrap handling on the hot loads).  Narrowband outputs live in per-channel power-of-two
 // rings addressed by the absolute output index.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -148,7 +149,26 @@ struct rcf {
     struct BankCache { std::vector<std::pair<int, uint64_t>> key; float *d = nullptr; size_t cap = 0; };
     std::map<std::pair<int, int>, BankCache> banks;
     uint64_t taps_clock = 0;
-    std::vector<void *> graveyard;   // device buffers to free once the stream is idle
+    // device buffers to release once the stream is idle: (pointer, pool slice bytes; 0 = plain hipFree)
+    std::vector<std::pair<void *, size_t>> graveyard;
+    // Channel buffers (rings, composite taps) come from slabs cut into equal slices, one pool per slice size:
+    // opening a channel is a free-list pop instead of three hipMalloc + two memsets, closing one returns the
+    // slices once the stream has passed them (create / release is what the reference's own self-test times,
+    // frontend_connector.py:242-251)
+    struct SlicePool { std::vector<void *> slabs, free_; };
+    std::map<size_t, SlicePool> pools;
+    std::map<int, std::vector<float>> proto_cache;   // channel_rate -> low_pass_2 prototype (rcf_chan_open)
+    // H2D of block n+1 runs on its own stream while block n's kernels run (push_iq / push_raw)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t buf_done[2] = {nullptr, nullptr};   // the kernels that read d_buf[i] have finished
+    hipEvent_t copy_ev = nullptr, raw_done = nullptr;
+    bool buf_done_set[2] = {false, false};
+    bool raw_done_set = false;
+    // RCCL communicator for the peak-list all-gather (rcf_comm_init); librccl is dlopen'ed on first use
+    void *comm = nullptr;
+    int comm_rank = 0, comm_size = 1;
+    int64_t *d_gather = nullptr;
+    size_t gather_cap = 0;
     // optional per-kernel-class HIP-event timing (rcf_timing_*)
     bool timing = false;
     unsigned timing_mask = ~0u;
@@ -170,15 +190,18 @@ int set_dev(rcf_t *h)
     return RCF_OK;
 }
 
-void bury(rcf_t *h, void *p)
+void bury(rcf_t *h, void *p, size_t slice = 0)
 {
-    if (p) h->graveyard.push_back(p);
+    if (p) h->graveyard.push_back({p, slice});
 }
 
 // the stream is known to be idle (the caller just synchronised it): buried buffers can go
 void free_graveyard_idle(rcf_t *h)
 {
-    for (void *p : h->graveyard) (void)hipFree(p);
+    for (auto &e : h->graveyard) {
+        if (e.second) h->pools[e.second].free_.push_back(e.first);
+        else (void)hipFree(e.first);
+    }
     h->graveyard.clear();
 }
 
@@ -187,6 +210,25 @@ void drain_graveyard(rcf_t *h)
     if (h->graveyard.empty()) return;
     (void)hipStreamSynchronize(h->stream);
     free_graveyard_idle(h);
+}
+
+size_t slice_round(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+
+// one slice of `bytes` (a multiple of 256) from the handle's pools; nullptr + error set on failure
+void *pool_get(rcf_t *h, size_t bytes)
+{
+    rcf::SlicePool &p = h->pools[bytes];
+    if (p.free_.empty()) {
+        size_t n = (size_t(64) << 20) / bytes;               // ~64 MiB slabs
+        n = std::max<size_t>(1, std::min<size_t>(n, 512));
+        void *slab = nullptr;
+        if (!hip_ok(hipMalloc(&slab, n * bytes), "hipMalloc(channel slab)")) return nullptr;
+        p.slabs.push_back(slab);
+        for (size_t i = n; i-- > 0;) p.free_.push_back(static_cast<unsigned char *>(slab) + i * bytes);
+    }
+    void *r = p.free_.back();
+    p.free_.pop_back();
+    return r;
 }
 
 hipEvent_t time_event(rcf_t *h)
@@ -258,10 +300,14 @@ int upload_composite(rcf_t *h, Chan *c)
     float incr[2];
     design_composite(c->proto.data(), c->T, c->D, c->offset_hz + (c->src < 0 ? h->shift_hz : 0.0), c->src_rate,
                      ct, incr);
-    float2 *fresh = nullptr;
-    RCF_HIP(hipMalloc(&fresh, sizeof(float2) * (size_t)c->T));
-    RCF_HIP(hipMemcpy(fresh, ct.data(), sizeof(float2) * (size_t)c->T, hipMemcpyHostToDevice));
-    bury(h, c->d_ctaps);
+    const size_t slice = slice_round(sizeof(float2) * (size_t)c->T);
+    float2 *fresh = static_cast<float2 *>(pool_get(h, slice));
+    if (!fresh) return RCF_ENOMEM;
+    if (!hip_ok(hipMemcpy(fresh, ct.data(), sizeof(float2) * (size_t)c->T, hipMemcpyHostToDevice), "hipMemcpy(taps)")) {
+        h->pools[slice].free_.push_back(fresh);
+        return RCF_EHIP;
+    }
+    bury(h, c->d_ctaps, slice);
     c->d_ctaps = fresh;
     c->taps_version = ++h->taps_clock;
     // GR iterates phase *= incr in float32; model it by the increment's actual angle and magnitude
@@ -298,12 +344,17 @@ int new_channel(rcf_t *h, int src, int D, const float *taps, int T, double offse
     }
     if (src >= 0 && (size_t)(T + D) * 2 > h->out_cap) { set_error("source ring too small for T=%d", T); return RCF_ECAP; }
     c->k_abs0 = ceil_div(c->start_sample, D);
-    RCF_HIP(hipMalloc(&c->d_iq, sizeof(float2) * h->out_cap));
-    RCF_HIP(hipMalloc(&c->d_fm, sizeof(float) * h->out_cap));
-    RCF_HIP(hipMemsetAsync(c->d_iq, 0, sizeof(float2) * h->out_cap, h->stream));
-    RCF_HIP(hipMemsetAsync(c->d_fm, 0, sizeof(float) * h->out_cap, h->stream));
+    // iq ring + discriminator ring in one slice.  Not cleared: readers never go past `produced`, and every
+    // kernel masks what lies before a channel's first output (GR zero history)
+    const size_t ring_slice = slice_round(12 * h->out_cap);
+    c->d_iq = static_cast<float2 *>(pool_get(h, ring_slice));
+    if (!c->d_iq) return RCF_ENOMEM;
+    c->d_fm = reinterpret_cast<float *>(c->d_iq + h->out_cap);
     int rc = upload_composite(h, c.get());
-    if (rc != RCF_OK) return rc;
+    if (rc != RCF_OK) {
+        h->pools[ring_slice].free_.push_back(c->d_iq);      // never seen by the stream: straight back
+        return rc;
+    }
     c->id = h->next_id++;
     *chan_id = c->id;
     h->chans[c->id] = std::move(c);
@@ -312,9 +363,8 @@ int new_channel(rcf_t *h, int src, int D, const float *taps, int T, double offse
 
 void free_channel(rcf_t *h, Chan *c)
 {
-    bury(h, c->d_ctaps);
-    bury(h, c->d_iq);
-    bury(h, c->d_fm);
+    bury(h, c->d_ctaps, slice_round(sizeof(float2) * (size_t)c->T));
+    bury(h, c->d_iq, slice_round(12 * h->out_cap));       // d_fm lives in the same slice
     bury(h, c->d_sym);
     bury(h, c->d_symtaps);
     if (c->audio) { bury(h, c->audio->d_state); bury(h, c->audio->d_rings); bury(h, c->audio->d_taps); c->audio.reset(); }
@@ -405,6 +455,20 @@ int process_block(rcf_t *h, size_t n)
     double audf_ratio = 0;
     int audf_num = 1, audf_den = 1;
 
+    // how far back every consumer of a ring reaches beyond the block's new samples (a block's writes must not
+    // overwrite what the same block's readers still need): derived channels T - 1 + D of source output, the
+    // discriminator one sample, the symbol filter its taps
+    std::map<int, size_t> reach;                            // source id (channel id / RCF_SRC_PFB_BIN0 + bin) -> samples
+    for (auto &kv : h->chans) {
+        const Chan &c = *kv.second;
+        size_t &own = reach[c.id];
+        own = std::max<size_t>(own, std::max<size_t>(1, c.d_sym ? (size_t)c.sym_ntaps : 0));
+        if (c.src >= 0) {
+            size_t &r = reach[c.src >= RCF_SRC_PFB_BIN0 ? RCF_SRC_PFB_BIN0 : c.src];
+            r = std::max<size_t>(r, (size_t)(c.T - 1 + c.D));
+        }
+    }
+
     // ---- PFB bookkeeping first (derived channels need its new range)
     PfbLaunch pl{};
     bool run_pfb = false;
@@ -415,7 +479,11 @@ int process_block(rcf_t *h, size_t n)
         p.produced_before = p.produced;
         if (n_hi >= n_lo) {
             const int64_t cnt = n_hi - n_lo + 1;
-            if ((size_t)cnt > h->out_cap) { set_error("block yields %lld PFB frames > ring capacity", (long long)cnt); return RCF_ECAP; }
+            if ((size_t)cnt + reach[RCF_SRC_PFB_BIN0] > h->out_cap) {
+                set_error("block yields %lld PFB frames (+%zu of history its stage-2 channels need) > ring capacity %zu",
+                          (long long)cnt, reach[RCF_SRC_PFB_BIN0], h->out_cap);
+                return RCF_ECAP;
+            }
             pl.src.base = h->d_buf[h->cur];
             pl.src.mask = ~0ull;
             pl.src.origin = S0 - (int64_t)h->hist_cap;
@@ -471,7 +539,11 @@ int process_block(rcf_t *h, size_t n)
                 const int64_t before = c->produced;
                 if (sr.p1 <= sr.p0 || k_hi < k_lo) { chan_new[c->id] = {before, before}; continue; }
                 const int64_t cnt = k_hi - k_lo + 1;
-                if ((size_t)cnt > h->out_cap) { set_error("block yields %lld outputs > ring capacity", (long long)cnt); return RCF_ECAP; }
+                if ((size_t)cnt + reach[c->id] > h->out_cap) {
+                    set_error("block yields %lld outputs (+%zu of history its consumers need) > ring capacity %zu",
+                              (long long)cnt, reach[c->id], h->out_cap);
+                    return RCF_ECAP;
+                }
                 ChanLaunch L{};
                 L.ctaps = c->d_ctaps;
                 L.fm_ring = c->d_fm;
@@ -721,6 +793,8 @@ int process_block(rcf_t *h, size_t n)
         RCF_HIP(hipMemcpyAsync(h->d_buf[other], h->d_buf[h->cur] + n, sizeof(float2) * h->hist_cap,
                                hipMemcpyDeviceToDevice, st));
     }
+    RCF_HIP(hipEventRecord(h->buf_done[h->cur], st));        // everything that reads this buffer is queued
+    h->buf_done_set[h->cur] = true;
     h->cur = other;
     h->total_in = S1;
     RCF_HIP(hipGetLastError());
@@ -756,10 +830,173 @@ int64_t ring_read(rcf_t *h, const void *ring, size_t elem, int64_t produced, int
     return n;
 }
 
+// ------------------------------------------------------------------ RCCL (peak-list all-gather over xGMI)
+// librccl.so is loaded on first use: a single-GPU front-end never pays for it.  Types are restated from rccl.h
+// (ncclUniqueId = 128 opaque bytes passed BY VALUE, ncclInt64 = 4, ncclFloat64 = 8, ncclMax = 2).
+struct RcclId { char internal[128]; };
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(RcclId *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+RcclApi *rccl()
+{
+    static std::mutex mu;
+    static RcclApi api;
+    static bool tried = false;
+    std::lock_guard<std::mutex> g(mu);
+    if (!tried) {
+        tried = true;
+        void *l = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!l) l = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!l) l = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (l) {
+            api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(l, "ncclGetUniqueId"));
+            api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(l, "ncclCommInitRank"));
+            api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(l, "ncclCommDestroy"));
+            api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(l, "ncclAllGather"));
+            api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(l, "ncclAllReduce"));
+            api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(l, "ncclGetErrorString"));
+            if (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.AllReduce) api.lib = l;
+        }
+    }
+    return api.lib ? &api : nullptr;
+}
+
+bool rccl_ok(RcclApi *r, int rc, const char *what)
+{
+    if (rc == 0) return true;
+    set_error("RCCL error %d (%s) in %s", rc, r && r->GetErrorString ? r->GetErrorString(rc) : "?", what);
+    return false;
+}
+
+void comm_destroy(rcf_t *h)
+{
+    if (!h->comm) return;
+    if (RcclApi *r = rccl()) (void)r->CommDestroy(h->comm);
+    h->comm = nullptr;
+    h->comm_rank = 0;
+    h->comm_size = 1;
+}
+
 }  // namespace
 
 // =================================================================== C ABI
 extern "C" {
+
+int rcf_comm_unique_id(void *id128)
+{
+    if (!id128) { set_error("bad arguments"); return RCF_EINVAL; }
+    RcclApi *r = rccl();
+    if (!r) { set_error("librccl.so not available"); return RCF_ESTATE; }
+    RcclId id;
+    if (!rccl_ok(r, r->GetUniqueId(&id), "ncclGetUniqueId")) return RCF_EHIP;
+    std::memcpy(id128, id.internal, sizeof(id.internal));
+    return RCF_OK;
+}
+
+int rcf_comm_init(rcf_t *h, int rank, int n_ranks, const void *id128)
+{
+    if (!h || n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !id128)) {
+        set_error("bad communicator arguments");
+        return RCF_EINVAL;
+    }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    comm_destroy(h);
+    if (n_ranks == 1 && !id128) return RCF_OK;      // one front-end, no id: the gather is a local copy
+    // (n_ranks == 1 WITH an id builds a real one-rank communicator: the same RCCL calls, on one GPU)
+    RcclApi *r = rccl();
+    if (!r) { set_error("librccl.so not available"); return RCF_ESTATE; }
+    RcclId id;
+    std::memcpy(id.internal, id128, sizeof(id.internal));
+    void *comm = nullptr;
+    if (!rccl_ok(r, r->CommInitRank(&comm, n_ranks, id, rank), "ncclCommInitRank")) return RCF_EHIP;
+    h->comm = comm;
+    h->comm_rank = rank;
+    h->comm_size = n_ranks;
+    return RCF_OK;
+}
+
+int rcf_comm_destroy(rcf_t *h)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    comm_destroy(h);
+    return RCF_OK;
+}
+
+int rcf_comm_size(rcf_t *h) { return h ? h->comm_size : RCF_EINVAL; }
+
+int rcf_allgather_peaks(rcf_t *h, const int64_t *mine, int n, int64_t *all, int cap, int *counts)
+{
+    if (!h || n < 0 || cap < 1 || (n && !mine) || !all || !counts) { set_error("bad all-gather arguments"); return RCF_EINVAL; }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    const int W = h->comm_size, keep = std::min(n, cap);
+    if (!h->comm) {                                 // single rank
+        counts[0] = keep;
+        std::memcpy(all, mine, sizeof(int64_t) * (size_t)keep);
+        return RCF_OK;
+    }
+    RcclApi *r = rccl();
+    if (!r) { set_error("librccl.so not available"); return RCF_ESTATE; }
+    // fixed-size record per rank: [count, v_0 .. v_{cap-1}] int64 (8 KiB at cap = 1024: latency-bound)
+    const size_t rec = (size_t)cap + 1, need = rec * (size_t)(W + 1);
+    if (need > h->gather_cap) {
+        bury(h, h->d_gather);
+        h->d_gather = nullptr;
+        h->gather_cap = 0;
+        RCF_HIP(hipMalloc(&h->d_gather, sizeof(int64_t) * need));
+        h->gather_cap = need;
+    }
+    std::vector<int64_t> host(need, -1);
+    host[0] = keep;
+    std::memcpy(host.data() + 1, mine, sizeof(int64_t) * (size_t)keep);
+    int64_t *d_send = h->d_gather, *d_recv = h->d_gather + rec;
+    RCF_HIP(hipMemcpyAsync(d_send, host.data(), sizeof(int64_t) * rec, hipMemcpyHostToDevice, h->stream));
+    if (!rccl_ok(r, r->AllGather(d_send, d_recv, rec, 4 /* ncclInt64 */, h->comm, h->stream), "ncclAllGather")) return RCF_EHIP;
+    RCF_HIP(hipMemcpyAsync(host.data() + rec, d_recv, sizeof(int64_t) * rec * (size_t)W, hipMemcpyDeviceToHost, h->stream));
+    RCF_HIP(hipStreamSynchronize(h->stream));
+    for (int w = 0; w < W; ++w) {
+        const int64_t *rc = host.data() + rec * (size_t)(w + 1);
+        const int c = (int)std::max<int64_t>(0, std::min<int64_t>(rc[0], cap));
+        counts[w] = c;
+        std::memcpy(all + (size_t)w * cap, rc + 1, sizeof(int64_t) * (size_t)c);
+    }
+    return RCF_OK;
+}
+
+int rcf_allreduce_max(rcf_t *h, double *value)
+{
+    if (!h || !value) { set_error("bad arguments"); return RCF_EINVAL; }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    RCF_HIP(hipStreamSynchronize(h->stream));
+    if (!h->comm) return RCF_OK;
+    RcclApi *r = rccl();
+    if (!r) { set_error("librccl.so not available"); return RCF_ESTATE; }
+    if (h->gather_cap < 2) {
+        bury(h, h->d_gather);
+        h->d_gather = nullptr;
+        h->gather_cap = 0;
+        RCF_HIP(hipMalloc(&h->d_gather, sizeof(int64_t) * 16));
+        h->gather_cap = 16;
+    }
+    double *d = reinterpret_cast<double *>(h->d_gather);
+    RCF_HIP(hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (!rccl_ok(r, r->AllReduce(d, d, 1, 8 /* ncclFloat64 */, 2 /* ncclMax */, h->comm, h->stream), "ncclAllReduce")) return RCF_EHIP;
+    RCF_HIP(hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RCF_HIP(hipStreamSynchronize(h->stream));
+    return RCF_OK;
+}
+
 
 const char *rcf_version(void) { return "rcf-mi355x 0.1 (gfx950)"; }
 const char *rcf_last_error(void) { return g_err; }
@@ -841,6 +1078,10 @@ int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_c
         RCF_HIP(hipMalloc(&h->d_arena[i], h->arena_cap));
         RCF_HIP(hipEventCreateWithFlags(&h->arena_ev[i], hipEventDisableTiming));
     }
+    RCF_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) RCF_HIP(hipEventCreateWithFlags(&h->buf_done[i], hipEventDisableTiming));
+    RCF_HIP(hipEventCreateWithFlags(&h->copy_ev, hipEventDisableTiming));
+    RCF_HIP(hipEventCreateWithFlags(&h->raw_done, hipEventDisableTiming));
     RCF_HIP(hipMalloc(&h->d_atan, sizeof(float) * 257));
     RCF_HIP(hipMemcpy(h->d_atan, atan_table_host(), sizeof(float) * 257, hipMemcpyHostToDevice));
     RCF_HIP(hipStreamSynchronize(h->stream));
@@ -871,9 +1112,18 @@ int rcf_close(rcf_t *h)
         if (h->h_arena[i]) (void)hipHostFree(h->h_arena[i]);
         if (h->arena_ev[i]) (void)hipEventDestroy(h->arena_ev[i]);
     }
+    bury(h, h->d_gather);
     drain_graveyard(h);
+    for (auto &kv : h->pools)
+        for (void *slab : kv.second.slabs) (void)hipFree(slab);
+    h->pools.clear();
     time_collect(h);
     for (hipEvent_t e : h->time_pool) (void)hipEventDestroy(e);
+    comm_destroy(h);
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    for (int i = 0; i < 2; ++i) if (h->buf_done[i]) (void)hipEventDestroy(h->buf_done[i]);
+    if (h->copy_ev) (void)hipEventDestroy(h->copy_ev);
+    if (h->raw_done) (void)hipEventDestroy(h->raw_done);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return RCF_OK;
@@ -918,6 +1168,10 @@ void *rcf_stream(rcf_t *h) { return h ? (void *)h->stream : nullptr; }
 int rcf_device(rcf_t *h) { return h ? h->device : RCF_EINVAL; }
 int64_t rcf_samples_in(rcf_t *h) { return h ? h->total_in : RCF_EINVAL; }
 
+// The H2D copy of a block runs on the copy stream: it waits only for the kernels that last read the target buffer
+// (the block before the previous one), so it overlaps the previous block's kernels; the compute stream waits for
+// the copy.  The call returns when the copy has been read from the caller's buffer (pageable copies are staged by
+// the runtime, pinned ones -- rcf_host_alloc -- are DMA'd in place), not when the kernels are done.
 int rcf_push_iq(rcf_t *h, const float *iq, size_t n)
 {
     if (!h || (!iq && n)) { set_error("bad push arguments"); return RCF_EINVAL; }
@@ -925,15 +1179,13 @@ int rcf_push_iq(rcf_t *h, const float *iq, size_t n)
     if (n > h->block_cap) { set_error("push of %zu samples exceeds block capacity %zu", n, h->block_cap); return RCF_ECAP; }
     std::lock_guard<std::mutex> g(h->mu);
     if (set_dev(h)) return RCF_EHIP;
-    RCF_HIP(hipMemcpyAsync(h->d_buf[h->cur] + h->hist_cap, iq, sizeof(float2) * n, hipMemcpyHostToDevice, h->stream));
-    // the caller may reuse `iq` as soon as we return: pageable copies are staged by the runtime, pinned
-    // ones are not -- wait for the copy itself (cheap next to PCIe time) but not for the kernels.
-    hipEvent_t ev;
-    RCF_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    RCF_HIP(hipEventRecord(ev, h->stream));
+    if (h->buf_done_set[h->cur]) RCF_HIP(hipStreamWaitEvent(h->copy_stream, h->buf_done[h->cur], 0));
+    RCF_HIP(hipMemcpyAsync(h->d_buf[h->cur] + h->hist_cap, iq, sizeof(float2) * n, hipMemcpyHostToDevice,
+                           h->copy_stream));
+    RCF_HIP(hipEventRecord(h->copy_ev, h->copy_stream));
+    RCF_HIP(hipStreamWaitEvent(h->stream, h->copy_ev, 0));
     int rc = process_block(h, n);
-    (void)hipEventSynchronize(ev);
-    (void)hipEventDestroy(ev);
+    (void)hipEventSynchronize(h->copy_ev);
     return rc;
 }
 
@@ -946,15 +1198,31 @@ int rcf_push_raw(rcf_t *h, const void *iq_raw, size_t n, int fmt, float scale, f
     std::lock_guard<std::mutex> g(h->mu);
     if (set_dev(h)) return RCF_EHIP;
     if (!h->d_raw) RCF_HIP(hipMalloc(&h->d_raw, h->block_cap * 4));       // staging for the widest format
-    RCF_HIP(hipMemcpyAsync(h->d_raw, iq_raw, n * bps, hipMemcpyHostToDevice, h->stream));
-    hipEvent_t ev;
-    RCF_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    RCF_HIP(hipEventRecord(ev, h->stream));
+    if (h->raw_done_set) RCF_HIP(hipStreamWaitEvent(h->copy_stream, h->raw_done, 0));   // previous conversion read it
+    RCF_HIP(hipMemcpyAsync(h->d_raw, iq_raw, n * bps, hipMemcpyHostToDevice, h->copy_stream));
+    RCF_HIP(hipEventRecord(h->copy_ev, h->copy_stream));
+    RCF_HIP(hipStreamWaitEvent(h->stream, h->copy_ev, 0));
     launch_convert(fmt, h->d_raw, h->d_buf[h->cur] + h->hist_cap, n, scale, offset, h->stream);
+    RCF_HIP(hipEventRecord(h->raw_done, h->stream));
+    h->raw_done_set = true;
     int rc = process_block(h, n);
-    (void)hipEventSynchronize(ev);      // the caller may reuse its buffer once the H2D copy has been read
-    (void)hipEventDestroy(ev);
+    (void)hipEventSynchronize(h->copy_ev);      // the caller may reuse its buffer once the H2D copy has been read
     return rc;
+}
+
+void *rcf_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        set_error("pinned host allocation of %zu bytes failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void rcf_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 int rcf_ingest_ptr(rcf_t *h, float **dev_ptr, size_t *max_samples)
@@ -996,10 +1264,11 @@ int rcf_chan_open(rcf_t *h, int channel_rate, double offset_hz, int *chan_id)
     int rc = rcf_channel_params(h->fs, channel_rate, &D, &T);
     if (rc != RCF_OK) return rc;
     if (!(std::fabs(offset_hz) < h->fs / 2)) { set_error("offset %g Hz outside +-fs/2", offset_hz); return RCF_ERANGE; }
-    std::vector<float> taps = design_low_pass_2(1.0, h->fs, channel_rate / 2.0, channel_rate / 2.0, 20.0,
-                                                RCF_WIN_HAMMING);
     std::lock_guard<std::mutex> g(h->mu);
     if (set_dev(h)) return RCF_EHIP;
+    std::vector<float> &taps = h->proto_cache[channel_rate];
+    if (taps.empty())
+        taps = design_low_pass_2(1.0, h->fs, channel_rate / 2.0, channel_rate / 2.0, 20.0, RCF_WIN_HAMMING);
     return new_channel(h, -1, D, taps.data(), (int)taps.size(), offset_hz, chan_id);
 }
 

@@ -11,8 +11,11 @@ for consumers that want the discriminator done on the GPU.
 """
 from __future__ import annotations
 
+import logging
 import threading
 import time
+
+log = logging.getLogger("egress")
 
 
 def zmq_pub_factory():
@@ -38,36 +41,77 @@ class EgressPump:
         self.fm_socks = {}
         self.continue_running = True
         self.bytes_out = 0
+        self.errors = 0
         self._thread = None
+        self.prebound = {}                               # port -> (iq socket, fm socket or None)
+        # bind when the channel is created, as the reference does (the PUB sink is part of the channel flowgraph,
+        # channel.py:36, so a port in use fails channel construction and receiver.py:322-329 picks another)
+        tb.bind_port = self.bind_port
+
+    def bind_port(self, port):
+        """-> True when the channel's socket(s) could be bound on `port`"""
+        try:
+            iq = self.make(port)
+        except Exception as e:
+            log.error("Failed to bind channel port %s: %s" % (port, e))
+            return False
+        fm = None
+        if self.fm_gain is not None:
+            try:
+                fm = self.make(port + self.fm_port_offset)
+            except Exception as e:
+                log.error("Failed to bind fm port %s: %s" % (port + self.fm_port_offset, e))
+                iq.close()
+                return False
+        self.prebound[port] = (iq, fm)
+        return True
 
     def pump_once(self):
         with self.tb.access_lock:
             chans = dict(self.tb.channels)
         for block_id, ch in chans.items():
-            if ch.chan_id is None:
-                continue
-            if block_id not in self.socks:
-                self.socks[block_id] = self.make(ch.port)
-                if self.fm_gain is not None:
-                    self.fm_socks[block_id] = self.make(ch.port + self.fm_port_offset)
-            iq = ch.read_iq()
-            if len(iq):
-                payload = iq.tobytes()                   # raw gr_complex items, arbitrary chunking
-                self.socks[block_id].send(payload)
-                self.bytes_out += len(payload)
-            if block_id in self.fm_socks:
-                fm = ch.read_fm(self.fm_gain)
-                if len(fm):
+            # one channel's failure (destroyed between the snapshot and the read, port already bound, reader error)
+            # must not end the pump for everybody else: log, drop that channel's sockets, go on
+            try:
+                with self.tb.access_lock:                # destroy() / the idle sweep run under the same lock
+                    if ch.chan_id is None:
+                        continue
+                    if block_id not in self.socks:
+                        iq_s, fm_s = self.prebound.pop(ch.port, (None, None))
+                        self.socks[block_id] = iq_s if iq_s is not None else self.make(ch.port)
+                        if self.fm_gain is not None:
+                            self.fm_socks[block_id] = fm_s if fm_s is not None else self.make(ch.port + self.fm_port_offset)
+                    iq = ch.read_iq()
+                    fm = ch.read_fm(self.fm_gain) if block_id in self.fm_socks else None
+                if len(iq):
+                    payload = iq.tobytes()               # raw gr_complex items, arbitrary chunking
+                    self.socks[block_id].send(payload)
+                    self.bytes_out += len(payload)
+                if fm is not None and len(fm):
                     self.fm_socks[block_id].send(fm.tobytes())
+            except Exception as e:
+                self.errors += 1
+                log.error("egress of channel %s failed: %s" % (block_id, e))
+                self._drop(block_id)
         for block_id in [b for b in self.socks if b not in chans]:   # destroyed channels
-            for table in (self.socks, self.fm_socks):
-                s = table.pop(block_id, None)
-                if s is not None:
+            self._drop(block_id)
+
+    def _drop(self, block_id):
+        for table in (self.socks, self.fm_socks):
+            s = table.pop(block_id, None)
+            if s is not None:
+                try:
                     s.close()
+                except Exception:
+                    pass
 
     def run(self):
         while self.continue_running:
-            self.pump_once()
+            try:
+                self.pump_once()
+            except Exception as e:                       # never let the daemon thread die silently
+                self.errors += 1
+                log.error("egress pump: %s" % e)
             time.sleep(self.period)
 
     def start(self):

@@ -33,6 +33,8 @@ SYMBOLS = [
     "rcf_ingest_write", "rcf_push_raw", "rcf_chan_fm_filter", "rcf_chan_read_sym", "rcf_chan_fm_level",
     "rcf_design_firdes", "rcf_design_optfir_low_pass", "rcf_design_fm_deemph", "rcf_design_resampler", "rcf_chan_audio_open",
     "rcf_chan_audio_close", "rcf_chan_audio_produced", "rcf_chan_read_audio",
+    "rcf_host_alloc", "rcf_host_free", "rcf_comm_unique_id", "rcf_comm_init", "rcf_comm_destroy", "rcf_comm_size",
+    "rcf_allgather_peaks", "rcf_allreduce_max",
 ]
 FMT_U8, FMT_S8, FMT_S16 = 1, 2, 3
 T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY, T_FIR_MFMA, T_AUDIO = range(9)
@@ -120,6 +122,14 @@ def lib():
         "rcf_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(i64), C.c_int]),
         "rcf_scan_find_peaks": (C.c_int, [vp, C.c_double, C.POINTER(i64), i64, C.POINTER(i64),
                                           C.POINTER(C.c_double), C.POINTER(vp)]),
+        "rcf_host_alloc": (vp, [sz]),
+        "rcf_host_free": (None, [vp]),
+        "rcf_comm_unique_id": (C.c_int, [vp]),
+        "rcf_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+        "rcf_comm_destroy": (C.c_int, [vp]),
+        "rcf_comm_size": (C.c_int, [vp]),
+        "rcf_allgather_peaks": (C.c_int, [vp, C.POINTER(i64), C.c_int, C.POINTER(i64), C.c_int, ip]),
+        "rcf_allreduce_max": (C.c_int, [vp, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -218,6 +228,38 @@ def peak_frequency(line, samp_rate, fft_len, center_freq) -> int:
     return lib().rcf_peak_frequency(int(line), samp_rate, int(fft_len), center_freq)
 
 
+class PinnedArray:
+    """numpy view of page-locked host memory (rcf_host_alloc): the buffer an SDR driver fills and hands to
+    Frontend.push / push_raw; freed when the object goes away"""
+
+    def __init__(self, n, dtype):
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(n) * self.dtype.itemsize
+        self._p = lib().rcf_host_alloc(self.nbytes)
+        if not self._p:
+            raise RcfError(RCF_ENOMEM, lib().rcf_last_error().decode("utf-8", "replace"))
+        self.array = np.frombuffer((C.c_char * self.nbytes).from_address(self._p), dtype=self.dtype)
+
+    def free(self):
+        if self._p:
+            self.array = None
+            lib().rcf_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def comm_unique_id() -> bytes:
+    """rank 0: the 128-byte RCCL id every rank passes to Frontend.comm_init"""
+    buf = C.create_string_buffer(128)
+    _check(lib().rcf_comm_unique_id(C.cast(buf, C.c_void_p)))
+    return buf.raw
+
+
 class Frontend:
     """One SDR source: owner of the HBM wideband buffer, channels, PFB and scanner (rcf_t)."""
 
@@ -257,6 +299,30 @@ class Frontend:
     @property
     def samples_in(self):
         return lib().rcf_samples_in(self._h)
+
+    # -- multi-GPU (one front-end per GPU; the only exchange is the detected-peak lists)
+    def comm_init(self, rank, n_ranks, unique_id=None):
+        buf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        _check(lib().rcf_comm_init(self._h, int(rank), int(n_ranks), C.cast(buf, C.c_void_p) if buf is not None else None))
+
+    def comm_destroy(self):
+        _check(lib().rcf_comm_destroy(self._h))
+
+    def allgather_peaks(self, mine, cap=1024):
+        """-> list (one int64 array per rank) of every rank's values, via ncclAllGather on the handle's device"""
+        mine = np.ascontiguousarray(mine, dtype=np.int64)
+        w = lib().rcf_comm_size(self._h)
+        out = np.empty(w * cap, dtype=np.int64)
+        counts = (C.c_int * w)()
+        _check(lib().rcf_allgather_peaks(self._h, mine.ctypes.data_as(C.POINTER(C.c_int64)), len(mine),
+                                         out.ctypes.data_as(C.POINTER(C.c_int64)), int(cap), counts))
+        return [out[r * cap: r * cap + counts[r]].copy() for r in range(w)]
+
+    def allreduce_max(self, value: float) -> float:
+        """barrier + max over ranks (syncs the stream first); identity without a communicator"""
+        v = C.c_double(float(value))
+        _check(lib().rcf_allreduce_max(self._h, C.byref(v)))
+        return v.value
 
     # -- measurement
     def timing_enable(self, on=True, classes=None):

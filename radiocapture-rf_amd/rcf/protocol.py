@@ -135,7 +135,13 @@ class FrontendServer:
             except zmq.Again:
                 time.sleep(0.001)
                 continue
-            resp = self.handle(msg)
+            # the reference's main loop catches and logs whatever its handler raises and keeps serving
+            # (receiver.py:686-699); a REP socket must also answer every request or it wedges
+            try:
+                resp = self.handle(msg)
+            except Exception as e:                       # malformed request, failed retune, ...
+                log.error("handler error on %r: %s" % (msg, e))
+                resp = "na"
             sock.send_string(resp if resp is not None else "")
 
 

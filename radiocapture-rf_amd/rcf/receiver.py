@@ -34,6 +34,7 @@ class receiver:
         self.channel_idle_timeout = 10                     # receiver.py:51
         self.last_channel_cleanup = time.time()
         self.scan_mode = bool(getattr(config, "scan_mode", False))
+        self.bind_port = None                              # set by the egress pump: port -> bound?
         if frontend_factory is None:
             from . import native
 
@@ -130,7 +131,15 @@ class receiver:
                     block.channel_close_time = 0
                     break
             if block is None:
-                port = random.randint(10000, 60000)         # receiver.py:323 (kept: the egress pump binds it)
+                port = None
+                for attempt in range(3):                    # receiver.py:322-329
+                    cand = random.randint(10000, 60000)
+                    if self.bind_port is None or self.bind_port(cand):
+                        port = cand
+                        break
+                    self.log.error("Failed to build channel on port: %s attempt: %s" % (cand, attempt))
+                if port is None:
+                    raise Exception("no free egress port")
                 block = channel_mod.channel(frontend, port, channel_rate, source_samp_rate, offset,
                                             parent_chan=self.sources[source_id].get("parent_chan"))
                 block.source_id = source_id

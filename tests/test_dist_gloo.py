@@ -44,7 +44,7 @@ def _worker(rank, world, port, q):
         lines, freqs = scan.peak_detect(x, fs, fc)              # product host picker (librcf, no GPU needed)
         l_ref, f_ref = P.peak_detect_scipy(x, fs, fc)
         assert list(lines) == list(l_ref) and freqs == f_ref and len(freqs) == 2
-        everyone = multigpu.allgather_peaks(dist, torch, freqs, "cpu")
+        everyone = multigpu.allgather_peaks_torch(dist, torch, freqs, "cpu")
         tmax = multigpu.max_over_ranks(dist, torch, 1.0 + rank, "cpu")
         q.put((rank, mine, freqs, everyone, tmax))
     finally:
@@ -79,3 +79,42 @@ def test_routing_and_packing_rules():
     rec = multigpu.pack_peaks([5, 3, 9], cap=8)
     assert rec.tolist() == [3, 5, 3, 9, -1, -1, -1, -1, -1]
     assert multigpu.unpack_peaks([rec, multigpu.pack_peaks([], cap=8)]) == [3, 5, 9]
+
+
+def _host_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "radiocapture-rf_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from rcf import multigpu
+    g = multigpu.HostGroup(rank, world, "127.0.0.1", port, timeout=60)
+    try:
+        uid = g.broadcast(bytes(range(128)) if rank == 0 else None)      # what init_comm does with the RCCL id
+        g.barrier()
+        tmax = g.max(1.0 + rank)
+        everyone = multigpu.allgather_peaks_host(g, [851000000 + 12500 * rank, 852000000 - rank], cap=8)
+        parts = g.all_gather(b"r%d" % rank * (rank + 1))
+        q.put((rank, uid, tmax, everyone, parts))
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_host_group_rendezvous_without_torch(world):
+    """The torch-free transport bench.py uses for N > 1: TCP star on 127.0.0.1 -- RCCL id broadcast, barrier,
+    max over ranks and the host fallback of the peak all-gather."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_host_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = sorted([851000000 + 12500 * r for r in range(world)] + [852000000 - r for r in range(world)])
+    for rank, uid, tmax, everyone, parts in res:
+        assert uid == bytes(range(128))
+        assert tmax == float(world)
+        assert everyone == want
+        assert parts == [b"r%d" % r * (r + 1) for r in range(world)]
