@@ -232,17 +232,25 @@ int rcf_source_shift(rcf_t *h, double delta_hz);
  * n_bins-channel PFB with prototype `taps` and decimation `decim` (n_bins % decim == 0): bin k is
  * exactly freq_xlating_fir_filter_ccc(decim, taps, k*fs/n_bins, fs) evaluated with exact phases
  * (SURVEY.md 7.2); it is the throughput path for on-grid channels and replaces the dead
- * pfb.channelizer_ccf branch of rc_frontend/receiver.py:242-261.  Output: n_bins rings at fs/decim.
- * n_bins must be a power of two in [16, 4096].
+ * pfb.channelizer_ccf branch of rc_frontend/receiver.py:242-261.  Output: n_bins streams at fs/decim.
+ * Supported shapes (anything else: RCF_EINVAL):
+ *   n_bins in {64, 128, 256, 512, 1024}, n_bins / decim in {1, 2}, up to 16 taps per branch
+ *   n_bins in {400, 800, 1600, 3200},    n_bins / decim in {1, 2, 4}, up to 4 (decim = n_bins) or 2 taps per branch
+ * The second family is what makes the bins the REFERENCE's channels: with the reference's own channel filter
+ * (rcf_channel_params: decim = int(fs/cr)/2, low_pass_2(1, fs, cr/2, cr/2, 20, HAMMING)) at fs = 20 Msps,
+ * cr = 12.5 kHz -- decim 800, 2909 taps -- a 1600-bin bank is every 12.5 kHz-grid channel and a 3200-bin bank every
+ * 6.25 kHz-grid channel rc_frontend/channel.py:31-35 could build, at the same 25 kS/s (10 Msps: 800 bins,
+ * 5 Msps: 400).
  */
 int rcf_pfb_open(rcf_t *h, int n_bins, int decim, const float *taps, int ntaps);
 int rcf_pfb_close(rcf_t *h);
 int64_t rcf_pfb_produced(rcf_t *h);
 /* bin index in [0, n_bins): bin k is centred at k*fs/n_bins for k < n_bins/2, (k-n_bins)*fs/n_bins above */
 int64_t rcf_pfb_read_bin(rcf_t *h, int bin, float *out_interleaved, size_t max_samples);
-/* device layout of the bin rings: sample n of bin k lives at bins_ring[k * pitch + (n & (capacity-1))]
- * (complex samples); pitch = capacity + pad is deliberately not a power of two so that the 256+
- * concurrently written rings do not alias onto one HBM channel */
+/* device layout of the bin outputs.  Power-of-two banks: per-bin rings, sample n of bin k at
+ * bins_ring[k * pitch + (n & (capacity-1))] (complex samples); pitch = capacity + pad is deliberately not a power
+ * of two so that the 256+ concurrently written rings do not alias onto one HBM channel.  400 / 800 / 1600 / 3200-bin
+ * banks: ONE ring of whole frames, sample n of bin k at bins_ring[(n & (capacity-1)) * n_bins + k], and *pitch = 0. */
 int rcf_pfb_rings(rcf_t *h, void **bins_ring, size_t *capacity, size_t *pitch);
 /* stage 2 on one bin: channel.py's own rule at the bin rate -- decim2 = int(bin_rate/cr)/2,
  * low_pass_2(1.0, bin_rate, cr/2, cr/2, 20, HAMMING), xlating by delta_hz -- output as a normal

@@ -72,6 +72,10 @@ __device__ __forceinline__ void dft4(cf &a0, cf &a1, cf &a2, cf &a3)
 // Dft<R>::reg_of(f).  All indices are compile-time after unrolling.
 template <int R, int SIGN> struct Dft;
 
+template <int SIGN> struct Dft<1, SIGN> {
+    static __device__ __forceinline__ void run(cf (&)[1]) {}
+    static __device__ __forceinline__ constexpr int reg_of(int f) { return f; }
+};
 template <int SIGN> struct Dft<2, SIGN> {
     static __device__ __forceinline__ void run(cf (&v)[2]) { dft2<SIGN>(v[0], v[1]); }
     static __device__ __forceinline__ constexpr int reg_of(int f) { return f; }
@@ -116,6 +120,60 @@ template <int SIGN> struct Dft<16, SIGN> {
     // register t = 4 k1 + k2 holds f = k1 + 4 k2
     static __device__ __forceinline__ constexpr int reg_of(int f) { return 4 * (f & 3) + (f >> 2); }
 };
+
+// 5-point DFT, natural order in and out:  X[k] = sum_n x[n] e^{SIGN 2 pi i n k / 5}
+template <int SIGN>
+__device__ __forceinline__ void dft5(cf &x0, cf &x1, cf &x2, cf &x3, cf &x4)
+{
+    const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;     // cos(2 pi/5), cos(4 pi/5)
+    const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;      // sin(2 pi/5), sin(4 pi/5)
+    const cf t1 = cadd(x1, x4), t2 = cadd(x2, x3), t3 = csub(x1, x4), t4 = csub(x2, x3);
+    const cf m1 = make_float2(x0.x + c1 * t1.x + c2 * t2.x, x0.y + c1 * t1.y + c2 * t2.y);
+    const cf m2 = make_float2(x0.x + c2 * t1.x + c1 * t2.x, x0.y + c2 * t1.y + c1 * t2.y);
+    const cf r1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+    const cf r2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    const cf i1 = mul_si<SIGN>(r1), i2 = mul_si<SIGN>(r2);                 // SIGN i (..)
+    x0 = make_float2(x0.x + t1.x + t2.x, x0.y + t1.y + t2.y);
+    x1 = cadd(m1, i1);
+    x4 = csub(m1, i1);
+    x2 = cadd(m2, i2);
+    x3 = csub(m2, i2);
+}
+
+template <int SIGN> struct Dft<5, SIGN> {
+    static __device__ __forceinline__ void run(cf (&v)[5]) { dft5<SIGN>(v[0], v[1], v[2], v[3], v[4]); }
+    static __device__ __forceinline__ constexpr int reg_of(int f) { return f; }
+};
+
+// 5 M points, M = 4 here (any M coprime with 5 that Dft<M> covers): Good-Thomas prime-factor form -- no twiddles between the stages.
+//   n = (M a + 5 b) mod 5M,  k = k1 (mod 5) = k2 (mod M):   X[k] = sum_b W_M^{b k2} sum_a W_5^{a k1} x[n(a, b)]
+// Everything is register renaming after unrolling: stage 1 runs M five-point DFTs in place (register n(a, b)
+// then holds Y[b][k1 = a]), stage 2 runs five M-point DFTs over b in place.
+template <int M, int SIGN> struct DftPfa5 {
+    static constexpr int R = 5 * M;
+    static __device__ __forceinline__ void run(cf (&v)[R])
+    {
+#pragma unroll
+        for (int b = 0; b < M; ++b)
+            dft5<SIGN>(v[(5 * b) % R], v[(M + 5 * b) % R], v[(2 * M + 5 * b) % R], v[(3 * M + 5 * b) % R],
+                       v[(4 * M + 5 * b) % R]);
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            cf w[M];
+#pragma unroll
+            for (int b = 0; b < M; ++b) w[b] = v[(M * a + 5 * b) % R];
+            Dft<M, SIGN>::run(w);
+#pragma unroll
+            for (int b = 0; b < M; ++b) v[(M * a + 5 * b) % R] = w[b];
+        }
+    }
+    // output k: k1 = k mod 5, k2 = k mod M; it sits where stage 2 left frequency k2 of row a = k1
+    static __device__ __forceinline__ constexpr int reg_of(int f)
+    {
+        return (M * (f % 5) + 5 * Dft<M, SIGN>::reg_of(f % M)) % R;
+    }
+};
+template <int SIGN> struct Dft<20, SIGN> : DftPfa5<4, SIGN> {};
 
 // padded LDS index: one spare complex after every 16
 __device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }

@@ -237,7 +237,8 @@ __global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *_
         for (int u = 0; u < LU; ++u) {
             const int p = p0 + u * kThreads;
             const int64_t sidx = s_first + (p < len ? p : len - 1);
-            v[u] = sidx >= L.start_sample ? sv.base[(uint64_t)(sidx - sv.origin) & sv.mask] : make_float2(0.f, 0.f);
+            v[u] = sidx >= L.start_sample ? sv.base[((uint64_t)(sidx - sv.origin) & sv.mask) * sv.stride]
+                                          : make_float2(0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < LU; ++u) {
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void fir_bank_kernel(const ChanLaunch *__
 
     const StreamView sv = L0.src;
     for (int p = tid; p < len; p += kThreads) {
-        const uint64_t idx = (uint64_t)(s_tile0 + p - sv.origin) & sv.mask;
+        const uint64_t idx = ((uint64_t)(s_tile0 + p - sv.origin) & sv.mask) * sv.stride;
         xs[p] = sv.base[idx];
     }
     __syncthreads();

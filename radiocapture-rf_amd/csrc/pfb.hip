@@ -281,7 +281,7 @@ bool dispatch(const PfbLaunch &p, bool probe, hipStream_t s)
         case 256:  return dispatch_nb<256>(p, OS, p.P, probe, s);
         case 512:  return dispatch_nb<512>(p, OS, p.P, probe, s);
         case 1024: return dispatch_nb<1024>(p, OS, p.P, probe, s);
-        default:   return false;
+        default:   return pfb5_dispatch(p, probe, s);      // 400 / 800 / 1600 / 3200 bins (pfb5.hip)
     }
 }
 
@@ -297,6 +297,7 @@ bool pfb_supported(int NB, int D, int P)
 
 int pfb_padded_p(int NB, int D, int P)
 {
+    if (NB % 25 == 0) return pfb5_padded_p(NB, D, P);
     return round_p(P, D > 0 ? NB / D : 1);
 }
 

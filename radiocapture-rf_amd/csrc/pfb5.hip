@@ -1,0 +1,263 @@
+// pfb5.hip -- polyphase filterbank for bin counts with a factor 25: NB = 20 * 20 * R3, R3 in {1, 2, 4, 8}
+// (400, 800, 1600, 3200 bins).
+//
+// Why these sizes: the reference's channel (rc_frontend/channel.py:31-35) is freq_xlating_fir_filter_ccc(D, h, f, fs)
+// with D = int(fs / cr) / 2 and T = |h| ~ 3.64 D taps; SURVEY.md 7.2 shows that ALL such channels on the
+// fs / NB grid are one NB-bin filterbank with the same D and h.  At fs = 20 Msps, cr = 12.5 kHz: D = 800,
+// T = 2909, and the grid that carries the reference's channel plans is 12.5 kHz (NB = 1600, OS = NB / D = 2,
+// 2 taps per branch) or 6.25 kHz (NB = 3200, OS = 4, 1 tap per branch) -- 2^6 5^2 and 2^7 5^2, not powers of two
+// (10 Msps: 800 bins, 5 Msps: 400).  Bin k of this kernel IS the reference's channel at offset k fs / NB: same
+// prototype, same decimation, same 25 kS/s output rate, phases exact (SURVEY 7.3 discusses the float32-phase
+// difference to GNU Radio's own; tests/test_gpu_round2.py reports it).
+//
+//   out_k[n] = e^{-j 2 pi k n D / NB} * sum_{rho<NB} e^{+j 2 pi k rho / NB} * u_rho[n]
+//   u_rho[n] = sum_{q<P} h[NB q + rho] * x[n D - rho - NB q]
+//
+// Mapping: workgroup = 320 threads, one chunk of F = 16 / R3 output frames (4 for 1600 bins, 2 for 3200); 53 KB of
+// LDS, three workgroups per CU; two workgroup barriers per chunk.
+//   NB-point inverse-sign DFT = 20 x 20 x R3 Stockham (Ns = 1, 20, 400), 20 = 5 x 4 as a Good-Thomas prime-factor
+//   butterfly held in registers (fft_core.hpp: no twiddles inside a butterfly):
+//   * phase A, thread = (frame, j < 20 R3): the branch FIR for the 20 inputs rho = j + 20 R3 t of first-pass
+//     butterfly j straight from global memory (x[m D - rho] for consecutive j is a reversed unit-stride run of the
+//     interleaved stream; P <= 4 real taps, rows m = n - OS q), the radix-20 butterfly in registers, results to LDS
+//     at 20 j + f (rows of 20 padded to 21: the stride-20 writes fall in distinct banks).  No LDS read, so no
+//     read-before-write hazard: the first pass costs one LDS write and nothing else.
+//   * barrier.
+//   * phase B, thread = (k < 20, g < R3, frame) with the frame fastest: second-pass butterfly j = 20 g + k reads
+//     positions j + 20 R3 t and writes 400 g + k + 20 f -- every position it touches is = k mod 20, and so is every
+//     position of the radix-R3 finish for bins k + 20 i.  The 16 lanes (g, frame) of one k are therefore a closed
+//     group inside one wavefront: the in-place hand-offs need wave-local ordering only (DS operations of a wave
+//     execute in order), no s_barrier.  Exact table twiddles W_400^{k t} between the passes, W_NB^{jj t} in the finish.
+//   * the finish writes its bins back in place (bin b at position b, bin phase factor e^{-j 2 pi k n D / NB} = a
+//     power of -j applied), one more barrier, then the chunk leaves as WHOLE FRAMES: the output is a frame-major ring
+//     bins_ring[(n & mask) NB + k] and every wavefront store is 512 contiguous bytes.  (Per-bin rings, as pfb.hip
+//     writes them, would get 32- or 16-byte pieces from a 4- or 2-frame chunk: measured 2x slower than the whole
+//     rest of the kernel, nt or not.)  Consumers read one bin with stride NB (StreamView.stride).
+// Bound: HBM.  Algorithmic bytes per input sample = 8 (read) + 8 NB / D (written) = 24 at OS = 2, 40 at OS = 4.
+#include <cstdlib>
+#include <mutex>
+
+#include "fft_core.hpp"
+#include "rcf_internal.h"
+
+namespace rcfx {
+
+namespace {
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kThreads5 = 320;
+
+// padded index: one spare complex after every R
+template <int R> __device__ __forceinline__ constexpr int pad5(int i) { return i + i / R; }
+
+__device__ __forceinline__ void wave_sync5()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int R, int R3, int OS, int P, bool ZH>
+__global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_wg)
+{
+    constexpr int NB = R * R * R3;
+    constexpr int N2 = R * R;                  // W_{N2}^n = e^{+2 pi i n / (R R)} = tw[n R3]
+    constexpr int F = 16 / R3;                 // frames per chunk
+    constexpr int D = NB / OS;
+    constexpr int BPF = NB / R;                // butterflies per frame and pass (= R R3)
+    constexpr int RS = NB + NB / R + 8;        // LDS row stride of a frame (complex): 24 mod 32 -> frames in distinct banks
+    static_assert(R == 20 && F * BPF == kThreads5, "one butterfly per thread and pass");
+    static_assert(OS == 1 || OS == 2 || OS == 4, "bin phase factor must be a power of -j");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+
+    const int tid = threadIdx.x;
+    // neighbouring chunks (they share input rows and complete each other's 128-byte output lines) on one XCD
+    const int b = blockIdx.x, q8 = n_wg / 8, r8 = n_wg % 8, xcd = b % 8;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    const int fb0 = wg * F;
+    if (fb0 >= p.n_frames) return;
+    const int nf = min(F, p.n_frames - fb0);
+    const int64_t n0 = p.n_lo + fb0;
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cf *>(p.src.base), 0, (int)(p.src_len * (int64_t)sizeof(cf)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.bins_ring, 0, (int)((int64_t)NB * (int64_t)(p.ring_mask + 1) * (int64_t)sizeof(cf)), 0x00020000);
+
+    // ---- phase A: branch FIR + first radix-20 pass.  u[t] = sum_q h[NB q + rho_t] x[(n - OS q) D - rho_t],
+    // rho_t = j + BPF t; X[f] -> buf[20 j + f]
+    {
+        const int frame = tid / BPF, j = tid % BPF;
+        const int64_t n = n0 + frame;
+        cf vv[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) vv[t] = make_float2(0.f, 0.f);
+        // lowest address this thread reads: row n - OS (P - 1), branch j + BPF (R - 1); everything else is a
+        // compile-time constant above it
+        const int vo = (int)(((n - OS * (P - 1)) * D - j - BPF * (R - 1) - p.src.origin) * (int64_t)sizeof(cf));
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            cf x[R];
+            float h[R];
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                // x[(n - OS q) D - j - BPF t]
+                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(
+                    in_rsrc, vo + (OS * (P - 1 - q) * D + BPF * (R - 1 - t)) * (int)sizeof(cf), 0, 0);
+                x[t] = make_float2(__uint_as_float(r.x), __uint_as_float(r.y));
+                h[t] = p.ptaps[q * NB + j + BPF * t];
+            }
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                if (ZH && (n - OS * q) * D - (j + BPF * t) < p.start_sample) x[t] = make_float2(0.f, 0.f);
+                vv[t].x = fmaf(h[t], x[t].x, vv[t].x);
+                vv[t].y = fmaf(h[t], x[t].y, vv[t].y);
+            }
+        }
+        Dft<R, +1>::run(vv);
+        cf *o = buf + frame * RS + j * (R + 1);              // pad5(j R + f) = j (R + 1) + f for f < R
+#pragma unroll
+        for (int f = 0; f < R; ++f) o[f] = vv[Dft<R, +1>::reg_of(f)];
+    }
+    __syncthreads();
+
+    // ---- phase B: second pass + radix-R3 finish + stores, closed inside the 16 lanes of one k
+    {
+        const int frame = tid % F, g = (tid / F) % R3, k = tid / (F * R3);      // F R3 = 16
+        cf *fbuf = buf + frame * RS;
+        // pass 2 (Ns = R): j = R g + k; v[t] = buf[j + t BPF] W_{R R}^{k t}; X[f] -> buf[N2 g + k + f R]
+        {
+            cf vv[R];
+            const cf *rd = fbuf + pad5<R>(R * g + k);        // pad5(j + t BPF) = pad5(j) + t (BPF + R3): BPF = R R3
+#pragma unroll
+            for (int t = 0; t < R; ++t) vv[t] = rd[t * (BPF + R3)];
+#pragma unroll
+            for (int t = 1; t < R; ++t) vv[t] = cmul(vv[t], p.tw[k * t * R3]);     // exact table entries, k t < R R
+            Dft<R, +1>::run(vv);
+            wave_sync5();                                    // the group's butterflies have read before any writes
+            cf *o = fbuf + pad5<R>(N2 * g + k);              // pad5(N2 g + k + f R) = pad5(N2 g + k) + f (R + 1)
+#pragma unroll
+            for (int f = 0; f < R; ++f) o[f * (R + 1)] = vv[Dft<R, +1>::reg_of(f)];
+            wave_sync5();
+        }
+        // finish (Ns = N2, radix R3): butterfly jj = k + R i reads positions jj + t N2, twiddles W_NB^{jj t},
+        // yields bins jj + f N2 -- written back in place (bin b at position b), with the bin phase factor;
+        // lane g takes i = g, g + R3, ...
+        const int64_t n = n0 + frame;
+        const int nph = (int)(n & 3);
+        auto phase = [&](cf z, int kk) {                     // e^{-j 2 pi kk n / OS} = (-j)^{(4 / OS) kk n}
+            if (OS == 1) return z;
+            const int e = ((4 / OS) * (kk & 3) * nph) & 3;
+            if (e == 1) return make_float2(z.y, -z.x);       // * -j
+            if (e == 2) return make_float2(-z.x, -z.y);
+            if (e == 3) return make_float2(-z.y, z.x);       // * +j
+            return z;
+        };
+        constexpr int SWEEPS = (R + R3 - 1) / R3;
+#pragma unroll
+        for (int s = 0; s < SWEEPS; ++s) {
+            const int i = g + R3 * s;
+            if (R % R3 != 0 && i >= R) break;
+            const int jj = k + R * i;
+            cf *pos = fbuf + pad5<R>(jj);
+            cf w[R3];
+#pragma unroll
+            for (int t = 0; t < R3; ++t) w[t] = pos[t * (N2 + N2 / R)];
+            if (R3 > 1) {
+#pragma unroll
+                for (int t = 1; t < R3; ++t) w[t] = cmul(w[t], p.tw[jj * t]);
+                Dft<R3, +1>::run(w);
+            }
+#pragma unroll
+            for (int f = 0; f < R3; ++f)
+                pos[f * (N2 + N2 / R)] = phase(R3 > 1 ? w[Dft<R3, +1>::reg_of(f)] : w[0], jj + f * N2);
+        }
+    }
+    __syncthreads();
+
+    // ---- copy-out: whole frames, bins consecutive across lanes -- every wavefront store is 512 contiguous bytes of
+    // the frame-major ring bins_ring[(n & mask) NB + k]
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        if (f >= nf) break;
+        const int64_t slot = (int64_t)((uint64_t)(n0 + f - p.n_abs0) & p.ring_mask);
+        const int so = (int)(slot * NB * (int64_t)sizeof(cf));
+        const cf *row = buf + f * RS;
+#pragma unroll
+        for (int bb = 0; bb < NB / kThreads5; ++bb) {
+            const int bin = tid + bb * kThreads5;
+            const cf z = row[pad5<R>(bin)];
+            u32x2 o;
+            o.x = __float_as_uint(z.x);
+            o.y = __float_as_uint(z.y);
+            __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, bin * (int)sizeof(cf), so, 2);
+        }
+        if (NB % kThreads5 != 0) {
+            const int bin = tid + (NB / kThreads5) * kThreads5;
+            if (bin < NB) {
+                const cf z = row[pad5<R>(bin)];
+                u32x2 o;
+                o.x = __float_as_uint(z.x);
+                o.y = __float_as_uint(z.y);
+                __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, bin * (int)sizeof(cf), so, 2);
+            }
+        }
+    }
+}
+
+template <int R, int R3, int OS, int P>
+void launch5(const PfbLaunch &p, hipStream_t s)
+{
+    constexpr int NB = R * R * R3, F = 16 / R3;
+    const int n_wg = (p.n_frames + F - 1) / F;
+    const size_t lds = (size_t)F * (NB + NB / R + 8) * sizeof(cf);
+    static std::mutex mu;
+    static bool attr_set[64] = {false};
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> g(mu);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pfb5_kernel<R, R3, OS, P, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pfb5_kernel<R, R3, OS, P, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set[dev] = true;
+        }
+    }
+    const bool zh = (p.n_lo - (int64_t)OS * (P - 1)) * (NB / OS) - (NB - 1) < p.start_sample;
+    if (zh) hipLaunchKernelGGL((pfb5_kernel<R, R3, OS, P, true>), dim3(n_wg), dim3(kThreads5), lds, s, p, n_wg);
+    else    hipLaunchKernelGGL((pfb5_kernel<R, R3, OS, P, false>), dim3(n_wg), dim3(kThreads5), lds, s, p, n_wg);
+}
+
+}  // namespace
+
+// shapes: (NB, OS) with taps per branch P <= 2 (OS 2, 4) or <= 4 (OS 1); the reference's own prototype gives
+// P = ceil(3.64 D / NB) = 2 at OS = 2 and 1 at OS = 4
+bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s)
+{
+    if (p.D <= 0 || p.NB % p.D) return false;
+    const int OS = p.NB / p.D;
+    const int PR = p.P <= 1 ? 1 : (p.P <= 2 ? 2 : (p.P <= 4 ? 4 : 0));
+    if (PR == 0) return false;
+#define RCF_PFB5(R_, R3_, OS_, P_)                                  \
+    if (p.NB == R_ * R_ * R3_ && OS == OS_ && PR == P_) {            \
+        if (!probe) launch5<R_, R3_, OS_, P_>(p, s);                 \
+        return true;                                                 \
+    }
+    RCF_PFB5(20, 4, 2, 2) RCF_PFB5(20, 4, 2, 1) RCF_PFB5(20, 4, 1, 4) RCF_PFB5(20, 4, 4, 1)      // 1600 bins
+    RCF_PFB5(20, 8, 4, 1) RCF_PFB5(20, 8, 2, 2) RCF_PFB5(20, 8, 2, 1) RCF_PFB5(20, 8, 1, 4)      // 3200 bins
+    RCF_PFB5(20, 2, 2, 2) RCF_PFB5(20, 2, 2, 1) RCF_PFB5(20, 2, 1, 4) RCF_PFB5(20, 2, 4, 1)      // 800 bins
+    RCF_PFB5(20, 1, 2, 2) RCF_PFB5(20, 1, 2, 1) RCF_PFB5(20, 1, 1, 4) RCF_PFB5(20, 1, 4, 1)      // 400 bins
+#undef RCF_PFB5
+    return false;
+}
+
+int pfb5_padded_p(int NB, int D, int P)
+{
+    (void)NB; (void)D;
+    return P <= 1 ? 1 : (P <= 2 ? 2 : 4);
+}
+
+}  // namespace rcfx

@@ -96,10 +96,12 @@ struct Chan {
 
 struct Pfb {
     bool open = false;
+    bool frame_major = false;      // output ring layout (PfbLaunch.frame_major)
     int NB = 0, D = 0, T = 0, P = 0, Ppad = 0;
     float *d_ptaps = nullptr;
     float2 *d_tw = nullptr;
     float2 *d_bins = nullptr;
+    float2 *d_stage = nullptr;     // frame-major banks: contiguous staging for rcf_pfb_read_bin
     std::vector<int64_t> rd;       // per-bin read cursors
     int64_t start_sample = 0, n_abs0 = 0, produced = 0;
     int64_t produced_before = 0;   // value of `produced` before the current commit (for derived channels)
@@ -277,6 +279,7 @@ bool source_range(rcf_t *h, int src, int64_t S0, int64_t S1, SrcRange *out)
         out->view.base = h->d_buf[h->cur];
         out->view.mask = ~0ull;
         out->view.origin = S0 - (int64_t)h->hist_cap;
+        out->view.stride = 1;
         out->p0 = S0;
         out->p1 = S1;
         return true;
@@ -284,7 +287,13 @@ bool source_range(rcf_t *h, int src, int64_t S0, int64_t S1, SrcRange *out)
     if (src >= RCF_SRC_PFB_BIN0) {
         if (!h->pfb.open) return false;
         const int bin = src - RCF_SRC_PFB_BIN0;
-        out->view.base = h->pfb.d_bins + (size_t)bin * h->bin_pitch;
+        if (h->pfb.frame_major) {                           // bins_ring[(n & mask) NB + bin]
+            out->view.base = h->pfb.d_bins + bin;
+            out->view.stride = h->pfb.NB;
+        } else {                                            // bins_ring[bin * pitch + (n & mask)]
+            out->view.base = h->pfb.d_bins + (size_t)bin * h->bin_pitch;
+            out->view.stride = 1;
+        }
         out->view.mask = h->ring_mask;
         out->view.origin = 0;
         out->p0 = h->pfb.produced_before;
@@ -487,6 +496,8 @@ int process_block(rcf_t *h, size_t n)
             pl.src.base = h->d_buf[h->cur];
             pl.src.mask = ~0ull;
             pl.src.origin = S0 - (int64_t)h->hist_cap;
+            pl.src.stride = 1;
+            pl.frame_major = p.frame_major ? 1 : 0;
             pl.ptaps = p.d_ptaps;
             pl.tw = p.d_tw;
             pl.bins_ring = p.d_bins;
@@ -528,6 +539,7 @@ int process_block(rcf_t *h, size_t n)
                     sr.view.base = it->second->d_iq;
                     sr.view.mask = h->ring_mask;
                     sr.view.origin = 0;
+                    sr.view.stride = 1;
                     sr.p0 = rng == chan_new.end() ? it->second->produced : rng->second.first;
                     sr.p1 = rng == chan_new.end() ? it->second->produced : rng->second.second;
                 } else if (!source_range(h, c->src, S0, S1, &sr)) {
@@ -768,6 +780,7 @@ int process_block(rcf_t *h, size_t n)
             sl.src.base = h->d_buf[h->cur];
             sl.src.mask = ~0ull;
             sl.src.origin = S0 - (int64_t)h->hist_cap;
+            sl.src.stride = 1;
             sl.s0 = sc.start_sample + (int64_t)sc.frames_done * sc.N;
             sl.window = sc.d_window;
             sl.tw = sc.d_tw;
@@ -1097,7 +1110,7 @@ int rcf_close(rcf_t *h)
     for (auto &kv : h->chans) free_channel(h, kv.second.get());
     h->chans.clear();
     Pfb &p = h->pfb;
-    bury(h, p.d_ptaps); bury(h, p.d_tw); bury(h, p.d_bins);
+    bury(h, p.d_ptaps); bury(h, p.d_tw); bury(h, p.d_bins); bury(h, p.d_stage);
     Scan &s = h->scan;
     bury(h, s.d_window); bury(h, s.d_vring); bury(h, s.d_sum); bury(h, s.d_out); bury(h, s.d_tw);
     bury(h, s.d_scratch); bury(h, s.d_peaks); bury(h, s.d_peak_ws);
@@ -1587,7 +1600,9 @@ int rcf_pfb_open(rcf_t *h, int n_bins, int decim, const float *taps, int ntaps)
         set_error("unsupported PFB shape: bins=%d decim=%d taps/branch=%d", n_bins, decim, P);
         return RCF_EINVAL;
     }
-    if ((uint64_t)n_bins * h->bin_pitch * sizeof(float2) >= (1ull << 31) ||
+    const bool fm = pfb_frame_major(n_bins);
+    const size_t ring_samples = fm ? (size_t)n_bins * h->out_cap : (size_t)n_bins * h->bin_pitch;
+    if ((uint64_t)ring_samples * sizeof(float2) >= (1ull << 31) ||
         (uint64_t)(h->hist_cap + h->block_cap) * sizeof(float2) >= (1ull << 31)) {
         set_error("PFB rings / wideband buffer exceed the 2 GiB range of 32-bit buffer offsets");
         return RCF_ECAP;
@@ -1608,8 +1623,9 @@ int rcf_pfb_open(rcf_t *h, int n_bins, int decim, const float *taps, int ntaps)
     RCF_HIP(hipMemcpy(p.d_ptaps, pt.data(), sizeof(float) * pt.size(), hipMemcpyHostToDevice));
     RCF_HIP(hipMalloc(&p.d_tw, sizeof(float2) * (size_t)n_bins));
     RCF_HIP(hipMemcpy(p.d_tw, tw.data(), sizeof(float2) * (size_t)n_bins, hipMemcpyHostToDevice));
-    RCF_HIP(hipMalloc(&p.d_bins, sizeof(float2) * (size_t)n_bins * h->bin_pitch));
-    RCF_HIP(hipMemsetAsync(p.d_bins, 0, sizeof(float2) * (size_t)n_bins * h->bin_pitch, h->stream));
+    p.frame_major = fm;
+    RCF_HIP(hipMalloc(&p.d_bins, sizeof(float2) * ring_samples));
+    RCF_HIP(hipMemsetAsync(p.d_bins, 0, sizeof(float2) * ring_samples, h->stream));
     p.rd.assign(n_bins, 0);
     p.start_sample = h->total_in;
     p.n_abs0 = ceil_div(p.start_sample, decim);
@@ -1629,7 +1645,7 @@ int rcf_pfb_close(rcf_t *h)
         if (it->second->src >= RCF_SRC_PFB_BIN0) { free_channel(h, it->second.get()); it = h->chans.erase(it); }
         else ++it;
     }
-    bury(h, p.d_ptaps); bury(h, p.d_tw); bury(h, p.d_bins);
+    bury(h, p.d_ptaps); bury(h, p.d_tw); bury(h, p.d_bins); bury(h, p.d_stage);
     p = Pfb();
     return RCF_OK;
 }
@@ -1648,6 +1664,23 @@ int64_t rcf_pfb_read_bin(rcf_t *h, int bin, float *out, size_t max_samples)
     if (set_dev(h)) return RCF_EHIP;
     Pfb &p = h->pfb;
     if (!p.open || bin < 0 || bin >= p.NB) { set_error("no such PFB bin %d", bin); return RCF_EINVAL; }
+    if (p.frame_major) {
+        // one bin out of the frame-major ring: gather its unread samples into a contiguous staging buffer
+        int64_t avail = p.produced - p.rd[bin];
+        if (avail <= 0 || max_samples == 0) return 0;
+        if ((size_t)avail > h->out_cap) { p.rd[bin] = p.produced - (int64_t)h->out_cap; avail = (int64_t)h->out_cap; }
+        const int64_t n = std::min<int64_t>(avail, (int64_t)max_samples);
+        if (!p.d_stage) RCF_HIP(hipMalloc(&p.d_stage, sizeof(float2) * h->out_cap));
+        const size_t pos = (size_t)((uint64_t)p.rd[bin] & h->ring_mask);
+        const size_t first = std::min<size_t>((size_t)n, h->out_cap - pos);
+        launch_gather_strided(p.d_bins + pos * (size_t)p.NB + bin, p.NB, p.d_stage, first, h->stream);
+        launch_gather_strided(p.d_bins + bin, p.NB, p.d_stage + first, (size_t)n - first, h->stream);
+        RCF_HIP(hipMemcpyAsync(out, p.d_stage, sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+        RCF_HIP(hipStreamSynchronize(h->stream));
+        free_graveyard_idle(h);
+        p.rd[bin] += n;
+        return n;
+    }
     return ring_read(h, p.d_bins + (size_t)bin * h->bin_pitch, sizeof(float2), p.produced, &p.rd[bin], out,
                      max_samples);
 }
@@ -1657,7 +1690,7 @@ int rcf_pfb_rings(rcf_t *h, void **bins_ring, size_t *capacity, size_t *pitch)
     if (!h || !h->pfb.open) return RCF_ESTATE;
     if (bins_ring) *bins_ring = h->pfb.d_bins;
     if (capacity) *capacity = h->out_cap;
-    if (pitch) *pitch = h->bin_pitch;
+    if (pitch) *pitch = h->pfb.frame_major ? 0 : h->bin_pitch;
     return RCF_OK;
 }
 

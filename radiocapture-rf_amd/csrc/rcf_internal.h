@@ -38,11 +38,13 @@ bool hip_ok(hipError_t e, const char *what);
     } while (0)
 
 // ---------------------------------------------------------------- stream views
-// sample s of a stream lives at base[(s - origin) & mask]   (linear buffer: mask = ~0)
+// sample s of a stream lives at base[((s - origin) & mask) * stride]   (linear buffer: mask = ~0; stride = 1
+// except for one bin of a frame-major filterbank ring, where consecutive samples are n_bins apart)
 struct StreamView {
     const float2 *base;
     uint64_t mask;
     int64_t origin;
+    int64_t stride;
 };
 
 // ---------------------------------------------------------------- direct xlating-FIR bank
@@ -181,10 +183,21 @@ struct PfbLaunch {
     int64_t src_len;         // samples addressable from src.base (linear view), for the buffer descriptor
     int32_t n_frames;        // frames in this launch
     int32_t NB, D, P;
+    // output layout: channel-major rings bins_ring[k * ring_cap + (n & ring_mask)] (pfb.hip), or -- frame_major --
+    // one ring of whole frames bins_ring[(n & ring_mask) * NB + k] (pfb5.hip: a chunk of 2-4 frames cannot fill
+    // 128-byte lines of per-bin rings, whole frames leave as contiguous rows)
+    int32_t frame_major;
+    int32_t pad_;
 };
 bool pfb_supported(int NB, int D, int P);
 int pfb_padded_p(int NB, int D, int P);   // rows the kernel instantiation reads from ptaps (zero padded)
 void launch_pfb(const PfbLaunch &p, hipStream_t s);
+// bin counts with a factor 25 (pfb5.hip): 400, 800, 1600, 3200
+bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s);
+inline bool pfb_frame_major(int NB) { return NB % 25 == 0; }
+// dst[i] = src[i * stride], i < n (one bin's samples out of a frame-major ring; ingest.hip)
+void launch_gather_strided(const float2 *src, int64_t stride, float2 *dst, size_t n, hipStream_t s);
+int pfb5_padded_p(int NB, int D, int P);
 
 // ---------------------------------------------------------------- scan
 struct ScanLaunch {

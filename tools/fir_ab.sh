@@ -1,10 +1,10 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-L=gpurun_out/fir_ab.log
+L=gpurun_out/pfb_ab.log
 : > $L
-run() { echo "## $*" >> $L; env "$@" timeout 600 python tools/fir_probe.py 2>&1 | tail -1 >> $L; }
-for C in 256 1024 4096 16384; do run C=$C STEPS=10; done
-run C=64 CR=6250
-run C=512 CR=6250
-run C=1024 FS=2400000 BLOCK=1048576
+run() { echo "## $*" >> $L; env "$@" timeout 600 python tools/pfb_probe.py 2>&1 | tail -2 >> $L; }
+run NB=1600 BLOCK=16777216 RCF_PFB5_DBG=3
+run NB=1600 BLOCK=16777216 RCF_PFB5_DBG=3 RCF_PFB5_LDSPAD=20000
+run NB=1600 BLOCK=16777216 RCF_PFB5_DBG=3 RCF_PFB5_LDSPAD=40000
+run NB=1600 BLOCK=33554432 RCF_PFB5_DBG=3
 cat $L

@@ -1,10 +1,13 @@
 #!/bin/bash
-# PMC passes over the matrix-core FIR bank (tools/fir_probe.py), on the GPU box:  tools/fir_pmc.sh <tag> [env...]
+# PMC passes over one kernel of a probe script, on the GPU box:  tools/fir_pmc.sh <tag> [env...]
+#   PROBE=tools/fir_probe.py (default) | tools/pfb_probe.py ...   KERNEL=fir_mfma (substring of the kernel name)
 # Counter passes carry only --kernel-trace.  Summaries -> gpurun_out/<tag>_pmc.txt
 cd "$(dirname "$0")/.."
 ROOT=$PWD
 TAG=$1; shift
 export TMPDIR=/tmp
+PROBE=${PROBE:-tools/fir_probe.py}
+KERNEL=${KERNEL:-fir_mfma}
 OUT=gpurun_out/${TAG}_pmc.txt
 : > $OUT
 i=0
@@ -14,17 +17,17 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU
   i=$((i+1))
   d=$ROOT/gpurun_out/${TAG}_pmc_$i
   rm -rf $d
-  (cd /tmp && env "$@" STEPS=3 timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -- python $ROOT/tools/fir_probe.py > $d.log 2>&1)
+  (cd /tmp && env "$@" STEPS=3 timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -- python $ROOT/$PROBE > $d.log 2>&1)
   echo "## pass $i: $set" >> $OUT
   tail -1 $d.log >> $OUT
-  python tools/pmc_summary.py $d fir_mfma >> $OUT
+  python tools/pmc_summary.py $d $KERNEL >> $OUT
   # per-dispatch duration of the same kernel in this (profiled) pass
-  python - "$d" >> $OUT <<'PY'
+  python - "$d" "$KERNEL" >> $OUT <<'PY'
 import csv, glob, os, sys
 d = []
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "fir_mfma" in r["Kernel_Name"]:
+        if sys.argv[2] in r["Kernel_Name"]:
             d.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 if d:
     print("%-32s %16.1f  (n=%d)" % ("kernel_us(profiled pass)", sum(d) / len(d), len(d)))

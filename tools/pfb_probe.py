@@ -11,8 +11,14 @@ B = int(os.environ.get("BLOCK", 1 << 25)); steps = int(os.environ.get("STEPS", 1
 fs = 20e6
 D = nb // osf
 bw = fs / nb
-taps = native.design_low_pass_2(1.0, fs, 0.4 * bw, 0.2 * bw, 60.0, native.WIN_BLACKMAN_HARRIS) if osf == 1 \
-    else native.design_low_pass_2(1.0, fs, bw / 4, bw / 4, 20.0)
+if nb % 25 == 0:
+    # the reference's own channel filter (channel.py:31-33): every bin is one of its 25 kS/s channels
+    D, T = native.channel_params(fs, 12500)
+    osf = nb // D
+    taps = native.design_low_pass_2(1.0, fs, 6250.0, 6250.0, 20.0)
+else:
+    taps = native.design_low_pass_2(1.0, fs, 0.4 * bw, 0.2 * bw, 60.0, native.WIN_BLACKMAN_HARRIS) if osf == 1 \
+        else native.design_low_pass_2(1.0, fs, bw / 4, bw / 4, 20.0)
 frames = B // D
 cap = 1
 while cap < 2 * frames: cap <<= 1
