@@ -257,6 +257,16 @@ int rcf_pfb_rings(rcf_t *h, void **bins_ring, size_t *capacity, size_t *pitch);
  * channel id (read_iq / read_fm). */
 #define RCF_SRC_PFB_BIN0 0x40000000
 int rcf_pfb_chan_open(rcf_t *h, int bin, int channel_rate, double delta_hz, int *chan_id);
+/* One bin AS a channel: when the bank was opened with the reference's own channel filter (rcf_channel_params
+ * decimation and prototype), bin k already is channel.channel(.., channel_rate, samp_rate, k*fs/n_bins)
+ * (rc_frontend/channel.py:31-35) -- the tap copies its new frames into a normal channel id (read_iq / read_fm /
+ * audio / symbol filter all work), discriminator fused into the copy.  This is what the reference's dead
+ * connect_channel_pfb (rc_frontend/receiver.py:343-383) was meant to do, without its second filter stage.
+ * gr_phase != 0: the channel's rotator also carries the per-output phase and magnitude increment by which GNU
+ * Radio's float32 rotator differs from the bank's exact phases, so the discriminator DC matches the reference's. */
+int rcf_pfb_tap_open(rcf_t *h, int bin, int gr_phase, int *chan_id);
+/* 1 when rcf_pfb_open would accept this shape (no device needed) */
+int rcf_pfb_shape_supported(int n_bins, int decim, int ntaps);
 
 /* ------------------------------------------------------------------ scan (fft_vector.py + fft_peak_detection.py) */
 /*

@@ -87,6 +87,7 @@ struct Chan {
     };
     std::unique_ptr<Audio> audio;
     // rotator model
+    double extra_dangle = 0, extra_dlogmag = 0;   // added to the increment's own angle / log magnitude (filterbank taps)
     double dangle = 0, dlogmag = 0;
     long double angle0 = 0;
     double logmag0 = 0;
@@ -307,7 +308,10 @@ int upload_composite(rcf_t *h, Chan *c)
 {
     std::vector<float> ct;
     float incr[2];
-    design_composite(c->proto.data(), c->T, c->D, c->offset_hz + (c->src < 0 ? h->shift_hz : 0.0), c->src_rate,
+    // rcf_source_shift moves every signal of the source by -shift at baseband: the wideband channels' NCOs follow,
+    // and so do the channels fed by filterbank bins (same Hz, at the bin rate)
+    const bool shifted = c->src < 0 || c->src >= RCF_SRC_PFB_BIN0;
+    design_composite(c->proto.data(), c->T, c->D, c->offset_hz + (shifted ? h->shift_hz : 0.0), c->src_rate,
                      ct, incr);
     const size_t slice = slice_round(sizeof(float2) * (size_t)c->T);
     float2 *fresh = static_cast<float2 *>(pool_get(h, slice));
@@ -320,8 +324,8 @@ int upload_composite(rcf_t *h, Chan *c)
     c->d_ctaps = fresh;
     c->taps_version = ++h->taps_clock;
     // GR iterates phase *= incr in float32; model it by the increment's actual angle and magnitude
-    c->dangle = std::atan2((double)incr[1], (double)incr[0]);
-    c->dlogmag = std::log(std::hypot((double)incr[0], (double)incr[1]));
+    c->dangle = std::atan2((double)incr[1], (double)incr[0]) + c->extra_dangle;
+    c->dlogmag = std::log(std::hypot((double)incr[0], (double)incr[1])) + c->extra_dlogmag;
     return RCF_OK;
 }
 
@@ -1309,6 +1313,37 @@ int rcf_pfb_chan_open(rcf_t *h, int bin, int channel_rate, double delta_hz, int 
     return new_channel(h, RCF_SRC_PFB_BIN0 + bin, D, taps.data(), (int)taps.size(), delta_hz, chan_id);
 }
 
+int rcf_pfb_tap_open(rcf_t *h, int bin, int gr_phase, int *chan_id)
+{
+    if (!h || !chan_id) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    Pfb &p = h->pfb;
+    if (!p.open || bin < 0 || bin >= p.NB) { set_error("no such PFB bin %d", bin); return RCF_EINVAL; }
+    const float one = 1.0f;
+    int rc = new_channel(h, RCF_SRC_PFB_BIN0 + bin, 1, &one, 1, 0.0, chan_id);
+    if (rc != RCF_OK) return rc;
+    if (gr_phase) {
+        // What GNU Radio's freq_xlating_fir_filter_ccc(D, h, f_k, fs) would have done differently from the bank's
+        // exact phases: its rotator advances by a = float32(-float32(2 pi f_k / fs) * D) per output instead of
+        // -2 pi k D / NB, and the float32 increment (cosf a, sinf a) is not exactly of unit length.  Both are
+        // per-output factors: this channel's own rotator carries them.
+        Chan *c = h->chans[*chan_id].get();
+        const int ks = bin < p.NB / 2 ? bin : bin - p.NB;
+        const double f_k = (double)ks * h->fs / p.NB;
+        const float fwT0 = (float)(kTwoPi * f_k / h->fs);
+        const float a = -fwT0 * (float)p.D;
+        const long double exact = -2.0L * 3.14159265358979323846264338327950288L *
+                                  (long double)(((int64_t)ks * p.D) % p.NB) / (long double)p.NB;
+        long double d = (long double)a - exact;
+        d = remainderl(d, 2.0L * 3.14159265358979323846264338327950288L);
+        c->extra_dangle = (double)d;
+        c->extra_dlogmag = std::log(std::hypot((double)std::cos(a), (double)std::sin(a)));
+        rc = upload_composite(h, c);
+    }
+    return rc;
+}
+
 #define FIND_CHAN(h, id, c)                                                 \
     auto it_ = (h)->chans.find(id);                                         \
     if (it_ == (h)->chans.end()) { set_error("no such channel %d", id); return RCF_ENOCHAN; } \
@@ -1581,7 +1616,7 @@ int rcf_source_shift(rcf_t *h, double delta_hz)
     if (set_dev(h)) return RCF_EHIP;
     h->shift_hz += delta_hz;
     for (auto &kv : h->chans)
-        if (kv.second->src < 0) {
+        if (kv.second->src < 0 || kv.second->src >= RCF_SRC_PFB_BIN0) {
             int rc = upload_composite(h, kv.second.get());
             if (rc != RCF_OK) return rc;
         }
@@ -1648,6 +1683,12 @@ int rcf_pfb_close(rcf_t *h)
     bury(h, p.d_ptaps); bury(h, p.d_tw); bury(h, p.d_bins); bury(h, p.d_stage);
     p = Pfb();
     return RCF_OK;
+}
+
+int rcf_pfb_shape_supported(int n_bins, int decim, int ntaps)
+{
+    if (n_bins < 1 || decim < 1 || ntaps < 1 || n_bins % decim) return 0;
+    return pfb_supported(n_bins, decim, (ntaps + n_bins - 1) / n_bins) ? 1 : 0;
 }
 
 int64_t rcf_pfb_produced(rcf_t *h)

@@ -11,10 +11,12 @@ import time
 
 
 class channel:
-    def __init__(self, frontend, port, channel_rate, samp_rate, offset, parent_chan=None):
+    def __init__(self, frontend, port, channel_rate, samp_rate, offset, parent_chan=None, pfb=None):
         """frontend: rcf.native.Frontend (the HBM-resident source that replaces `parent_zmq_address`).
         parent_chan: channel id of a receiver_split2 half-band source (receiver.py:205-237) this channel
-        reads instead of the wideband stream; samp_rate is then that half's rate."""
+        reads instead of the wideband stream; samp_rate is then that half's rate.
+        pfb: the source's filterbank plan (receiver._open_pfb) when frontend_mode == 'pfb': requests that fall on
+        its grid are served by a bin of the bank, everything else by the direct kernel."""
         self.frontend = frontend
         self.samp_rate = samp_rate
         self.channel_rate = channel_rate
@@ -23,24 +25,45 @@ class channel:
         self.in_use = False
         self.source_id = None
         self.block_id = None
+        self.parent_chan = parent_chan
+        self.pfb = pfb
+        self.pfb_bin = None
+        self.chan_id = None
+        self._build(offset)
+        self.init_time = time.time()
+        self.channel_close_time = 0
+        self._started = False
+
+    def _build(self, offset):
+        """(re)create the native channel for `offset`: a filterbank bin when the request is on the bank's grid
+        (the intent of connect_channel_pfb, receiver.py:343-383: bin = round(offset / grid), residual handled
+        separately -- here a non-zero residual simply takes the direct path), else the direct xlating FIR."""
+        frontend, channel_rate, samp_rate = self.frontend, self.channel_rate, self.samp_rate
+        self.pfb_bin = None
+        pfb = self.pfb
+        if pfb is not None and self.parent_chan is None and channel_rate == pfb["channel_rate"]:
+            k = int(round(offset / pfb["grid"]))
+            if offset == k * pfb["grid"] and abs(k) <= pfb["n_bins"] // 2 and abs(offset) < samp_rate / 2:
+                self.pfb_bin = k % pfb["n_bins"]               # receiver.py:373-375: wrap negative bins
         # rc_frontend/channel.py:31-35: decim = int(fs/cr)/2, low_pass_2(1.0, fs, cr/2, cr/2, 20, HAMMING);
         # the C ABI derives both (rcf_chan_open) and rejects non-integral decimations
-        if parent_chan is None:
+        if self.pfb_bin is not None:
+            self.chan_id = frontend.pfb_tap_open(self.pfb_bin, gr_phase=True)
+            self.decim, self.ntaps = pfb["decim"], pfb["ntaps"]
+            self.out_rate = samp_rate / pfb["decim"]
+            return
+        if self.parent_chan is None:
             self.chan_id = frontend.chan_open(channel_rate, offset)
         else:
             from . import native
             decim, ntaps = native.channel_params(samp_rate, channel_rate)
             taps = native.design_low_pass_2(1.0, samp_rate, channel_rate / 2, channel_rate / 2, 20.0)
             assert len(taps) == ntaps
-            self.chan_id = frontend.chan_open_taps(parent_chan, decim, taps, offset)
+            self.chan_id = frontend.chan_open_taps(self.parent_chan, decim, taps, offset)
         info = frontend.chan_info(self.chan_id)
         self.decim = info["decim"]
         self.ntaps = info["ntaps"]
         self.out_rate = info["out_rate"]
-        self.init_time = time.time()
-        self.channel_close_time = 0
-        self._started = False
-
     def __str__(self):
         return "Channel: port:%s channel_rate:%s samp_rate:%s offset:%s init_time:%s" % (
             self.port, self.channel_rate, self.samp_rate, self.offset, self.init_time)
@@ -68,7 +91,18 @@ class channel:
     def set_offset(self, offset):
         """channel.py:61-63 -> prefilter.set_center_freq: retune, rotator phase and history kept."""
         self.offset = offset
-        self.frontend.chan_set_offset(self.chan_id, offset)
+        if self.pfb is None:
+            self.frontend.chan_set_offset(self.chan_id, offset)
+            return
+        # filterbank mode: a channel may move between bins, or between a bin and the direct kernel; the native
+        # channel is rebuilt (the reference only retunes channels it is re-using after they sat idle)
+        k = int(round(offset / self.pfb["grid"]))
+        if self.pfb_bin is None and offset != k * self.pfb["grid"]:
+            self.frontend.chan_set_offset(self.chan_id, offset)        # direct stays direct
+            return
+        old = self.chan_id
+        self._build(offset)
+        self.frontend.chan_close(old)
 
     def destroy(self):
         """channel.py:64-67"""

@@ -34,7 +34,7 @@ SYMBOLS = [
     "rcf_design_firdes", "rcf_design_optfir_low_pass", "rcf_design_fm_deemph", "rcf_design_resampler", "rcf_chan_audio_open",
     "rcf_chan_audio_close", "rcf_chan_audio_produced", "rcf_chan_read_audio",
     "rcf_host_alloc", "rcf_host_free", "rcf_comm_unique_id", "rcf_comm_init", "rcf_comm_destroy", "rcf_comm_size",
-    "rcf_allgather_peaks", "rcf_allreduce_max",
+    "rcf_allgather_peaks", "rcf_allreduce_max", "rcf_pfb_tap_open", "rcf_pfb_shape_supported",
 ]
 FMT_U8, FMT_S8, FMT_S16 = 1, 2, 3
 T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY, T_FIR_MFMA, T_AUDIO = range(9)
@@ -111,6 +111,8 @@ def lib():
         "rcf_pfb_read_bin": (i64, [vp, C.c_int, fp, sz]),
         "rcf_pfb_rings": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
         "rcf_pfb_chan_open": (C.c_int, [vp, C.c_int, C.c_int, C.c_double, ip]),
+        "rcf_pfb_tap_open": (C.c_int, [vp, C.c_int, C.c_int, ip]),
+        "rcf_pfb_shape_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
         "rcf_scan_start": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "rcf_scan_result": (C.c_int, [vp, fp]),
         "rcf_scan_frames_done": (C.c_int, [vp]),
@@ -213,6 +215,10 @@ def channel_params(samp_rate, channel_rate):
     d, t = C.c_int(), C.c_int()
     _check(lib().rcf_channel_params(samp_rate, int(channel_rate), C.byref(d), C.byref(t)))
     return d.value, t.value
+
+
+def pfb_shape_supported(n_bins, decim, ntaps) -> bool:
+    return bool(lib().rcf_pfb_shape_supported(int(n_bins), int(decim), int(ntaps)))
 
 
 def find_peaks(spectrum, min_w, max_w, prominence=1.0, cap=4096):
@@ -379,6 +385,12 @@ class Frontend:
     def pfb_chan_open(self, bin_, channel_rate, delta_hz) -> int:
         cid = C.c_int()
         _check(lib().rcf_pfb_chan_open(self._h, int(bin_), int(channel_rate), float(delta_hz), C.byref(cid)))
+        return cid.value
+
+    def pfb_tap_open(self, bin_, gr_phase=True) -> int:
+        """bin `bin_` of the open filterbank as a channel id (rcf_pfb_tap_open)"""
+        cid = C.c_int()
+        _check(lib().rcf_pfb_tap_open(self._h, int(bin_), 1 if gr_phase else 0, C.byref(cid)))
         return cid.value
 
     def chan_set_offset(self, cid, offset_hz):

@@ -69,12 +69,36 @@ class receiver:
                 "center_freq": src["center_freq"], "samp_rate": src["samp_rate"],
                 "block": fe, "source_id": source, "offset": src.get("offset", 0),
             }
+            if getattr(config, "frontend_mode", "xlat") == "pfb":
+                self.sources[numsources]["pfb"] = self._open_pfb(fe, float(src["samp_rate"]))
             numsources += 1
         if getattr(config, "frontend_mode", "xlat") not in ("xlat", "pfb"):
             self.access_lock.release()
             raise Exception("No frontend_mode selected")
         self.channels = {}
         self.access_lock.release()
+
+    def _open_pfb(self, fe, samp_rate):
+        """frontend_mode == 'pfb' (the reference's receiver.py:242-261 built pfb.channelizer_ccf(fs / 400 kHz bins)
+        + a second xlating stage per channel and never finished it).  Here the bank is built from the channel
+        filter itself -- decim = int(fs/cr)/2, low_pass_2(1, fs, cr/2, cr/2, 20, HAMMING) (channel.py:31-33) on a
+        `pfb_grid` Hz raster (default: cr = 12.5 kHz) -- so every bin IS the channel the xlat path would have built
+        at that frequency and no second stage is needed.  Returns the plan, or None when librcf has no kernel for
+        the shape (then every request takes the direct path, as in 'xlat' mode)."""
+        from . import native
+        cr = int(getattr(self.config, "pfb_channel_rate", 12500))
+        grid = float(getattr(self.config, "pfb_grid", cr))
+        try:
+            decim, ntaps = native.channel_params(samp_rate, cr)
+        except native.RcfError:
+            return None
+        n_bins = samp_rate / grid
+        if n_bins != int(n_bins) or int(n_bins) % decim or not native.pfb_shape_supported(int(n_bins), decim, ntaps):
+            self.log.warning("no filterbank kernel for fs=%s grid=%s: direct channels only" % (samp_rate, grid))
+            return None
+        taps = native.design_low_pass_2(1.0, samp_rate, cr / 2, cr / 2, 20.0)
+        fe.pfb_open(int(n_bins), decim, taps)
+        return {"n_bins": int(n_bins), "grid": grid, "decim": decim, "ntaps": ntaps, "channel_rate": cr}
 
     # ------------------------------------------------------------------ data plane
     def feed(self, source_id, iq):
@@ -94,8 +118,10 @@ class receiver:
     def connect_channel(self, channel_rate, freq):
         mode = getattr(self.config, "frontend_mode", "xlat")
         if mode in ("xlat", "pfb"):
-            # the reference's 'pfb' branch is dead code (receiver.py:403 calls channel() with 4 args);
-            # on-grid requests are served by the PFB transparently, the API is the xlat one
+            # one entry point for both modes: in 'pfb' mode the source carries a filterbank plan and the channel
+            # object picks bin or direct kernel per request (channel._build); source selection, idle re-use and the
+            # return value are the xlat ones (the reference's own 'pfb' branch is dead code: receiver.py:403 calls
+            # channel() with four arguments)
             return self.connect_channel_xlat(channel_rate, freq)
         raise Exception("No frontend_mode selected")
 
@@ -141,7 +167,8 @@ class receiver:
                 if port is None:
                     raise Exception("no free egress port")
                 block = channel_mod.channel(frontend, port, channel_rate, source_samp_rate, offset,
-                                            parent_chan=self.sources[source_id].get("parent_chan"))
+                                            parent_chan=self.sources[source_id].get("parent_chan"),
+                                            pfb=self.sources[source_id].get("pfb"))
                 block.source_id = source_id
                 block.block_id = "%s" % uuid.uuid4()
                 self.channels[block.block_id] = block
@@ -185,6 +212,8 @@ class receiver:
             # distance, so the shift to apply is the change of the accumulated offset
             src["block"].source_shift(total_offset - accumulated_offset)
             src["accumulated_offset"] = total_offset
+            # (filterbank mode: bins stay on the raster, the taps' rotators carry the correction -- rcf_source_shift
+            # applies to channels fed by bins too -- and new requests keep landing on bins)
         return True
 
     def scan_mode_set_freq(self, freq):

@@ -5,6 +5,8 @@ import os
 import random
 import types
 
+import numpy as np
+
 import pytest
 
 from rcf import frontend_connector as FC
@@ -246,3 +248,149 @@ def test_receiver_split2_makes_two_half_rate_sources_per_real_source():
     assert c["src"] == hi["parent_chan"] and c["D"] == 48          # int(1.2e6 / 12500) / 2
     tb.close()
     assert fe.closed
+
+
+# ------------------------------------------------------------------ frontend_mode == 'pfb': bin routing
+class StubPfbFrontend(StubFrontend):
+    def __init__(self, samp_rate, center_freq, device=0):
+        super().__init__(samp_rate, center_freq, device)
+        self.pfb = None
+
+    def pfb_open(self, n_bins, decim, taps):
+        self.pfb = dict(n_bins=n_bins, decim=decim, ntaps=len(taps))
+
+    def pfb_tap_open(self, bin_, gr_phase=True):
+        assert self.pfb is not None and 0 <= bin_ < self.pfb["n_bins"]
+        cid = self.next
+        self.next += 1
+        self.chans[cid] = dict(cr=None, off=0.0, D=1, bin=bin_, gr_phase=gr_phase)
+        return cid
+
+
+def test_pfb_mode_routes_on_grid_requests_to_bins_and_the_rest_to_the_direct_kernel():
+    """The intent of connect_channel_pfb (/root/reference/rc_frontend/receiver.py:343-383): bin = round(offset /
+    grid), negative bins wrap, off-grid requests take the other path.  Here the bank is built from the channel
+    filter itself (20 Msps, cr 12.5 kHz: 1600 bins, decim 800, 2909 taps), so a bin needs no second stage."""
+    cfg = types.SimpleNamespace(sources={0: dict(type="synthetic", center_freq=855000000, samp_rate=20000000)},
+                                frontend_mode="pfb")
+    StubFrontend.instances = []
+    tb = receiver.receiver(cfg, frontend_factory=StubPfbFrontend)
+    fe = StubFrontend.instances[0]
+    assert fe.pfb == dict(n_bins=1600, decim=800, ntaps=2909)
+    plan = tb.sources[0]["pfb"]
+    assert plan["grid"] == 12500.0 and plan["n_bins"] == 1600
+    # on the raster, above and below the centre
+    b1, _ = tb.connect_channel(12500, 855000000 + 80 * 12500)
+    b2, _ = tb.connect_channel(12500, 855000000 - 3 * 12500)
+    assert fe.chans[tb.channels[b1].chan_id]["bin"] == 80 and tb.channels[b1].pfb_bin == 80
+    assert fe.chans[tb.channels[b2].chan_id]["bin"] == 1600 - 3            # receiver.py:373-375: wrapped
+    assert tb.channels[b1].decim == 800 and tb.channels[b1].ntaps == 2909 and tb.channels[b1].out_rate == 25000.0
+    # off the raster (6.25 kHz offset) and another channel rate: the direct xlating FIR
+    b3, _ = tb.connect_channel(12500, 855000000 + 6250)
+    assert tb.channels[b3].pfb_bin is None and fe.chans[tb.channels[b3].chan_id]["cr"] == 12500
+    b4, _ = tb.connect_channel(6250, 855000000 + 12500)
+    assert tb.channels[b4].pfb_bin is None and fe.chans[tb.channels[b4].chan_id]["cr"] == 6250
+    # an idle bin channel re-used for another frequency moves to that bin (or to the direct kernel)
+    tb.release_channel(b1)
+    b5, _ = tb.connect_channel(12500, 855000000 + 81 * 12500)
+    assert b5 == b1 and tb.channels[b1].pfb_bin == 81 and fe.chans[tb.channels[b1].chan_id]["bin"] == 81
+    tb.release_channel(b1)
+    b6, _ = tb.connect_channel(12500, 855000000 + 81 * 12500 + 100)
+    assert b6 == b1 and tb.channels[b1].pfb_bin is None and fe.chans[tb.channels[b1].chan_id]["off"] == 81 * 12500 + 100
+    assert len(fe.chans) == 4                                               # rebuilt channels were closed
+    # a 6.25 kHz raster is a config knob
+    cfg2 = types.SimpleNamespace(sources={0: dict(type="synthetic", center_freq=855000000, samp_rate=20000000)},
+                                 frontend_mode="pfb", pfb_grid=6250)
+    tb2 = receiver.receiver(cfg2, frontend_factory=StubPfbFrontend)
+    assert StubFrontend.instances[-1].pfb["n_bins"] == 3200
+    b7, _ = tb2.connect_channel(12500, 855000000 - 6250)
+    assert tb2.channels[b7].pfb_bin == 3199
+    # a source rate with no kernel for its bank (2.4 Msps: 192 bins): everything direct, nothing breaks
+    cfg3 = types.SimpleNamespace(sources={0: dict(type="synthetic", center_freq=855050000, samp_rate=2400000)},
+                                 frontend_mode="pfb")
+    tb3 = receiver.receiver(cfg3, frontend_factory=StubPfbFrontend)
+    assert tb3.sources[0]["pfb"] is None and StubFrontend.instances[-1].pfb is None
+    b8, _ = tb3.connect_channel(12500, 854987500)
+    assert tb3.channels[b8].pfb_bin is None
+
+
+def test_rep_loop_survives_handler_errors_and_egress_isolates_channels():
+    """a malformed request must not end serve_zmq (the reference's loop catches and keeps serving,
+    receiver.py:686-699); one channel's egress failure must not stop the pump for the others."""
+    import sys
+    from rcf import egress
+
+    tb = make_receiver()
+    srv = protocol.FrontendServer(tb)
+
+    class Again(Exception):
+        pass
+
+    class FakeSock:
+        def __init__(self, inbox):
+            self.inbox, self.sent = list(inbox), []
+
+        def bind(self, addr):
+            pass
+
+        def getsockopt(self, opt):
+            return b"tcp://0.0.0.0:5555"
+
+        def recv_string(self, flags=0):
+            if not self.inbox:
+                raise Again()
+            return self.inbox.pop(0)
+
+        def send_string(self, s):
+            self.sent.append(s)
+
+    sock = FakeSock(["connect", "create,x", "offset,1", "scan_mode_set_freq,notanumber", "hb,1", "quit,1"])
+    fake_zmq = types.SimpleNamespace(Context=lambda: types.SimpleNamespace(socket=lambda kind: sock), REP=4,
+                                     LAST_ENDPOINT=32, NOBLOCK=1, Again=Again)
+    sys.modules["zmq"] = fake_zmq
+    try:
+        srv.serve_zmq(stop=lambda: not sock.inbox and len(sock.sent) >= 6)
+    finally:
+        del sys.modules["zmq"]
+    assert len(sock.sent) == 6                                    # every request answered: the REP socket never wedges
+    assert sock.sent[0].startswith("connect,") and sock.sent[-1] == "quit,1"
+
+    # egress: channel A's socket raises on send, channel B keeps flowing
+    class Chan:
+        def __init__(self, port):
+            self.port, self.chan_id, self.reads = port, 1, 0
+
+        def read_iq(self):
+            self.reads += 1
+            return np.ones(4, dtype=np.complex64)
+
+        def read_fm(self, gain):
+            return np.zeros(0, dtype=np.float32)
+
+    class Sock:
+        def __init__(self, port):
+            self.port, self.sent, self.closed = port, 0, False
+
+        def send(self, payload):
+            if self.port == 11111:
+                raise OSError("peer gone")
+            self.sent += len(payload)
+
+        def close(self):
+            self.closed = True
+
+    socks = {}
+
+    def factory(port):
+        if port == 12345:
+            raise OSError("address already in use")
+        socks[port] = Sock(port)
+        return socks[port]
+
+    tbx = types.SimpleNamespace(access_lock=tb.access_lock, channels={"a": Chan(11111), "b": Chan(22222)},
+                                bind_port=None)
+    pump = egress.EgressPump(tbx, socket_factory=factory)
+    assert tbx.bind_port is not None and tbx.bind_port(12345) is False and tbx.bind_port(23456) is True
+    pump.pump_once()
+    pump.pump_once()
+    assert pump.errors == 2 and socks[22222].sent == 64 and pump.bytes_out == 64
