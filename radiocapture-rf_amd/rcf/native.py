@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "librcf.so")
+# RCF_LIBRCF: another build of the same library (the AddressSanitizer build of the host layer, tools/asan_gpu.sh)
+_SO = os.environ.get("RCF_LIBRCF") or os.path.join(_HERE, "librcf.so")
 _lib = None
 
 RCF_OK, RCF_EINVAL, RCF_ENOMEM, RCF_EHIP, RCF_ENOCHAN = 0, -1, -2, -3, -4

@@ -449,3 +449,68 @@ def test_pfb_mode_end_to_end_through_create_channel(gpu_required):
     ct, incr = OC.xlating_composite(taps, D, off_direct, fs)
     yo, fo = OC.channel_bank(x, D, ct[None, :], np.array([incr]), gains=[gain])
     assert rel_rms(y, yo[0]) < 1e-5 and rms(fm, fo[0]) < 1e-4
+
+
+def test_threads_feed_control_read_concurrently(gpu_required):
+    """The reference's front-end has a feeder (GNU Radio's scheduler threads), a control thread (the REP handler:
+    create / release / retune / idle sweep) and per-channel consumers all touching the same receiver under
+    access_lock (rc_frontend/receiver.py:48).  Here: three Python threads on one handle -- librcf serialises every
+    call on the handle's mutex -- while channels come and go; the channel that lives through it all must still
+    equal the oracle sample for sample."""
+    import threading
+    nat = gpu_required
+    fs, cr = 2.4e6, 12500
+    D, taps = G.channel_params(fs, cr)
+    rng = np.random.default_rng(99)
+    n_blocks, blk = 60, D * 64
+    x = synth.awgn(rng, n_blocks * blk)
+    errors, kept = [], []
+    with nat.Frontend(fs, block_capacity=blk, out_capacity=1 << 14) as fe:
+        keeper = fe.chan_open(cr, 137500.0)
+        stop = threading.Event()
+
+        def feeder():
+            try:
+                for b in range(n_blocks):
+                    fe.push(x[b * blk:(b + 1) * blk])
+            except Exception as e:               # pragma: no cover
+                errors.append(e)
+            finally:
+                stop.set()
+
+        def control():
+            r = np.random.default_rng(5)
+            live = []
+            try:
+                while not stop.is_set():
+                    if len(live) < 24 and r.random() < 0.6:
+                        live.append(fe.chan_open(cr, float(r.integers(-150, 150)) * 6250.0))
+                    elif live and r.random() < 0.5:
+                        fe.chan_set_offset(live[int(r.integers(len(live)))], float(r.integers(-150, 150)) * 6250.0)
+                    elif live:
+                        fe.chan_close(live.pop(int(r.integers(len(live)))))
+                for c in live:
+                    fe.chan_close(c)
+            except Exception as e:               # pragma: no cover
+                errors.append(e)
+
+        def reader():
+            try:
+                while not stop.is_set():
+                    kept.append(fe.chan_read_iq(keeper))
+                    fe.chan_read_fm(keeper, 1.0)
+            except Exception as e:               # pragma: no cover
+                errors.append(e)
+
+        th = [threading.Thread(target=f) for f in (feeder, control, reader)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+        kept.append(fe.chan_read_iq(keeper))
+    assert not errors, errors
+    y = np.concatenate(kept)
+    ct, incr = OC.xlating_composite(taps, D, 137500.0, fs)
+    yo, _ = OC.channel_bank(x, D, ct[None, :], np.array([incr]), gains=[1.0])
+    assert len(y) == yo.shape[1]
+    assert rel_rms(y, yo[0]) < 1e-5

@@ -1,0 +1,18 @@
+#!/bin/bash
+# The whole C ABI host layer (rcf_api.cpp: mutexes, deferred frees, slab pools, double-buffered arenas, bank-matrix
+# cache) under AddressSanitizer on a GPU box, over the tests that churn channels the hardest.
+#   make -C radiocapture-rf_amd/csrc asan      (here: the .so travels with the snapshot)
+#   gpurun -- tools/asan_gpu.sh                -> gpurun_out/asan_gpu.txt
+cd "$(dirname "$0")/.."
+RT=$(gcc -print-file-name=libasan.so)
+OUT=gpurun_out/asan_gpu.txt
+mkdir -p gpurun_out
+{
+  echo "# ASan runtime: $RT"
+  RCF_LIBRCF=$PWD/radiocapture-rf_amd/rcf/librcf_asan.so LD_PRELOAD=$RT \
+  ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 \
+  timeout 1500 python -m pytest tests/test_gpu_round2.py tests/test_gpu_parity.py tests/test_gpu_end_to_end.py -m gpu -x -q \
+      -k "threads or churn or arena or pinned or chunked or mid_stream or ring_wrap or retune or create_channel or pfb_mode or source_offset" 2>&1 | tail -25
+  echo "# exit: $?"
+} > $OUT 2>&1
+cat $OUT
