@@ -27,7 +27,8 @@
 //     positions j + 20 R3 t and writes 400 g + k + 20 f -- every position it touches is = k mod 20, and so is every
 //     position of the radix-R3 finish for bins k + 20 i.  The 16 lanes (g, frame) of one k are therefore a closed
 //     group inside one wavefront: the in-place hand-offs need wave-local ordering only (DS operations of a wave
-//     execute in order), no s_barrier.  Exact table twiddles W_400^{k t} between the passes, W_NB^{jj t} in the finish.
+//     execute in order), no s_barrier.  Twiddles W_400^{k t} / W_NB^{jj t}: one exact table entry per butterfly,
+//     the other powers by binary powering in registers.
 //   * the finish writes its bins back in place (bin b at position b, bin phase factor e^{-j 2 pi k n D / NB} = a
 //     power of -j applied), one more barrier, then the chunk leaves as WHOLE FRAMES: the output is a frame-major ring
 //     bins_ring[(n & mask) NB + k] and every wavefront store is 512 contiguous bytes.  (Per-bin rings, as pfb.hip
@@ -65,7 +66,10 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
     constexpr int F = 16 / R3;                 // frames per chunk
     constexpr int D = NB / OS;
     constexpr int BPF = NB / R;                // butterflies per frame and pass (= R R3)
-    constexpr int RS = NB + NB / R + 8;        // LDS row stride of a frame (complex): 24 mod 32 -> frames in distinct banks
+    // LDS row stride of a frame (complex), = 1 mod 16: in the second pass's stores the 16 lanes (g, frame) of a k
+    // write dwords 2 RS frame + 840 g (+ const) = 2 frame + 8 g mod 32 -- sixteen distinct bank pairs.  (With a
+    // stride of 8 mod 16 those stores were 4-way conflicts and LDS conflict cycles were 5x the LDS instructions.)
+    constexpr int RS = NB + NB / R + 1;
     static_assert(R == 20 && F * BPF == kThreads5, "one butterfly per thread and pass");
     static_assert(OS == 1 || OS == 2 || OS == 4, "bin phase factor must be a power of -j");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -132,8 +136,14 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
             const cf *rd = fbuf + pad5<R>(R * g + k);        // pad5(j + t BPF) = pad5(j) + t (BPF + R3): BPF = R R3
 #pragma unroll
             for (int t = 0; t < R; ++t) vv[t] = rd[t * (BPF + R3)];
+            {
+                // W_{R R}^{k t}, t < R, from ONE table entry by binary powering (depth <= 5 multiplications, a few
+                // 1e-7 of error): nineteen table loads per thread were a third of the kernel's L2 traffic
+                cf w[R];
+                twiddle_powers<R>(p.tw[k * R3], w);
 #pragma unroll
-            for (int t = 1; t < R; ++t) vv[t] = cmul(vv[t], p.tw[k * t * R3]);     // exact table entries, k t < R R
+                for (int t = 1; t < R; ++t) vv[t] = cmul(vv[t], w[t]);
+            }
             Dft<R, +1>::run(vv);
             wave_sync5();                                    // the group's butterflies have read before any writes
             cf *o = fbuf + pad5<R>(N2 * g + k);              // pad5(N2 g + k + f R) = pad5(N2 g + k) + f (R + 1)
@@ -165,8 +175,12 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
 #pragma unroll
             for (int t = 0; t < R3; ++t) w[t] = pos[t * (N2 + N2 / R)];
             if (R3 > 1) {
+                {
+                    cf wp[R3 > 1 ? R3 : 2];
+                    twiddle_powers<(R3 > 1 ? R3 : 2)>(p.tw[jj], wp);       // W_NB^{jj t} from one entry
 #pragma unroll
-                for (int t = 1; t < R3; ++t) w[t] = cmul(w[t], p.tw[jj * t]);
+                    for (int t = 1; t < R3; ++t) w[t] = cmul(w[t], wp[t]);
+                }
                 Dft<R3, +1>::run(w);
             }
 #pragma unroll
@@ -211,7 +225,7 @@ void launch5(const PfbLaunch &p, hipStream_t s)
 {
     constexpr int NB = R * R * R3, F = 16 / R3;
     const int n_wg = (p.n_frames + F - 1) / F;
-    const size_t lds = (size_t)F * (NB + NB / R + 8) * sizeof(cf);
+    const size_t lds = (size_t)F * (NB + NB / R + 1) * sizeof(cf);
     static std::mutex mu;
     static bool attr_set[64] = {false};
     {
