@@ -18,6 +18,7 @@ Outside the timed region, rank 0 at N = 1 also reports:
   channels.direct_bank   the reference-shaped bank (one 2909-tap xlating FIR /800 + discriminator per channel)
                          actually opened and run at 256 .. 131072 (--sweep-max) channels, kernel ms per block
                          and TFLOP/s at each point
+  channels.reference_grid_filterbank   the 1600-bin bank whose bins are the reference's channels (20 Msps, D = 800)
   scan                   BASELINE configs[2]: 1M-point FFT x 1000 frames / 100-frame average + peak pick
   end_to_end             PCIe-inclusive ingest (pinned cf32 rcf_push_iq, u8 rcf_push_raw), copy overlapped
   control_plane          100 x create / release through the frontend_connector protocol
@@ -197,6 +198,50 @@ def direct_bank_sweep(native, tile, device, counts, block=1 << 22):
             "note": "every count was opened and run (no extrapolation); flop = 8 T per output per channel; "
                     "peak 157.3 TF (datasheet) -- a bare v_mfma_f32_16x16x4_f32 loop with non-zero operands "
                     "sustains ~140 TF on this chip (tools/mfma_peak_probe.hip)"}
+
+
+def reference_grid_leg(native, tile, device, B=1 << 24, n_taps=256):
+    """The filterbank whose bins ARE the reference's channels: 1600 bins on the 12.5 kHz grid of one
+    20 Msps front-end, built from channel.py's own filter (D = 800, T = 2909), every bin a 25 kS/s channel;
+    256 of them tapped as channels with the discriminator (what frontend_mode = 'pfb' serves requests from)."""
+    D, T = native.channel_params(FS, 12500)
+    taps = native.design_low_pass_2(1.0, FS, 6250.0, 6250.0, 20.0)
+    fe = native.Frontend(FS, 0.0, device=device, block_capacity=B, hist_capacity=1 << 16, out_capacity=1 << 16)
+    fe.pfb_open(1600, D, taps)
+    ids = [fe.pfb_tap_open((7 + 6 * i) % 1600, gr_phase=True) for i in range(n_taps)]
+    for _ in range(2):
+        for at in range(0, B, len(tile)):
+            fe.ingest_write(tile[: min(len(tile), B - at)], at)
+        fe.commit(B)
+    fe.commit(B)
+    fe.sync()
+    fe.timing_enable(True, classes=[native.T_PFB, native.T_FIR_DERIVED])
+    fe.timing_read(native.T_PFB)
+    fe.timing_read(native.T_FIR_DERIVED)
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        fe.commit(B)
+    fe.sync()
+    wall = (time.perf_counter() - t0) / n
+    pfb_ms, pn = fe.timing_read(native.T_PFB)
+    tap_ms, tn = fe.timing_read(native.T_FIR_DERIVED)
+    fe.timing_enable(False)
+    assert fe.chan_produced(ids[0]) > 0
+    fe.close()
+    pfb_s = pfb_ms / max(pn, 1) * 1e-3
+    alg = 24.0 * B                                    # 8 B read + 8 * 1600 / 800 B written per input sample
+    return {
+        "workload": "1600-bin filterbank, decim 800, 2909-tap channel.py prototype (every bin == one reference "
+                    "channel at 25 kS/s), 20 Msps cf32, block %d; %d bins tapped as channels with discriminator" % (B, n_taps),
+        "kernel": "pfb5_kernel<20,4,2,2>", "pfb_ms_per_block": pfb_s * 1e3,
+        "taps_ms_per_block": tap_ms / max(tn, 1), "wall_ms_per_block": wall * 1e3,
+        "input_Msamples_per_s_kernel": B / pfb_s / 1e6,
+        "realtime_factor_at_20Msps": B / FS / wall,
+        "reference_channels_per_frontend": 1600,
+        "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": alg, "achieved": alg / pfb_s / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / pfb_s / 1e9 / HBM_PEAK_GBS},
+    }
 
 
 def scan_leg(native, synth, device):
@@ -498,6 +543,7 @@ def main():
     if extras:
         counts = [c for c in (256, 1024, 4096, 16384, 65536, 131072, 196608) if c <= args.sweep_max]
         out["channels"]["direct_bank"] = direct_bank_sweep(native, tile, local_rank, counts)
+        out["channels"]["reference_grid_filterbank"] = reference_grid_leg(native, tile, local_rank)
         out["scan"] = scan_leg(native, synth, local_rank)
         out["end_to_end"] = end_to_end_leg(native, tile, local_rank)
         out["control_plane"] = control_plane_leg(local_rank)
