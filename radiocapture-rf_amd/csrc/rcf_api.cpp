@@ -426,7 +426,7 @@ int process_block(rcf_t *h, size_t n)
     {
         size_t need = 4096;
         for (auto &kv : h->chans) {
-            need += sizeof(ChanLaunch) + sizeof(DiscLaunch) + 2 + 128;
+            need += 2 * sizeof(ChanLaunch) + sizeof(DiscLaunch) + 2 + 128;
             if (kv.second->d_sym) need += sizeof(FmFirLaunch);
             if (kv.second->audio) need += sizeof(AudioLaunch);
         }
@@ -646,11 +646,14 @@ int process_block(rcf_t *h, size_t n)
             job.dims.max_n_k = max_n;
             job.dims.ring_mask = h->ring_mask;
             job.dims.atan_tab = h->d_atan;
-            // Matrix-core path: channels on one shared source with one common output range and no zero-history taps
-            // in range.  Channels that do not qualify yet (just opened: their first outputs still see zero history,
-            // or start later in the block) go through the vector kernel in a launch of their own, so channel churn
-            // does not pull the whole class off the matrix cores.
-            std::vector<ChanLaunch> clean, rest;
+            // Matrix-core path: channels on one shared source with one common output range.  A channel that was just
+            // opened still has outputs whose taps reach before its start (GR zero history) -- at most ceil((T-1)/D)
+            // of them, four for the reference's shapes.  It joins the matrix-core launch anyway (which computes those
+            // few outputs from real history, i.e. wrongly) and a vector-kernel launch AFTER it on the same stream
+            // rewrites just those outputs with the per-tap mask: opening 16384 channels at once used to put one
+            // whole block (70 ms) on the vector kernel.  Channels that start later inside the block keep the vector
+            // kernel for that block.
+            std::vector<ChanLaunch> clean, rest, fixups;
             std::vector<Chan *> clean_ch;
             int n_common_of_clean = max_n;
             if (shared_src && depth == 0 && mfma2_applicable(D, T, h->hist_cap) && !h->no_mfma) {
@@ -661,15 +664,23 @@ int process_block(rcf_t *h, size_t n)
                 n_common_of_clean = n_common;
                 for (size_t i = 0; i < launches.size(); ++i) {
                     const ChanLaunch &L = launches[i];
-                    const bool ok = L.k_lo == k_common && L.n_k == n_common &&
-                                    L.k_lo * D - L.start_sample >= (int64_t)(T - 1);
-                    if (ok) { clean.push_back(L); clean_ch.push_back(launched[i]); }
-                    else rest.push_back(L);
+                    const bool ok = L.k_lo == k_common && L.n_k == n_common;
+                    if (!ok) { rest.push_back(L); continue; }
+                    clean.push_back(L);
+                    clean_ch.push_back(launched[i]);
+                    if (L.k_lo * D - L.start_sample < (int64_t)(T - 1)) {
+                        // outputs k with k D - (T-1) < start: k < ceil((start + T - 1) / D)
+                        const int64_t k_end = ceil_div(L.start_sample + (int64_t)(T - 1), D);
+                        ChanLaunch F = L;
+                        F.n_k = (int32_t)std::min<int64_t>(L.n_k, std::max<int64_t>(0, k_end - L.k_lo));
+                        if (F.n_k > 0) fixups.push_back(F);
+                    }
                 }
                 // (no size limit on a class: every group of 32 channels has its own tap slab)
                 if ((int)clean.size() < h->mfma_min) {
                     clean.clear();
                     clean_ch.clear();
+                    fixups.clear();
                     rest = launches;
                 }
             } else {
@@ -720,6 +731,20 @@ int process_block(rcf_t *h, size_t n)
                 mj.dims.src_len = (int64_t)(h->hist_cap + n);
                 if (!ar.put(clean, &mj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
                 fir_by_depth[depth].push_back(mj);
+            }
+            if (!fixups.empty()) {                          // queued behind the matrix-core launch: see above
+                FirJob fj = job;
+                fj.bc = nullptr;
+                fj.repack = false;
+                fj.dirty = nullptr;
+                fj.dims.n_chans = (int)fixups.size();
+                fj.dims.max_n_k = 0;
+                for (auto &F : fixups) fj.dims.max_n_k = std::max(fj.dims.max_n_k, (int)F.n_k);
+                fj.dims.small = 0;
+                fj.dims.mfma = 0;
+                fj.dims.chans_per_wg = 1;                   // per-channel n_k differ: one channel per workgroup
+                if (!ar.put(fixups, &fj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+                fir_by_depth[depth].push_back(fj);
             }
             if (!rest.empty()) {
                 job.dims.n_chans = (int)rest.size();

@@ -33,9 +33,11 @@ def test_reference_shaped_bank_256_channels_at_20msps_equals_oracle(gpu_required
     with nat.Frontend(FS, block_capacity=1 << 22, out_capacity=1 << 14) as fe:
         ids = [fe.chan_open(12500, f) for f in offs]
         fe.timing_enable(True)
-        fe.push(x[:n1])                                        # history becomes real
-        fe.push(x[n1:])                                        # the full-size block: matrix-core kernel
-        assert fe.timing_read(nat.T_FIR_MFMA)[1] == (0 if os.environ.get("RCF_FIR_NOMFMA") else 1)
+        fe.push(x[:n1])                  # history becomes real: the matrix-core kernel already runs, and a vector
+        #                                  launch behind it redoes the few outputs that still see zero history
+        fe.push(x[n1:])                  # the full-size block: matrix-core kernel only
+        if not os.environ.get("RCF_FIR_NOMFMA"):
+            assert fe.timing_read(nat.T_FIR_MFMA)[1] == 2 and fe.timing_read(nat.T_FIR)[1] == 1
         ys = np.stack([fe.chan_read_iq(c) for c in ids])
     cts = np.stack([OC.xlating_composite(taps, D, f, FS)[0] for f in offs])
     inc = np.array([OC.xlating_composite(taps, D, f, FS)[1] for f in offs], dtype=np.complex64)

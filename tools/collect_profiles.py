@@ -1,42 +1,107 @@
 #!/usr/bin/env python3
 """Copy what tools/make_profiles.sh left under gpurun_out/ into profiles/ (run where gpurun_out/ was merged):
-   python tools/collect_profiles.py r01"""
-import shutil, os, re
-import collections, csv, glob, json, os, sys
+   python tools/collect_profiles.py r02"""
+import csv, glob, json, os, re, shutil, sys
 R = sys.argv[1]
-vals = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    v = []
-    for f in sorted(glob.glob("gpurun_out/%s_pmc_%s/**/*counter_collection.csv" % (R, c), recursive=True),
-                    key=os.path.getmtime)[-1:]:                            # newest run only
+
+
+def newest(pattern):
+    fs = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return fs[-1] if fs else None
+
+
+def counters(d, kernel, skip_first=True):
+    """average per dispatch of every counter for kernels whose name contains `kernel`; + the dispatch durations"""
+    acc, dur, name = {}, [], None
+    f = newest(os.path.join(d, "**", "*counter_collection.csv"))
+    if f:
         for r in csv.DictReader(open(f)):
-            if "pfb_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
-                v.append(float(r["Counter_Value"]))
+            if kernel in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
                 name = r["Kernel_Name"]
-    v = v[1:] if len(v) > 2 else v      # drop the first (zero-history instantiation / cold) launch
-    vals[c] = (sum(v) / len(v), len(v)) if v else (None, 0)
-if vals["FETCH_SIZE"][0] is not None and vals["WRITE_SIZE"][0] is not None:
-    fetch = vals["FETCH_SIZE"][0] * 1024 * 2       # KiB -> B, gfx950 x2 correction (MI355X_MICROARCH.md)
-    write = vals["WRITE_SIZE"][0] * 1024
+    f = newest(os.path.join(d, "**", "*kernel_trace.csv"))
+    if f:
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"]:
+                dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    out = {}
+    for k, v in acc.items():
+        v = v[1:] if skip_first and len(v) > 2 else v
+        out[k] = sum(v) / len(v)
+    if dur:
+        dur = dur[1:] if skip_first and len(dur) > 2 else dur
+        out["kernel_us"] = sum(dur) / len(dur)
+        out["launches_averaged"] = len(dur)
+    return out, name
+
+
+def short(name):
+    m = re.search(r"(pfb5?_kernel\w*<[^>]*>|fir_mfma_kernel<[^>]*>|[A-Za-z_0-9]+_kernel[A-Za-z_0-9<>, ]*)", name or "")
+    return m.group(0) if m else name
+
+
+# ---- timed configuration: PFB traffic
+v = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    v[c], name = counters("gpurun_out/%s_pmc_%s" % (R, c), "pfb_kernel")
+if v["FETCH_SIZE"].get("FETCH_SIZE") is not None and v["WRITE_SIZE"].get("WRITE_SIZE") is not None:
+    fetch = v["FETCH_SIZE"]["FETCH_SIZE"] * 1024 * 2       # KiB -> B, gfx950 x2 correction (MI355X_MICROARCH.md)
+    write = v["WRITE_SIZE"]["WRITE_SIZE"] * 1024
     B = 1 << 25
-    json.dump({"block": B, "kernel": (re.search(r"pfb_kernel\w*<[^>]*>", name) or re.search(r".*", name)).group(0), "launches_averaged": vals["FETCH_SIZE"][1],
-               "FETCH_SIZE_KiB_raw": vals["FETCH_SIZE"][0], "WRITE_SIZE_KiB_raw": vals["WRITE_SIZE"][0],
+    json.dump({"block": B, "kernel": short(name), "launches_averaged": v["FETCH_SIZE"].get("launches_averaged"),
+               "FETCH_SIZE_KiB_raw": v["FETCH_SIZE"]["FETCH_SIZE"], "WRITE_SIZE_KiB_raw": v["WRITE_SIZE"]["WRITE_SIZE"],
                "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
                "algorithmic_bytes_per_launch": 16.0 * B,
                "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of `rocprofv3 --pmc X --kernel-trace -- python "
-                       "bench.py --steps 5 --warmup 1 --no-cpu-baseline`; KiB units and the gfx950 FETCH_SIZE x2 "
+                       "bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras`; KiB units and the gfx950 FETCH_SIZE x2 "
                        "correction per MI355X_MICROARCH.md; counters sit at the L2<->fabric boundary, so Infinity-Cache "
                        "hits are included"}, open("profiles/pfb_traffic.json", "w"), indent=1)
     print("traffic: fetch %.1f MB write %.1f MB (algorithmic %.1f MB)" % (fetch / 1e6, write / 1e6, 16.0 * B / 1e6))
 else:
-    print("traffic: counters missing", vals)
+    print("traffic: counters missing")
 
-for src, dst in (("gpurun_out/%s_bench.json" % R, "profiles/%s_bench.json" % R),):
-    if os.path.exists(src):
-        with open(src) as f:
-            lines = [l for l in f.read().splitlines() if l.startswith("{")]
-        if lines:
-            open(dst, "w").write(lines[-1] + "\n")
-fs = sorted(glob.glob("gpurun_out/%s_trace/**/*kernel_stats.csv" % R, recursive=True), key=os.path.getmtime)
-if fs:
-    shutil.copy(fs[-1], "profiles/%s_bench_kernel_stats.csv" % R)       # newest run
+
+def pmc_record(tag, kernel, out, extra):
+    rec = {}
+    for i in (1, 2, 3, 4):
+        c, name = counters("gpurun_out/%s_pmc_%d" % (tag, i), kernel)
+        if not c:
+            continue
+        us = c.pop("kernel_us", None)
+        c.pop("launches_averaged", None)
+        rec["pass%d" % i] = dict(c, kernel_us_in_this_pass=us)
+        rec["kernel"] = short(name)
+    if rec:
+        rec.update(extra)
+        json.dump(rec, open(out, "w"), indent=1)
+        print("wrote", out)
+
+
+pmc_record("%s_fir4096" % R, "fir_mfma", "profiles/%s_fir_mfma_pmc.json" % R, {
+    "workload": "tools/fir_probe.py C=4096: 4096 reference-shaped channels (D=800, T=2909), 20 Msps, block 2^22",
+    "ideal_mfma_instructions": 4096 * 5243 * 2909 * 8 / 2048.0,
+    "how_to_read": "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); clock = "
+                   "GRBM_GUI_ACTIVE / 8 / kernel_us; SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles; "
+                   "FETCH_SIZE in KiB and x2 on gfx950 (MI355X_MICROARCH.md)"})
+pmc_record("%s_pfb512" % R, "pfb_kernel", "profiles/%s_pfb512_traffic.json" % R, {
+    "workload": "tools/pfb_probe.py NB=512: 512-bin critically sampled bank, block 2^25; algorithmic 16 B/sample = 536.9 MB",
+    "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
+pmc_record("%s_pfb1600" % R, "pfb5_kernel", "profiles/%s_pfb1600_pmc.json" % R, {
+    "workload": "tools/pfb_probe.py NB=1600 BLOCK=2^24: 1600-bin bank, D = 800, 2909 taps; algorithmic 24 B/sample = 402.7 MB",
+    "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
+
+src = "gpurun_out/%s_bench.json" % R
+if os.path.exists(src):
+    lines = [l for l in open(src).read().splitlines() if l.startswith("{")]
+    if lines:
+        open("profiles/%s_bench.json" % R, "w").write(lines[-1] + "\n")
+f = newest("gpurun_out/%s_trace/**/*kernel_stats.csv" % R)
+if f:
+    shutil.copy(f, "profiles/%s_bench_kernel_stats.csv" % R)
+    rows = [r for r in csv.DictReader(open(f)) if re.search(r"scan|movsum|k_pick|k_prep|k_min|k_tables|k_sort", r["Name"])]
+    if rows:
+        with open("profiles/%s_scan_kernel_stats.csv" % R, "w", newline="") as fh:
+            w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)
+    print("kernel stats:", f)
