@@ -365,7 +365,8 @@ struct MfmaArgs {
     const float *bank;
     int64_t src_len;
     uint64_t ring_mask;
-    int D, T, n_chans, n_groups, n_wt;
+    float2 *partial;         // n_parts > 1: [part][channel][n_k] partial sums, finished by fir_mfma_finish_kernel
+    int D, T, n_chans, n_groups, n_wt, n_parts, n_k;
 };
 
 template <int NT, int PD>
@@ -383,13 +384,16 @@ __global__ __launch_bounds__(kM2Threads, 2) void fir_mfma_kernel(const ChanLaunc
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // groups fastest: the workgroups resident together mostly share their output tiles, i.e. their samples, through
     // L2 (each streams its own taps once) -- measured 2-4 % better than tiles fastest
-    const int g = blockIdx.x % d.n_groups, wt = blockIdx.x / d.n_groups;
+    const int g = blockIdx.x % d.n_groups;
+    const int part = (blockIdx.x / d.n_groups) % d.n_parts, wt = blockIdx.x / (d.n_groups * d.n_parts);
     const ChanLaunch &L0 = chans[g * kM2Group];
     const int n_k = L0.n_k;
     const int k_rel0 = (wt * (kM2Threads / kWave) + wave) * (NT * 16);
     const int j = lane & 15, kap = lane >> 4;
     const int NS = bank2_steps(d.T);
-    const int NC = NS / CS;
+    const int NC_all = NS / CS;
+    const int c_first = (part * NC_all) / d.n_parts;         // this workgroup's range of tap chunks
+    const int NC = ((part + 1) * NC_all) / d.n_parts - c_first;
 
     const StreamView sv = L0.src;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -400,10 +404,10 @@ __global__ __launch_bounds__(kM2Threads, 2) void fir_mfma_kernel(const ChanLaunc
         int kr = k_rel0 + n * 16 + j;
         if (kr > n_k - 1) kr = n_k - 1;                     // past the block: recompute the last output, never stored
         if (kr < 0) kr = 0;
-        const int64_t sidx = (L0.k_lo + kr) * (int64_t)d.D - sv.origin - 8 * (NS - 1) - 2 * kap;
+        const int64_t sidx = (L0.k_lo + kr) * (int64_t)d.D - sv.origin - 8 * (NS - 1) - 2 * kap + 8 * CS * c_first;
         voff[n] = (int)(sidx * (int64_t)sizeof(float2));
     }
-    const float *bank_g = d.bank + (size_t)g * bank2_group_floats(d.T);
+    const float *bank_g = d.bank + (size_t)g * bank2_group_floats(d.T) + (size_t)c_first * (kM2ChunkBytes / 4);
 
     v4f acc[MT][NT];
 #pragma unroll
@@ -485,9 +489,33 @@ __global__ __launch_bounds__(kM2Threads, 2) void fir_mfma_kernel(const ChanLaunc
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int ci = g * kM2Group + t * 8 + 2 * kap + hh;
-                if (ci < d.n_chans) rotate_store(chans[ci], L0.k_lo + kr, acc[t][n][2 * hh], acc[t][n][2 * hh + 1], d.ring_mask);
+                if (ci >= d.n_chans) continue;
+                if (d.n_parts == 1)
+                    rotate_store(chans[ci], L0.k_lo + kr, acc[t][n][2 * hh], acc[t][n][2 * hh + 1], d.ring_mask);
+                else                                           // 16 lanes j = 128 contiguous bytes of the slab
+                    d.partial[((size_t)part * d.n_chans + ci) * d.n_k + kr] =
+                        make_float2(acc[t][n][2 * hh], acc[t][n][2 * hh + 1]);
             }
     }
+}
+
+// split-K finish: y = rotator * (part 0 + part 1 + ...), the parts added in order (deterministic)
+__global__ __launch_bounds__(kThreads) void fir_mfma_finish_kernel(const ChanLaunch *__restrict__ chans,
+                                                                   const float2 *__restrict__ partial, int n_chans,
+                                                                   int n_k, int n_parts, uint64_t ring_mask)
+{
+    const int kr = blockIdx.x * kThreads + threadIdx.x;
+    const int ci = blockIdx.y;
+    if (kr >= n_k) return;
+    const size_t at = (size_t)ci * n_k + kr, slab = (size_t)n_chans * n_k;
+    float2 s = partial[at];
+    for (int p = 1; p < n_parts; ++p) {
+        const float2 v = partial[at + p * slab];
+        s.x = __fadd_rn(s.x, v.x);
+        s.y = __fadd_rn(s.y, v.y);
+    }
+    const ChanLaunch &L = chans[ci];
+    rotate_store(L, L.k_lo + kr, s.x, s.y, ring_mask);
 }
 
 __global__ __launch_bounds__(kThreads) void fir_pack_kernel(const ChanLaunch *__restrict__ chans, int n_chans, int T,
@@ -609,8 +637,8 @@ static void launch_mfma_t(const ChanLaunch *d_chans, MfmaArgs a, int max_n_k, hi
         }
     }
     a.n_wt = (max_n_k + 64 * NT - 1) / (64 * NT);
-    hipLaunchKernelGGL((fir_mfma_kernel<NT, PD>), dim3((unsigned)(a.n_wt * a.n_groups)), dim3(kM2Threads), lds, s,
-                       d_chans, a);
+    hipLaunchKernelGGL((fir_mfma_kernel<NT, PD>), dim3((unsigned)(a.n_wt * a.n_groups * a.n_parts)), dim3(kM2Threads), lds,
+                       s, d_chans, a);
 }
 
 static void launch_mfma(const ChanLaunch *d_chans, const FirLaunchDims &dims, hipStream_t s)
@@ -621,15 +649,14 @@ static void launch_mfma(const ChanLaunch *d_chans, const FirLaunchDims &dims, hi
     a.ring_mask = dims.ring_mask;
     a.D = dims.D; a.T = dims.T; a.n_chans = dims.n_chans;
     a.n_groups = (dims.n_chans + kM2Group - 1) / kM2Group;
-    // outputs per workgroup: 4 waves x NT x 16.  NT = 2 halves the A-operand LDS reads and the tap traffic per
-    // MFMA; NT = 1 halves the work unit, which is what matters while the launch is only a round or two of workgroups
-    // (512 resident: two per CU)
-    static const int force_nt = [] { const char *e = getenv("RCF_FIR_MFMA_NT"); return e ? atoi(e) : 0; }();
-    const int wt2 = (dims.max_n_k + 127) / 128;
-    int nt = ((int64_t)a.n_groups * wt2 >= 1024) ? 2 : 1;
-    if (force_nt == 1 || force_nt == 2) nt = force_nt;
-    if (nt == 2) launch_mfma_t<2, 3>(d_chans, a, dims.max_n_k, s);
-    else         launch_mfma_t<1, 3>(d_chans, a, dims.max_n_k, s);
+    a.n_parts = dims.partial ? dims.mfma_parts : 1;
+    a.partial = dims.partial;
+    a.n_k = dims.max_n_k;
+    if (dims.mfma_nt == 2) launch_mfma_t<2, 3>(d_chans, a, dims.max_n_k, s);
+    else                   launch_mfma_t<1, 3>(d_chans, a, dims.max_n_k, s);
+    if (a.n_parts > 1)
+        hipLaunchKernelGGL(fir_mfma_finish_kernel, dim3((dims.max_n_k + kThreads - 1) / kThreads, dims.n_chans),
+                           dim3(kThreads), 0, s, d_chans, a.partial, dims.n_chans, dims.max_n_k, a.n_parts, dims.ring_mask);
 }
 
 void launch_fir_bank(const ChanLaunch *d_chans, const FirLaunchDims &dims, hipStream_t s)

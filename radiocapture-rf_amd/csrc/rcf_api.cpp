@@ -176,6 +176,9 @@ struct rcf {
     bool timing = false;
     unsigned timing_mask = ~0u;
     int mfma_min = 8;             // fewest channels of a class worth a matrix-core launch (RCF_FIR_MFMA_MIN)
+    int mfma_nt = 0, mfma_parts = 0;   // RCF_FIR_MFMA_NT / RCF_FIR_MFMA_PARTS: override the launch plan (measurements)
+    float2 *d_partial = nullptr;  // split-K slabs of the matrix-core bank
+    size_t partial_cap = 0;       // in float2
     bool no_mfma = false;         // RCF_FIR_NOMFMA=1: keep the vector-FMA bank kernel (A/B measurements)
     struct TimeRec { int what; hipEvent_t a, b; };
     std::vector<TimeRec> time_pending;
@@ -729,6 +732,23 @@ int process_block(rcf_t *h, size_t n)
                 mj.dims.bank = bc.d;
                 mj.dims.max_n_k = n_common_of_clean;
                 mj.dims.src_len = (int64_t)(h->hist_cap + n);
+                {
+                    const MfmaPlan plan = mfma_plan((int)clean.size(), n_common_of_clean, T, h->mfma_nt, h->mfma_parts);
+                    mj.dims.mfma_nt = plan.nt;
+                    mj.dims.mfma_parts = plan.parts;
+                    mj.dims.partial = nullptr;
+                    if (plan.parts > 1) {
+                        const size_t need = (size_t)plan.parts * clean.size() * (size_t)n_common_of_clean;
+                        if (need > h->partial_cap) {
+                            float2 *np_ = nullptr;
+                            RCF_HIP(hipMalloc(&np_, sizeof(float2) * need));
+                            bury(h, h->d_partial);
+                            h->d_partial = np_;
+                            h->partial_cap = need;
+                        }
+                        mj.dims.partial = h->d_partial;
+                    }
+                }
                 if (!ar.put(clean, &mj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
                 fir_by_depth[depth].push_back(mj);
             }
@@ -1107,6 +1127,8 @@ int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_c
     {
         if (const char *nm = getenv("RCF_FIR_NOMFMA")) h->no_mfma = atoi(nm) != 0;
     if (const char *nm = getenv("RCF_FIR_MFMA_MIN")) h->mfma_min = std::max(1, atoi(nm));
+        if (const char *nm = getenv("RCF_FIR_MFMA_NT")) h->mfma_nt = atoi(nm);
+        if (const char *nm = getenv("RCF_FIR_MFMA_PARTS")) h->mfma_parts = atoi(nm);
         const char *e = getenv("RCF_PFB_PITCH_PAD");
         h->bin_pitch = h->out_cap + (e ? (size_t)atol(e) : 80);
     }
@@ -1155,6 +1177,7 @@ int rcf_close(rcf_t *h)
         if (h->arena_ev[i]) (void)hipEventDestroy(h->arena_ev[i]);
     }
     bury(h, h->d_gather);
+    bury(h, h->d_partial);
     drain_graveyard(h);
     for (auto &kv : h->pools)
         for (void *slab : kv.second.slabs) (void)hipFree(slab);

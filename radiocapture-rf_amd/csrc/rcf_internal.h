@@ -94,6 +94,35 @@ inline bool mfma2_applicable(int D, int T, size_t hist_cap)
     return D >= 1 && T >= 64 && (size_t)(8 * bank2_steps(T) + 8 + D) <= hist_cap;
 }
 
+// Work split of one matrix-core launch.  A workgroup is 4 waves x NT tiles of 16 outputs for one group of 32
+// channels over a RANGE of the taps; 512 workgroups are resident (two per CU) and the dispatcher runs the grid in
+// rounds of 512.  NT = 2 halves the operand traffic per MFMA; tap parts > 1 (split-K: every part writes its partial
+// sums to its own slab, fir_mfma_finish_kernel adds the slabs in order and applies the rotator -- deterministic for
+// any part count) shrink the unit when the whole launch is only a few units per CU: 256 channels x 5243 outputs are
+// 2.56 units per CU, which unsplit run as two full rounds (0.59 of peak), in three parts as four rounds of thirds.
+struct MfmaPlan { int nt, parts; };
+inline MfmaPlan mfma_plan(int n_chans, int n_k, int T, int force_nt = 0, int force_parts = 0)
+{
+    const int groups = (n_chans + kM2Group - 1) / kM2Group;
+    const int n_chunks = bank2_steps(T) / kM2ChunkSteps;
+    MfmaPlan best{1, 1};
+    double best_cost = 1e300;
+    for (int nt = 1; nt <= 2; ++nt) {
+        if (force_nt && nt != force_nt) continue;
+        const int64_t wgs = (int64_t)groups * ((n_k + 64 * nt - 1) / (64 * nt));
+        for (int parts = 1; parts <= 8 && parts <= n_chunks; ++parts) {
+            if (force_parts && parts != force_parts) continue;
+            const int64_t rounds = (wgs * parts + 511) / 512;
+            // time in units of one NT = 1 full-K round; NT = 2 units are twice as long but ~6 % more efficient;
+            // split launches pay the finishing pass (partials written + read) and a little per part
+            double cost = (double)rounds * nt / parts * (nt == 2 ? 0.94 : 1.0);
+            if (parts > 1) cost += 0.06 + 0.01 * parts;
+            if (cost < best_cost - 1e-9) { best_cost = cost; best = MfmaPlan{nt, parts}; }
+        }
+    }
+    return best;
+}
+
 struct FirLaunchDims {
     int D, T, KT;            // decimation, taps, outputs per workgroup tile
     int n_chans;             // entries in the ChanLaunch array
@@ -103,6 +132,8 @@ struct FirLaunchDims {
     int mfma;                // 1: every channel shares source, k_lo and n_k, and no zero-history masking is needed
     const float *bank;       // mfma: the class's tap slabs (bank2 layout above)
     int64_t src_len;         // mfma: samples addressable from the source view's base (buffer descriptor range)
+    int mfma_nt, mfma_parts; // mfma: the launch's MfmaPlan
+    float2 *partial;         // mfma, parts > 1: mfma_parts slabs of n_chans x max_n_k partial sums
     int small;               // 1: one-thread-per-output kernel with the discriminator fused in (no DiscLaunch)
     const float *atan_tab;   // small: gr::fast_atan2f table
 };

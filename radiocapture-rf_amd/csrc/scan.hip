@@ -122,11 +122,15 @@ __global__ __launch_bounds__(scan_threads<N>()) void scan_fft_kernel(ScanLaunch 
 // yet fft-shifted): the running sum does not care about the order of bins, so the un-permute and the
 // fftshift are applied only to the ONE emitted vector.
 constexpr int kMovThreads = 64;
+// U frames per batch: the 2 U loads of a batch are independent, the 2 U adds behind them are the sequential part.
+// A scan of N bins is N independent chains and nothing else: at N = 16384 (the reference's size) that is one
+// wavefront per CU, so the only latency hiding there is per thread -- U = 32 (208 -> ~60 us per 512-frame launch);
+// at N = 2^20 there are 16 K wavefronts and U = 8 keeps the registers down.
+template <int U>
 __global__ __launch_bounds__(kMovThreads) void movsum_kernel(const float *__restrict__ vring, int N, int R, int L, int f0,
                                                             int n_frames, int emit_frame, float *__restrict__ sum,
                                                             float *__restrict__ out_base, int n1, int n2)
 {
-    constexpr int U = 8;
     const int k = blockIdx.x * kMovThreads + threadIdx.x;
     if (k >= N) return;
     float *out = out_base;
@@ -253,8 +257,12 @@ void launch_scan_movsum(float *vring, int N, int R, int L, int f0, int n_frames,
     if (n_frames <= 0) return;
     int n1 = 0, n2 = 0;
     if (N > 16384 && !scan4_split(N, &n1, &n2)) return;
-    hipLaunchKernelGGL(movsum_kernel, dim3((N + kMovThreads - 1) / kMovThreads), dim3(kMovThreads), 0, s, vring, N, R, L, f0, n_frames,
-                       emit_frame, sum, out, n1, n2);
+    if (N <= (1 << 17))
+        hipLaunchKernelGGL(movsum_kernel<32>, dim3((N + kMovThreads - 1) / kMovThreads), dim3(kMovThreads), 0, s, vring, N, R, L,
+                           f0, n_frames, emit_frame, sum, out, n1, n2);
+    else
+        hipLaunchKernelGGL(movsum_kernel<8>, dim3((N + kMovThreads - 1) / kMovThreads), dim3(kMovThreads), 0, s, vring, N, R, L,
+                           f0, n_frames, emit_frame, sum, out, n1, n2);
 }
 
 // rows of the four-step transform (called from scan4.hip after the column kernel)

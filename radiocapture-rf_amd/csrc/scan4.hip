@@ -22,7 +22,6 @@ void launch_scan4_rows(const ScanLaunch &p, const cf *tw2, int N1, int N2, hipSt
 
 namespace {
 
-constexpr int CW = 16;   // columns per workgroup
 
 template <int N> struct P4;
 template <> struct P4<128> { static constexpr int r[2] = {16, 8}; };
@@ -31,7 +30,7 @@ template <> struct P4<256> { static constexpr int r[2] = {16, 16}; };
 template <int N> constexpr int rs4() { return lds_padded_len(N) + 1; }   // odd: transposed accesses spread
 
 // one radix-R pass over CW length-N transforms in LDS, N threads, forward sign, twiddles e^{-2 pi i n/N}
-template <int N, int R, int NS>
+template <int N, int R, int NS, int CW>
 __device__ __forceinline__ void pass4(cf *buf, const cf *tw_lds, int tid)
 {
     constexpr int BPF = N / R;
@@ -74,7 +73,7 @@ struct Scan4Args {
 };
 
 // grid: (N2 / CW, frames)
-template <int N1>
+template <int N1, int CW>
 __global__ __launch_bounds__(N1) void scan4_cols(Scan4Args a)
 {
     constexpr int RS = rs4<N1>();
@@ -98,24 +97,40 @@ __global__ __launch_bounds__(N1) void scan4_cols(Scan4Args a)
         buf[c * RS + lds_pad(n1)] = make_float2(__fmul_rn(x.x, w), __fmul_rn(x.y, w));
     }
     __syncthreads();
-    pass4<N1, P4<N1>::r[0], 1>(buf, tw_lds, tid);
-    pass4<N1, P4<N1>::r[1], P4<N1>::r[0]>(buf, tw_lds, tid);
+    pass4<N1, P4<N1>::r[0], 1, CW>(buf, tw_lds, tid);
+    pass4<N1, P4<N1>::r[1], P4<N1>::r[0], CW>(buf, tw_lds, tid);
     cf *scr = a.p.scratch + (size_t)fl * N;
+    // W_N^{n2 k1}: this thread's column n2 is fixed and its k1 advances by N1 / CW per element, so after the first
+    // element (two table entries: W_N^{1024 j} W_N^{i}) the factor advances by one constant, W_N^{n2 N1 / CW}
+    // (again two table entries).  Sixteen steps of a float32 recurrence: a few 1e-7 of error, against 32 dependent
+    // table loads per thread before.
+    {
+        const int c = tid % CW, k10 = tid / CW;
+        const unsigned n2c = (unsigned)(c0 + c);
+        const unsigned m0 = n2c * (unsigned)k10;                              // < N
+        const unsigned ms = n2c * (unsigned)(N1 / CW);                        // < N
+        cf w = cmul(a.thi[m0 >> 10], a.tlo[m0 & 1023]);
+        const cf step = cmul(a.thi[ms >> 10], a.tlo[ms & 1023]);
 #pragma unroll
-    for (int i = 0; i < CW; ++i) {
-        const int e = tid + i * N1;
-        const int c = e % CW, k1 = e / CW;
-        const unsigned m = (unsigned)(c0 + c) * (unsigned)k1;          // < N
-        const cf w = cmul(a.thi[m >> 10], a.tlo[m & 1023]);
-        scr[(size_t)k1 * N2 + c0 + c] = cmul(buf[c * RS + lds_pad(k1)], w);
+        for (int i = 0; i < CW; ++i) {
+            const int k1 = k10 + i * (N1 / CW);
+            scr[(size_t)k1 * N2 + c0 + c] = cmul(buf[c * RS + lds_pad(k1)], w);
+            w = cmul(w, step);
+        }
     }
 }
 
-template <int N1>
+template <int N1, int CW>
 void launch_cols(const Scan4Args &a, hipStream_t s)
 {
     const size_t lds = ((size_t)CW * rs4<N1>() + N1) * sizeof(cf);
-    hipLaunchKernelGGL((scan4_cols<N1>), dim3(a.N2 / CW, a.p.n_frames), dim3(N1), lds, s, a);
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(scan4_cols<N1, CW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((scan4_cols<N1, CW>), dim3(a.N2 / CW, a.p.n_frames), dim3(N1), lds, s, a);
 }
 
 }  // namespace
@@ -144,8 +159,10 @@ void launch_scan4_fft(const ScanLaunch &p, hipStream_t s)
     const cf *tw2 = p.tw + a.N1;
     a.tlo = tw2 + a.N2;
     a.thi = a.tlo + 1024;
-    if (a.N1 == 128) launch_cols<128>(a, s);
-    else             launch_cols<256>(a, s);
+    // 16 columns per workgroup = one 128-byte line per row, 35 KB of LDS, four workgroups per CU (32 columns:
+    // 256-byte runs but two workgroups per CU -- measured 4 % faster, not worth the second instantiation)
+    if (a.N1 == 128) launch_cols<128, 16>(a, s);
+    else             launch_cols<256, 16>(a, s);
     launch_scan4_rows(p, tw2, a.N1, a.N2, s);
 }
 
