@@ -17,7 +17,6 @@
 // increment GNU Radio would iterate (angle and the |incr|^n drift between its every-512 renormal-
 // isations), so outputs do not depend on how the stream is cut into blocks.
 #include <cstdlib>
-#include <mutex>
 
 #include "rcf_internal.h"
 
@@ -622,20 +621,9 @@ void launch_fir_pack(const ChanLaunch *d_chans, int n_chans, int T, float *bank,
 template <int NT, int PD>
 static void launch_mfma_t(const ChanLaunch *d_chans, MfmaArgs a, int max_n_k, hipStream_t s)
 {
-    // 64 KB of dynamic LDS needs the attribute on every device the process uses (it is per function per device)
-    static std::mutex mu;
-    static bool attr_set[64] = {false};
-    const size_t lds = 2 * kM2ChunkSteps * 4096;
-    {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> g(mu);
-        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fir_mfma_kernel<NT, PD>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set[dev] = true;
-        }
-    }
+    const size_t lds = 2 * kM2ChunkSteps * 4096;             // 64 KB: two workgroups per CU
+    static DynLdsAttr attr;
+    attr.ensure(reinterpret_cast<const void *>(fir_mfma_kernel<NT, PD>), lds);
     a.n_wt = (max_n_k + 64 * NT - 1) / (64 * NT);
     hipLaunchKernelGGL((fir_mfma_kernel<NT, PD>), dim3((unsigned)(a.n_wt * a.n_groups * a.n_parts)), dim3(kM2Threads), lds,
                        s, d_chans, a);

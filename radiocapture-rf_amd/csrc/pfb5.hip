@@ -36,7 +36,6 @@
 //     rest of the kernel, nt or not.)  Consumers read one bin with stride NB (StreamView.stride).
 // Bound: HBM.  Algorithmic bytes per input sample = 8 (read) + 8 NB / D (written) = 24 at OS = 2, 40 at OS = 4.
 #include <cstdlib>
-#include <mutex>
 
 #include "fft_core.hpp"
 #include "rcf_internal.h"
@@ -226,20 +225,9 @@ void launch5(const PfbLaunch &p, hipStream_t s)
     constexpr int NB = R * R * R3, F = 16 / R3;
     const int n_wg = (p.n_frames + F - 1) / F;
     const size_t lds = (size_t)F * (NB + NB / R + 1) * sizeof(cf);
-    static std::mutex mu;
-    static bool attr_set[64] = {false};
-    {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> g(mu);
-        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pfb5_kernel<R, R3, OS, P, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pfb5_kernel<R, R3, OS, P, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set[dev] = true;
-        }
-    }
+    static DynLdsAttr attr_f, attr_t;
+    attr_f.ensure(reinterpret_cast<const void *>(pfb5_kernel<R, R3, OS, P, false>), lds);
+    attr_t.ensure(reinterpret_cast<const void *>(pfb5_kernel<R, R3, OS, P, true>), lds);
     const bool zh = (p.n_lo - (int64_t)OS * (P - 1)) * (NB / OS) - (NB - 1) < p.start_sample;
     if (zh) hipLaunchKernelGGL((pfb5_kernel<R, R3, OS, P, true>), dim3(n_wg), dim3(kThreads5), lds, s, p, n_wg);
     else    hipLaunchKernelGGL((pfb5_kernel<R, R3, OS, P, false>), dim3(n_wg), dim3(kThreads5), lds, s, p, n_wg);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -36,6 +37,25 @@ bool hip_ok(hipError_t e, const char *what);
     do {                                              \
         if (!::rcfx::hip_ok((call), #call)) return RCF_EHIP; \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, device): every launcher that needs more
+// than 64 KB of dynamic LDS calls this with its own static DynLdsAttr (one per kernel instantiation), so that a
+// second rcf_t on another GPU of the same process gets the attribute too and two handles' threads do not race
+struct DynLdsAttr {
+    std::mutex mu;
+    size_t set[64] = {0};
+    void ensure(const void *func, size_t lds)
+    {
+        if (lds <= 64 * 1024) return;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64) dev = 0;
+        std::lock_guard<std::mutex> g(mu);
+        if (set[dev] >= lds) return;
+        (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set[dev] = lds;
+    }
+};
 
 // ---------------------------------------------------------------- stream views
 // sample s of a stream lives at base[((s - origin) & mask) * stride]   (linear buffer: mask = ~0; stride = 1

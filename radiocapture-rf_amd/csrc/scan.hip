@@ -210,6 +210,8 @@ void launch_rows(const ScanLaunch &p, const cf *tw2, int N1, hipStream_t s)
 {
     constexpr int FPW = scan_fpw<N2>();
     const size_t lds = (size_t)FPW * scan_rs<N2>() * sizeof(cf);
+    static DynLdsAttr attr;
+    attr.ensure(reinterpret_cast<const void *>(&scan4_rows_kernel<N2>), lds);
     hipLaunchKernelGGL((scan4_rows_kernel<N2>), dim3(N1 / FPW, p.n_frames), dim3(scan_threads<N2>()), lds, s, p, tw2, N1);
 }
 
@@ -219,12 +221,8 @@ void launch_n(const ScanLaunch &p, hipStream_t s)
     constexpr int FPW = scan_fpw<N>();
     const int n_wg = (p.n_frames + FPW - 1) / FPW;
     const size_t lds = (size_t)FPW * scan_rs<N>() * sizeof(cf);
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_fft_kernel<N>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static DynLdsAttr attr;
+    attr.ensure(reinterpret_cast<const void *>(&scan_fft_kernel<N>), lds);
     hipLaunchKernelGGL((scan_fft_kernel<N>), dim3(n_wg), dim3(scan_threads<N>()), lds, s, p);
 }
 

@@ -124,12 +124,8 @@ template <int N1, int CW>
 void launch_cols(const Scan4Args &a, hipStream_t s)
 {
     const size_t lds = ((size_t)CW * rs4<N1>() + N1) * sizeof(cf);
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(scan4_cols<N1, CW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    static DynLdsAttr attr;
+    attr.ensure(reinterpret_cast<const void *>(scan4_cols<N1, CW>), lds);
     hipLaunchKernelGGL((scan4_cols<N1, CW>), dim3(a.N2 / CW, a.p.n_frames), dim3(N1), lds, s, a);
 }
 
