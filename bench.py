@@ -406,7 +406,26 @@ def main():
         group = multigpu.HostGroup(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
                                    int(os.environ.get("MASTER_PORT", "29500")) + 101)
         if use_rccl:
-            multigpu.init_comm(fe, group)            # ncclCommInitRank on this rank's GPU
+            # ncclCommInitRank on this rank's GPU.  If any rank cannot (no librccl, two ranks told to share one
+            # GPU, ...) every rank falls back to the host rendezvous for the barrier and the gather -- the data
+            # path has no collective, so the measurement itself does not depend on it.
+            uid = None
+            if group.rank == 0 and "RCF_BENCH_DEVICE" not in os.environ:
+                try:
+                    uid = native.comm_unique_id()
+                except Exception as e:
+                    print("note: RCCL unavailable on rank 0 (%s): host transport" % e, file=sys.stderr)
+            uid = group.broadcast(uid if uid is not None else b"")
+            ok = len(uid) == 128
+            if ok:
+                try:
+                    fe.comm_init(group.rank, group.world, uid)
+                except Exception as e:
+                    print("note: rank %d could not join the RCCL communicator (%s)" % (rank, e), file=sys.stderr)
+                    ok = False
+            use_rccl = all(p == b"1" for p in group.all_gather(b"1" if ok else b"0"))
+            if not use_rccl:
+                fe.comm_destroy()
     taps = proto_taps(native)
     fe.pfb_open(NB, NB, taps)
     tile, meta = synth.cfg2(n=1 << 20, seed=2002 if n_gpus == 1 else 4000 + rank, n_bins=NB,
@@ -468,6 +487,8 @@ def main():
         fe.commit(B)
         idx, _, _ = fe.scan_find_peaks(cap=1024)
         freqs = [native.peak_frequency(int(i), FS, 16384, 851e6 + 25e6 * rank) for i in idx]
+        if not freqs:                                # the filterbank tile has no scan-shaped carriers: exchange its
+            freqs = [int(851e6 + 25e6 * rank + c["f_off"]) for c in meta["carriers"]]   # 32 known ones instead
         gather = (lambda: multigpu.allgather_peaks(fe, freqs)) if use_rccl else \
                  (lambda: multigpu.allgather_peaks_host(group, freqs))
         gather()                                     # warm-up (RCCL ring setup)
