@@ -514,3 +514,115 @@ def test_threads_feed_control_read_concurrently(gpu_required):
     yo, _ = OC.channel_bank(x, D, ct[None, :], np.array([incr]), gains=[1.0])
     assert len(y) == yo.shape[1]
     assert rel_rms(y, yo[0]) < 1e-5
+
+
+def test_pfb1600_midstream_open_ring_wrap_and_ragged_pushes(gpu_required):
+    """Edge cases of the frame-major bank: opened after the stream has started (zero history from its start),
+    fed in ragged pushes (1 sample, an empty push, odd sizes), with an output ring shorter than the stream (wraps
+    several times, reader keeps up), and a reader that lags (oldest frames lost, as a PUB socket at its HWM)."""
+    nat = gpu_required
+    fs, nb = 20e6, 1600
+    D, taps = _ref_channel_taps(fs)
+    rng = np.random.default_rng(31)
+    pre = 12345                                         # samples before the bank exists
+    n_frames = 300
+    x = synth.awgn(rng, pre + D * n_frames + 77)
+    bins = [3, 801, 1599]
+    got = {k: [] for k in bins}
+    with nat.Frontend(fs, out_capacity=64) as fe:       # 64-frame ring: > 4 wraps
+        fe.push(x[:pre])
+        fe.pfb_open(nb, D, taps)
+        at = pre
+        sizes = [1, 0, 799, 1, 801, 4000, 13, 25000]
+        i = 0
+        while at < len(x):
+            n = min(sizes[i % len(sizes)], len(x) - at)
+            fe.push(x[at:at + n])
+            at += n
+            i += 1
+            for k in bins:
+                got[k].append(fe.pfb_read_bin(k))
+        total = fe.pfb_produced()
+        # a lagging reader: only the newest 64 frames of a bin nobody read are still there
+        lag = fe.pfb_read_bin(7)
+    assert len(lag) == 64
+    # frames on the absolute decimation grid from the first multiple of D at or after the bank's start
+    n0 = -(-pre // D)
+    n_last = (len(x) - 1) // D
+    assert total == n_last - n0 + 1
+    xz = x.copy()
+    xz[:pre] = 0                                        # GR zero history before the block's start
+    for k in bins:
+        y = np.concatenate(got[k])
+        f0 = k * fs / nb if k < nb // 2 else (k - nb) * fs / nb
+        want = G.xlating_fir_exact(xz, D, taps, f0, fs)[n0:n_last + 1]
+        assert len(y) == len(want) == total
+        assert rel_rms(y, want) < 2e-5, k
+    want7 = G.xlating_fir_exact(xz, D, taps, 7 * fs / nb, fs)[n0:n_last + 1][-64:]
+    assert rel_rms(lag, want7) < 2e-5
+
+
+def test_stage2_channel_and_voice_chain_on_a_frame_major_bin(gpu_required):
+    """A stage-2 xlating FIR reads one bin of the frame-major bank with stride n_bins (StreamView.stride): channel.py's
+    rule at the bin rate (25 kS/s -> D = 1, 3 taps) with a +2 kHz residual offset -- the other half of the reference's
+    connect_channel_pfb (bin + residual `pfb_offset`, rc_frontend/receiver.py:377) -- and a symbol filter behind a
+    plain bin tap."""
+    nat = gpu_required
+    fs, nb = 20e6, 1600
+    D, taps = _ref_channel_taps(fs)
+    rng = np.random.default_rng(41)
+    n_frames = 400
+    k, delta = 412, 2000.0
+    x = synth.awgn(rng, D * n_frames).astype(np.complex128)
+    x += synth.nbfm_carrier(len(x), fs, k * fs / nb + delta, 800.0, 2500.0, synth.snr_amp(30.0, 12500.0, fs))
+    x = x.astype(np.complex64)
+    bin_rate = fs / D
+    with nat.Frontend(fs, block_capacity=len(x)) as fe:
+        fe.pfb_open(nb, D, taps)
+        c2 = fe.pfb_chan_open(k, 12500, delta)
+        tap = fe.pfb_tap_open(k, gr_phase=False)
+        fe.chan_fm_filter(tap, 5.0, np.full(5, 0.2, dtype=np.float32))
+        half = D * 173 + 5
+        fe.push(x[:half])
+        fe.push(x[half:])
+        info = fe.chan_info(c2)
+        y2, fm2 = fe.chan_read_iq(c2), fe.chan_read_fm(c2, 5.0)
+        yt, sym = fe.chan_read_iq(tap), fe.chan_read_sym(tap)
+    stage1 = G.xlating_fir_exact(x, D, taps, k * fs / nb, fs).astype(np.complex64)
+    D2, taps2 = G.channel_params(bin_rate, 12500)
+    assert (info["decim"], info["ntaps"]) == (D2, len(taps2)) and D2 == 1
+    yo = G.xlating_fir_ccc(stage1, D2, taps2, delta, bin_rate)
+    fo = G.quadrature_demod_cf(yo, 5.0)
+    assert len(y2) == len(yo) == n_frames
+    assert rel_rms(y2, yo) < 2e-5 and rms(fm2[4:], fo[4:]) < 1e-4
+    # the plain tap is the bin itself; its symbol filter is fir_filter_fff over gain * discriminator
+    assert rel_rms(yt, stage1) < 2e-5
+    ft = G.quadrature_demod_cf(stage1, 5.0)
+    so = np.convolve(ft.astype(np.float64), np.full(5, 0.2))[:len(ft)]
+    assert len(sym) == n_frames and rms(sym[8:], so[8:]) < 1e-4
+
+
+def test_source_shift_reaches_filterbank_taps(gpu_required):
+    """receiver.source_offset in 'pfb' mode: the Hz correction is applied by the taps' rotators (the bins stay on the
+    raster): the discriminator DC of a tapped bin moves by 2 pi shift / rate, like a direct channel's."""
+    nat = gpu_required
+    fs, nb = 20e6, 1600
+    D, taps = _ref_channel_taps(fs)
+    rng = np.random.default_rng(43)
+    n_frames = 600
+    k = 88
+    x = synth.awgn(rng, D * n_frames).astype(np.complex128) * 0.05
+    x += synth.nbfm_carrier(len(x), fs, k * fs / nb, 1000.0, 1500.0, 1.0)
+    x = x.astype(np.complex64)
+    with nat.Frontend(fs, block_capacity=len(x)) as fe:
+        fe.pfb_open(nb, D, taps)
+        tap = fe.pfb_tap_open(k, gr_phase=False)
+        direct = fe.chan_open(12500, k * fs / nb)
+        fe.push(x[: D * 300])
+        fm_a, fd_a = fe.chan_read_fm(tap, 1.0), fe.chan_read_fm(direct, 1.0)
+        fe.source_shift(150.0)
+        fe.push(x[D * 300:])
+        fm_b, fd_b = fe.chan_read_fm(tap, 1.0), fe.chan_read_fm(direct, 1.0)
+    want = -2 * math.pi * 150.0 / 25000.0               # NCO moved up by 150 Hz: the carrier sits 150 Hz lower
+    assert abs((np.mean(fm_b[50:]) - np.mean(fm_a[50:])) - want) < 2e-3
+    assert abs((np.mean(fd_b[50:]) - np.mean(fd_a[50:])) - want) < 2e-3
