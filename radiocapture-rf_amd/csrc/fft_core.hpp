@@ -14,6 +14,20 @@ typedef float2 cf;
 
 __device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+// RCF_EXPLICIT_FMA (pfb5.hip): that file is compiled without implicit contraction -- its template instantiations
+// must round alike -- so the fused multiply-adds are spelled out there: four instructions per complex product
+// instead of six.  Elsewhere the plain form stays: the compiler contracts it, and the scan kernels' SLP-packed
+// (v_pk_*) version of it measures faster than the explicit-fma one.
+#ifdef RCF_EXPLICIT_FMA
+__device__ __forceinline__ cf cmul(cf a, cf b)
+{
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ cf cmulconj(cf a, cf b)   // a * conj(b)
+{
+    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -(a.x * b.y)));
+}
+#else
 __device__ __forceinline__ cf cmul(cf a, cf b)
 {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -22,6 +36,7 @@ __device__ __forceinline__ cf cmulconj(cf a, cf b)   // a * conj(b)
 {
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
+#endif
 __device__ __forceinline__ cf cscale(cf a, float s) { return make_float2(a.x * s, a.y * s); }
 
 // multiply by SIGN * i   (SIGN = -1: forward e^{-j..}, +1: inverse)
@@ -128,10 +143,10 @@ __device__ __forceinline__ void dft5(cf &x0, cf &x1, cf &x2, cf &x3, cf &x4)
     const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;     // cos(2 pi/5), cos(4 pi/5)
     const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;      // sin(2 pi/5), sin(4 pi/5)
     const cf t1 = cadd(x1, x4), t2 = cadd(x2, x3), t3 = csub(x1, x4), t4 = csub(x2, x3);
-    const cf m1 = make_float2(x0.x + c1 * t1.x + c2 * t2.x, x0.y + c1 * t1.y + c2 * t2.y);
-    const cf m2 = make_float2(x0.x + c2 * t1.x + c1 * t2.x, x0.y + c2 * t1.y + c1 * t2.y);
-    const cf r1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
-    const cf r2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    const cf m1 = make_float2(fmaf(c2, t2.x, fmaf(c1, t1.x, x0.x)), fmaf(c2, t2.y, fmaf(c1, t1.y, x0.y)));
+    const cf m2 = make_float2(fmaf(c1, t2.x, fmaf(c2, t1.x, x0.x)), fmaf(c1, t2.y, fmaf(c2, t1.y, x0.y)));
+    const cf r1 = make_float2(fmaf(s2, t4.x, s1 * t3.x), fmaf(s2, t4.y, s1 * t3.y));
+    const cf r2 = make_float2(fmaf(-s1, t4.x, s2 * t3.x), fmaf(-s1, t4.y, s2 * t3.y));
     const cf i1 = mul_si<SIGN>(r1), i2 = mul_si<SIGN>(r2);                 // SIGN i (..)
     x0 = make_float2(x0.x + t1.x + t2.x, x0.y + t1.y + t2.y);
     x1 = cadd(m1, i1);

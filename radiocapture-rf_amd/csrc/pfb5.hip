@@ -35,8 +35,13 @@
 //     writes them, would get 32- or 16-byte pieces from a 4- or 2-frame chunk: measured 2x slower than the whole
 //     rest of the kernel, nt or not.)  Consumers read one bin with stride NB (StreamView.stride).
 // Bound: HBM.  Algorithmic bytes per input sample = 8 (read) + 8 NB / D (written) = 24 at OS = 2, 40 at OS = 4.
+// Build notes: no SLP vectoriser (packed v_pk_*_f32 arithmetic issues slower than the scalar pair on gfx950: 0.137 ->
+// 0.111 ms), no implicit contraction (instantiations must round alike) with the FMAs of the complex products spelled
+// out (RCF_EXPLICIT_FMA).  Tried and dropped (git history): one frame per wavefront, 1600 = 25 x 64 with the 64-point
+// part done across the lanes by shuffles -- no barriers at all, but 1.7x the arithmetic: 0.118 ms against 0.111.
 #include <cstdlib>
 
+#define RCF_EXPLICIT_FMA 1
 #include "fft_core.hpp"
 #include "rcf_internal.h"
 
