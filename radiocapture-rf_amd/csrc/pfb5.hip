@@ -44,6 +44,7 @@
 #define RCF_EXPLICIT_FMA 1
 #include "fft_core.hpp"
 #include "rcf_internal.h"
+#include "rotator.hpp"
 
 namespace rcfx {
 
@@ -220,6 +221,57 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
                 o.y = __float_as_uint(z.y);
                 __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, bin * (int)sizeof(cf), so, 2);
             }
+        }
+    }
+
+    // ---- taps: bins that are open as channels go straight into those channels' rings, through their rotators
+    // (GNU Radio's per-output increment and / or the source shift; an idle rotator is skipped).  One lane per tap: the
+    // rotator is evaluated once in closed form (float64) for the chunk's first frame and advanced by the tap's
+    // increment for the others -- except across one of GNU Radio's every-512 renormalisations, where each frame is
+    // evaluated on its own -- and the lane's F outputs are F x 8 contiguous bytes of the ring.
+    for (int i = tid; i < p.n_taps; i += kThreads5) {
+        TapLaunch L;
+        {
+            int64_t w[kTapFields];
+#pragma unroll
+            for (int f = 0; f < kTapFields; ++f) w[f] = p.taps[(size_t)f * p.taps_pitch + i];
+            __builtin_memcpy(&L, w, sizeof(L));
+        }
+        const int64_t k0 = n0 - p.n_abs0;                    // the tap's output index = the bank's frame count
+        const bool idle = L.dangle == 0.0 && L.dlogmag == 0.0 && L.angle0 == 0.0 && L.logmag0 == 0.0;
+        const int64_t rel0 = k0 - L.k_abs0;
+        const bool crosses = (rel0 >> 9) != ((rel0 + nf - 1) >> 9) || rel0 < 0;
+        double pr = 1.0, pi = 0.0;
+        if (!idle && !crosses) {
+            // the closed form of rotate_value (rotator.hpp), kept in float64 for the increments below
+            const int64_t dk = rel0 - L.n_seg0;
+            const int64_t r512 = rel0 & ~(int64_t)511;
+            const double ang = L.angle0 + (double)dk * L.dangle;
+            const double lm = (r512 > L.n_seg0) ? (double)(rel0 - r512) * L.dlogmag : L.logmag0 + (double)dk * L.dlogmag;
+            double sn, cs;
+            sincos_fast(ang, sn, cs);
+            const double mag = fabs(lm) < 1e-3 ? 1.0 + lm * (1.0 + lm * (0.5 + lm * (1.0 / 6.0))) : exp(lm);
+            pr = mag * cs;
+            pi = mag * sn;
+        }
+        for (int f = 0; f < nf; ++f) {
+            const int64_t k = k0 + f;
+            const cf z = buf[f * RS + pad5<R>(L.bin)];
+            cf y = z;
+            if (!idle) {
+                if (crosses) {
+                    y = rotate_value(L, k - L.k_abs0, z.x, z.y);
+                } else {
+                    const float fr = (float)pr, fi = (float)pi;      // rotator::rotate(): unfused float32 complex multiply
+                    y.x = __fsub_rn(__fmul_rn(z.x, fr), __fmul_rn(z.y, fi));
+                    y.y = __fadd_rn(__fmul_rn(z.x, fi), __fmul_rn(z.y, fr));
+                    const double nr = pr * L.inc_re - pi * L.inc_im;
+                    pi = pr * L.inc_im + pi * L.inc_re;
+                    pr = nr;
+                }
+            }
+            if (k >= L.k_lo && k < L.k_lo + L.n_k && k >= L.k_abs0)
+                L.iq_ring[(uint64_t)(k - L.k_abs0) & p.ring_mask] = y;
         }
     }
 }

@@ -59,6 +59,7 @@ struct Chan {
     int src = -1;                 // -1 wideband; RCF_SRC_PFB_BIN0 + bin; else source channel id
     int D = 0, T = 0;
     double src_rate = 0, offset_hz = 0;
+    bool is_tap = false;          // a bin of a frame-major filterbank open as a channel: filled by the bank's kernel
     std::vector<float> proto;     // prototype taps (host)
     float2 *d_ctaps = nullptr;
     uint64_t taps_version = 0;    // bumped whenever d_ctaps changes (bank-matrix cache key)
@@ -429,7 +430,7 @@ int process_block(rcf_t *h, size_t n)
     {
         size_t need = 4096;
         for (auto &kv : h->chans) {
-            need += 2 * sizeof(ChanLaunch) + sizeof(DiscLaunch) + 2 + 128;
+            need += 2 * sizeof(ChanLaunch) + sizeof(TapLaunch) + sizeof(DiscLaunch) + 2 + 128;
             if (kv.second->d_sym) need += sizeof(FmFirLaunch);
             if (kv.second->audio) need += sizeof(AudioLaunch);
         }
@@ -466,6 +467,9 @@ int process_block(rcf_t *h, size_t n)
     std::vector<DiscJob> disc_jobs;
     std::vector<FmFirLaunch> symf;     // symbol filters, all channels in one launch
     int symf_max_n = 0;
+    std::vector<TapLaunch> tap_list;   // filterbank taps: stored by the bank's own kernel
+    std::vector<DiscLaunch> tap_discs;
+    int tap_max_n = 0;
     std::vector<AudioLaunch> audf;     // analog voice chains, all channels in one set of launches
     int audf_max_n = 0;
     double audf_ratio = 0;
@@ -577,15 +581,29 @@ int process_block(rcf_t *h, size_t n)
                 L.logmag0 = c->logmag0;
                 L.dlogmag = c->dlogmag;
                 L.n_k = (int32_t)cnt;
-                launches.push_back(L);
-                launched.push_back(c);
                 DiscLaunch dl{};
                 dl.iq_ring = c->d_iq;
                 dl.fm_ring = c->d_fm;
                 dl.n_lo = k_lo - c->k_abs0;
                 dl.n_k = (int32_t)cnt;
-                discs.push_back(dl);
-                max_n = std::max(max_n, (int)cnt);
+                if (c->is_tap) {                            // written by the filterbank kernel, not by a FIR launch
+                    TapLaunch tl{};
+                    tl.iq_ring = c->d_iq;
+                    tl.k_lo = L.k_lo; tl.k_abs0 = L.k_abs0; tl.n_seg0 = L.n_seg0;
+                    tl.angle0 = L.angle0; tl.dangle = L.dangle; tl.logmag0 = L.logmag0; tl.dlogmag = L.dlogmag;
+                    tl.inc_re = std::exp(c->dlogmag) * std::cos(c->dangle);
+                    tl.inc_im = std::exp(c->dlogmag) * std::sin(c->dangle);
+                    tl.n_k = L.n_k;
+                    tl.bin = c->src - RCF_SRC_PFB_BIN0;
+                    tap_list.push_back(tl);
+                    tap_discs.push_back(dl);
+                    tap_max_n = std::max(tap_max_n, (int)cnt);
+                } else {
+                    launches.push_back(L);
+                    launched.push_back(c);
+                    discs.push_back(dl);
+                    max_n = std::max(max_n, (int)cnt);
+                }
                 if (c->d_sym) {
                     FmFirLaunch fl{};
                     fl.fm_ring = c->d_fm;
@@ -781,6 +799,23 @@ int process_block(rcf_t *h, size_t n)
         }
     }
 
+    if (!tap_list.empty()) {
+        // field-major: row f holds field f of every tap
+        const size_t pitch = (tap_list.size() + 7) & ~size_t(7);
+        std::vector<int64_t> soa((size_t)kTapFields * pitch, 0);
+        for (size_t i = 0; i < tap_list.size(); ++i) {
+            int64_t w[kTapFields];
+            std::memcpy(w, &tap_list[i], sizeof(TapLaunch));
+            for (int f = 0; f < kTapFields; ++f) soa[(size_t)f * pitch + i] = w[f];
+        }
+        if (!ar.put(soa, &pl.taps)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+        pl.taps_pitch = (int64_t)pitch;
+        pl.n_taps = (int32_t)tap_list.size();
+        DiscJob dj{};
+        dj.n = (int)tap_discs.size(); dj.max_n = tap_max_n;
+        if (!ar.put(tap_discs, &dj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+        disc_jobs.push_back(dj);
+    }
     const FmFirLaunch *d_symf = nullptr;
     if (!symf.empty() && !ar.put(symf, &d_symf)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
     const AudioLaunch *d_audf = nullptr;
@@ -1371,6 +1406,7 @@ int rcf_pfb_tap_open(rcf_t *h, int bin, int gr_phase, int *chan_id)
     const float one = 1.0f;
     int rc = new_channel(h, RCF_SRC_PFB_BIN0 + bin, 1, &one, 1, 0.0, chan_id);
     if (rc != RCF_OK) return rc;
+    h->chans[*chan_id]->is_tap = p.frame_major;     // power-of-two banks: an ordinary D = 1, T = 1 channel on the bin's ring
     if (gr_phase) {
         // What GNU Radio's freq_xlating_fir_filter_ccc(D, h, f_k, fs) would have done differently from the bank's
         // exact phases: its rotator advances by a = float32(-float32(2 pi f_k / fs) * D) per output instead of

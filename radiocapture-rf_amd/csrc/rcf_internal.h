@@ -238,8 +238,29 @@ struct PfbLaunch {
     // one ring of whole frames bins_ring[(n & ring_mask) * NB + k] (pfb5.hip: a chunk of 2-4 frames cannot fill
     // 128-byte lines of per-bin rings, whole frames leave as contiguous rows)
     int32_t frame_major;
-    int32_t pad_;
+    int32_t n_taps;
+    // frame-major banks: bins that are open as channels (rcf_pfb_tap_open).  The kernel has every bin of the chunk in
+    // LDS when it writes the frames out, so it also puts each tapped bin's new outputs -- through the tap's rotator --
+    // straight into that channel's ring: a tap costs 8 bytes per frame instead of a strided 128-byte line read
+    // per frame in a kernel of its own.  Output index of a tap = frame - n_abs0.
+    // The records are stored FIELD-MAJOR (taps[field * taps_pitch + tap], kTapFields 8-byte fields): one lane
+    // handles one tap, so every field load of a wavefront is one contiguous run (as an array of structs the same
+    // loads touched 64 lines each and cost more than the whole filterbank).
+    const int64_t *taps;
+    int64_t taps_pitch;
 };
+struct TapLaunch {           // host-side record; on the device its fields are rows of PfbLaunch::taps
+    float2 *iq_ring;
+    int64_t k_lo, k_abs0;    // as in ChanLaunch
+    int64_t n_seg0;          // rotator model, as in ChanLaunch (rotate_value reads these five)
+    double angle0, dangle;
+    double logmag0, dlogmag;
+    double inc_re, inc_im;   // e^{dlogmag + j dangle}: one lane walks a chunk's frames by this increment
+    int32_t n_k;
+    int32_t bin;
+};
+constexpr int kTapFields = sizeof(TapLaunch) / 8;
+static_assert(sizeof(TapLaunch) % 8 == 0, "TapLaunch is a row of 8-byte fields");
 bool pfb_supported(int NB, int D, int P);
 int pfb_padded_p(int NB, int D, int P);   // rows the kernel instantiation reads from ptaps (zero padded)
 void launch_pfb(const PfbLaunch &p, hipStream_t s);

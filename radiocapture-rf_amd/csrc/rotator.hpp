@@ -1,0 +1,74 @@
+// rotator.hpp -- GNU Radio's rotator (phase *= incr in float32, renormalised every 512 calls) in closed form, shared
+// by the FIR bank kernels (fir.hip) and the filterbank taps (pfb5.hip).  Both files are compiled without implicit
+// FMA contraction: rotate() is an unfused float32 complex multiply in GNU Radio.
+#pragma once
+#include "rcf_internal.h"
+
+namespace rcfx {
+
+namespace {
+
+// sin / cos of a float64 angle of moderate size (|a| < 1e6 rad) to ~1e-16: Cody-Waite reduction by pi/2 and the
+// Taylor polynomials on |x| <= pi/4.  The library sincos() carries a Payne-Hanek path and costs ~10x as much;
+// with eight of them per lane it was a tenth of the matrix-core bank's time.
+__device__ __forceinline__ void sincos_fast(double a, double &sn, double &cs)
+{
+    const double k = rint(a * 0.63661977236758134308);
+    double x = fma(-k, 1.57079632679489655800e+00, a);
+    x = fma(-k, 6.12323399573676603587e-17, x);
+    const double x2 = x * x;
+    double ps = -1.0 / 1307674368000.0;
+    ps = fma(ps, x2, 1.0 / 6227020800.0);
+    ps = fma(ps, x2, -1.0 / 39916800.0);
+    ps = fma(ps, x2, 1.0 / 362880.0);
+    ps = fma(ps, x2, -1.0 / 5040.0);
+    ps = fma(ps, x2, 1.0 / 120.0);
+    ps = fma(ps, x2, -1.0 / 6.0);
+    const double S = fma(x * x2, ps, x);
+    double pc = 1.0 / 20922789888000.0;
+    pc = fma(pc, x2, -1.0 / 87178291200.0);
+    pc = fma(pc, x2, 1.0 / 479001600.0);
+    pc = fma(pc, x2, -1.0 / 3628800.0);
+    pc = fma(pc, x2, 1.0 / 40320.0);
+    pc = fma(pc, x2, -1.0 / 720.0);
+    pc = fma(pc, x2, 1.0 / 24.0);
+    pc = fma(pc, x2, -0.5);
+    const double Cc = fma(x2, pc, 1.0);
+    const int nq = (int)k & 3;
+    sn = (nq & 1) ? Cc : S;
+    cs = (nq & 1) ? S : Cc;
+    if (nq == 1 || nq == 2) cs = -cs;
+    if (nq >= 2) sn = -sn;
+}
+
+// GNU Radio's rotator (phase *= incr in float32, renormalised every 512 calls) in closed form: the
+// float32 increment's true angle and magnitude drive a float64 model, rebased by the host every block.
+template <class LT>
+__device__ __forceinline__ float2 rotate_value(const LT &L, int64_t n, float vr, float vi)
+{
+    const int64_t dk = n - L.n_seg0;
+    const int64_t r512 = n & ~(int64_t)511;
+    const double ang = L.angle0 + (double)dk * L.dangle;
+    const double lm = (r512 > L.n_seg0) ? (double)(n - r512) * L.dlogmag : L.logmag0 + (double)dk * L.dlogmag;
+    double sn, cs;
+    sincos_fast(ang, sn, cs);
+    // |lm| is a few hundred times log|incr| ~ 1e-7: four series terms are exact to double rounding
+    const double mag = fabs(lm) < 1e-3 ? 1.0 + lm * (1.0 + lm * (0.5 + lm * (1.0 / 6.0))) : exp(lm);
+    const float pr = (float)(mag * cs), pi = (float)(mag * sn);
+    // rotator::rotate(): z = in * phase, float32 complex multiply, unfused
+    float2 y;
+    y.x = __fsub_rn(__fmul_rn(vr, pr), __fmul_rn(vi, pi));
+    y.y = __fadd_rn(__fmul_rn(vr, pi), __fmul_rn(vi, pr));
+    return y;
+}
+
+__device__ __forceinline__ void rotate_store(const ChanLaunch &L, int64_t k, float vr, float vi, uint64_t ring_mask)
+{
+    if (k < L.k_lo || k >= L.k_lo + L.n_k || k < L.k_abs0) return;
+    const int64_t n = k - L.k_abs0;
+    L.iq_ring[(uint64_t)n & ring_mask] = rotate_value(L, n, vr, vi);
+}
+
+}  // namespace
+
+}  // namespace rcfx

@@ -424,8 +424,10 @@ def test_pfb_mode_end_to_end_through_create_channel(gpu_required):
         got = [(ch.read_iq(), ch.read_fm(gain)) for ch in chans]
         n_pfb = fe.timing_read(native.T_PFB)[1]
         n_wide = fe.timing_read(native.T_FIR)[1] + fe.timing_read(native.T_FIR_MFMA)[1]
-        n_taps = fe.timing_read(native.T_FIR_DERIVED)[1]
-        assert n_pfb > 0 and n_taps > 0 and n_wide == 0          # served by the filterbank, no wideband FIR ran
+        n_derived = fe.timing_read(native.T_FIR_DERIVED)[1]
+        # served by the filterbank kernel alone: it writes the tapped bins into the channels' rings itself -- no
+        # wideband FIR, no stage-2 launch either
+        assert n_pfb > 0 and n_wide == 0 and n_derived == 0
     finally:
         tb.close()
     for f, (y, fm) in zip(offs_grid, got):

@@ -30,6 +30,8 @@ for _ in range(2):
     for at in range(0, B, len(tile)):
         fe.ingest_write(tile[: min(len(tile), B - at)], at)
     fe.commit(B)
+ntap = int(os.environ.get("TAPS", 0))
+tids = [fe.pfb_tap_open((7 + 6 * i) % nb, gr_phase=bool(int(os.environ.get("GRPHASE", 1)))) for i in range(ntap)]
 for _ in range(3): fe.commit(B)
 fe.timing_enable(True); fe.timing_read(native.T_PFB)
 for _ in range(steps): fe.commit(B)
