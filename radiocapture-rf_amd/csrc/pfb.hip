@@ -225,6 +225,169 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
     }
 }
 
+
+// Persistent form of the kernel above: the grid is one resident round of workgroups (8 XCDs x wg_per_xcd), each
+// walks the chunks  c = first(xcd) + li, + wg_per_xcd, ...  of its XCD's contiguous chunk range, and the first PF
+// input rows of the NEXT chunk are requested right after the branch sums went to LDS, so that they travel while the
+// FFT passes and the epilogue of the current chunk run (registers: the 2 F accumulators are dead by then).
+template <int NB, int OS, int P, int MINW, bool ZH, int PF>
+__global__ __launch_bounds__(NB, MINW) void pfb_kernel_pp(PfbLaunch p, int n_chunks)
+{
+    constexpr int D = NB / OS;
+    constexpr int HALO = OS * (P - 1);
+    constexpr int W = F + HALO;
+    constexpr int G = 8;
+    constexpr int RS = row_stride<NB>();
+    static_assert(PF <= W && PF % G == 0, "prefetch depth");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+    cf *tw_lds = buf + F * RS;
+
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x % 8, li = blockIdx.x / 8, step = gridDim.x / 8;
+    const int q = n_chunks / 8, r = n_chunks % 8;
+    const int c_lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int c_hi = c_lo + (xcd < r ? q + 1 : q);
+    int c = c_lo + li;
+    if (c >= c_hi) return;
+
+    tw_lds[tid] = p.tw[tid];
+    float h[P];
+#pragma unroll
+    for (int qq = 0; qq < P; ++qq) h[qq] = p.ptaps[qq * NB + tid];
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cf *>(p.src.base), 0, (int)(p.src_len * (int64_t)sizeof(cf)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.bins_ring, 0, (int)((int64_t)NB * p.ring_cap * (int64_t)sizeof(cf)), 0x00020000);
+    const int64_t m_min = (p.start_sample + tid + D - 1) / D;
+    // byte offset of row 0 of chunk 0 for this lane; a chunk advances it by F * D samples
+    const int vo_in0 = (int)(((p.n_lo - HALO) * D - tid - p.src.origin) * (int64_t)sizeof(cf));
+    constexpr int CHUNK_BYTES = F * D * (int)sizeof(cf);
+
+    v2f xp[PF > 0 ? PF : 1];
+    {
+        const int vo = vo_in0 + c * CHUNK_BYTES;
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, vo, j * D * (int)sizeof(cf), 0);
+            xp[j].x = __uint_as_float(rr.x);
+            xp[j].y = __uint_as_float(rr.y);
+        }
+    }
+    for (;;) {
+        const int fb0 = c * F;
+        const int nf = min(F, p.n_frames - fb0);
+        const int64_t n0 = p.n_lo + fb0;
+        const int64_t m0 = n0 - HALO;
+        const int vo_in = vo_in0 + c * CHUNK_BYTES;
+
+        float ur[F], ui[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) ur[f] = ui[f] = 0.f;
+#pragma unroll
+        for (int j0 = 0; j0 < W; j0 += G) {
+            v2f x[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                x[g] = (v2f)(0.f);
+                if (j0 + g < W) {
+                    if (j0 + g < PF) {
+                        x[g] = xp[j0 + g];
+                    } else {
+                        const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, vo_in, (j0 + g) * D * (int)sizeof(cf), 0);
+                        x[g].x = __uint_as_float(rr.x);
+                        x[g].y = __uint_as_float(rr.y);
+                    }
+                    if (ZH && m0 + j0 + g < m_min) x[g] = (v2f)(0.f);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int j = j0 + g;
+                if (j < W) {
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        const int t = HALO + f - j;          // = OS * q
+                        if (t >= 0 && t % OS == 0 && t / OS < P) {
+                            ur[f] = fmaf(h[t / OS], x[g].x, ur[f]);
+                            ui[f] = fmaf(h[t / OS], x[g].y, ui[f]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) buf[f * RS + lds_pad(tid)] = make_float2(ur[f], ui[f]);
+        const int c_next = c + step;
+        const bool more = c_next < c_hi;
+        if (PF > 0) {
+            // next chunk's first rows; past the end the offset stays inside the descriptor or reads as zero
+            const int vo = vo_in0 + (more ? c_next : c) * CHUNK_BYTES;
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, vo, j * D * (int)sizeof(cf), 0);
+                xp[j].x = __uint_as_float(rr.x);
+                xp[j].y = __uint_as_float(rr.y);
+            }
+        }
+        __syncthreads();
+        {
+            using PL = Plan<NB>;
+            pfb_pass<NB, PL::r[0], 1, (PL::n < 2 || PL::r[1] != PL::r[0])>(buf, tw_lds, tid);
+            if constexpr (PL::n >= 2)
+                pfb_pass<NB, PL::r[1], PL::r[0], (PL::n < 3 || PL::r[2] != PL::r[1])>(buf, tw_lds, tid);
+        }
+        {
+            using PL = Plan<NB>;
+            const int k0 = tid / F, f_lane = tid % F;
+            const int out_so_step = (int)((int64_t)(NB / F) * p.ring_cap * (int64_t)sizeof(cf));
+            const int64_t n = n0 + f_lane;
+            const int ridx = (int)((uint64_t)(n - p.n_abs0) & p.ring_mask);
+            const int vo = (int)(((int64_t)k0 * p.ring_cap + ridx) * (int64_t)sizeof(cf));
+            if (f_lane < nf) {
+                cf vv[F];
+#pragma unroll
+                for (int i = 0; i < F; ++i) {
+                    const int k = k0 + i * (NB / F);
+                    vv[i] = ((NB / F) % 16 == 0) ? buf[f_lane * RS + lds_pad(k0) + i * ((NB / F) + (NB / F) / 16)]
+                                                 : buf[f_lane * RS + lds_pad(k)];
+                }
+                if constexpr (PL::n >= 3) {
+                    constexpr int R3 = PL::r[2];
+#pragma unroll
+                    for (int i = 0; i < F / R3; ++i) {
+                        const int j = k0 + i * (NB / F);
+                        cf w[R3];
+#pragma unroll
+                        for (int t = 0; t < R3; ++t) w[t] = vv[i + t * (F / R3)];
+#pragma unroll
+                        for (int t = 1; t < R3; ++t) w[t] = cmul(w[t], tw_lds[(j * t) & (NB - 1)]);
+                        Dft<R3, +1>::run(w);
+#pragma unroll
+                        for (int f = 0; f < R3; ++f) vv[i + f * (F / R3)] = w[Dft<R3, +1>::reg_of(f)];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < F; ++i) {
+                    const int k = k0 + i * (NB / F);
+                    cf v = vv[i];
+                    if (OS == 2) {
+                        if ((k & 1) && (n & 1)) v = make_float2(-v.x, -v.y);
+                    }
+                    u32x2 o;
+                    o.x = __float_as_uint(v.x);
+                    o.y = __float_as_uint(v.y);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, vo, i * out_so_step, 2);
+                }
+            }
+        }
+        if (!more) break;
+        c = c_next;
+        __syncthreads();                       // the epilogue's LDS reads before the next chunk's branch sums
+    }
+}
+
 int env_int(const char *name, int dflt)
 {
     const char *e = getenv(name);
@@ -239,6 +402,25 @@ void launch_os(const PfbLaunch &p, hipStream_t s)
     const int arg = no_remap ? -n_wg : n_wg;
     const size_t lds = ((size_t)F * row_stride<NB>() + NB) * sizeof(cf);
     const bool zh = (p.n_lo - (int64_t)OS * (P - 1)) * (NB / OS) - (NB - 1) < p.start_sample;
+    // 512 / 1024 bins run the persistent form (2 / 1 workgroups per CU: +2 % / +10 %); at 256 bins and below four
+    // independent workgroups per CU already overlap their phases and the persistent form's extra barrier per chunk
+    // costs 8 % (measured, block 2^25).  RCF_PFB_PP=0 / 1 forces it off / on.
+    static const int pp_env = env_int("RCF_PFB_PP", -1);
+    const bool pp = pp_env < 0 ? NB >= 512 : pp_env != 0;
+    if (pp && !zh) {
+        constexpr int PF = NB >= 1024 ? 8 : 16;
+        const int wg_per_cu = NB <= 256 ? 4 : (NB == 512 ? 2 : 1);
+        static const int cus = [] {
+            int d = 0, n = 256;
+            (void)hipGetDevice(&d);
+            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d);
+            return n > 8 ? n : 256;
+        }();
+        int grid = 8 * (cus / 8) * wg_per_cu;                 // one resident round, the same count on every XCD
+        if (grid > ((n_wg + 7) / 8) * 8) grid = ((n_wg + 7) / 8) * 8;
+        hipLaunchKernelGGL((pfb_kernel_pp<NB, OS, P, MINW, false, PF>), dim3(grid), dim3(NB), lds, s, p, n_wg);
+        return;
+    }
     if (zh) hipLaunchKernelGGL((pfb_kernel_os<NB, OS, P, MINW, true>), dim3(n_wg), dim3(NB), lds, s, p, arg);
     else    hipLaunchKernelGGL((pfb_kernel_os<NB, OS, P, MINW, false>), dim3(n_wg), dim3(NB), lds, s, p, arg);
 }

@@ -54,6 +54,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads5 = 320;
 
+// padded extent of one frame in LDS: pad5(NB - 1) + 1
+constexpr int pfb5_row_stride(int NB, int R) { return NB + NB / R - 1; }
+
 // padded index: one spare complex after every R
 template <int R> __device__ __forceinline__ constexpr int pad5(int i) { return i + i / R; }
 
@@ -71,16 +74,29 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
     constexpr int F = 16 / R3;                 // frames per chunk
     constexpr int D = NB / OS;
     constexpr int BPF = NB / R;                // butterflies per frame and pass (= R R3)
-    // LDS row stride of a frame (complex), = 1 mod 16: in the second pass's stores the 16 lanes (g, frame) of a k
-    // write dwords 2 RS frame + 840 g (+ const) = 2 frame + 8 g mod 32 -- sixteen distinct bank pairs.  (With a
-    // stride of 8 mod 16 those stores were 4-way conflicts and LDS conflict cycles were 5x the LDS instructions.)
-    constexpr int RS = NB + NB / R + 1;
+    // LDS row stride of a frame (complex) = the padded extent of a frame, which is odd (= -1 mod 16 for 1600 bins):
+    // in the second pass's stores the 16 lanes (g, frame) of a k write dwords 2 RS frame + 840 g (+ const) =
+    // -2 frame + 8 g mod 32 -- sixteen distinct bank pairs.  (With a stride of 8 mod 16 those stores were 4-way
+    // conflicts and LDS conflict cycles were 5x the LDS instructions.)  NOT one more: gfx950 hands out LDS in granules
+    // of 1280 bytes (tools/occ_probe.hip: 53760 bytes -> three workgroups per CU, 53776 -> two), and F (extent + 2)
+    // complex -- the stride this kernel had first -- is 53792 bytes: 32 bytes too many for the third workgroup.
+    constexpr int RS = pfb5_row_stride(NB, R);
+    static_assert((size_t)F * RS * sizeof(cf) <= 42 * 1280, "three workgroups per CU need <= 42 LDS granules each");
     static_assert(R == 20 && F * BPF == kThreads5, "one butterfly per thread and pass");
     static_assert(OS == 1 || OS == 2 || OS == 4, "bin phase factor must be a power of -j");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf *buf = reinterpret_cast<cf *>(smem_raw);
 
     const int tid = threadIdx.x;
+    // -DRCF_PFB5_TRACE: two workgroups print the cycle counts of their phases (how the time of this kernel was found:
+    // phase A ~45 %, phase B ~30 %; hipcc ... -DRCF_PFB5_TRACE -c pfb5.hip, link as another librcf, RCF_LIBRCF=...)
+#ifdef RCF_PFB5_TRACE
+    long long ts[8];
+    ts[0] = clock64();
+#define TS(i) ts[i] = clock64()
+#else
+#define TS(i)
+#endif
     // neighbouring chunks (they share input rows and complete each other's 128-byte output lines) on one XCD
     const int b = blockIdx.x, q8 = n_wg / 8, r8 = n_wg % 8, xcd = b % 8;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
@@ -129,7 +145,9 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
 #pragma unroll
         for (int f = 0; f < R; ++f) o[f] = vv[Dft<R, +1>::reg_of(f)];
     }
+    TS(1);
     __syncthreads();
+    TS(2);
 
     // ---- phase B: second pass + radix-R3 finish + stores, closed inside the 16 lanes of one k
     {
@@ -193,8 +211,46 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
                 pos[f * (N2 + N2 / R)] = phase(R3 > 1 ? w[Dft<R3, +1>::reg_of(f)] : w[0], jj + f * N2);
         }
     }
+    // ---- taps first, copy-out last.  Vector memory operations of a wavefront return in issue order and the compiler
+    // closes a loop over them with vmcnt(0): with the taps AFTER the copy-out, the tap records' loads waited for the
+    // acknowledgement of all 20 streaming stores of the lane (microseconds under this kernel's write load -- 64 taps
+    // cost a third of the kernel).  So: records requested before the barrier, taps served right behind it from LDS,
+    // and the frames leave last, with nothing waiting for them.
+    TS(3);
+    // ---- taps first, copy-out last: bins that are open as channels go straight into those channels' rings, through
+    // their rotators (GNU Radio's per-output increment and / or the source shift; an idle rotator is skipped).
+    // One lane per (tap, frame), frames fastest: the F lanes of a tap read the same record (one broadcast request)
+    // and write F x 8 contiguous bytes of the tap's ring; the rotator is rotate_value()'s closed form per output, the
+    // same arithmetic as the FIR bank's epilogue.  The first batch of records is requested before the barrier.
+    // (The first version gave a tap to one lane, which walked the chunk's frames after the copy-out: with 64 taps
+    // only wavefront 0 had work, its chain of record loads -> rotator -> F LDS reads and stores ran behind the
+    // acknowledgement of its 20 streaming stores, and the kernel took a third longer.)
+    const int tap_items = p.n_taps * F;
+    int64_t tap_w[kTapFields];
+    if (tid < tap_items) {
+#pragma unroll
+        for (int f = 0; f < kTapFields; ++f) tap_w[f] = p.taps[(size_t)f * p.taps_pitch + tid / F];
+    }
     __syncthreads();
+    TS(4);
+    for (int it = tid; it < tap_items; it += kThreads5) {
+        const int f = it % F;
+        TapLaunch L;
+        if (it != tid) {
+#pragma unroll
+            for (int q = 0; q < kTapFields; ++q) tap_w[q] = p.taps[(size_t)q * p.taps_pitch + it / F];
+        }
+        __builtin_memcpy(&L, tap_w, sizeof(L));
+        const int64_t k = n0 - p.n_abs0 + f;                 // the tap's output index = the bank's frame count
+        if (f < nf && k >= L.k_lo && k < L.k_lo + L.n_k && k >= L.k_abs0) {
+            const cf z = buf[f * RS + pad5<R>(L.bin)];
+            const bool idle = L.dangle == 0.0 && L.dlogmag == 0.0 && L.angle0 == 0.0 && L.logmag0 == 0.0;
+            const int64_t n = k - L.k_abs0;
+            L.iq_ring[(uint64_t)n & p.ring_mask] = idle ? z : rotate_value(L, n, z.x, z.y);
+        }
+    }
 
+    TS(5);
     // ---- copy-out: whole frames, bins consecutive across lanes -- every wavefront store is 512 contiguous bytes of
     // the frame-major ring bins_ring[(n & mask) NB + k]
 #pragma unroll
@@ -223,57 +279,14 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
             }
         }
     }
-
-    // ---- taps: bins that are open as channels go straight into those channels' rings, through their rotators
-    // (GNU Radio's per-output increment and / or the source shift; an idle rotator is skipped).  One lane per tap: the
-    // rotator is evaluated once in closed form (float64) for the chunk's first frame and advanced by the tap's
-    // increment for the others -- except across one of GNU Radio's every-512 renormalisations, where each frame is
-    // evaluated on its own -- and the lane's F outputs are F x 8 contiguous bytes of the ring.
-    for (int i = tid; i < p.n_taps; i += kThreads5) {
-        TapLaunch L;
-        {
-            int64_t w[kTapFields];
-#pragma unroll
-            for (int f = 0; f < kTapFields; ++f) w[f] = p.taps[(size_t)f * p.taps_pitch + i];
-            __builtin_memcpy(&L, w, sizeof(L));
-        }
-        const int64_t k0 = n0 - p.n_abs0;                    // the tap's output index = the bank's frame count
-        const bool idle = L.dangle == 0.0 && L.dlogmag == 0.0 && L.angle0 == 0.0 && L.logmag0 == 0.0;
-        const int64_t rel0 = k0 - L.k_abs0;
-        const bool crosses = (rel0 >> 9) != ((rel0 + nf - 1) >> 9) || rel0 < 0;
-        double pr = 1.0, pi = 0.0;
-        if (!idle && !crosses) {
-            // the closed form of rotate_value (rotator.hpp), kept in float64 for the increments below
-            const int64_t dk = rel0 - L.n_seg0;
-            const int64_t r512 = rel0 & ~(int64_t)511;
-            const double ang = L.angle0 + (double)dk * L.dangle;
-            const double lm = (r512 > L.n_seg0) ? (double)(rel0 - r512) * L.dlogmag : L.logmag0 + (double)dk * L.dlogmag;
-            double sn, cs;
-            sincos_fast(ang, sn, cs);
-            const double mag = fabs(lm) < 1e-3 ? 1.0 + lm * (1.0 + lm * (0.5 + lm * (1.0 / 6.0))) : exp(lm);
-            pr = mag * cs;
-            pi = mag * sn;
-        }
-        for (int f = 0; f < nf; ++f) {
-            const int64_t k = k0 + f;
-            const cf z = buf[f * RS + pad5<R>(L.bin)];
-            cf y = z;
-            if (!idle) {
-                if (crosses) {
-                    y = rotate_value(L, k - L.k_abs0, z.x, z.y);
-                } else {
-                    const float fr = (float)pr, fi = (float)pi;      // rotator::rotate(): unfused float32 complex multiply
-                    y.x = __fsub_rn(__fmul_rn(z.x, fr), __fmul_rn(z.y, fi));
-                    y.y = __fadd_rn(__fmul_rn(z.x, fi), __fmul_rn(z.y, fr));
-                    const double nr = pr * L.inc_re - pi * L.inc_im;
-                    pi = pr * L.inc_im + pi * L.inc_re;
-                    pr = nr;
-                }
-            }
-            if (k >= L.k_lo && k < L.k_lo + L.n_k && k >= L.k_abs0)
-                L.iq_ring[(uint64_t)(k - L.k_abs0) & p.ring_mask] = y;
-        }
-    }
+#ifdef RCF_PFB5_TRACE
+    TS(6);
+    __builtin_amdgcn_s_waitcnt(0);
+    TS(7);
+    if ((wg == 1000 || wg == 3000) && (tid == 0 || tid == 256))
+        printf("wg %d tid %d: A %lld bar1 %lld B %lld bar2 %lld taps %lld copy %lld acks %lld\n", wg, tid, ts[1] - ts[0], ts[2] - ts[1],
+               ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[6] - ts[5], ts[7] - ts[6]);
+#endif
 }
 
 template <int R, int R3, int OS, int P>
@@ -281,7 +294,7 @@ void launch5(const PfbLaunch &p, hipStream_t s)
 {
     constexpr int NB = R * R * R3, F = 16 / R3;
     const int n_wg = (p.n_frames + F - 1) / F;
-    const size_t lds = (size_t)F * (NB + NB / R + 1) * sizeof(cf);
+    const size_t lds = (size_t)F * pfb5_row_stride(NB, R) * sizeof(cf);
     static DynLdsAttr attr_f, attr_t;
     attr_f.ensure(reinterpret_cast<const void *>(pfb5_kernel<R, R3, OS, P, false>), lds);
     attr_t.ensure(reinterpret_cast<const void *>(pfb5_kernel<R, R3, OS, P, true>), lds);

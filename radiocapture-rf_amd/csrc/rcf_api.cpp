@@ -591,8 +591,6 @@ int process_block(rcf_t *h, size_t n)
                     tl.iq_ring = c->d_iq;
                     tl.k_lo = L.k_lo; tl.k_abs0 = L.k_abs0; tl.n_seg0 = L.n_seg0;
                     tl.angle0 = L.angle0; tl.dangle = L.dangle; tl.logmag0 = L.logmag0; tl.dlogmag = L.dlogmag;
-                    tl.inc_re = std::exp(c->dlogmag) * std::cos(c->dangle);
-                    tl.inc_im = std::exp(c->dlogmag) * std::sin(c->dangle);
                     tl.n_k = L.n_k;
                     tl.bin = c->src - RCF_SRC_PFB_BIN0;
                     tap_list.push_back(tl);
@@ -1830,7 +1828,8 @@ int rcf_scan_start(rcf_t *h, int fft_len, int n_frames, int avg_len)
     Scan &s = h->scan;
     // frames per launch: enough workgroups to fill 256 CUs (2^25 samples per launch), bounded so that
     // the log-magnitude ring ((avg_len + chunk) x N floats) and the four-step scratch stay modest
-    int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(512, (int64_t(1) << 25) / fft_len));
+    static const int chunk_log2 = [] { const char *e = getenv("RCF_SCAN_CHUNK_LOG2"); return e ? atoi(e) : 25; }();
+    int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(512, (int64_t(1) << chunk_log2) / fft_len));
     chunk = std::min(chunk, n_frames);
     if (s.d_vring && s.N == fft_len && s.L == avg_len && s.chunk == chunk) {
         // same geometry as the previous scan: keep every buffer (fresh device allocations cost tens of

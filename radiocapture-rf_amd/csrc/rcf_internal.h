@@ -255,7 +255,6 @@ struct TapLaunch {           // host-side record; on the device its fields are r
     int64_t n_seg0;          // rotator model, as in ChanLaunch (rotate_value reads these five)
     double angle0, dangle;
     double logmag0, dlogmag;
-    double inc_re, inc_im;   // e^{dlogmag + j dangle}: one lane walks a chunk's frames by this increment
     int32_t n_k;
     int32_t bin;
 };

@@ -165,6 +165,81 @@ __global__ __launch_bounds__(kMovThreads) void movsum_kernel(const float *__rest
     sum[k] = s;
 }
 
+// Small spectra (N <= 2^17): with one thread per bin there are too few wavefronts to keep HBM busy.  Here a
+// workgroup of kCoopWaves wavefronts owns 64 bins; the frames go by in tiles of TT: every wavefront fetches its share
+// of the tile's newest and oldest rows (64 bins = one 256-byte run per row) into registers, the tile is handed over
+// through LDS, and wavefront 0 alone runs the sequential add/subtract chain from LDS while everyone's loads for the
+// NEXT tile are already in flight: 2 TT loads per bin outstanding instead of 64.
+constexpr int kCoopWaves = 4;
+template <int TT>
+__global__ __launch_bounds__(64 * kCoopWaves) void movsum_coop_kernel(const float *__restrict__ vring, int N, int R, int L,
+                                                                      int f0, int n_frames, int emit_frame,
+                                                                      float *__restrict__ sum, float *__restrict__ out_base,
+                                                                      int n1, int n2)
+{
+    constexpr int RPW = TT / kCoopWaves;                   // rows per wavefront per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *lds = reinterpret_cast<float *>(smem_raw);      // [2 buffers][new | old][TT][64]
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = blockIdx.x * 64 + lane;
+    const bool live = k < N;
+    const int kk = live ? k : 0;
+    float *out = out_base;
+    if (n1 > 0) {
+        const int k1 = kk / n2, k2 = kk - k1 * n2;
+        out = out_base + (((k1 + n1 * k2) + N / 2) & (N - 1)) - kk;
+    }
+    float s = (w == 0 && live) ? sum[kk] : 0.f;
+    const int f_end = f0 + n_frames;
+    float vn[RPW], vo[RPW];
+    // ring slots of a tile: one modulo per tile, then +1 per frame with a conditional wrap (TT <= R, checked by the
+    // launcher); rows past the end / before frame 0 are fetched from a valid slot and never enter the chain
+    auto fetch = [&](int ft) {
+        const int sn0 = ft % R;
+        const int so0 = (int)(((int64_t)ft - (L - 1) + (int64_t)R * (1 + (L - 1) / R)) % R);
+        const float *col = vring + kk;
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            const int d = w + u * kCoopWaves;
+            int sn = sn0 + d, so = so0 + d;
+            if (sn >= R) sn -= R;
+            if (so >= R) so -= R;
+            vn[u] = col[(size_t)sn * N];
+            vo[u] = col[(size_t)so * N];
+        }
+    };
+    fetch(f0);
+    int t = 0;
+    for (int ft = f0; ft < f_end; ft += TT, t ^= 1) {
+        float *bn = lds + (size_t)t * (2 * TT * 64), *bo = bn + TT * 64;
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            bn[(w + u * kCoopWaves) * 64 + lane] = vn[u];
+            bo[(w + u * kCoopWaves) * 64 + lane] = vo[u];
+        }
+        __syncthreads();
+        if (ft + TT < f_end) fetch(ft + TT);
+        if (w == 0) {
+            const int nr = min(TT, f_end - ft);
+            for (int r0 = 0; r0 < nr; r0 += 16) {
+                float a[16], b[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { a[u] = bn[(r0 + u) * 64 + lane]; b[u] = bo[(r0 + u) * 64 + lane]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int f = ft + r0 + u;
+                    if (f < f_end) {
+                        s = __fadd_rn(s, a[u]);
+                        if (f == emit_frame && live) out[kk] = s;
+                        if (f - (L - 1) >= 0) s = __fsub_rn(s, b[u]);
+                    }
+                }
+            }
+        }
+    }
+    if (w == 0 && live) sum[kk] = s;
+}
+
 // Four-step, second half: length-N2 FFTs along the CONTIGUOUS rows of the scratch matrix [N1][N2] the
 // column kernel (scan4.hip) produced, then |X|^2 -> log10 -> +1.  Output stays in row order
 // (p = k1 * N2 + k2): fully coalesced float stores, no transpose -- movsum_kernel un-permutes the one
@@ -255,7 +330,15 @@ void launch_scan_movsum(float *vring, int N, int R, int L, int f0, int n_frames,
     if (n_frames <= 0) return;
     int n1 = 0, n2 = 0;
     if (N > 16384 && !scan4_split(N, &n1, &n2)) return;
-    if (N <= (1 << 17))
+    static const int coop = [] { const char *e = getenv("RCF_SCAN_MOVSUM_COOP"); return e ? atoi(e) : 1; }();
+    if (N <= (1 << 15) && coop && R >= 128) {   // measured: 16384 bins 53 -> 34 us per 512 frames, 131072 bins 2x slower
+        constexpr int TT = 128;
+        const size_t lds = sizeof(float) * 2 * 2 * TT * 64;
+        static DynLdsAttr attr;
+        attr.ensure(reinterpret_cast<const void *>(movsum_coop_kernel<TT>), lds);
+        hipLaunchKernelGGL(movsum_coop_kernel<TT>, dim3((N + 63) / 64), dim3(64 * kCoopWaves), lds, s, vring, N, R, L, f0,
+                           n_frames, emit_frame, sum, out, n1, n2);
+    } else if (N <= (1 << 17))
         hipLaunchKernelGGL(movsum_kernel<32>, dim3((N + kMovThreads - 1) / kMovThreads), dim3(kMovThreads), 0, s, vring, N, R, L,
                            f0, n_frames, emit_frame, sum, out, n1, n2);
     else

@@ -33,7 +33,7 @@ for _ in range(2):
 ntap = int(os.environ.get("TAPS", 0))
 tids = [fe.pfb_tap_open((7 + 6 * i) % nb, gr_phase=bool(int(os.environ.get("GRPHASE", 1)))) for i in range(ntap)]
 for _ in range(3): fe.commit(B)
-fe.timing_enable(True); fe.timing_read(native.T_PFB)
+fe.timing_enable(True, classes=None if os.environ.get('TIME_ALL') else [native.T_PFB]); fe.timing_read(native.T_PFB)
 for _ in range(steps): fe.commit(B)
 ms, n = fe.timing_read(native.T_PFB)
 ms /= n
