@@ -628,3 +628,76 @@ def test_source_shift_reaches_filterbank_taps(gpu_required):
     want = -2 * math.pi * 150.0 / 25000.0               # NCO moved up by 150 Hz: the carrier sits 150 Hz lower
     assert abs((np.mean(fm_b[50:]) - np.mean(fm_a[50:])) - want) < 2e-3
     assert abs((np.mean(fd_b[50:]) - np.mean(fd_a[50:])) - want) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb", [512, 1024])
+def test_pfb_persistent_form_walks_many_chunks(gpu_required, nb):
+    """512 / 1024-bin banks run the persistent kernel (one resident round of workgroups, each walking several chunks
+    with the next chunk's rows prefetched): a block long enough for 2.5 chunks per workgroup must give bit-identical
+    bins to the same stream pushed in small blocks (one chunk per workgroup), and the oracle's bins at the tail."""
+    nat = gpu_required
+    fs = 20e6
+    bw = fs / nb
+    taps = G.low_pass_2(1.0, fs, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+    wg_resident = 256 * (2 if nb == 512 else 1)
+    n_frames = int(2.5 * wg_resident) * 16 + 5          # ragged last chunk
+    n = nb * n_frames
+    rng = np.random.default_rng(nb)
+    x = synth.awgn(rng, n)
+    bins = [1, nb // 2 - 1, nb - 3]
+    for k in bins:
+        f0 = k * fs / nb if k < nb // 2 else (k - nb) * fs / nb
+        x = x + synth.nbfm_carrier(n, fs, f0 + 1500.0, 700.0, 2500.0, 1.0).astype(np.complex64)
+    x = x.astype(np.complex64)
+    cap = 1
+    while cap < 2 * n_frames:
+        cap <<= 1
+    first = nb * 40                                     # the zero-history launch, out of the way
+    with nat.Frontend(fs, block_capacity=n, hist_capacity=1 << 16, out_capacity=cap) as fe:
+        fe.pfb_open(nb, nb, taps)
+        fe.push(x[:first])
+        fe.push(x[first:])                              # one launch: ~2.5 chunks per resident workgroup
+        assert fe.pfb_produced() == n_frames
+        big = {k: fe.pfb_read_bin(k) for k in bins + [0, 7, nb // 2]}
+    with nat.Frontend(fs, block_capacity=n, hist_capacity=1 << 16, out_capacity=cap) as fe:
+        fe.pfb_open(nb, nb, taps)
+        step = nb * 16 * 64 + 3 * nb                    # 67 frames: every launch is a single round
+        for at in range(0, n, step):
+            fe.push(x[at:at + step])
+        small = {k: fe.pfb_read_bin(k) for k in big}
+    for k in big:
+        assert len(big[k]) == n_frames
+        assert np.array_equal(big[k], small[k]), k
+    tail = 300                                           # oracle on the last frames (absolute phase: k fs / nb is
+    lo = n_frames - tail                                 # periodic in nb samples, so a cut at a frame boundary is exact)
+    hist_frames = len(taps) // nb + 2
+    xs = x[(lo - hist_frames) * nb:]
+    for k in bins:
+        f0 = k * fs / nb if k < nb // 2 else (k - nb) * fs / nb
+        want = G.xlating_fir_exact(xs, nb, taps, f0, fs)[hist_frames:]
+        got = big[k][lo:]
+        assert len(want) == len(got) == tail
+        scale = np.sqrt(np.mean(np.abs(want) ** 2))
+        assert np.sqrt(np.mean(np.abs(got - want) ** 2)) / scale < 2e-5, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,F,L", [(4096, 700, 100), (16384, 1300, 37)])
+def test_scan_running_sum_cooperative_tiles(gpu_required, N, F, L):
+    """Small spectra use the cooperative running sum (four wavefronts fetch 128-frame tiles, one sums): launches of
+    512 frames = four tiles, a ragged last launch, the ring of log-magnitude frames wrapping, and the first L - 1
+    frames that have nothing to subtract -- against the oracle's chain."""
+    nat = gpu_required
+    fs = 2.4e6
+    carriers = [(N // 5, 9000.0, 40.0), (N // 2 + 300, 6000.0, 35.0), (N - N // 7, 12000.0, 45.0)]
+    reps = -(-F // 100)
+    tile = synth.scan_stream(fs, N, 100, carriers, seed=N + L)
+    x = np.tile(tile, reps)
+    with nat.Frontend(fs, block_capacity=len(x), hist_capacity=max(N, 1 << 16)) as fe:
+        fe.scan_start(N, F, L)
+        fe.push(x)                                       # ONE commit: launches of 512, 512, ... frames
+        assert fe.scan_frames_done() == F
+        spec = fe.scan_result()
+    want = OC.scan_chain(x, N, F, L)
+    assert np.abs(spec - want).max() < 5e-3
