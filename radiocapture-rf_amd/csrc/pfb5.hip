@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
 
     const int tid = threadIdx.x;
     // -DRCF_PFB5_TRACE: two workgroups print the cycle counts of their phases (how the time of this kernel was found:
-    // phase A ~45 %, phase B ~30 %; hipcc ... -DRCF_PFB5_TRACE -c pfb5.hip, link as another librcf, RCF_LIBRCF=...)
+    // phase A ~45 % before the window was staged through LDS, phase B ~30 %; hipcc ... -DRCF_PFB5_TRACE -c pfb5.hip, link as another librcf, RCF_LIBRCF=...)
 #ifdef RCF_PFB5_TRACE
     long long ts[8];
     ts[0] = clock64();
@@ -112,32 +112,78 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
 
     // ---- phase A: branch FIR + first radix-20 pass.  u[t] = sum_q h[NB q + rho_t] x[(n - OS q) D - rho_t],
     // rho_t = j + BPF t; X[f] -> buf[20 j + f]
+    // Every input sample of the chunk's window is used by up to OS P (frame, branch) pairs -- by different threads.
+    // Where the window (WIN samples) fits the chunk's LDS buffer, which is idle until the first pass writes it, the
+    // workgroup first stages the window there with coalesced loads -- ONE round trip, 18 loads per thread instead
+    // of 40 in two dependent rounds, each sample fetched once per workgroup instead of 2.3 times -- and the branch
+    // FIR reads LDS (consecutive lanes = consecutive samples, conflict free).  Shapes whose window does not fit
+    // (OS = 1 with 4 taps per branch) keep the direct form.
+    constexpr int WIN = (F - 1 + OS * (P - 1)) * D + NB;
+    constexpr bool STAGE = WIN <= F * RS;
     {
         const int frame = tid / BPF, j = tid % BPF;
         const int64_t n = n0 + frame;
         cf vv[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) vv[t] = make_float2(0.f, 0.f);
-        // lowest address this thread reads: row n - OS (P - 1), branch j + BPF (R - 1); everything else is a
-        // compile-time constant above it
-        const int vo = (int)(((n - OS * (P - 1)) * D - j - BPF * (R - 1) - p.src.origin) * (int64_t)sizeof(cf));
+        if constexpr (STAGE) {
+            constexpr int NLD = (WIN + kThreads5 - 1) / kThreads5;
+            const int64_t m_lo = (n0 - OS * (P - 1)) * D - (NB - 1);          // first sample of the window
+            const int vo0 = (int)((m_lo + tid - p.src.origin) * (int64_t)sizeof(cf));
+            cf xs[NLD];
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-            cf x[R];
-            float h[R];
-#pragma unroll
-            for (int t = 0; t < R; ++t) {
-                // x[(n - OS q) D - j - BPF t]
-                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(
-                    in_rsrc, vo + (OS * (P - 1 - q) * D + BPF * (R - 1 - t)) * (int)sizeof(cf), 0, 0);
-                x[t] = make_float2(__uint_as_float(r.x), __uint_as_float(r.y));
-                h[t] = p.ptaps[q * NB + j + BPF * t];
+            for (int r = 0; r < NLD; ++r) {
+                const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, vo0, r * kThreads5 * (int)sizeof(cf), 0);
+                xs[r] = make_float2(__uint_as_float(w.x), __uint_as_float(w.y));
             }
+            float h[P][R];
 #pragma unroll
-            for (int t = 0; t < R; ++t) {
-                if (ZH && (n - OS * q) * D - (j + BPF * t) < p.start_sample) x[t] = make_float2(0.f, 0.f);
-                vv[t].x = fmaf(h[t], x[t].x, vv[t].x);
-                vv[t].y = fmaf(h[t], x[t].y, vv[t].y);
+            for (int q = 0; q < P; ++q)
+#pragma unroll
+                for (int t = 0; t < R; ++t) h[q][t] = p.ptaps[q * NB + j + BPF * t];
+#pragma unroll
+            for (int r = 0; r < NLD; ++r) {
+                const int idx = tid + r * kThreads5;
+                if (ZH && m_lo + idx < p.start_sample) xs[r] = make_float2(0.f, 0.f);
+                if (NLD * kThreads5 == WIN || idx < WIN) buf[idx] = xs[r];
+            }
+            __syncthreads();
+            // x[(n - OS q) D - j - BPF t] = window[(frame + OS (P - 1 - q)) D + NB - 1 - j - BPF t]
+            const cf *sb = buf + frame * D + BPF - 1 - j;                   // q = P - 1, t = R - 1
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                cf x[R];
+#pragma unroll
+                for (int t = 0; t < R; ++t) x[t] = sb[OS * (P - 1 - q) * D + BPF * (R - 1 - t)];
+#pragma unroll
+                for (int t = 0; t < R; ++t) {
+                    vv[t].x = fmaf(h[q][t], x[t].x, vv[t].x);
+                    vv[t].y = fmaf(h[q][t], x[t].y, vv[t].y);
+                }
+            }
+            __syncthreads();                                 // every thread has read the window before it is overwritten
+        } else {
+            // lowest address this thread reads: row n - OS (P - 1), branch j + BPF (R - 1); everything else is a
+            // compile-time constant above it
+            const int vo = (int)(((n - OS * (P - 1)) * D - j - BPF * (R - 1) - p.src.origin) * (int64_t)sizeof(cf));
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                cf x[R];
+                float h[R];
+#pragma unroll
+                for (int t = 0; t < R; ++t) {
+                    // x[(n - OS q) D - j - BPF t]
+                    const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(
+                        in_rsrc, vo + (OS * (P - 1 - q) * D + BPF * (R - 1 - t)) * (int)sizeof(cf), 0, 0);
+                    x[t] = make_float2(__uint_as_float(r.x), __uint_as_float(r.y));
+                    h[t] = p.ptaps[q * NB + j + BPF * t];
+                }
+#pragma unroll
+                for (int t = 0; t < R; ++t) {
+                    if (ZH && (n - OS * q) * D - (j + BPF * t) < p.start_sample) x[t] = make_float2(0.f, 0.f);
+                    vv[t].x = fmaf(h[t], x[t].x, vv[t].x);
+                    vv[t].y = fmaf(h[t], x[t].y, vv[t].y);
+                }
             }
         }
         Dft<R, +1>::run(vv);
@@ -211,20 +257,14 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
                 pos[f * (N2 + N2 / R)] = phase(R3 > 1 ? w[Dft<R3, +1>::reg_of(f)] : w[0], jj + f * N2);
         }
     }
-    // ---- taps first, copy-out last.  Vector memory operations of a wavefront return in issue order and the compiler
-    // closes a loop over them with vmcnt(0): with the taps AFTER the copy-out, the tap records' loads waited for the
-    // acknowledgement of all 20 streaming stores of the lane (microseconds under this kernel's write load -- 64 taps
-    // cost a third of the kernel).  So: records requested before the barrier, taps served right behind it from LDS,
-    // and the frames leave last, with nothing waiting for them.
     TS(3);
     // ---- taps first, copy-out last: bins that are open as channels go straight into those channels' rings, through
     // their rotators (GNU Radio's per-output increment and / or the source shift; an idle rotator is skipped).
     // One lane per (tap, frame), frames fastest: the F lanes of a tap read the same record (one broadcast request)
     // and write F x 8 contiguous bytes of the tap's ring; the rotator is rotate_value()'s closed form per output, the
     // same arithmetic as the FIR bank's epilogue.  The first batch of records is requested before the barrier.
-    // (The first version gave a tap to one lane, which walked the chunk's frames after the copy-out: with 64 taps
-    // only wavefront 0 had work, its chain of record loads -> rotator -> F LDS reads and stores ran behind the
-    // acknowledgement of its 20 streaming stores, and the kernel took a third longer.)
+    // (The first version gave a tap to one lane, which walked the chunk's frames after the copy-out, behind the
+    // acknowledgement of its 20 streaming stores -- vector memory operations of a wavefront return in issue order.)
     const int tap_items = p.n_taps * F;
     int64_t tap_w[kTapFields];
     if (tid < tap_items) {
