@@ -35,6 +35,10 @@ class receiver:
         self.last_channel_cleanup = time.time()
         self.scan_mode = bool(getattr(config, "scan_mode", False))
         self.bind_port = None                              # set by the egress pump: port -> bound?
+        self.fault = None                                  # first data-plane failure (GPU / driver error): healthy() -> False
+        self._fed = {}                                     # source_id -> samples delivered
+        self._fed_t0 = time.time()
+        self._fed_mark = (self._fed_t0, 0)
         if frontend_factory is None:
             from . import native
 
@@ -105,14 +109,46 @@ class receiver:
         """Deliver wideband cf32 samples for one source (replaces source -> pub_sink, receiver.py:201).
         With receiver_split2 both halves of a real source share one front-end: feed either, once."""
         src = self.sources[source_id]
-        if "parent_chan" in src:
-            # the half-band channel writes n/2 samples per push into a ring of the front-end's out_capacity
-            # (default 2^16): deliver in pieces that fit, block cuts do not change the result
-            step = src.get("feed_chunk", 1 << 16)
-            for at in range(0, len(iq), step):
-                src["block"].push(iq[at:at + step])
-            return
-        src["block"].push(iq)
+        try:
+            if "parent_chan" in src:
+                # the half-band channel writes n/2 samples per push into a ring of the front-end's out_capacity
+                # (default 2^16): deliver in pieces that fit, block cuts do not change the result
+                step = src.get("feed_chunk", 1 << 16)
+                for at in range(0, len(iq), step):
+                    src["block"].push(iq[at:at + step])
+            else:
+                src["block"].push(iq)
+        except Exception as e:
+            # a failed launch / copy leaves the front-end's stream state undefined: remember it (the registry
+            # publisher stops heartbeating on healthy() == False, so clients move to another channelizer within
+            # the manager's 5 s expiry) and let the producer see the error
+            if self.fault is None:
+                self.fault = "%s: %s" % (type(e).__name__, e)
+                self.log.error("data plane failed on source %s: %s" % (source_id, self.fault))
+            raise
+        self._fed[source_id] = self._fed.get(source_id, 0) + len(iq)
+
+    def healthy(self):
+        """False once a push has failed (GPU / driver error).  The reference has no such signal: a dead flowgraph
+        keeps publishing; here the heartbeat stops (registry.redis_channel_publisher(health=...))."""
+        return self.fault is None
+
+    def metrics(self):
+        """Additive keys for the registry record (metrics): samples delivered and the input rate since the
+        previous call, channels in use, the fault string if any.  Nothing the reference's readers look at."""
+        now = time.time()
+        total = sum(self._fed.values())
+        t_prev, n_prev = self._fed_mark
+        rate = (total - n_prev) / (now - t_prev) / 1e6 if now > t_prev else 0.0
+        self._fed_mark = (now, total)
+        with self.access_lock:
+            in_use = sum(1 for c in self.channels.values() if getattr(c, "in_use", False))
+            n_chan = len(self.channels)
+        out = {"rcf_samples_in": int(total), "rcf_msps_in": rate, "rcf_channels_in_use": in_use,
+               "rcf_channels_open": n_chan, "rcf_healthy": self.fault is None}
+        if self.fault is not None:
+            out["rcf_fault"] = self.fault
+        return out
 
     # ------------------------------------------------------------------ control plane
     def connect_channel(self, channel_rate, freq):

@@ -17,7 +17,7 @@ class redis_channel_publisher():
     """Every 1 s: SADD channelizers <uuid>; SET <uuid> json{...} (redis_channel_publisher.py:59-93)."""
 
     def __init__(self, sources=None, channels=None, port=None, index=None, client=None, address=None,
-                 extra=None, start_thread=True):
+                 extra=None, start_thread=True, health=None):
         if sources is None:
             raise Exception('Sources must be provided at initialization')
         if channels is None:
@@ -30,7 +30,10 @@ class redis_channel_publisher():
         self.port = port
         self.index = index
         self.address = address
-        self.extra = extra or (lambda: {})       # additive keys only: Msps in, kernel ms, HBM GB/s ...
+        self.extra = extra or (lambda: {})       # additive keys only: receiver.metrics (Msps in, channels, fault)
+        # health() -> False (or raising) stops the heartbeat: the manager side expires the record after 5 s and
+        # clients reconnect elsewhere ("GPU error => stop heartbeating"); receiver.healthy is the feed
+        self.health = health
         self.instance_uuid = str(uuid.uuid4())
         if client is None:
             import redis
@@ -68,7 +71,17 @@ class redis_channel_publisher():
         publish_data.update(self.extra())
         return publish_data
 
+    def is_healthy(self):
+        if self.health is None:
+            return True
+        try:
+            return bool(self.health())
+        except Exception:
+            return False
+
     def publish_once(self, now=None):
+        if not self.is_healthy():
+            return None
         data = self.build(now)
         self.client.sadd('channelizers', self.instance_uuid)
         self.client.set(self.instance_uuid, json.dumps(data))

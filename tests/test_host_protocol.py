@@ -223,6 +223,55 @@ def test_registry_publish_and_expiry():
     assert other.channelizers == {}                      # index filter (redis_channelizer_manager.py:94)
 
 
+def test_data_plane_fault_stops_the_heartbeat_and_metrics_are_additive():
+    """SURVEY 5 (failure handling / metrics): a failed push (GPU / driver error) marks the receiver unhealthy, the
+    registry publisher stops publishing (the manager expires the record after 5 s), and receiver.metrics() only adds
+    keys to the reference's record."""
+    class FakeRedis:
+        def __init__(self): self.kv, self.sets = {}, {}
+        def sadd(self, k, v): self.sets.setdefault(k, set()).add(v)
+        def set(self, k, v): self.kv[k] = v
+        def smembers(self, k): return set(self.sets.get(k, set()))
+        def get(self, k): return self.kv.get(k)
+        def srem(self, k, v): self.sets.get(k, set()).discard(v)
+        def delete(self, k): self.kv.pop(k, None)
+
+    rx = make_receiver()
+    fe = StubFrontend.instances[0]
+    pushed = []
+    fe.push = lambda iq: pushed.append(len(iq))
+    r = FakeRedis()
+    pub = registry.redis_channel_publisher(sources=rx.sources, channels=rx.channels, port=5555, client=r,
+                                           address="10.0.0.1", start_thread=False, extra=rx.metrics, health=rx.healthy)
+    rx.feed(0, np.zeros(1000, np.complex64))
+    block_id, _ = rx.connect_channel(12500, 855000000)
+    d = pub.publish_once(now=10.0)
+    assert d["rcf_samples_in"] == 1000 and d["rcf_healthy"] is True and d["rcf_channels_open"] == 1
+    assert d["rcf_channels_in_use"] == 1 and "rcf_fault" not in d
+    for key in ("instance_uuid", "start_time", "current_time", "hostname", "pid", "address", "port",
+                "channel_count", "source_count", "sources"):
+        assert key in d                                  # the reference's keys are all still there
+    mgr = registry.redis_channelizer_manager(clients=[r], start_thread=False)
+    mgr.poll_once(now=10.5)
+    assert mgr.get_channelizer_for_frequency(855000000) == ("10.0.0.1", 5555)
+
+    def broken(iq):
+        raise RuntimeError("librcf error -2: hipErrorLaunchFailure")
+    fe.push = broken
+    with pytest.raises(RuntimeError):
+        rx.feed(0, np.zeros(10, np.complex64))
+    assert not rx.healthy() and "hipErrorLaunchFailure" in rx.fault
+    assert pub.publish_once(now=11.0) is None            # no heartbeat
+    assert json.loads(r.get(pub.instance_uuid))["current_time"] == 10.0
+    mgr.poll_once(now=16.0)                              # > 5 s since the last record: gone
+    assert mgr.get_channelizer_for_frequency(855000000) == (None, None)
+    assert rx.metrics()["rcf_fault"].startswith("RuntimeError")
+    # a health callable that itself fails counts as unhealthy
+    pub2 = registry.redis_channel_publisher(sources=rx.sources, channels={}, port=1, client=r, start_thread=False,
+                                            health=lambda: 1 / 0)
+    assert pub2.publish_once() is None
+
+
 def test_receiver_split2_makes_two_half_rate_sources_per_real_source():
     """receiver.py:205-237: centre -/+ fs/4, rate fs/2, through a /2 xlating FIR with firdes.low_pass taps;
     channels of a half are chained behind it with channel.py's rule at the HALF rate."""

@@ -84,10 +84,10 @@ pmc_record("%s_fir4096" % R, "fir_mfma", "profiles/%s_fir_mfma_pmc.json" % R, {
                    "GRBM_GUI_ACTIVE / 8 / kernel_us; SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles; "
                    "FETCH_SIZE in KiB and x2 on gfx950 (MI355X_MICROARCH.md)"})
 pmc_record("%s_pfb512" % R, "pfb_kernel", "profiles/%s_pfb512_traffic.json" % R, {
-    "workload": "tools/pfb_probe.py NB=512: 512-bin critically sampled bank, block 2^25; algorithmic 16 B/sample = 536.9 MB",
+    "workload": "tools/pfb_probe.py NB=512: 512-bin critically sampled bank (persistent form pfb_kernel_pp), block 2^25; algorithmic 16 B/sample = 536.9 MB",
     "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
 pmc_record("%s_pfb1600" % R, "pfb5_kernel", "profiles/%s_pfb1600_pmc.json" % R, {
-    "workload": "tools/pfb_probe.py NB=1600 BLOCK=2^24: 1600-bin bank, D = 800, 2909 taps; algorithmic 24 B/sample = 402.7 MB",
+    "workload": "tools/pfb_probe.py NB=1600 BLOCK=2^25: 1600-bin bank, D = 800, 2909 taps; algorithmic 24 B/sample = 805.3 MB",
     "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
 
 src = "gpurun_out/%s_bench.json" % R
