@@ -247,10 +247,12 @@ int rcf_pfb_close(rcf_t *h);
 int64_t rcf_pfb_produced(rcf_t *h);
 /* bin index in [0, n_bins): bin k is centred at k*fs/n_bins for k < n_bins/2, (k-n_bins)*fs/n_bins above */
 int64_t rcf_pfb_read_bin(rcf_t *h, int bin, float *out_interleaved, size_t max_samples);
-/* device layout of the bin outputs.  Power-of-two banks: per-bin rings, sample n of bin k at
- * bins_ring[k * pitch + (n & (capacity-1))] (complex samples); pitch = capacity + pad is deliberately not a power
- * of two so that the 256+ concurrently written rings do not alias onto one HBM channel.  400 / 800 / 1600 / 3200-bin
- * banks: ONE ring of whole frames, sample n of bin k at bins_ring[(n & (capacity-1)) * n_bins + k], and *pitch = 0. */
+/* device layout of the bin outputs (complex samples; i = n & (capacity-1), n = frame index since rcf_pfb_open).
+ * Power-of-two banks: tiles of 16 frames, sample n of bin k at bins_ring[(i >> 4) * tile_pitch + 16 * k + (i & 15)]
+ * with tile_pitch = 16 * n_bins + 80 (a chunk of 16 frames is one contiguous run for the kernel that writes it, a bin's
+ * 16 frames are one 128-byte line for whoever reads it; the padding keeps one bin's lines off a single memory channel),
+ * and *pitch = 16 (frames per tile).  400 / 800 / 1600 / 3200-bin banks: ONE ring of whole frames, sample n of bin k at
+ * bins_ring[i * n_bins + k], and *pitch = 0. */
 int rcf_pfb_rings(rcf_t *h, void **bins_ring, size_t *capacity, size_t *pitch);
 /* stage 2 on one bin: channel.py's own rule at the bin rate -- decim2 = int(bin_rate/cr)/2,
  * low_pass_2(1.0, bin_rate, cr/2, cr/2, 20, HAMMING), xlating by delta_hz -- output as a normal

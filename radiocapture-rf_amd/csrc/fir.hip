@@ -156,9 +156,12 @@ __global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *_
     float2 *ys = xs + (size_t)KB * D + T;                        // KB + 1 outputs: ys[t] = y[k0 - 1 + t]
     float2 *cts = ys + KB + 1;                                   // T composite taps
     float *tab = reinterpret_cast<float *>(cts + T);             // 257 + pad
-    const ChanLaunch &L = chans[blockIdx.y];
+    // grid = (channels, output tiles): workgroups that run together work on the SAME stretch of time of different
+    // channels -- when the channels are bins of one filterbank ring (tiled or frame-major) their lines sit in the
+    // same tiles, i.e. the same pages
+    const ChanLaunch &L = chans[blockIdx.x];
     const int tid = threadIdx.x;
-    const int j0 = blockIdx.x * KB;
+    const int j0 = blockIdx.y * KB;
     if (j0 >= L.n_k) return;
     const int nj = min(KB, L.n_k - j0);
     for (int i = tid; i < 257; i += kThreads) tab[i] = atan_tab[i];
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *_
         for (int u = 0; u < LU; ++u) {
             const int p = p0 + u * kThreads;
             const int64_t sidx = s_first + (p < len ? p : len - 1);
-            v[u] = sidx >= L.start_sample ? sv.base[((uint64_t)(sidx - sv.origin) & sv.mask) * sv.stride]
+            v[u] = sidx >= L.start_sample ? sv.base[sv.at(sidx)]
                                           : make_float2(0.f, 0.f);
         }
 #pragma unroll
@@ -247,8 +250,7 @@ __global__ __launch_bounds__(kThreads) void fir_bank_kernel(const ChanLaunch *__
 
     const StreamView sv = L0.src;
     for (int p = tid; p < len; p += kThreads) {
-        const uint64_t idx = ((uint64_t)(s_tile0 + p - sv.origin) & sv.mask) * sv.stride;
-        xs[p] = sv.base[idx];
+        xs[p] = sv.base[sv.at(s_tile0 + p)];
     }
     __syncthreads();
 
@@ -595,7 +597,7 @@ void launch_fir_bank(const ChanLaunch *d_chans, const FirLaunchDims &dims, hipSt
     if (dims.small) {
         const int KB = fir_small_outputs(dims.D, dims.T);
         const size_t lds = ((size_t)KB * dims.D + 2 * dims.T + KB + 1) * sizeof(float2) + 264 * sizeof(float);
-        hipLaunchKernelGGL(fir_small_kernel, dim3((dims.max_n_k + KB - 1) / KB, dims.n_chans), dim3(kThreads), lds, s,
+        hipLaunchKernelGGL(fir_small_kernel, dim3(dims.n_chans, (dims.max_n_k + KB - 1) / KB), dim3(kThreads), lds, s,
                            d_chans, dims.D, dims.T, KB, dims.ring_mask, dims.atan_tab);
         return;
     }

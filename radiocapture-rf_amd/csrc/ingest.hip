@@ -54,19 +54,18 @@ void launch_t(const void *raw, float2 *out, size_t n, float scale, float offset,
         hipLaunchKernelGGL((convert_tail<T>), dim3(1), dim3(64), 0, s, r + 2 * (n - 1), out + (n - 1), scale, offset);
 }
 
-__global__ __launch_bounds__(256) void gather_strided_kernel(const float2 *__restrict__ src, int64_t stride,
-                                                             float2 *__restrict__ dst, size_t n)
+__global__ __launch_bounds__(256) void gather_view_kernel(StreamView v, int64_t first, float2 *__restrict__ dst, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = src[i * (size_t)stride];
+    if (i < n) dst[i] = v.base[v.at(first + (int64_t)i)];
 }
 
 }  // namespace
 
-void launch_gather_strided(const float2 *src, int64_t stride, float2 *dst, size_t n, hipStream_t s)
+void launch_gather_view(const StreamView &v, int64_t first, float2 *dst, size_t n, hipStream_t s)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(gather_strided_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, stride, dst, n);
+    hipLaunchKernelGGL(gather_view_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, first, dst, n);
 }
 
 size_t raw_sample_bytes(int fmt)

@@ -128,7 +128,6 @@ struct rcf {
     int device = 0;
     double fs = 0, fc = 0;
     size_t block_cap = 0, hist_cap = 0, out_cap = 0;
-    size_t bin_pitch = 0;          // samples between consecutive PFB bin rings (out_cap + pad: not a power of two)
     uint64_t ring_mask = 0;
     hipStream_t stream = nullptr;
     float2 *d_buf[2] = {nullptr, nullptr};
@@ -292,12 +291,14 @@ bool source_range(rcf_t *h, int src, int64_t S0, int64_t S1, SrcRange *out)
     if (src >= RCF_SRC_PFB_BIN0) {
         if (!h->pfb.open) return false;
         const int bin = src - RCF_SRC_PFB_BIN0;
-        if (h->pfb.frame_major) {                           // bins_ring[(n & mask) NB + bin]
+        if (h->pfb.frame_major) {                           // bins_ring[i NB + bin]
             out->view.base = h->pfb.d_bins + bin;
             out->view.stride = h->pfb.NB;
-        } else {                                            // bins_ring[bin * pitch + (n & mask)]
-            out->view.base = h->pfb.d_bins + (size_t)bin * h->bin_pitch;
-            out->view.stride = 1;
+            out->view.tshift = 0;
+        } else {                                            // bins_ring[(i >> 4) tile_pitch + 16 bin + (i & 15)]
+            out->view.base = h->pfb.d_bins + ((size_t)bin << kPfbTileLog2);
+            out->view.stride = pfb_tile_pitch(h->pfb.NB);
+            out->view.tshift = kPfbTileLog2;
         }
         out->view.mask = h->ring_mask;
         out->view.origin = 0;
@@ -513,7 +514,7 @@ int process_block(rcf_t *h, size_t n)
             pl.tw = p.d_tw;
             pl.bins_ring = p.d_bins;
             pl.ring_mask = h->ring_mask;
-            pl.ring_cap = (int64_t)h->bin_pitch;
+            pl.tile_pitch = pfb_tile_pitch(p.NB);
             pl.n_lo = n_lo;
             pl.n_abs0 = p.n_abs0;
             pl.start_sample = p.start_sample;
@@ -1162,8 +1163,6 @@ int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_c
     if (const char *nm = getenv("RCF_FIR_MFMA_MIN")) h->mfma_min = std::max(1, atoi(nm));
         if (const char *nm = getenv("RCF_FIR_MFMA_NT")) h->mfma_nt = atoi(nm);
         if (const char *nm = getenv("RCF_FIR_MFMA_PARTS")) h->mfma_parts = atoi(nm);
-        const char *e = getenv("RCF_PFB_PITCH_PAD");
-        h->bin_pitch = h->out_cap + (e ? (size_t)atol(e) : 80);
     }
     RCF_HIP(hipSetDevice(device));
     RCF_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -1718,7 +1717,8 @@ int rcf_pfb_open(rcf_t *h, int n_bins, int decim, const float *taps, int ntaps)
         return RCF_EINVAL;
     }
     const bool fm = pfb_frame_major(n_bins);
-    const size_t ring_samples = fm ? (size_t)n_bins * h->out_cap : (size_t)n_bins * h->bin_pitch;
+    if (!fm && h->out_cap < (size_t(1) << kPfbTileLog2)) { set_error("output capacity %zu < one ring tile", h->out_cap); return RCF_ECAP; }
+    const size_t ring_samples = fm ? (size_t)n_bins * h->out_cap : (size_t)(h->out_cap >> kPfbTileLog2) * (size_t)pfb_tile_pitch(n_bins);
     if ((uint64_t)ring_samples * sizeof(float2) >= (1ull << 31) ||
         (uint64_t)(h->hist_cap + h->block_cap) * sizeof(float2) >= (1ull << 31)) {
         set_error("PFB rings / wideband buffer exceed the 2 GiB range of 32-bit buffer offsets");
@@ -1787,25 +1787,20 @@ int64_t rcf_pfb_read_bin(rcf_t *h, int bin, float *out, size_t max_samples)
     if (set_dev(h)) return RCF_EHIP;
     Pfb &p = h->pfb;
     if (!p.open || bin < 0 || bin >= p.NB) { set_error("no such PFB bin %d", bin); return RCF_EINVAL; }
-    if (p.frame_major) {
-        // one bin out of the frame-major ring: gather its unread samples into a contiguous staging buffer
-        int64_t avail = p.produced - p.rd[bin];
-        if (avail <= 0 || max_samples == 0) return 0;
-        if ((size_t)avail > h->out_cap) { p.rd[bin] = p.produced - (int64_t)h->out_cap; avail = (int64_t)h->out_cap; }
-        const int64_t n = std::min<int64_t>(avail, (int64_t)max_samples);
-        if (!p.d_stage) RCF_HIP(hipMalloc(&p.d_stage, sizeof(float2) * h->out_cap));
-        const size_t pos = (size_t)((uint64_t)p.rd[bin] & h->ring_mask);
-        const size_t first = std::min<size_t>((size_t)n, h->out_cap - pos);
-        launch_gather_strided(p.d_bins + pos * (size_t)p.NB + bin, p.NB, p.d_stage, first, h->stream);
-        launch_gather_strided(p.d_bins + bin, p.NB, p.d_stage + first, (size_t)n - first, h->stream);
-        RCF_HIP(hipMemcpyAsync(out, p.d_stage, sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
-        RCF_HIP(hipStreamSynchronize(h->stream));
-        free_graveyard_idle(h);
-        p.rd[bin] += n;
-        return n;
-    }
-    return ring_read(h, p.d_bins + (size_t)bin * h->bin_pitch, sizeof(float2), p.produced, &p.rd[bin], out,
-                     max_samples);
+    // one bin out of the bank's ring (tiled or frame-major): gather its unread samples into a contiguous staging buffer
+    int64_t avail = p.produced - p.rd[bin];
+    if (avail <= 0 || max_samples == 0) return 0;
+    if ((size_t)avail > h->out_cap) { p.rd[bin] = p.produced - (int64_t)h->out_cap; avail = (int64_t)h->out_cap; }
+    const int64_t n = std::min<int64_t>(avail, (int64_t)max_samples);
+    if (!p.d_stage) RCF_HIP(hipMalloc(&p.d_stage, sizeof(float2) * h->out_cap));
+    SrcRange sr{};
+    if (!source_range(h, RCF_SRC_PFB_BIN0 + bin, 0, 0, &sr)) return RCF_ESTATE;
+    launch_gather_view(sr.view, p.rd[bin], p.d_stage, (size_t)n, h->stream);
+    RCF_HIP(hipMemcpyAsync(out, p.d_stage, sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    RCF_HIP(hipStreamSynchronize(h->stream));
+    free_graveyard_idle(h);
+    p.rd[bin] += n;
+    return n;
 }
 
 int rcf_pfb_rings(rcf_t *h, void **bins_ring, size_t *capacity, size_t *pitch)
@@ -1813,7 +1808,7 @@ int rcf_pfb_rings(rcf_t *h, void **bins_ring, size_t *capacity, size_t *pitch)
     if (!h || !h->pfb.open) return RCF_ESTATE;
     if (bins_ring) *bins_ring = h->pfb.d_bins;
     if (capacity) *capacity = h->out_cap;
-    if (pitch) *pitch = h->pfb.frame_major ? 0 : h->bin_pitch;
+    if (pitch) *pitch = h->pfb.frame_major ? 0 : (size_t(1) << kPfbTileLog2);   // frames per tile (0: frame-major)
     return RCF_OK;
 }
 

@@ -58,14 +58,28 @@ struct DynLdsAttr {
 };
 
 // ---------------------------------------------------------------- stream views
-// sample s of a stream lives at base[((s - origin) & mask) * stride]   (linear buffer: mask = ~0; stride = 1
-// except for one bin of a frame-major filterbank ring, where consecutive samples are n_bins apart)
+// sample s of a stream lives at base[at(i)], i = (s - origin) & mask, at(i) = (i >> tshift) * stride + (i & tmask):
+//   linear buffers and channel rings      stride 1, tshift 0
+//   one bin of a frame-major bank ring    stride n_bins, tshift 0       (pfb5.hip: bins_ring[i * NB + k])
+//   one bin of a tiled bank ring          stride tile_pitch, tshift 4   (pfb.hip: bins_ring[(i >> 4) tile_pitch + 16 k + (i & 15)])
 struct StreamView {
     const float2 *base;
     uint64_t mask;
     int64_t origin;
     int64_t stride;
+    int32_t tshift;
+    int32_t pad_;
+    __host__ __device__ __forceinline__ uint64_t at(int64_t s) const
+    {
+        const uint64_t i = (uint64_t)(s - origin) & mask;
+        return (i >> tshift) * (uint64_t)stride + (i & ((1ull << tshift) - 1));
+    }
 };
+constexpr int kPfbTileLog2 = 4;          // frames per tile of a power-of-two bank's ring = pfb.hip's chunk (F = 16)
+// A tile holds 16 frames of all NB bins (16 NB samples, contiguous for the writer).  Its pitch is NOT that power of two:
+// a reader of ONE bin takes one 128-byte line per tile, and at a pitch of exactly 16 NB 8 bytes (32 KB for 256 bins)
+// all of them would fall on the same one or two L2 / HBM channels.  Five lines of padding spread them.
+inline int64_t pfb_tile_pitch(int NB) { return ((int64_t)NB << kPfbTileLog2) + 80; }
 
 // ---------------------------------------------------------------- direct xlating-FIR bank
 // One entry per channel per launch (device array).
@@ -225,18 +239,21 @@ struct PfbLaunch {
     StreamView src;
     const float *ptaps;      // [P][NB] polyphase taps: ptaps[p*NB + rho] = h[NB p + rho] (0 beyond T)
     const float2 *tw;        // e^{+2 pi i n / NB}, n in [0, NB)
-    float2 *bins_ring;       // [NB][ring_cap]
+    float2 *bins_ring;       // layout below
     uint64_t ring_mask;
-    int64_t ring_cap;
+    int64_t tile_pitch;      // tiled layout: samples between consecutive tiles (>= 16 NB; see pfb_tile_pitch)
     int64_t n_lo;            // first absolute frame index of this launch
     int64_t n_abs0;          // absolute frame index of the PFB's first-ever frame
     int64_t start_sample;
     int64_t src_len;         // samples addressable from src.base (linear view), for the buffer descriptor
     int32_t n_frames;        // frames in this launch
     int32_t NB, D, P;
-    // output layout: channel-major rings bins_ring[k * ring_cap + (n & ring_mask)] (pfb.hip), or -- frame_major --
-    // one ring of whole frames bins_ring[(n & ring_mask) * NB + k] (pfb5.hip: a chunk of 2-4 frames cannot fill
-    // 128-byte lines of per-bin rings, whole frames leave as contiguous rows)
+    // output layout, i = (n - n_abs0) & ring_mask:
+    //   tiled (pfb.hip, power-of-two banks)   bins_ring[(i >> 4) tile_pitch + 16 k + (i & 15)]: a chunk of 16 frames is ONE
+    //     contiguous run of 16 NB samples for the writer, and a bin's 16 frames are one 128-byte line for its readers
+    //     (the first layout -- one ring per bin -- scattered a chunk over NB separate lines: 5 % slower)
+    //   frame_major (pfb5.hip)                bins_ring[i NB + k]: a chunk of 2-4 frames cannot fill 128-byte lines
+    //     per bin; whole frames leave as contiguous rows
     int32_t frame_major;
     int32_t n_taps;
     // frame-major banks: bins that are open as channels (rcf_pfb_tap_open).  The kernel has every bin of the chunk in
@@ -266,8 +283,8 @@ void launch_pfb(const PfbLaunch &p, hipStream_t s);
 // bin counts with a factor 25 (pfb5.hip): 400, 800, 1600, 3200
 bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s);
 inline bool pfb_frame_major(int NB) { return NB % 25 == 0; }
-// dst[i] = src[i * stride], i < n (one bin's samples out of a frame-major ring; ingest.hip)
-void launch_gather_strided(const float2 *src, int64_t stride, float2 *dst, size_t n, hipStream_t s);
+// dst[i] = view sample (first + i), i < n (one bin's samples out of a bank ring; ingest.hip)
+void launch_gather_view(const StreamView &v, int64_t first, float2 *dst, size_t n, hipStream_t s);
 int pfb5_padded_p(int NB, int D, int P);
 
 // ---------------------------------------------------------------- scan

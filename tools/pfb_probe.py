@@ -38,6 +38,6 @@ for _ in range(steps): fe.commit(B)
 ms, n = fe.timing_read(native.T_PFB)
 ms /= n
 gbs = (8.0 * B + 8.0 * B * osf) / (ms * 1e-3) / 1e9
-print("NB=%d OS=%d taps=%d pad=%s remap=%s : %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (
-    nb, osf, len(taps), os.environ.get("RCF_PFB_PITCH_PAD", "dflt"),
+print("NB=%d OS=%d taps=%d remap=%s : %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (
+    nb, osf, len(taps),
     "off" if os.environ.get("RCF_PFB_NOREMAP") else "on", ms, gbs, gbs / 80.0))
