@@ -29,7 +29,7 @@ constexpr int kWave = 64;
 constexpr int kThreads = 256;
 constexpr int CT = 2;   // channels per wave item
 constexpr int KR = 8;   // outputs per wave item
-constexpr int kSmallPerThread = 1;   // outputs per thread of the small-T kernel (fir_small_outputs <= 256 n - 1)
+constexpr int kSmallPerThread = 2;   // outputs per thread of the small-T kernel (fir_small_outputs <= 256 n - 1): 1 -> 2 took the stage-2 launch of the timed configuration from 0.030 to 0.025 ms, 4 is slower again
 
 __device__ __forceinline__ float wave_sum(float v)
 {

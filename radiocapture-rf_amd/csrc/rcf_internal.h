@@ -98,13 +98,13 @@ struct ChanLaunch {
     float *fm_ring;          // discriminator ring (written by the fused small-T kernel only)
 };
 
-// outputs per workgroup of the small-T kernel (tile of KB D + T samples within ~24 KB of LDS, one output per
+// outputs per workgroup of the small-T kernel (tile of KB D + T samples within ~26 KB of LDS, two outputs per
 // thread minus the recomputed predecessor); 0 = not applicable
 inline int fir_small_outputs(int D, int T)
 {
     if (T > 96) return 0;
-    int kb = (3000 - T) / D;
-    if (kb > 255) kb = 255;          // 256 slots: one is the predecessor output the discriminator needs
+    int kb = (3300 - T) / D;
+    if (kb > 511) kb = 511;          // 512 slots (fir.hip kSmallPerThread = 2): one is the predecessor output the discriminator needs
     return kb >= 32 ? kb : 0;
 }
 
