@@ -701,3 +701,62 @@ def test_scan_running_sum_cooperative_tiles(gpu_required, N, F, L):
         spec = fe.scan_result()
     want = OC.scan_chain(x, N, F, L)
     assert np.abs(spec - want).max() < 5e-3
+
+
+def test_two_front_ends_on_one_gpu_do_not_disturb_each_other(gpu_required):
+    """The reference runs several sources in one receiver process (rc_frontend/receiver.py:186-240): here that is
+    several rcf_t handles on one GPU, alive together, fed alternately.  Each must produce bit for bit what it
+    produces alone (per-handle streams, arenas, bank caches; the per-kernel LDS attributes and the env-derived
+    constants are the only process-wide state) -- one with 3 direct channels at 2.4 Msps, the other with a
+    matrix-core bank of 9 channels and a 256-bin filterbank with a stage-2 channel at 20 Msps."""
+    nat = gpu_required
+    fs_a, fs_b = 2.4e6, 20e6
+    rng = np.random.default_rng(77)
+    xa = synth.awgn(rng, 600000).astype(np.complex64)
+    xb = synth.awgn(rng, 1 << 21).astype(np.complex64)
+    offs_a = [-300e3, 12.5e3, 777e3]
+    offs_b = [(-9 + 2.2 * i) * 1e6 for i in range(9)]
+    taps_b = G.low_pass_2(1.0, fs_b, fs_b / 256 * 0.4, fs_b / 256 * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+
+    def open_a(fe):
+        return [fe.chan_open(12500, o) for o in offs_a]
+
+    def open_b(fe):
+        ids = [fe.chan_open(12500, o) for o in offs_b]
+        fe.pfb_open(256, 256, taps_b)
+        ids.append(fe.pfb_chan_open(37, 12500, 1500.0))
+        return ids
+
+    def read(fe, ids):
+        return [(fe.chan_read_iq(c), fe.chan_read_fm(c, 1.0)) for c in ids]
+
+    cuts_a = [0, 150000, 150001, 420000, len(xa)]
+    cuts_b = [0, 700000, 1400000 + 7, len(xb)]
+    with nat.Frontend(fs_a) as fa:                                   # alone
+        ia = open_a(fa)
+        for lo, hi in zip(cuts_a[:-1], cuts_a[1:]):
+            fa.push(xa[lo:hi])
+        want_a = read(fa, ia)
+    with nat.Frontend(fs_b, block_capacity=1 << 21) as fb:
+        ib = open_b(fb)
+        for lo, hi in zip(cuts_b[:-1], cuts_b[1:]):
+            fb.push(xb[lo:hi])
+        want_b = read(fb, ib)
+        want_bin = fb.pfb_read_bin(37)
+    with nat.Frontend(fs_a) as fa, nat.Frontend(fs_b, block_capacity=1 << 21) as fb:   # together, interleaved
+        ia, ib = open_a(fa), open_b(fb)
+        pa = list(zip(cuts_a[:-1], cuts_a[1:]))
+        pb = list(zip(cuts_b[:-1], cuts_b[1:]))
+        for i in range(max(len(pa), len(pb))):
+            if i < len(pb):
+                fb.push(xb[pb[i][0]:pb[i][1]])
+            if i < len(pa):
+                fa.push(xa[pa[i][0]:pa[i][1]])
+        got_a, got_b = read(fa, ia), read(fb, ib)
+        got_bin = fb.pfb_read_bin(37)
+    for (y, f), (yw, fw) in zip(got_a + got_b, want_a + want_b):
+        assert len(y) == len(yw) > 0 and np.array_equal(y, yw) and np.array_equal(f, fw)
+    assert np.array_equal(got_bin, want_bin)
+    # and the alone-run is the oracle's (spot check: first channel of each)
+    D, taps = G.channel_params(fs_a, 12500)
+    assert rel_rms(want_a[0][0], G.xlating_fir_ccc(xa, D, taps, offs_a[0], fs_a)) < 1e-5
