@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <unordered_map>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -94,6 +95,10 @@ struct Chan {
     double logmag0 = 0;
     int64_t n_seg0 = 0;
     int depth = 0;
+    // output range [blk_before, blk_after) the block with serial blk_serial gave this channel (its derived channels'
+    // input range; process_block)
+    uint64_t blk_serial = 0;
+    int64_t blk_before = 0, blk_after = 0;
 };
 
 struct Pfb {
@@ -128,6 +133,7 @@ struct rcf {
     int device = 0;
     double fs = 0, fc = 0;
     size_t block_cap = 0, hist_cap = 0, out_cap = 0;
+    uint64_t blk_serial = 0;       // process_block count (Chan::blk_serial)
     uint64_t ring_mask = 0;
     hipStream_t stream = nullptr;
     float2 *d_buf[2] = {nullptr, nullptr};
@@ -479,16 +485,23 @@ int process_block(rcf_t *h, size_t n)
     // how far back every consumer of a ring reaches beyond the block's new samples (a block's writes must not
     // overwrite what the same block's readers still need): derived channels T - 1 + D of source output, the
     // discriminator one sample, the symbol filter its taps
-    std::map<int, size_t> reach;                            // source id (channel id / RCF_SRC_PFB_BIN0 + bin) -> samples
+    // Every ring reaches back 1 (the discriminator); only sources of other channels and channels with a symbol filter
+    // reach further -- the map holds just those (with 131072 plain wideband channels it stays empty: a std::map entry
+    // per channel and block was a tenth of the host's schedule time).
+    std::unordered_map<int, size_t> reach_x;                // source id (channel id / RCF_SRC_PFB_BIN0) -> samples
     for (auto &kv : h->chans) {
         const Chan &c = *kv.second;
-        size_t &own = reach[c.id];
-        own = std::max<size_t>(own, std::max<size_t>(1, c.d_sym ? (size_t)c.sym_ntaps : 0));
+        if (c.d_sym) { size_t &own = reach_x[c.id]; own = std::max<size_t>(own, std::max<size_t>(1, (size_t)c.sym_ntaps)); }
         if (c.src >= 0) {
-            size_t &r = reach[c.src >= RCF_SRC_PFB_BIN0 ? RCF_SRC_PFB_BIN0 : c.src];
+            size_t &r = reach_x[c.src >= RCF_SRC_PFB_BIN0 ? RCF_SRC_PFB_BIN0 : c.src];
             r = std::max<size_t>(r, (size_t)(c.T - 1 + c.D));
         }
     }
+    auto reach = [&](int id) -> size_t {
+        if (reach_x.empty()) return 1;
+        auto it = reach_x.find(id);
+        return it == reach_x.end() ? (size_t)1 : std::max<size_t>(1, it->second);
+    };
 
     // ---- PFB bookkeeping first (derived channels need its new range)
     PfbLaunch pl{};
@@ -500,9 +513,9 @@ int process_block(rcf_t *h, size_t n)
         p.produced_before = p.produced;
         if (n_hi >= n_lo) {
             const int64_t cnt = n_hi - n_lo + 1;
-            if ((size_t)cnt + reach[RCF_SRC_PFB_BIN0] > h->out_cap) {
+            if ((size_t)cnt + (reach_x.count(RCF_SRC_PFB_BIN0) ? reach_x[RCF_SRC_PFB_BIN0] : 0) > h->out_cap) {
                 set_error("block yields %lld PFB frames (+%zu of history its stage-2 channels need) > ring capacity %zu",
-                          (long long)cnt, reach[RCF_SRC_PFB_BIN0], h->out_cap);
+                          (long long)cnt, reach_x.count(RCF_SRC_PFB_BIN0) ? reach_x[RCF_SRC_PFB_BIN0] : (size_t)0, h->out_cap);
                 return RCF_ECAP;
             }
             pl.src.base = h->d_buf[h->cur];
@@ -530,7 +543,7 @@ int process_block(rcf_t *h, size_t n)
     int max_depth = 0;
     for (auto &kv : h->chans) max_depth = std::max(max_depth, kv.second->depth);
     fir_by_depth.resize(max_depth + 1);
-    std::map<int, std::pair<int64_t, int64_t>> chan_new;   // channel id -> [produced_before, produced_after)
+    const uint64_t serial = ++h->blk_serial;               // Chan::blk_before / blk_after of this block carry it
     for (int depth = 0; depth <= max_depth; ++depth) {
         std::map<std::pair<int, int>, std::vector<Chan *>> classes;
         for (auto &kv : h->chans)
@@ -540,6 +553,9 @@ int process_block(rcf_t *h, size_t n)
             std::vector<ChanLaunch> launches;
             std::vector<Chan *> launched;
             std::vector<DiscLaunch> discs;
+            launches.reserve(cls.second.size());
+            launched.reserve(cls.second.size());
+            discs.reserve(cls.second.size());
             int max_n = 0;
             bool shared_src = true;
             for (Chan *c : cls.second) {
@@ -547,13 +563,14 @@ int process_block(rcf_t *h, size_t n)
                 if (c->src >= 0 && c->src < RCF_SRC_PFB_BIN0) {
                     auto it = h->chans.find(c->src);
                     if (it == h->chans.end()) continue;            // source closed: channel starves
-                    auto rng = chan_new.find(c->src);
-                    sr.view.base = it->second->d_iq;
+                    const Chan &sc_ = *it->second;
+                    const bool fresh = sc_.blk_serial == serial;
+                    sr.view.base = sc_.d_iq;
                     sr.view.mask = h->ring_mask;
                     sr.view.origin = 0;
                     sr.view.stride = 1;
-                    sr.p0 = rng == chan_new.end() ? it->second->produced : rng->second.first;
-                    sr.p1 = rng == chan_new.end() ? it->second->produced : rng->second.second;
+                    sr.p0 = fresh ? sc_.blk_before : sc_.produced;
+                    sr.p1 = fresh ? sc_.blk_after : sc_.produced;
                 } else if (!source_range(h, c->src, S0, S1, &sr)) {
                     continue;
                 }
@@ -561,11 +578,11 @@ int process_block(rcf_t *h, size_t n)
                 const int64_t k_lo = std::max(ceil_div(sr.p0, D), c->k_abs0);
                 const int64_t k_hi = floor_div(sr.p1 - 1, D);
                 const int64_t before = c->produced;
-                if (sr.p1 <= sr.p0 || k_hi < k_lo) { chan_new[c->id] = {before, before}; continue; }
+                if (sr.p1 <= sr.p0 || k_hi < k_lo) { c->blk_serial = serial; c->blk_before = c->blk_after = before; continue; }
                 const int64_t cnt = k_hi - k_lo + 1;
-                if ((size_t)cnt + reach[c->id] > h->out_cap) {
+                if ((size_t)cnt + reach(c->id) > h->out_cap) {
                     set_error("block yields %lld outputs (+%zu of history its consumers need) > ring capacity %zu",
-                              (long long)cnt, reach[c->id], h->out_cap);
+                              (long long)cnt, reach(c->id), h->out_cap);
                     return RCF_ECAP;
                 }
                 ChanLaunch L{};
@@ -657,7 +674,7 @@ int process_block(rcf_t *h, size_t n)
                 c->angle0 = fmodl(c->angle0 + adv, (long double)kTwoPi);
                 c->n_seg0 = n_next;
                 c->produced = n_next;
-                chan_new[c->id] = {before, n_next};
+                c->blk_serial = serial; c->blk_before = before; c->blk_after = n_next;
             }
             if (launches.empty()) continue;
             FirJob job{};
@@ -682,12 +699,23 @@ int process_block(rcf_t *h, size_t n)
                 for (auto &L : launches)                                   // the range most channels share: the earliest
                     if (k_common < 0 || L.k_lo < k_common) { k_common = L.k_lo; n_common = L.n_k; }
                 n_common_of_clean = n_common;
-                for (size_t i = 0; i < launches.size(); ++i) {
-                    const ChanLaunch &L = launches[i];
-                    const bool ok = L.k_lo == k_common && L.n_k == n_common;
-                    if (!ok) { rest.push_back(L); continue; }
-                    clean.push_back(L);
-                    clean_ch.push_back(launched[i]);
+                size_t n_ok = 0;
+                for (const ChanLaunch &L : launches) n_ok += (L.k_lo == k_common && L.n_k == n_common) ? 1 : 0;
+                if (n_ok == launches.size()) {              // the steady state: the whole class, no record copied
+                    clean.swap(launches);
+                    clean_ch.swap(launched);
+                } else {
+                    clean.reserve(n_ok);
+                    clean_ch.reserve(n_ok);
+                    for (size_t i = 0; i < launches.size(); ++i) {
+                        const ChanLaunch &L = launches[i];
+                        const bool ok = L.k_lo == k_common && L.n_k == n_common;
+                        if (!ok) { rest.push_back(L); continue; }
+                        clean.push_back(L);
+                        clean_ch.push_back(launched[i]);
+                    }
+                }
+                for (const ChanLaunch &L : clean)
                     if (L.k_lo * D - L.start_sample < (int64_t)(T - 1)) {
                         // outputs k with k D - (T-1) < start: k < ceil((start + T - 1) / D)
                         const int64_t k_end = ceil_div(L.start_sample + (int64_t)(T - 1), D);
@@ -695,22 +723,22 @@ int process_block(rcf_t *h, size_t n)
                         F.n_k = (int32_t)std::min<int64_t>(L.n_k, std::max<int64_t>(0, k_end - L.k_lo));
                         if (F.n_k > 0) fixups.push_back(F);
                     }
-                }
                 // (no size limit on a class: every group of 32 channels has its own tap slab)
                 if ((int)clean.size() < h->mfma_min) {
+                    rest.insert(rest.end(), clean.begin(), clean.end());   // (order within a vector launch is free)
                     clean.clear();
                     clean_ch.clear();
                     fixups.clear();
-                    rest = launches;
                 }
             } else {
-                rest = launches;
+                rest.swap(launches);
             }
             if (!clean.empty()) {
                 FirJob mj = job;
                 mj.bc = nullptr;
                 rcf::BankCache &bc = h->banks[cls.first];
                 std::vector<std::pair<int, uint64_t>> key;
+                key.reserve(clean_ch.size());
                 for (Chan *c : clean_ch) key.push_back({c->id, c->taps_version});
                 mj.repack = key != bc.key;
                 mj.dirty = nullptr;
