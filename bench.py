@@ -147,7 +147,7 @@ def fm_parity(G, tile, chk):
 # ------------------------------------------------------------------------------------------- GPU legs (untimed)
 def direct_bank_sweep(native, tile, device, counts, block=1 << 22):
     """The reference-shaped bank on this GPU: C channels of rcf_chan_open(12500, f) == channel.py:31-38 each
-    (D = 800, T = 2909, GR-faithful float32 phases), opened for real, eight blocks timed per point."""
+    (D = 800, T = 2909, GR-faithful float32 phases), opened for real, twelve blocks timed per point."""
     D, T = native.channel_params(FS, 12500)
     fd = native.Frontend(FS, 0.0, device=device, block_capacity=block, hist_capacity=1 << 16, out_capacity=1 << 13)
     for at in range(0, block, len(tile)):
@@ -170,10 +170,10 @@ def direct_bank_sweep(native, tile, device, counts, block=1 << 22):
         for w in (native.T_FIR, native.T_FIR_MFMA, native.T_DISC):
             fd.timing_read(w)
         # wall clock per block in steady state: rcf_commit builds the block's launch records on the host (~0.5 us
-        # per channel) and queues the kernels; the next commit's host work runs while they execute.  Eight blocks,
-        # one sync: (host + 8 x max(host, GPU)) / 8 -- the first block's host work is not hidden, so this is an
+        # per channel) and queues the kernels; the next commit's host work runs while they execute.  Twelve blocks,
+        # one sync: (host + 12 x max(host, GPU)) / 12 -- the first block's host work is not hidden, so this is an
         # upper bound on the steady-state period
-        n_timed = 8
+        n_timed = 12
         t0 = time.perf_counter()
         for _ in range(n_timed):
             fd.commit(block)

@@ -432,14 +432,32 @@ int process_block(rcf_t *h, size_t n)
     hipStream_t st = h->stream;
     if (h->graveyard.size() > 512) drain_graveyard(h);     // bounded even if nobody ever syncs or reads
 
+    // how far back every consumer of a ring reaches beyond the block's new samples (a block's writes must not
+    // overwrite what the same block's readers still need): derived channels T - 1 + D of source output, the
+    // discriminator one sample, the symbol filter its taps.  Every ring reaches back 1 (the discriminator); only
+    // sources of other channels and channels with a symbol filter reach further -- the map holds just those (with
+    // 131072 plain wideband channels it stays empty: a std::map entry per channel and block was a tenth of the
+    // host's schedule time).
+    std::unordered_map<int, size_t> reach_x;                // source id (channel id / RCF_SRC_PFB_BIN0) -> samples
+    int max_depth = 0;
+
     // arena for this commit: sized for every channel's launch records before anything is scheduled, so the
     // schedule below cannot run out half way (it mutates channel state as it goes)
     {
+        // (one pass over the channel map for everything that needs one: at 196608 channels each pass is ~8 ms of
+        // pointer chasing)
         size_t need = 4096;
         for (auto &kv : h->chans) {
+            const Chan &c = *kv.second;
             need += 2 * sizeof(ChanLaunch) + sizeof(TapLaunch) + sizeof(DiscLaunch) + 2 + 128;
-            if (kv.second->d_sym) need += sizeof(FmFirLaunch);
-            if (kv.second->audio) need += sizeof(AudioLaunch);
+            if (c.d_sym) need += sizeof(FmFirLaunch);
+            if (c.audio) need += sizeof(AudioLaunch);
+            max_depth = std::max(max_depth, c.depth);
+            if (c.d_sym) { size_t &own = reach_x[c.id]; own = std::max<size_t>(own, std::max<size_t>(1, (size_t)c.sym_ntaps)); }
+            if (c.src >= 0) {
+                size_t &r = reach_x[c.src >= RCF_SRC_PFB_BIN0 ? RCF_SRC_PFB_BIN0 : c.src];
+                r = std::max<size_t>(r, (size_t)(c.T - 1 + c.D));
+            }
         }
         need += 64 * (h->chans.size() / 4 + 64);              // per-class alignment slack
         if (need > h->arena_cap) {
@@ -482,21 +500,6 @@ int process_block(rcf_t *h, size_t n)
     double audf_ratio = 0;
     int audf_num = 1, audf_den = 1;
 
-    // how far back every consumer of a ring reaches beyond the block's new samples (a block's writes must not
-    // overwrite what the same block's readers still need): derived channels T - 1 + D of source output, the
-    // discriminator one sample, the symbol filter its taps
-    // Every ring reaches back 1 (the discriminator); only sources of other channels and channels with a symbol filter
-    // reach further -- the map holds just those (with 131072 plain wideband channels it stays empty: a std::map entry
-    // per channel and block was a tenth of the host's schedule time).
-    std::unordered_map<int, size_t> reach_x;                // source id (channel id / RCF_SRC_PFB_BIN0) -> samples
-    for (auto &kv : h->chans) {
-        const Chan &c = *kv.second;
-        if (c.d_sym) { size_t &own = reach_x[c.id]; own = std::max<size_t>(own, std::max<size_t>(1, (size_t)c.sym_ntaps)); }
-        if (c.src >= 0) {
-            size_t &r = reach_x[c.src >= RCF_SRC_PFB_BIN0 ? RCF_SRC_PFB_BIN0 : c.src];
-            r = std::max<size_t>(r, (size_t)(c.T - 1 + c.D));
-        }
-    }
     auto reach = [&](int id) -> size_t {
         if (reach_x.empty()) return 1;
         auto it = reach_x.find(id);
@@ -540,8 +543,6 @@ int process_block(rcf_t *h, size_t n)
     }
 
     // ---- channels, by depth then by (D, T) class
-    int max_depth = 0;
-    for (auto &kv : h->chans) max_depth = std::max(max_depth, kv.second->depth);
     fir_by_depth.resize(max_depth + 1);
     const uint64_t serial = ++h->blk_serial;               // Chan::blk_before / blk_after of this block carry it
     for (int depth = 0; depth <= max_depth; ++depth) {
