@@ -127,29 +127,52 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
 #pragma unroll
         for (int t = 0; t < R; ++t) vv[t] = make_float2(0.f, 0.f);
         if constexpr (STAGE) {
-            constexpr int NLD = (WIN + kThreads5 - 1) / kThreads5;
             const int64_t m_lo = (n0 - OS * (P - 1)) * D - (NB - 1);          // first sample of the window
-            const int vo0 = (int)((m_lo + tid - p.src.origin) * (int64_t)sizeof(cf));
-            cf xs[NLD];
-#pragma unroll
-            for (int r = 0; r < NLD; ++r) {
-                const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, vo0, r * kThreads5 * (int)sizeof(cf), 0);
-                xs[r] = make_float2(__uint_as_float(w.x), __uint_as_float(w.y));
-            }
             float h[P][R];
+            int odd = 0;
+            if constexpr (!ZH) {
+                // steady state: the window goes global -> LDS directly (buffer_load_dwordx4 ... lds, 16 bytes per lane,
+                // a wavefront = 1 KB contiguous on both sides): no staging registers, 9 requests per thread instead of
+                // 18 loads + 18 LDS writes.  The window starts at an even sample so that every request is 16-byte
+                // aligned; rounds past its end read zeros (descriptor range) into LDS nobody looks at.
+                constexpr int PER = kThreads5 * 2;                            // samples per round of the workgroup
+                constexpr int NLD = (WIN + 1 + PER - 1) / PER;
+                static_assert((size_t)NLD * PER * sizeof(cf) <= (size_t)F * RS * sizeof(cf), "window rounds fit the buffer");
+                odd = (int)((m_lo - p.src.origin) & 1);
+                const int vo0 = (int)((m_lo - odd - p.src.origin) * (int64_t)sizeof(cf)) + tid * 16;
+                unsigned char *lds_wave = reinterpret_cast<unsigned char *>(buf) + (tid >> 6) * (64 * 16);
 #pragma unroll
-            for (int q = 0; q < P; ++q)
+                for (int r = 0; r < NLD; ++r)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (__attribute__((address_space(3))) void *)(lds_wave + r * PER * (int)sizeof(cf)),
+                                                             16, vo0, r * PER * (int)sizeof(cf), 0, 0);
 #pragma unroll
-                for (int t = 0; t < R; ++t) h[q][t] = p.ptaps[q * NB + j + BPF * t];
+                for (int q = 0; q < P; ++q)
 #pragma unroll
-            for (int r = 0; r < NLD; ++r) {
-                const int idx = tid + r * kThreads5;
-                if (ZH && m_lo + idx < p.start_sample) xs[r] = make_float2(0.f, 0.f);
-                if (NLD * kThreads5 == WIN || idx < WIN) buf[idx] = xs[r];
+                    for (int t = 0; t < R; ++t) h[q][t] = p.ptaps[q * NB + j + BPF * t];
+                __builtin_amdgcn_s_waitcnt(0);                               // the DMA writes count on vmcnt
+            } else {
+                constexpr int NLD = (WIN + kThreads5 - 1) / kThreads5;
+                const int vo0 = (int)((m_lo + tid - p.src.origin) * (int64_t)sizeof(cf));
+                cf xs[NLD];
+#pragma unroll
+                for (int r = 0; r < NLD; ++r) {
+                    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, vo0, r * kThreads5 * (int)sizeof(cf), 0);
+                    xs[r] = make_float2(__uint_as_float(w.x), __uint_as_float(w.y));
+                }
+#pragma unroll
+                for (int q = 0; q < P; ++q)
+#pragma unroll
+                    for (int t = 0; t < R; ++t) h[q][t] = p.ptaps[q * NB + j + BPF * t];
+#pragma unroll
+                for (int r = 0; r < NLD; ++r) {
+                    const int idx = tid + r * kThreads5;
+                    if (m_lo + idx < p.start_sample) xs[r] = make_float2(0.f, 0.f);
+                    if (NLD * kThreads5 == WIN || idx < WIN) buf[idx] = xs[r];
+                }
             }
             __syncthreads();
             // x[(n - OS q) D - j - BPF t] = window[(frame + OS (P - 1 - q)) D + NB - 1 - j - BPF t]
-            const cf *sb = buf + frame * D + BPF - 1 - j;                   // q = P - 1, t = R - 1
+            const cf *sb = buf + frame * D + BPF - 1 - j + odd;             // q = P - 1, t = R - 1
 #pragma unroll
             for (int q = 0; q < P; ++q) {
                 cf x[R];
