@@ -760,3 +760,30 @@ def test_two_front_ends_on_one_gpu_do_not_disturb_each_other(gpu_required):
     # and the alone-run is the oracle's (spot check: first channel of each)
     D, taps = G.channel_params(fs_a, 12500)
     assert rel_rms(want_a[0][0], G.xlating_fir_ccc(xa, D, taps, offs_a[0], fs_a)) < 1e-5
+
+
+def test_tap_on_a_power_of_two_bank_is_the_bin(gpu_required):
+    """rcf_pfb_tap_open on a power-of-two bank (tiled ring): the tap is an ordinary 1-tap channel reading the bin's
+    tiles through the view -- bit for bit the bin, its discriminator the oracle's, across ragged block cuts."""
+    nat = gpu_required
+    fs, nb = 20e6, 256
+    bw = fs / nb
+    taps = G.low_pass_2(1.0, fs, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+    rng = np.random.default_rng(5)
+    n_frames = 700
+    k = 201
+    x = synth.awgn(rng, nb * n_frames).astype(np.complex128) * 0.05
+    x += synth.nbfm_carrier(len(x), fs, (k - nb) * fs / nb + 3000.0, 1000.0, 2500.0, 1.0)
+    x = x.astype(np.complex64)
+    with nat.Frontend(fs, block_capacity=len(x)) as fe:
+        fe.pfb_open(nb, nb, taps)
+        tap = fe.pfb_tap_open(k, gr_phase=False)
+        for lo, hi in ((0, nb * 37 + 11), (nb * 37 + 11, nb * 300), (nb * 300, len(x))):
+            fe.push(x[lo:hi])
+        y, fm = fe.chan_read_iq(tap), fe.chan_read_fm(tap, 1.0)
+        b = fe.pfb_read_bin(k)
+    assert len(y) == len(b) == n_frames
+    assert np.array_equal(y, b)
+    assert rms(fm, G.quadrature_demod_cf(b, 1.0)) < 1e-6
+    want = G.xlating_fir_exact(x, nb, taps, (k - nb) * fs / nb, fs)
+    assert rel_rms(b, want) < 2e-5
