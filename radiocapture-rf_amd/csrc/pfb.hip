@@ -99,6 +99,71 @@ __device__ __forceinline__ void pfb_pass(cf *buf, const cf *tw_lds, int tid)
     if (WAVE_LOCAL && !END_WG) wave_sync(); else __syncthreads();
 }
 
+// the FFT passes over the chunk in LDS (after the barrier that follows the branch sums' LDS writes)
+template <int NB>
+__device__ __forceinline__ void pfb_fft(cf *buf, const cf *tw_lds, int tid)
+{
+    using PL = Plan<NB>;
+    pfb_pass<NB, PL::r[0], 1, (PL::n < 2 || PL::r[1] != PL::r[0])>(buf, tw_lds, tid);
+    if constexpr (PL::n >= 2)
+        pfb_pass<NB, PL::r[1], PL::r[0], (PL::n < 3 || PL::r[2] != PL::r[1])>(buf, tw_lds, tid);
+    // a third pass (radix 2 for 512 bins, 4 for 1024) is NOT run over LDS: its butterfly j reads and writes
+    // the same R3 positions j + t NB/R3, and those are exactly the bins one epilogue lane handles (bins
+    // k0 + i NB/F), so it is done in registers on the way out -- one LDS round trip and two barriers less
+}
+
+// epilogue: LDS read transposed (lane = (bin k0, frame f_lane)), the radix-2 / 4 finish of 512 / 1024-bin banks in
+// registers, the OS = 2 bin phase factor, and the stores into the tiled ring
+template <int NB, int OS>
+__device__ __forceinline__ void pfb_epilogue(const cf *buf, const cf *tw_lds, const PfbLaunch &p,
+                                             const __amdgpu_buffer_rsrc_t out_rsrc, int64_t n0, int nf, int tid)
+{
+    using PL = Plan<NB>;
+    constexpr int RS = row_stride<NB>();
+    const int k0 = tid / F, f_lane = tid % F;
+    // tiled ring: (i >> 4) tile_pitch + 16 k + (i & 15); the lane's bins k0 + i NB / F are NB / F lines apart
+    constexpr int out_so_step = (NB / F) * F * (int)sizeof(cf);
+    const int64_t n = n0 + f_lane;
+    const int64_t ridx = (int64_t)((uint64_t)(n - p.n_abs0) & p.ring_mask);
+    const int vo = (int)(((ridx >> 4) * p.tile_pitch + k0 * F + (ridx & 15)) * (int64_t)sizeof(cf));
+    if (f_lane >= nf) return;
+    cf vv[F];
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+        const int k = k0 + i * (NB / F);
+        vv[i] = ((NB / F) % 16 == 0) ? buf[f_lane * RS + lds_pad(k0) + i * ((NB / F) + (NB / F) / 16)]
+                                     : buf[f_lane * RS + lds_pad(k)];
+    }
+    if constexpr (PL::n >= 3) {
+        constexpr int R3 = PL::r[2];                 // bins j + t NB/R3 = registers i + t F/R3
+        static_assert(PL::r[0] * PL::r[1] * R3 == NB && F % R3 == 0, "final radix must divide the chunk");
+#pragma unroll
+        for (int i = 0; i < F / R3; ++i) {
+            const int j = k0 + i * (NB / F);         // butterfly index, < NB / R3
+            cf w[R3];
+#pragma unroll
+            for (int t = 0; t < R3; ++t) w[t] = vv[i + t * (F / R3)];
+#pragma unroll
+            for (int t = 1; t < R3; ++t) w[t] = cmul(w[t], tw_lds[(j * t) & (NB - 1)]);   // W_NB^{j t}, exact entry
+            Dft<R3, +1>::run(w);
+#pragma unroll
+            for (int f = 0; f < R3; ++f) vv[i + f * (F / R3)] = w[Dft<R3, +1>::reg_of(f)];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+        const int k = k0 + i * (NB / F);
+        cf v = vv[i];
+        if (OS == 2) {
+            if ((k & 1) && (n & 1)) v = make_float2(-v.x, -v.y);
+        }
+        u32x2 o;
+        o.x = __float_as_uint(v.x);
+        o.y = __float_as_uint(v.y);
+        __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, vo, i * out_so_step, 2);   // nt: +4 %
+    }
+}
+
 // n_wg < 0: probe without the XCD-aware block -> chunk map (RCF_PFB_NOREMAP=1)
 template <int NB, int OS, int P, int MINW, bool ZH>
 __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
@@ -172,63 +237,9 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
 #pragma unroll
     for (int f = 0; f < F; ++f) buf[f * RS + lds_pad(tid)] = make_float2(ur[f], ui[f]);
     __syncthreads();
-    {
-        using PL = Plan<NB>;
-        pfb_pass<NB, PL::r[0], 1, (PL::n < 2 || PL::r[1] != PL::r[0])>(buf, tw_lds, tid);
-        if constexpr (PL::n >= 2)
-            pfb_pass<NB, PL::r[1], PL::r[0], (PL::n < 3 || PL::r[2] != PL::r[1])>(buf, tw_lds, tid);
-        // a third pass (radix 2 for 512 bins, 4 for 1024) is NOT run over LDS: its butterfly j reads and writes
-        // the same R3 positions j + t NB/R3, and those are exactly the bins one epilogue lane handles (bins
-        // k0 + i NB/F), so it is done in registers on the way out -- one LDS round trip and two barriers less
-    }
-    {
-        using PL = Plan<NB>;
-        const int k0 = tid / F, f_lane = tid % F;
-        // tiled ring: (i >> 4) tile_pitch + 16 k + (i & 15); the lane's bins k0 + i NB / F are NB / F lines apart
-        constexpr int out_so_step = (NB / F) * F * (int)sizeof(cf);
-        const int64_t n = n0 + f_lane;
-        const int64_t ridx = (int64_t)((uint64_t)(n - p.n_abs0) & p.ring_mask);
-        const int vo = (int)(((ridx >> 4) * p.tile_pitch + k0 * F + (ridx & 15)) * (int64_t)sizeof(cf));
-        if (f_lane < nf) {
-            cf vv[F];
-#pragma unroll
-            for (int i = 0; i < F; ++i) {
-                const int k = k0 + i * (NB / F);
-                vv[i] = ((NB / F) % 16 == 0) ? buf[f_lane * RS + lds_pad(k0) + i * ((NB / F) + (NB / F) / 16)]
-                                             : buf[f_lane * RS + lds_pad(k)];
-            }
-            if constexpr (PL::n >= 3) {
-                constexpr int R3 = PL::r[2];                 // bins j + t NB/R3 = registers i + t F/R3
-                static_assert(PL::r[0] * PL::r[1] * R3 == NB && F % R3 == 0, "final radix must divide the chunk");
-#pragma unroll
-                for (int i = 0; i < F / R3; ++i) {
-                    const int j = k0 + i * (NB / F);         // butterfly index, < NB / R3
-                    cf w[R3];
-#pragma unroll
-                    for (int t = 0; t < R3; ++t) w[t] = vv[i + t * (F / R3)];
-#pragma unroll
-                    for (int t = 1; t < R3; ++t) w[t] = cmul(w[t], tw_lds[(j * t) & (NB - 1)]);   // W_NB^{j t}, exact entry
-                    Dft<R3, +1>::run(w);
-#pragma unroll
-                    for (int f = 0; f < R3; ++f) vv[i + f * (F / R3)] = w[Dft<R3, +1>::reg_of(f)];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < F; ++i) {
-                const int k = k0 + i * (NB / F);
-                cf v = vv[i];
-                if (OS == 2) {
-                    if ((k & 1) && (n & 1)) v = make_float2(-v.x, -v.y);
-                }
-                u32x2 o;
-                o.x = __float_as_uint(v.x);
-                o.y = __float_as_uint(v.y);
-                __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, vo, i * out_so_step, 2);   // nt: +4 %
-            }
-        }
-    }
+    pfb_fft<NB>(buf, tw_lds, tid);
+    pfb_epilogue<NB, OS>(buf, tw_lds, p, out_rsrc, n0, nf, tid);
 }
-
 
 // Persistent form of the kernel above: the grid is one resident round of workgroups (8 XCDs x wg_per_xcd), each
 // walks the chunks  c = first(xcd) + li, + wg_per_xcd, ...  of its XCD's contiguous chunk range, and the first PF
@@ -337,57 +348,8 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_pp(PfbLaunch p, int n_chu
             }
         }
         __syncthreads();
-        {
-            using PL = Plan<NB>;
-            pfb_pass<NB, PL::r[0], 1, (PL::n < 2 || PL::r[1] != PL::r[0])>(buf, tw_lds, tid);
-            if constexpr (PL::n >= 2)
-                pfb_pass<NB, PL::r[1], PL::r[0], (PL::n < 3 || PL::r[2] != PL::r[1])>(buf, tw_lds, tid);
-        }
-        {
-            using PL = Plan<NB>;
-            const int k0 = tid / F, f_lane = tid % F;
-            // tiled ring: (i >> 4) tile_pitch + 16 k + (i & 15); the lane's bins k0 + i NB / F are NB / F lines apart
-            constexpr int out_so_step = (NB / F) * F * (int)sizeof(cf);
-            const int64_t n = n0 + f_lane;
-            const int64_t ridx = (int64_t)((uint64_t)(n - p.n_abs0) & p.ring_mask);
-            const int vo = (int)(((ridx >> 4) * p.tile_pitch + k0 * F + (ridx & 15)) * (int64_t)sizeof(cf));
-            if (f_lane < nf) {
-                cf vv[F];
-#pragma unroll
-                for (int i = 0; i < F; ++i) {
-                    const int k = k0 + i * (NB / F);
-                    vv[i] = ((NB / F) % 16 == 0) ? buf[f_lane * RS + lds_pad(k0) + i * ((NB / F) + (NB / F) / 16)]
-                                                 : buf[f_lane * RS + lds_pad(k)];
-                }
-                if constexpr (PL::n >= 3) {
-                    constexpr int R3 = PL::r[2];
-#pragma unroll
-                    for (int i = 0; i < F / R3; ++i) {
-                        const int j = k0 + i * (NB / F);
-                        cf w[R3];
-#pragma unroll
-                        for (int t = 0; t < R3; ++t) w[t] = vv[i + t * (F / R3)];
-#pragma unroll
-                        for (int t = 1; t < R3; ++t) w[t] = cmul(w[t], tw_lds[(j * t) & (NB - 1)]);
-                        Dft<R3, +1>::run(w);
-#pragma unroll
-                        for (int f = 0; f < R3; ++f) vv[i + f * (F / R3)] = w[Dft<R3, +1>::reg_of(f)];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < F; ++i) {
-                    const int k = k0 + i * (NB / F);
-                    cf v = vv[i];
-                    if (OS == 2) {
-                        if ((k & 1) && (n & 1)) v = make_float2(-v.x, -v.y);
-                    }
-                    u32x2 o;
-                    o.x = __float_as_uint(v.x);
-                    o.y = __float_as_uint(v.y);
-                    __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, vo, i * out_so_step, 2);
-                }
-            }
-        }
+        pfb_fft<NB>(buf, tw_lds, tid);
+        pfb_epilogue<NB, OS>(buf, tw_lds, p, out_rsrc, n0, nf, tid);
         if (!more) break;
         c = c_next;
         __syncthreads();                       // the epilogue's LDS reads before the next chunk's branch sums
