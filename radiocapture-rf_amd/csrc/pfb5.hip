@@ -130,6 +130,8 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
             const int64_t m_lo = (n0 - OS * (P - 1)) * D - (NB - 1);          // first sample of the window
             float h[P][R];
             int odd = 0;
+            int hq_staged = 0;                                               // (compile-time after inlining)
+            const float *h_lds = nullptr;
             if constexpr (!ZH) {
                 // steady state: the window goes global -> LDS directly (buffer_load_dwordx4 ... lds, 16 bytes per lane,
                 // a wavefront = 1 KB contiguous on both sides): no staging registers, 9 requests per thread instead of
@@ -145,11 +147,33 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
                 for (int r = 0; r < NLD; ++r)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (__attribute__((address_space(3))) void *)(lds_wave + r * PER * (int)sizeof(cf)),
                                                              16, vo0, r * PER * (int)sizeof(cf), 0, 0);
+                // The prototype taps a thread needs (P x 20 floats, the same for every chunk) are 40 dependent-address
+                // loads from L2 per thread -- global loads are what this kernel pays for most (19 table loads in the
+                // second pass cost 13 %).  As many whole rows h[q][.] as fit behind the window in the buffer go the
+                // same direct way, one or two requests per thread, and are read back from LDS (consecutive lanes =
+                // consecutive floats); the rest still comes from L2.
+                constexpr int WIN_BYTES = NLD * PER * (int)sizeof(cf);
+                constexpr int HROW = NB * (int)sizeof(float);
+                constexpr int HQ_ = ((int)(F * RS * sizeof(cf)) - WIN_BYTES) / HROW;
+                constexpr int HQ = HQ_ > P ? P : HQ_;                         // rows of h staged in LDS
+                if constexpr (HQ > 0) {
+                    const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float *>(p.ptaps), 0, P * HROW, 0x00020000);
+                    constexpr int HR = (HQ * HROW + kThreads5 * 16 - 1) / (kThreads5 * 16);
 #pragma unroll
-                for (int q = 0; q < P; ++q)
+                    for (int r = 0; r < HR; ++r)
+                        if ((r * kThreads5 + tid) * 16 < HQ * HROW)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                h_rsrc, (__attribute__((address_space(3))) void *)(lds_wave + WIN_BYTES + r * kThreads5 * 16), 16,
+                                tid * 16, r * kThreads5 * 16, 0, 0);
+                }
+#pragma unroll
+                for (int q = HQ; q < P; ++q)
 #pragma unroll
                     for (int t = 0; t < R; ++t) h[q][t] = p.ptaps[q * NB + j + BPF * t];
                 __builtin_amdgcn_s_waitcnt(0);                               // the DMA writes count on vmcnt
+                hq_staged = HQ;
+                h_lds = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(buf) + WIN_BYTES);
             } else {
                 constexpr int NLD = (WIN + kThreads5 - 1) / kThreads5;
                 const int vo0 = (int)((m_lo + tid - p.src.origin) * (int64_t)sizeof(cf));
@@ -171,6 +195,12 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
                 }
             }
             __syncthreads();
+#pragma unroll
+            for (int q = 0; q < P; ++q)
+                if (q < hq_staged) {
+#pragma unroll
+                    for (int t = 0; t < R; ++t) h[q][t] = h_lds[q * NB + j + BPF * t];
+                }
             // x[(n - OS q) D - j - BPF t] = window[(frame + OS (P - 1 - q)) D + NB - 1 - j - BPF t]
             const cf *sb = buf + frame * D + BPF - 1 - j + odd;             // q = P - 1, t = R - 1
 #pragma unroll
