@@ -68,8 +68,53 @@ static Result work(unsigned seed)
     return r;
 }
 
+// index arithmetic the kernels and the host share (rcf_internal.h): ring views, launch plans, kernel geometry
+static int check_index_math()
+{
+    // StreamView::at against the layouts it stands for
+    const int NB = 256;
+    const int64_t pitch = pfb_tile_pitch(NB);
+    if (pitch % 16 != 0 || pitch < 16 * NB) return 10;                    // whole lines, room for every bin's line
+    for (int bin : {0, 1, 37, NB - 1}) {
+        StreamView tiled{};
+        tiled.base = nullptr; tiled.mask = 4095; tiled.origin = 0; tiled.stride = pitch; tiled.tshift = kPfbTileLog2;
+        StreamView fm{};
+        fm.mask = 4095; fm.origin = 0; fm.stride = 1600; fm.tshift = 0;
+        StreamView lin{};
+        lin.mask = ~0ull; lin.origin = -777; lin.stride = 1; lin.tshift = 0;
+        for (int64_t n = 0; n < 3 * 4096; n += 7) {
+            const uint64_t i = (uint64_t)n & 4095;
+            if (tiled.at(n) + (uint64_t)bin * 16 != (i >> 4) * (uint64_t)pitch + (uint64_t)bin * 16 + (i & 15)) return 11;
+            if (fm.at(n) != i * 1600) return 12;
+            if (lin.at(n) != (uint64_t)(n + 777)) return 13;
+        }
+        // one bin's 16 frames of a tile are one 128-byte line, consecutive tiles never overlap
+        if (tiled.at(15) - tiled.at(0) != 15 || tiled.at(16) - tiled.at(0) != (uint64_t)pitch) return 14;
+    }
+    // the matrix-core launch plan: always a legal (NT, parts), parts never more than the tap chunks
+    for (int C : {8, 31, 32, 33, 256, 1024, 4096, 131072})
+        for (int T : {65, 2909, 5817})
+            for (int n_k : {1, 63, 64, 5243}) {
+                const MfmaPlan pl = mfma_plan(C, n_k, T);
+                if (pl.nt < 1 || pl.nt > 2 || pl.parts < 1 || pl.parts > 8) return 20;
+                if (pl.parts > bank2_steps(T) / kM2ChunkSteps) return 21;
+            }
+    if (bank2_steps(2909) % kM2ChunkSteps != 0 || bank2_steps(2909) * 8 < 2909) return 22;
+    // small-T kernel geometry: outputs per workgroup fit its 512 slots and its LDS tile
+    for (int D : {1, 2, 3, 12, 40})
+        for (int T : {1, 11, 69, 96, 97}) {
+            const int kb = fir_small_outputs(D, T);
+            if (T > 96 ? kb != 0 : (kb < 0 || kb > 511 || (kb > 0 && (kb < 32 || kb * D + T > 3300)))) return 30;
+        }
+    return 0;
+}
+
 int main()
 {
+    if (const int rc = check_index_math()) {
+        std::fprintf(stderr, "host_stress: index arithmetic check %d failed\n", rc);
+        return 3;
+    }
     const int kThreads = 8, kRounds = 6;
     std::vector<Result> want;
     for (int t = 0; t < kThreads; ++t) want.push_back(work((unsigned)t));
