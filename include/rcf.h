@@ -267,6 +267,16 @@ int rcf_pfb_chan_open(rcf_t *h, int bin, int channel_rate, double delta_hz, int 
  * gr_phase != 0: the channel's rotator also carries the per-output phase and magnitude increment by which GNU
  * Radio's float32 rotator differs from the bank's exact phases, so the discriminator DC matches the reference's. */
 int rcf_pfb_tap_open(rcf_t *h, int bin, int gr_phase, int *chan_id);
+/* How far bin `bin` of an exact-phase bank is from GNU Radio's own channel at that offset, before any sample is seen
+ * (no device needed).  freq_xlating_fir_filter_ccc (rc_frontend/channel.py:35) builds its composite taps as
+ * h[i] e^{j float32(i * fwT0)}; the float32 product is rounded to 2.4-9.8e-4 rad at |offset| -> fs/2,
+ * the bank's tap phases 2 pi k i / n_bins are exact.  The difference is a constant rotation (*const_phase, radians:
+ * rcf_pfb_tap_open(gr_phase) puts it into the tap's rotator) plus an error filter g[i] = h[i] (e^{j (d[i] - const)} - 1)
+ * whose output -- leakage of the whole wideband input, white input power P giving P * leak_l2^2 -- is what a bin tap
+ * cannot reproduce.  rcf/receiver.py routes a request to the direct kernel (rcf_chan_open, GNU Radio's float32 phases
+ * tap for tap) when the predicted discriminator error gain * leak_l2 * sqrt(P_wideband / P_carrier) exceeds its budget. */
+int rcf_pfb_tap_leakage(double samp_rate, int n_bins, const float *taps, int ntaps, int bin, double *leak_l2,
+                        double *const_phase);
 /* 1 when rcf_pfb_open would accept this shape (no device needed) */
 int rcf_pfb_shape_supported(int n_bins, int decim, int ntaps);
 

@@ -105,6 +105,7 @@ struct Pfb {
     bool open = false;
     bool frame_major = false;      // output ring layout (PfbLaunch.frame_major)
     int NB = 0, D = 0, T = 0, P = 0, Ppad = 0;
+    std::vector<float> proto;      // prototype taps (host): rcf_pfb_tap_open's GNU-Radio phase model needs them
     float *d_ptaps = nullptr;
     float2 *d_tw = nullptr;
     float2 *d_bins = nullptr;
@@ -1449,6 +1450,12 @@ int rcf_pfb_tap_open(rcf_t *h, int bin, int gr_phase, int *chan_id)
         d = remainderl(d, 2.0L * 3.14159265358979323846264338327950288L);
         c->extra_dangle = (double)d;
         c->extra_dlogmag = std::log(std::hypot((double)std::cos(a), (double)std::sin(a)));
+        // ... and GNU Radio's float32 tap phases float32(i * fwT0) differ from the bank's 2 pi k i / NB by a constant
+        // (their filter-weighted mean, up to ~3e-4 rad) plus rounding noise (rcf_pfb_tap_leakage): the constant is a
+        // rotation of the whole output and goes into the rotator's start phase
+        double cphase = 0.0;
+        design_tap_leakage(h->fs, p.NB, p.proto.data(), (int)p.proto.size(), bin, nullptr, &cphase);
+        c->angle0 = (long double)cphase;
         rc = upload_composite(h, c);
     }
     return rc;
@@ -1756,6 +1763,7 @@ int rcf_pfb_open(rcf_t *h, int n_bins, int decim, const float *taps, int ntaps)
     if ((size_t)P * n_bins + (size_t)decim > h->hist_cap) { set_error("history capacity %zu < P*bins", h->hist_cap); return RCF_ECAP; }
     Pfb &p = h->pfb;
     p.NB = n_bins; p.D = decim; p.T = ntaps; p.P = P;
+    p.proto.assign(taps, taps + ntaps);
     p.Ppad = pfb_padded_p(n_bins, decim, P);
     std::vector<float> pt((size_t)p.Ppad * n_bins, 0.f);
     for (int i = 0; i < ntaps; ++i) pt[i] = taps[i];          // pt[p*NB + rho] = h[NB p + rho]
@@ -1793,6 +1801,17 @@ int rcf_pfb_close(rcf_t *h)
     }
     bury(h, p.d_ptaps); bury(h, p.d_tw); bury(h, p.d_bins); bury(h, p.d_stage);
     p = Pfb();
+    return RCF_OK;
+}
+
+int rcf_pfb_tap_leakage(double samp_rate, int n_bins, const float *taps, int ntaps, int bin, double *leak_l2,
+                        double *const_phase)
+{
+    if (!(samp_rate > 0) || n_bins < 1 || !taps || ntaps < 1 || bin < 0 || bin >= n_bins) {
+        set_error("bad tap-leakage arguments");
+        return RCF_EINVAL;
+    }
+    design_tap_leakage(samp_rate, n_bins, taps, ntaps, bin, leak_l2, const_phase);
     return RCF_OK;
 }
 

@@ -168,6 +168,41 @@ void design_composite(const float *taps, int T, int D, double f0, double fs,
     incr[1] = std::sin(a);
 }
 
+// What a bin of an exact-phase filterbank differs by from GNU Radio's channel at the same offset (SURVEY.md 8(c)
+// [GR-spec] (i)): GR builds its composite taps as h[i] e^{j float32(i * fwT0)}, fwT0 = float32(2 pi f_k / fs) -- the
+// product is rounded to float32, at |i fwT0| ~ 4-9e3 rad to a grid of 2.4-9.8e-4 rad -- where the bank has
+// h[i] e^{j 2 pi k i / NB}.  d[i] = float32(i fwT0) - 2 pi k i / NB splits into a constant (the h^2-weighted mean:
+// a rotation of the whole output, returned in *const_phase and carried by the tap's rotator) and an error filter
+// g[i] = h[i] (e^{j (d[i] - const)} - 1) whose output is added to the channel: white input of power P leaks
+// P |g|_2^2 into it.  *leak_l2 = |g|_2.
+void design_tap_leakage(double fs, int n_bins, const float *taps, int T, int bin, double *leak_l2, double *const_phase)
+{
+    const int ks = bin < n_bins / 2 ? bin : bin - n_bins;
+    const double f_k = (double)ks * fs / n_bins;
+    const float fwT0 = (float)(2.0 * kPi * f_k / fs);
+    std::vector<double> d((size_t)T);
+    double sw = 0.0, swd = 0.0;
+    for (unsigned i = 0; i < (unsigned)T; ++i) {
+        const float th = (float)i * fwT0;
+        // exact phase reduced before the subtraction: k i mod NB keeps the argument small
+        const long long ki = ((long long)ks * (long long)i) % n_bins;
+        const double ex = 2.0 * kPi * (double)ki / n_bins;
+        d[i] = std::remainder((double)th - ex, 2.0 * kPi);
+        const double w = (double)taps[i] * (double)taps[i];
+        sw += w;
+        swd += w * d[i];
+    }
+    const double c = sw > 0.0 ? swd / sw : 0.0;
+    double l2 = 0.0;
+    for (int i = 0; i < T; ++i) {
+        const double e = d[i] - c;
+        const double gr = (double)taps[i] * (std::cos(e) - 1.0), gi = (double)taps[i] * std::sin(e);
+        l2 += gr * gr + gi * gi;
+    }
+    if (leak_l2) *leak_l2 = std::sqrt(l2);
+    if (const_phase) *const_phase = c;
+}
+
 }  // namespace rcfx
 
 // ---------------------------------------------------------------- Parks-McClellan (equiripple) design

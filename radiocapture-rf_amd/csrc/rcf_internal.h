@@ -26,6 +26,8 @@ std::vector<float> design_low_pass_2(double gain, double fs, double fc, double t
 void design_composite(const float *taps, int T, int D, double f0, double fs,
                       std::vector<float> &ctaps_interleaved, float incr[2]);
 
+void design_tap_leakage(double fs, int n_bins, const float *taps, int T, int bin, double *leak_l2, double *const_phase);
+
 // ---------------------------------------------------------------- host peak picker (rcf_peaks.cpp)
 int64_t find_peaks_host(const float *spectrum, int64_t n, double min_w, double max_w, double prominence,
                         int64_t *idx, int64_t cap, double *mean_out);

@@ -34,36 +34,50 @@ class channel:
         self.channel_close_time = 0
         self._started = False
 
-    def _build(self, offset):
-        """(re)create the native channel for `offset`: a filterbank bin when the request is on the bank's grid
-        (the intent of connect_channel_pfb, receiver.py:343-383: bin = round(offset / grid), residual handled
-        separately -- here a non-zero residual simply takes the direct path), else the direct xlating FIR."""
-        frontend, channel_rate, samp_rate = self.frontend, self.channel_rate, self.samp_rate
-        self.pfb_bin = None
+    def _target_bin(self, offset):
+        """the bank bin that serves `offset`, or None for the direct kernel (the intent of connect_channel_pfb,
+        receiver.py:343-383: bin = round(offset / grid); a non-zero residual simply takes the direct path, and so
+        does a bin whose exact phases are too far from GNU Radio's float32 ones for the discriminator budget --
+        receiver._open_pfb)"""
         pfb = self.pfb
-        if pfb is not None and self.parent_chan is None and channel_rate == pfb["channel_rate"]:
-            k = int(round(offset / pfb["grid"]))
-            if offset == k * pfb["grid"] and abs(k) <= pfb["n_bins"] // 2 and abs(offset) < samp_rate / 2:
-                self.pfb_bin = k % pfb["n_bins"]               # receiver.py:373-375: wrap negative bins
+        if pfb is None or self.parent_chan is not None or self.channel_rate != pfb["channel_rate"]:
+            return None
+        k = int(round(offset / pfb["grid"]))
+        if offset != k * pfb["grid"] or abs(k) > pfb["n_bins"] // 2 or not abs(offset) < self.samp_rate / 2:
+            return None
+        from .receiver import receiver
+        if not receiver.pfb_serves_bin(pfb, k):
+            return None
+        return k % pfb["n_bins"]                               # receiver.py:373-375: wrap negative bins
+
+    def _build(self, offset):
+        """(re)create the native channel for `offset`: a filterbank bin when _target_bin() names one, else the direct
+        xlating FIR.  The object's state changes only after the native open succeeded."""
+        frontend, channel_rate, samp_rate = self.frontend, self.channel_rate, self.samp_rate
+        pfb = self.pfb
+        bin_ = self._target_bin(offset)
         # rc_frontend/channel.py:31-35: decim = int(fs/cr)/2, low_pass_2(1.0, fs, cr/2, cr/2, 20, HAMMING);
         # the C ABI derives both (rcf_chan_open) and rejects non-integral decimations
-        if self.pfb_bin is not None:
-            self.chan_id = frontend.pfb_tap_open(self.pfb_bin, gr_phase=True)
+        if bin_ is not None:
+            chan_id = frontend.pfb_tap_open(bin_, gr_phase=True)
+            self.chan_id, self.pfb_bin = chan_id, bin_
             self.decim, self.ntaps = pfb["decim"], pfb["ntaps"]
             self.out_rate = samp_rate / pfb["decim"]
             return
         if self.parent_chan is None:
-            self.chan_id = frontend.chan_open(channel_rate, offset)
+            chan_id = frontend.chan_open(channel_rate, offset)
         else:
             from . import native
             decim, ntaps = native.channel_params(samp_rate, channel_rate)
             taps = native.design_low_pass_2(1.0, samp_rate, channel_rate / 2, channel_rate / 2, 20.0)
             assert len(taps) == ntaps
-            self.chan_id = frontend.chan_open_taps(self.parent_chan, decim, taps, offset)
-        info = frontend.chan_info(self.chan_id)
+            chan_id = frontend.chan_open_taps(self.parent_chan, decim, taps, offset)
+        info = frontend.chan_info(chan_id)
+        self.chan_id, self.pfb_bin = chan_id, None
         self.decim = info["decim"]
         self.ntaps = info["ntaps"]
         self.out_rate = info["out_rate"]
+
     def __str__(self):
         return "Channel: port:%s channel_rate:%s samp_rate:%s offset:%s init_time:%s" % (
             self.port, self.channel_rate, self.samp_rate, self.offset, self.init_time)
@@ -89,19 +103,22 @@ class channel:
         return self.offset
 
     def set_offset(self, offset):
-        """channel.py:61-63 -> prefilter.set_center_freq: retune, rotator phase and history kept."""
-        self.offset = offset
-        if self.pfb is None:
-            self.frontend.chan_set_offset(self.chan_id, offset)
-            return
-        # filterbank mode: a channel may move between bins, or between a bin and the direct kernel; the native
-        # channel is rebuilt (the reference only retunes channels it is re-using after they sat idle)
-        k = int(round(offset / self.pfb["grid"]))
-        if self.pfb_bin is None and offset != k * self.pfb["grid"]:
+        """channel.py:61-63 -> prefilter.set_center_freq.  A direct channel is retuned in place: rotator phase and
+        FIR history kept, as GNU Radio does.  In filterbank mode a retune that changes the serving path (another bin,
+        bin -> direct, direct -> bin) replaces the native channel: the new one starts with zero history and a fresh
+        rotator, and symbol-filter / voice-chain attachments of the old id are gone (the reference only retunes
+        channels it is re-using after they sat idle, receiver.py:311-319)."""
+        new_bin = self._target_bin(offset)
+        if new_bin is None and self.pfb_bin is None:
             self.frontend.chan_set_offset(self.chan_id, offset)        # direct stays direct
+            self.offset = offset
+            return
+        if new_bin is not None and new_bin == self.pfb_bin:
+            self.offset = offset                                       # same bin: nothing to do
             return
         old = self.chan_id
-        self._build(offset)
+        self._build(offset)                                            # raises before any state changed
+        self.offset = offset
         self.frontend.chan_close(old)
 
     def destroy(self):

@@ -36,6 +36,7 @@ SYMBOLS = [
     "rcf_chan_audio_close", "rcf_chan_audio_produced", "rcf_chan_read_audio",
     "rcf_host_alloc", "rcf_host_free", "rcf_comm_unique_id", "rcf_comm_init", "rcf_comm_destroy", "rcf_comm_size",
     "rcf_allgather_peaks", "rcf_allreduce_max", "rcf_pfb_tap_open", "rcf_pfb_shape_supported",
+    "rcf_pfb_tap_leakage",
 ]
 FMT_U8, FMT_S8, FMT_S16 = 1, 2, 3
 T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY, T_FIR_MFMA, T_AUDIO = range(9)
@@ -114,6 +115,8 @@ def lib():
         "rcf_pfb_chan_open": (C.c_int, [vp, C.c_int, C.c_int, C.c_double, ip]),
         "rcf_pfb_tap_open": (C.c_int, [vp, C.c_int, C.c_int, ip]),
         "rcf_pfb_shape_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+        "rcf_pfb_tap_leakage": (C.c_int, [C.c_double, C.c_int, fp, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double)]),
         "rcf_scan_start": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "rcf_scan_result": (C.c_int, [vp, fp]),
         "rcf_scan_frames_done": (C.c_int, [vp]),
@@ -220,6 +223,16 @@ def channel_params(samp_rate, channel_rate):
 
 def pfb_shape_supported(n_bins, decim, ntaps) -> bool:
     return bool(lib().rcf_pfb_shape_supported(int(n_bins), int(decim), int(ntaps)))
+
+
+def pfb_tap_leakage(samp_rate, n_bins, taps, bin):
+    """(leak_l2, const_phase) of rcf_pfb_tap_leakage: how far bin `bin` of an exact-phase bank is from GNU Radio's
+    float32-phase channel at the same offset."""
+    t = np.ascontiguousarray(taps, dtype=np.float32)
+    l2, cp = C.c_double(), C.c_double()
+    _check(lib().rcf_pfb_tap_leakage(float(samp_rate), int(n_bins), _fp(t), len(t), int(bin), C.byref(l2),
+                                     C.byref(cp)))
+    return l2.value, cp.value
 
 
 def find_peaks(spectrum, min_w, max_w, prominence=1.0, cap=4096):

@@ -15,6 +15,7 @@ from __future__ import annotations
 import logging
 import random
 import threading
+import math
 import time
 import uuid
 
@@ -102,7 +103,45 @@ class receiver:
             return None
         taps = native.design_low_pass_2(1.0, samp_rate, cr / 2, cr / 2, 20.0)
         fe.pfb_open(int(n_bins), decim, taps)
-        return {"n_bins": int(n_bins), "grid": grid, "decim": decim, "ntaps": ntaps, "channel_rate": cr}
+        plan = {"n_bins": int(n_bins), "grid": grid, "decim": decim, "ntaps": ntaps, "channel_rate": cr,
+                "samp_rate": samp_rate, "taps": taps, "leak": {}}
+        # Parity routing.  A bin of the bank has exact tap phases; GNU Radio's channel at the same offset has
+        # float32-rounded ones (freq_xlating_fir_filter_ccc: float32(i * fwT0)) -- a per-bin error filter
+        # the bank cannot reproduce (native.pfb_tap_leakage).  A request is served by its bin only while the
+        # discriminator error predicted from that filter stays inside the budget; otherwise it takes the direct
+        # kernel, which carries GNU Radio's phases tap for tap.
+        #   predicted fm rms = gain * margin * leak_l2(bin) * 10^(env_db / 20)
+        #   gain    discriminator gain the consumers use (P25: out_rate / (2 pi 600), p25_control_demod.py:120)
+        #   env_db  wideband input power over the served carrier's power.  Default = the SURVEY 8(d) cfg2 stream:
+        #           unit-variance noise + 32 carriers of +30 dB in 12.5 kHz at 20 Msps, 10 log10(21 / 0.625)
+        #   margin  the leakage is not white (images of strong carriers); 2.4 was the largest measured / predicted
+        #           ratio over all 1600 bins (profiles/r03_pfb_allbins_vs_gr.json)
+        budget = getattr(self.config, "pfb_parity_budget", 1e-4)
+        plan["parity"] = None if budget is None else {
+            "budget": float(budget),
+            "gain": float(getattr(self.config, "pfb_parity_gain", (samp_rate / decim) / (2 * math.pi * 600.0))),
+            "env_db": float(getattr(self.config, "pfb_parity_env_db", 10 * math.log10(21.0 / 0.625))),
+            "margin": float(getattr(self.config, "pfb_parity_margin", 2.5)),
+        }
+        return plan
+
+    @staticmethod
+    def pfb_predicted_fm_error(plan, k):
+        """discriminator rms error predicted for bin k served by the bank (see _open_pfb); 0.0 when routing is off"""
+        from . import native
+        par = plan.get("parity")
+        if par is None:
+            return 0.0
+        k %= plan["n_bins"]
+        if k not in plan["leak"]:
+            plan["leak"][k] = native.pfb_tap_leakage(plan["samp_rate"], plan["n_bins"], plan["taps"], k)[0]
+        return par["gain"] * par["margin"] * plan["leak"][k] * 10 ** (par["env_db"] / 20)
+
+    @staticmethod
+    def pfb_serves_bin(plan, k):
+        """True when the parity budget lets the bank's bin k stand in for GNU Radio's channel at that offset"""
+        par = plan.get("parity")
+        return par is None or receiver.pfb_predicted_fm_error(plan, k) <= par["budget"]
 
     # ------------------------------------------------------------------ data plane
     def feed(self, source_id, iq):

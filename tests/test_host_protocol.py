@@ -1,6 +1,7 @@
 """Host-side mirror of the reference's control plane, checked against goldens captured from the
 reference itself (tests/golden/protocol.json, made by tests/golden/make_protocol_goldens.py)."""
 import json
+import math
 import os
 import random
 import types
@@ -361,6 +362,89 @@ def test_pfb_mode_routes_on_grid_requests_to_bins_and_the_rest_to_the_direct_ker
     assert tb3.sources[0]["pfb"] is None and StubFrontend.instances[-1].pfb is None
     b8, _ = tb3.connect_channel(12500, 854987500)
     assert tb3.channels[b8].pfb_bin is None
+
+
+def test_pfb_mode_parity_budget_routes_high_offset_bins_to_the_direct_kernel():
+    """the bank's tap phases are exact, GNU Radio's are float32(i * fwT0) -- a per-bin error
+    filter (rcf_pfb_tap_leakage) that grows with |offset| (2.4e-4 .. 9.8e-4 rad grid above ~fs/8).
+    A request whose predicted discriminator error exceeds pfb_parity_budget takes the direct kernel; the default
+    budget is the north-star bar in the cfg2 environment, pfb_parity_budget = None turns the routing off."""
+    from rcf import native
+    fs = 20000000
+    cfg = types.SimpleNamespace(sources={0: dict(type="synthetic", center_freq=855000000, samp_rate=fs)},
+                                frontend_mode="pfb")
+    tb = receiver.receiver(cfg, frontend_factory=StubPfbFrontend)
+    fe = StubFrontend.instances[-1]
+    plan = tb.sources[0]["pfb"]
+    par = plan["parity"]
+    assert par["budget"] == 1e-4 and abs(par["gain"] - 25000.0 / (2 * math.pi * 600)) < 1e-9
+    served, routed = [], []
+    for k in (8, 80, -160, 401, -560, 700, 799, -799):
+        bid, _ = tb.connect_channel(12500, 855000000 + k * 12500)
+        ch = tb.channels[bid]
+        pred = receiver.receiver.pfb_predicted_fm_error(plan, k)
+        l2, _ = native.pfb_tap_leakage(fs, 1600, plan["taps"], k % 1600)
+        assert abs(pred - par["gain"] * par["margin"] * l2 * 10 ** (par["env_db"] / 20)) < 1e-12
+        if pred <= par["budget"]:
+            assert ch.pfb_bin == k % 1600 and fe.chans[ch.chan_id]["bin"] == k % 1600
+            served.append(k)
+        else:
+            assert ch.pfb_bin is None and fe.chans[ch.chan_id]["cr"] == 12500 and fe.chans[ch.chan_id]["off"] == k * 12500
+            routed.append(k)
+    # low offsets stay on the bank, the band edge goes direct
+    assert 8 in served and 80 in served and 799 in routed and -799 in routed
+    # the prediction is monotone in the float32 exponent ranges: no bin above fs/4 is cheaper than one below fs/32
+    assert receiver.receiver.pfb_predicted_fm_error(plan, 799) > 4 * receiver.receiver.pfb_predicted_fm_error(plan, 40)
+    # retune of a served channel to a routed bin moves it to the direct kernel, same object
+    bid, _ = tb.connect_channel(12500, 855000000 + 16 * 12500)
+    ch = tb.channels[bid]
+    assert ch.pfb_bin == 16
+    ch.set_offset(799 * 12500.0)
+    assert ch.pfb_bin is None and fe.chans[ch.chan_id]["off"] == 799 * 12500.0
+    ch.set_offset(799 * 12500.0 + 50.0)                       # direct stays direct: retuned in place
+    assert fe.chans[ch.chan_id]["off"] == 799 * 12500.0 + 50.0
+    # a failed open leaves the object as it was (ADVICE r02)
+    old_id = ch.chan_id
+    def boom(*a, **k):
+        raise RuntimeError("no slot")
+    fe.pfb_tap_open, keep = boom, fe.pfb_tap_open
+    with pytest.raises(RuntimeError):
+        ch.set_offset(16 * 12500.0)
+    assert ch.chan_id == old_id and ch.pfb_bin is None and ch.offset == 799 * 12500.0 + 50.0
+    fe.pfb_tap_open = keep
+    # routing off: every on-grid request is a bin
+    cfg2 = types.SimpleNamespace(sources={0: dict(type="synthetic", center_freq=855000000, samp_rate=fs)},
+                                 frontend_mode="pfb", pfb_parity_budget=None)
+    tb2 = receiver.receiver(cfg2, frontend_factory=StubPfbFrontend)
+    bid, _ = tb2.connect_channel(12500, 855000000 + 799 * 12500)
+    assert tb2.channels[bid].pfb_bin == 799
+
+
+def test_tap_leakage_matches_the_float32_phase_model():
+    """rcf_pfb_tap_leakage against a numpy restatement of its definition: d[i] = float32(i * float32(2 pi f_k / fs))
+    - 2 pi k i / NB, const = h^2-weighted mean, leak = |h (e^{j (d - const)} - 1)|_2; and against the oracle's own
+    GNU-Radio composite taps (the error filter IS composite_GR - e^{j const} composite_exact)."""
+    from oracle import grspec as G
+    from rcf import native
+    fs, nb = 20e6, 1600
+    D, taps = G.channel_params(fs, 12500)
+    i = np.arange(len(taps), dtype=np.float64)
+    h = taps.astype(np.float64)
+    for k in (0, 1, 80, 401, 799, 800, 801, 1163, 1599):
+        ks = k if k < nb // 2 else k - nb
+        fw = np.float32(2 * np.pi * (ks * fs / nb) / fs)
+        th = (np.arange(len(taps), dtype=np.float32) * fw).astype(np.float64)
+        d = th - 2 * np.pi * ks * i / nb
+        c = np.sum(h * h * d) / np.sum(h * h)
+        want = np.sqrt(np.sum(np.abs(h * (np.exp(1j * (d - c)) - 1)) ** 2))
+        l2, cp = native.pfb_tap_leakage(fs, nb, taps, k)
+        assert abs(cp - c) < 1e-9 and abs(l2 - want) <= 1e-9 + 1e-6 * want, (k, l2, want, cp, c)
+        ct, _ = G.xlating_composite(taps, D, ks * fs / nb, fs)
+        g = ct.astype(np.complex128) - np.exp(1j * c) * h * np.exp(2j * np.pi * ks * i / nb)
+        assert abs(np.sqrt(np.sum(np.abs(g) ** 2)) - l2) < 3e-8       # float32 taps: 6e-8 relative per tap
+    assert native.pfb_tap_leakage(fs, nb, taps, 0) == (0.0, 0.0)
+    with pytest.raises(native.RcfError):
+        native.pfb_tap_leakage(fs, nb, taps, nb)
 
 
 def test_rep_loop_survives_handler_errors_and_egress_isolates_channels():
