@@ -25,6 +25,12 @@ Outside the timed region, rank 0 at N = 1 also reports:
   cpu_baseline           the oracle's C port of the reference path on the host cores (+ the parity check of the
                          timed configuration's FM outputs against the oracle)
 
+--config cfg5 = BASELINE configs[4]'s per-GPU shape instead (25 Msps slice, 512-bin bank, N = 2^20 / 1000 / 100 scan on
+the slice, <= 1024 peaks per rank into the all-gather); the default (cfg4) is configs[1] / configs[3].
+
+`sustained`: the metric says "sustained" -- after the timed region the same commit loop runs for >= 2 s and reports the
+filterbank launch time per window of 100 launches (first, last, slowest) with the shader clock read from sysfs.
+
 Launch: python bench.py [--gpus 1 --steps K --warmup W]   or, for N > 1,
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
@@ -46,17 +52,70 @@ NB = 256
 N_ACTIVE = 32
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 FP32_MATRIX_PEAK_TF = 157.3    # MI355X_MICROARCH.md: FP32 matrix = FP32 vector peak
+SCAN_CEILING_NOTE = ("a 1M-point FFT cannot live in LDS: the four-step form moves 8+8 B (columns) + 8+4 B (rows) "
+                     "+ 4+4 B (running sum) = 36 B/sample against 12 B algorithmic, at the 5.5 TB/s a plain copy "
+                     "sustains on this chip: ceiling 12/36 x 5.5/8 = 0.23 of the HBM peak (DESIGN 4.4)")
 
 
-def proto_taps(native):
+def proto_taps(native, fs=FS, nb=NB):
     # SURVEY 8(d) cfg2 prototype by the reference's own low_pass_2 rule: fc = 0.4 bin, tw = 0.2 bin,
-    # 60 dB, Blackman-Harris -> 3491 taps (13.6 per branch)
-    bw = FS / NB
-    return native.design_low_pass_2(1.0, FS, 0.4 * bw, 0.2 * bw, 60.0, native.WIN_BLACKMAN_HARRIS)
+    # 60 dB, Blackman-Harris -> 3491 taps (13.6 per branch) at 256 bins, 6983 at 512
+    bw = fs / nb
+    return native.design_low_pass_2(1.0, fs, 0.4 * bw, 0.2 * bw, 60.0, native.WIN_BLACKMAN_HARRIS)
+
+
+def read_sclk_mhz(device=0):
+    """current shader clock from sysfs (pp_dpm_sclk marks the active level with '*'); None when not exposed"""
+    import glob
+    best = None
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            for line in open(f):
+                if "*" in line:
+                    best = float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+            if best is not None:
+                return best
+        except Exception:
+            continue
+    return best
+
+
+def sustained_leg(fe, native, B, alg_bytes, seconds=2.0, window=100):
+    """>= `seconds` of back-to-back commits of the resident block, the filterbank launch timed with HIP events on
+    librcf's stream and read back every `window` launches (one stream sync per window: < 0.5 % of the time).
+    The fraction that counts as sustained is the LAST window's."""
+    fe.sync()
+    fe.timing_enable(True, classes=[native.T_PFB])
+    fe.timing_read(native.T_PFB)
+    wins, clocks = [], []
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(window):
+            fe.commit(B)
+        clocks.append(read_sclk_mhz())                 # the GPU is still busy: the host runs <= 2 commits ahead
+        ms, n = fe.timing_read(native.T_PFB)
+        wins.append(ms / max(n, 1))
+        if time.perf_counter() - t0 >= seconds and len(wins) >= 3:
+            break
+    wall = time.perf_counter() - t0
+    fe.timing_enable(False)
+    frac = lambda ms: alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    ck = [c for c in clocks if c]
+    return {
+        "seconds": wall, "launches": len(wins) * window, "window": window,
+        "kernel_us_first_window": wins[0] * 1e3, "kernel_us_last_window": wins[-1] * 1e3,
+        "kernel_us_slowest_window": max(wins) * 1e3, "kernel_us_fastest_window": min(wins) * 1e3,
+        "frac_first_window": frac(wins[0]), "frac_last_window": frac(wins[-1]), "frac_slowest_window": frac(max(wins)),
+        "wall_ms_per_step": wall / (len(wins) * window) * 1e3,
+        "sclk_mhz_first": ck[0] if ck else None, "sclk_mhz_last": ck[-1] if ck else None,
+        "kernel_us_by_window": [round(w * 1e3, 2) for w in wins[:: max(1, len(wins) // 32)]],
+        "note": "HIP events around every filterbank launch, read back per window of %d launches; sclk from "
+                "/sys/class/drm/card*/device/pp_dpm_sclk while the queue is full" % window,
+    }
 
 
 # ------------------------------------------------------------------------------------------- CPU baseline leg
-def cpu_baseline(tile, carriers, fm_check=None, seconds=0.5, reps=3):
+def cpu_baseline(tile, carriers, fm_check=None, seconds=0.5, reps=3, FS=FS):
     """The reference's structure on the host cores: one 2909-tap xlating FIR (D=800) + discriminator per
     channel over the whole 20 Msps stream (rc_frontend/channel.py:31-38), oracle C port.  This leg is the only
     place bench.py touches oracle/: as the timed CPU baseline and as the checker of the GPU's FM outputs."""
@@ -98,10 +157,10 @@ def cpu_baseline(tile, carriers, fm_check=None, seconds=0.5, reps=3):
         "cores_are": "hardware threads (OpenMP max threads of the box%s)" % (
             "; %d physical cores" % phys if phys else ""),
         "kind": "port",
-        "sample": "%.2f s of the same 20 Msps synthetic stream, %d concurrent 12.5 kHz channels "
-                  "(2909-tap xlating FIR /800 + discriminator each, one per host thread), median of %d, OpenMP over channels; "
+        "sample": "%.2f s of the same %g Msps synthetic stream, %d concurrent 12.5 kHz channels "
+                  "(%d-tap xlating FIR /%d + discriminator each, one per host thread), median of %d, OpenMP over channels; "
                   "CPU restatement of the reference's GNU Radio path (GNU Radio itself unavailable)"
-                  % (seconds, len(offs), reps),
+                  % (seconds, FS / 1e6, len(offs), len(taps), D, reps),
         "channels": len(offs),
         "realtime_channels_at_20Msps": len(offs) * seconds / t,
         "single_channel_one_core": {"seconds_per_second_of_signal": t1 / seconds,
@@ -238,6 +297,7 @@ def reference_grid_leg(native, tile, device, B=1 << 25, n_taps=256):
         return pfb_ms / max(pn, 1), disc_ms / max(dn, 1), wall * 1e3
 
     bank_ms, _, bank_wall = timed()
+    sustained = sustained_leg(fe, native, B, 24.0 * B)
     ids = [fe.pfb_tap_open((7 + 6 * i) % 1600, gr_phase=True) for i in range(n_taps)]
     fe.commit(B)
     tap_ms, disc_ms, tap_wall = timed()
@@ -253,6 +313,7 @@ def reference_grid_leg(native, tile, device, B=1 << 25, n_taps=256):
         "reference_channels_per_frontend": 1600,
         "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": alg, "achieved": alg / (bank_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (bank_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "sustained": sustained,
         "with_taps": {"bins_tapped": n_taps, "note": "taps (GNU Radio rotator per tap) served inside the bank's kernel "
                       "from LDS; one discriminator launch behind it",
                       "pfb_ms_per_block": tap_ms, "discriminator_ms_per_block": disc_ms,
@@ -302,8 +363,7 @@ def scan_leg(native, synth, device):
                          "achieved": 12.0 * samples / ((fft_ms + mov_ms) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s",
                          "frac": 12.0 * samples / ((fft_ms + mov_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "ceiling_note": "a 1M-point FFT cannot live in LDS: the four-step form moves 28 B/sample "
-                                         "against 12 B algorithmic, so its ceiling is 12/28 = 0.43 of the HBM peak"},
+                         "ceiling_note": SCAN_CEILING_NOTE},
         }
     fe.close()
     return res
@@ -390,8 +450,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--block", type=int, default=1 << 25, help="samples per step (resident batch)")
+    ap.add_argument("--config", choices=["cfg4", "cfg5"], default="cfg4",
+                    help="cfg4: BASELINE configs[1] per GPU (x N = configs[3]); cfg5: BASELINE configs[4]'s per-GPU shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs (sweep, scan, end-to-end, ...)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained leg")
     ap.add_argument("--sweep-max", type=int, default=196608, help="largest direct-bank channel count to open")
     args = ap.parse_args()
 
@@ -408,13 +471,19 @@ def main():
     if native.device_count() < 1:
         raise RuntimeError("bench.py needs an MI355X (no HIP device visible)")
 
+    cfg5 = args.config == "cfg5"
+    # cfg5 (BASELINE configs[4]): 8 spectrum slices of 25 Msps, a 512-bin bank each = 4096 channels at 200 Msps
+    # aggregate; every rank scans its slice (N = 2^20, 1000 frames, 100-frame average: fft_vector.py:31-60) and
+    # contributes <= 1024 peaks (fft_peak_detection.py:38-73) to the all-gather
+    fs, nb, n_active = (25e6, 512, 0) if cfg5 else (FS, NB, N_ACTIVE)
+    SCAN_N, SCAN_F, SCAN_L = 1 << 20, 1000, 100
     B = args.block
-    assert B % NB == 0
-    frames = B // NB
+    assert B % nb == 0 and (not cfg5 or B % SCAN_N == 0)
+    frames = B // nb
     out_cap = 1
     while out_cap < 2 * frames:
         out_cap <<= 1
-    fe = native.Frontend(FS, 0.0, device=local_rank, block_capacity=B, hist_capacity=1 << 16,
+    fe = native.Frontend(fs, 0.0, device=local_rank, block_capacity=B, hist_capacity=SCAN_N if cfg5 else 1 << 16,
                          out_capacity=out_cap)
     group = None
     use_rccl = os.environ.get("RCF_BENCH_TRANSPORT", "rccl") == "rccl"
@@ -442,11 +511,21 @@ def main():
             use_rccl = all(p == b"1" for p in group.all_gather(b"1" if ok else b"0"))
             if not use_rccl:
                 fe.comm_destroy()
-    taps = proto_taps(native)
-    fe.pfb_open(NB, NB, taps)
-    tile, meta = synth.cfg2(n=1 << 20, seed=2002 if n_gpus == 1 else 4000 + rank, n_bins=NB,
-                            n_active=N_ACTIVE)
-    chans = [fe.pfb_chan_open(c["bin"] % NB, 12500, c["delta"]) for c in meta["carriers"]]
+    taps = proto_taps(native, fs, nb)
+    fe.pfb_open(nb, nb, taps)
+    if cfg5:
+        # the slice's stream: a 16-frame periodic tile with 12 scan-shaped carriers (SURVEY 8(d) cfg3's recipe at
+        # 25 Msps: occupied widths 4-9 kHz = 170-380 bins of 23.8 Hz, inside find_peaks' [126, 1258] window)
+        rng = np.random.default_rng(5000 + rank)
+        centres = [40000 + 80000 * i + int(rng.integers(-3000, 3000)) for i in range(12)]
+        scan_carriers = [(c, float(rng.uniform(4000, 9000)), 45.0) for c in centres]
+        tile = synth.scan_stream(fs, SCAN_N, 16, scan_carriers, seed=5000 + rank)
+        meta = {"carriers": [{"f_off": (k - nb // 2 + 0.5) * fs / nb * 0.9} for k in range(0, nb, nb // 32)]}
+        chans = []
+    else:
+        tile, meta = synth.cfg2(n=1 << 20, seed=2002 if n_gpus == 1 else 4000 + rank, n_bins=nb,
+                                n_active=n_active)
+        chans = [fe.pfb_chan_open(c["bin"] % nb, 12500, c["delta"]) for c in meta["carriers"]]
 
     # make the batch resident in both ping-pong buffers (not timed: "inputs already resident in HBM")
     for _ in range(2):
@@ -480,7 +559,7 @@ def main():
     pfb_ms, pfb_n = fe.timing_read(native.T_PFB)
     # the FM channels' newest outputs, for the parity check against the oracle (done in the cpu_baseline leg)
     fm_check = None
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and chans:
         fm_check = {"taps": taps, "total_in": fe.samples_in, "carriers": meta["carriers"],
                     "fm": [fe.chan_read_fm(c, 1.0, max_samples=out_cap) for c in chans]}
     # per-kernel breakdown of the other launches: a few extra, untimed steps with every class instrumented
@@ -494,17 +573,50 @@ def main():
     disc_ms, _ = fe.timing_read(native.T_DISC)
     hist_ms, _ = fe.timing_read(native.T_HISTORY)
     fe.timing_enable(False)
-    assert fe.chan_produced(chans[0]) > 0            # the FM channels really produced output
+    if chans:
+        assert fe.chan_produced(chans[0]) > 0        # the FM channels really produced output
 
-    # ---- peak-list all-gather (BASELINE configs[4] collective), outside the timed region
-    allgather_us, gathered_n = None, None
-    if group is not None:
-        fe.scan_start(16384, 8, 4)
-        fe.commit(B)
+    alg_bytes = 16.0 * B                              # 8 B read + 8 B written per input sample (critically sampled)
+    sustained = None
+    if not args.no_sustained:                         # every rank runs it (the ranks stay in step); rank 0 reports
+        sustained = sustained_leg(fe, native, B, alg_bytes)
+        if group is not None:
+            sustained["kernel_us_last_window_max_over_ranks"] = barrier_max(sustained["kernel_us_last_window"])
+
+    # ---- scan of the rank's slice (cfg5) and the peak-list all-gather, outside the timed region
+    allgather_us, gathered_n, scan_out = None, None, None
+    freqs = []
+    if cfg5:
+        fe.timing_enable(True, classes=[native.T_SCAN_FFT, native.T_SCAN_MOVSUM])
+        fe.timing_read(native.T_SCAN_FFT)
+        fe.timing_read(native.T_SCAN_MOVSUM)
+        fe.scan_start(SCAN_N, SCAN_F, SCAN_L)
+        ts = time.perf_counter()
+        while fe.scan_frames_done() < SCAN_F:
+            fe.commit(B)                              # the bank keeps running: scan and channelizer share the stream
+        fe.sync()
+        scan_wall = time.perf_counter() - ts
+        fft_ms, _ = fe.timing_read(native.T_SCAN_FFT)
+        mov_ms, _ = fe.timing_read(native.T_SCAN_MOVSUM)
+        fe.timing_enable(False)
+        tp = time.perf_counter()
         idx, _, _ = fe.scan_find_peaks(cap=1024)
-        freqs = [native.peak_frequency(int(i), FS, 16384, 851e6 + 25e6 * rank) for i in idx]
-        if not freqs:                                # the filterbank tile has no scan-shaped carriers: exchange its
-            freqs = [int(851e6 + 25e6 * rank + c["f_off"]) for c in meta["carriers"]]   # 32 known ones instead
+        pick_ms = (time.perf_counter() - tp) * 1e3
+        centre = 851e6 + fs * rank                    # slice g is centred fs * g above the first
+        freqs = [native.peak_frequency(int(i), fs, SCAN_N, centre) for i in idx]
+        scan_out = {"workload": "N=2^20, 1000 frames, 100-frame average over the rank's 25 Msps slice, 12 carriers",
+                    "fft_logmag_ms": fft_ms, "moving_sum_ms": mov_ms, "peak_pick_ms_incl_readback": pick_ms,
+                    "wall_ms_with_the_bank_running": scan_wall * 1e3, "peaks_found_rank0": int(len(idx)),
+                    "scan_ms_max_over_ranks": barrier_max(fft_ms + mov_ms),
+                    "realtime_factor_at_25Msps": float(SCAN_N) * SCAN_F / fs / ((fft_ms + mov_ms) * 1e-3)}
+    if group is not None:
+        if not cfg5:
+            fe.scan_start(16384, 8, 4)
+            fe.commit(B)
+            idx, _, _ = fe.scan_find_peaks(cap=1024)
+            freqs = [native.peak_frequency(int(i), fs, 16384, 851e6 + 25e6 * rank) for i in idx]
+            if not freqs:                            # the filterbank tile has no scan-shaped carriers: exchange its
+                freqs = [int(851e6 + 25e6 * rank + c["f_off"]) for c in meta["carriers"]]   # 32 known ones instead
         gather = (lambda: multigpu.allgather_peaks(fe, freqs)) if use_rccl else \
                  (lambda: multigpu.allgather_peaks_host(group, freqs))
         gather()                                     # warm-up (RCCL ring setup)
@@ -513,23 +625,35 @@ def main():
         everyone = gather()
         allgather_us = barrier_max((time.perf_counter() - ta) * 1e6)
         gathered_n = len(everyone)
+    pfb_avg_ms_max = barrier_max(pfb_ms / max(pfb_n, 1)) if group is not None else pfb_ms / max(pfb_n, 1)
 
     if rank == 0:
         total_samples = float(B) * args.steps * n_gpus
         value = total_samples / elapsed / 1e6
         avg_pfb_s = (pfb_ms / max(pfb_n, 1)) * 1e-3
-        alg_bytes = 16.0 * B                                  # 8 B read + 8 B written per input sample
         achieved = alg_bytes / avg_pfb_s / 1e9 if avg_pfb_s > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pfb_traffic.json")
+        traffic, traffic_src = None, None
+        tname = "pfb512_traffic.json" if cfg5 else "pfb_traffic.json"
+        tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
                     tj = json.load(f)
                 if tj.get("block") == B:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s (not measured " \
+                                  "in this run)" % (tname, tj.get("measured", "an earlier run of this configuration"))
             except Exception:
                 traffic = None
+        if cfg5:
+            workload = ("BASELINE configs[4], per-GPU shape: 512-bin critically-sampled PFB (6983-tap prototype) over "
+                        "one 25 Msps cf32 spectrum slice per GPU (x8 = 4096 channels at 200 Msps), N=2^20 scan of the "
+                        "slice + <=1024 peaks per rank into the all-gather outside the timed region")
+            kname = "pfb_kernel_pp<512,1,14,...> (persistent form)"
+        else:
+            workload = ("BASELINE configs[1]: 256-bin critically-sampled PFB (3491-tap prototype) over one "
+                        "20 Msps cf32 stream per GPU, stage-2 xlating FIR /3 + FM discriminator on 32 active bins")
+            kname = "pfb_kernel_os<256,1,14,4,false>"
         out = {
             "metric": "input IQ Msamples/s + concurrent 12.5 kHz FM channels sustained",
             "value": value,
@@ -544,20 +668,21 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: 256-bin critically-sampled PFB (3491-tap prototype) over one "
-                            "20 Msps cf32 stream per GPU, stage-2 xlating FIR /3 + FM discriminator on 32 active bins",
-                "samp_rate": FS, "pfb_bins": NB, "fm_channels_per_gpu": N_ACTIVE,
+                "workload": workload,
+                "samp_rate": fs, "pfb_bins": nb, "fm_channels_per_gpu": n_active,
                 "block_samples": B, "parallelism": "1 front-end per GPU x%d" % n_gpus,
             },
-            "channels": {"pfb_bins_total": NB * n_gpus, "fm_demod_total": N_ACTIVE * n_gpus,
-                         "realtime_factor_at_20Msps": value / n_gpus / (FS / 1e6)},
+            "channels": {"pfb_bins_total": nb * n_gpus, "fm_demod_total": n_active * n_gpus,
+                         "realtime_factor_at_%dMsps" % int(fs / 1e6): value / n_gpus / (fs / 1e6)},
             "roofline": {
-                "bound": "hbm", "kernel": "pfb_kernel_os<256,1,14,4,false>",
+                "bound": "hbm", "kernel": kname,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_pfb_s * 1e3, "launches": pfb_n,
+                "avg_launch_ms_slowest_rank": pfb_avg_ms_max,
+                "frac_slowest_rank": alg_bytes / (pfb_avg_ms_max * 1e-3) / 1e9 / HBM_PEAK_GBS if pfb_avg_ms_max > 0 else 0.0,
             },
             "kernel_ms_per_step": {
                 "pfb": pfb_ms / max(pfb_n, 1),
@@ -566,17 +691,23 @@ def main():
                 "history_copy": hist_ms / max(n_extra, 1),
             },
         }
+        if sustained is not None:
+            out["sustained"] = sustained
+        if scan_out is not None:
+            out["scan"] = scan_out
         if allgather_us is not None:
             out["peaks_allgather_us"] = allgather_us
             out["peaks_allgather"] = {"transport": "ncclAllGather via rcf_allgather_peaks" if use_rccl else "host TCP",
-                                      "values_gathered": gathered_n, "ranks": world}
+                                      "values_gathered": gathered_n, "ranks": world,
+                                      "peaks_from": "N=2^20 scan of each rank's slice" if cfg5 else
+                                                    "16384-point scan / the tile's known carriers"}
     fe.close()
     if group is not None:
         group.close()
     if rank != 0:
         return
 
-    extras = n_gpus == 1 and not args.no_extras
+    extras = n_gpus == 1 and not args.no_extras and not cfg5
     if extras:
         # the bandwidth-bound legs first: seconds of matrix-core work at full power (the sweep) leave the chip at
         # lower clocks for whatever runs next (measured: the same filterbank launch 0.112 ms before it, 0.139 after)
@@ -587,7 +718,11 @@ def main():
         counts = [c for c in (256, 1024, 4096, 16384, 65536, 131072, 196608) if c <= args.sweep_max]
         out["channels"]["direct_bank"] = direct_bank_sweep(native, tile, local_rank, counts)
     if n_gpus == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(tile, meta["carriers"], fm_check)
+        if cfg5:
+            # same structure on the slice's stream: the reference would run one 3637-tap xlating FIR /1000 per channel
+            out["cpu_baseline"] = cpu_baseline(tile[: 1 << 20], meta["carriers"], None, FS=fs)
+        else:
+            out["cpu_baseline"] = cpu_baseline(tile, meta["carriers"], fm_check)
         db = out["channels"].get("direct_bank")
         if db:
             out["cpu_baseline"]["gpu_channels_run_in_real_time_over_cpu_realtime_channels"] = (

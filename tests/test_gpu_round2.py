@@ -396,9 +396,12 @@ def test_pfb_mode_end_to_end_through_create_channel(gpu_required):
     rng = np.random.default_rng(17)
     n_out = 900
     x = synth.awgn(rng, D * n_out).astype(np.complex128)
-    offs_grid = [1000000.0, -5012500.0, 9987500.0, -62500.0]
+    # bins inside the parity budget (receiver._open_pfb: |offset| up to ~3.2 MHz at 20 Msps); 9.9875 MHz is on the grid
+    # but over the budget -- GNU Radio's float32 tap phases are 4.9e-4 rad coarse there -- and goes direct (below)
+    offs_grid = [1000000.0, -2012500.0, 3000000.0, -62500.0]
+    off_routed = 9987500.0
     off_direct = 3003125.0                                # 6.25 kHz raster: not a bin of the 12.5 kHz bank
-    for f in offs_grid + [off_direct]:
+    for f in offs_grid + [off_direct, off_routed]:
         x += synth.nbfm_carrier(len(x), fs, f, 1000.0, 2500.0, synth.snr_amp(30.0, 12500.0, fs))
     x = x.astype(np.complex64)
     gain = G.p25_fm_gain(25000.0)
@@ -437,20 +440,21 @@ def test_pfb_mode_end_to_end_through_create_channel(gpu_required):
         # discriminator: the north-star bar.  IQ: the bank's exact tap phases vs GNU Radio's float32-rounded ones
         # (a -80 dBc leakage floor at |offset| -> fs/2) -- reported by the delta test, bounded here
         assert rms(fm[8:], fo[0][8:]) < 1e-4, (f, rms(fm[8:], fo[0][8:]))
-        assert rel_rms(y[8:], yo[0][8:]) < 2e-3, (f, rel_rms(y[8:], yo[0][8:]))
-    # and the off-grid request, same front-end: direct kernel, full parity
+        assert rel_rms(y[8:], yo[0][8:]) < 1e-4, (f, rel_rms(y[8:], yo[0][8:]))
+    # and the off-grid request + the on-grid one over the parity budget, same front-end: direct kernel, full parity
     tb = receiver.receiver(cfg, frontend_factory=lambda sr, cf, dev: native.Frontend(sr, cf, device=dev,
                                                                                       block_capacity=len(x)))
     try:
-        bid, _ = tb.connect_channel(12500, int(fc_hz + off_direct))
-        assert tb.channels[bid].pfb_bin is None
+        bids = [tb.connect_channel(12500, int(fc_hz + f))[0] for f in (off_direct, off_routed)]
+        assert all(tb.channels[b].pfb_bin is None for b in bids)
         tb.feed(0, x)
-        y, fm = tb.channels[bid].read_iq(), tb.channels[bid].read_fm(gain)
+        outs = [(tb.channels[b].read_iq(), tb.channels[b].read_fm(gain)) for b in bids]
     finally:
         tb.close()
-    ct, incr = OC.xlating_composite(taps, D, off_direct, fs)
-    yo, fo = OC.channel_bank(x, D, ct[None, :], np.array([incr]), gains=[gain])
-    assert rel_rms(y, yo[0]) < 1e-5 and rms(fm, fo[0]) < 1e-4
+    for f, (y, fm) in zip((off_direct, off_routed), outs):
+        ct, incr = OC.xlating_composite(taps, D, f, fs)
+        yo, fo = OC.channel_bank(x, D, ct[None, :], np.array([incr]), gains=[gain])
+        assert rel_rms(y, yo[0]) < 1e-5 and rms(fm, fo[0]) < 1e-4
 
 
 def test_threads_feed_control_read_concurrently(gpu_required):

@@ -107,8 +107,8 @@ def test_pfb_mode_every_on_grid_request_meets_the_fm_bar(gpu_required):
         "bank_tap_fm_rms_max_all_bins": max(r["bank_tap_fm_rms"] for r in table),
         "bank_tap_bins_over_1e-4": sum(1 for r in table if r["bank_tap_fm_rms"] > 1e-4),
         "measured_over_predicted_max_margin_removed":
-            max(r["bank_tap_fm_rms"] / max(r["predicted_fm_rms"] / plan["parity"]["margin"], 1e-12) for r in table
-                if r["leak_l2"] > 0),
+            max(r["bank_tap_fm_rms"] / (r["predicted_fm_rms"] / plan["parity"]["margin"]) for r in table
+                if r["predicted_fm_rms"] / plan["parity"]["margin"] > 1e-5),   # below that the float32 floor dominates
     }
     _dump("r03_pfb_allbins_vs_gr.json", {
         "fs": fs, "bins": nb, "decim": D, "taps": len(taps), "outputs": n_out, "fm_gain": gain,
@@ -125,46 +125,67 @@ def test_pfb_mode_every_on_grid_request_meets_the_fm_bar(gpu_required):
 
 
 def test_direct_channel_iq_error_growth_over_a_million_outputs(gpu_required):
-    """The direct kernel's rotator is GNU Radio's in closed form (float64 model of the float32 increment); GNU Radio
-    iterates phase *= incr in float32, whose rounding is a random walk the closed form cannot follow.
-    10^6 outputs (40 s of a 25 kS/s channel) against the oracle, which iterates like GNU Radio: the IQ error grows
-    like sqrt(n) -- a slowly wandering common phase -- and the discriminator (phase differences) does not see it.
-    Reports the relative IQ error per decade of n and asserts the law; written to gpurun_out/r03_iq_drift.json."""
+    """The direct kernel's rotator is GNU Radio's in closed form (a float64 model of the float32 increment); GNU Radio
+    iterates phase *= incr in float32.  10^6 outputs (40 s of a 25 kS/s channel) against the oracle, which
+    iterates like GNU Radio, for three increments:
+      generic     the per-output angle is nowhere near a multiple of pi/2: the iteration's rounding is a random walk,
+                  the IQ error grows like sqrt(n);
+      quarter / half   f0 D / fs = 3/4 and 1/2 -- what EVERY on-grid channel of the reference's plan has (fs = 20 M,
+                  D = 800, 12.5 kHz raster: angle = -pi k + float32 rounding): one component of incr is ~1e-7, its
+                  products fall under half an ulp of the other and are absorbed or not depending on the phase --
+                  GNU Radio's own rotator then turns at a rate that is not the angle of its increment, and the closed
+                  form (which follows the increment) parts from it LINEARLY, up to half an ulp (6e-8 rad) per output.
+    In every case the difference is a slowly turning common phase: removing a constant + slope per window leaves the
+    summation-order floor, and the discriminator (phase differences) does not see it -- fm rms <= 1e-6 throughout.
+    Reports per decade of n to gpurun_out/r03_iq_drift.json."""
     nat = gpu_required
     fs, D, cr = 400e3, 8, 12500
-    # channel.py's own rule at 400 kS/s: D = int(fs / cr) / 2 = 16 would need 1.6e7 inputs; D = 8 halves the stream
     taps = G.low_pass_2(1.0, fs, cr, cr / 2, 20.0, G.WIN_HAMMING)
-    f0 = 37500.0
+    cases = [("generic", 37213.0), ("quarter_turn", 37500.0), ("half_turn", 25000.0)]
     n_out = 1 << 20
     rng = np.random.default_rng(31)
     x = synth.awgn(rng, D * n_out)
-    x += synth.nbfm_carrier(len(x), fs, f0, 1000.0, 2500.0, synth.snr_amp(30.0, 12500.0, fs)).astype(np.complex64)
+    for _, f0 in cases:
+        x += synth.nbfm_carrier(len(x), fs, f0, 1000.0, 2500.0, synth.snr_amp(30.0, 12500.0, fs)).astype(np.complex64)
     blk = 1 << 19
     with nat.Frontend(fs, block_capacity=blk, out_capacity=1 << 17) as fe:
-        cid = fe.chan_open_taps(-1, D, taps, f0)
-        ys, fms = [], []
+        cids = [fe.chan_open_taps(-1, D, taps, f0) for _, f0 in cases]
+        ys, fms = [[] for _ in cases], [[] for _ in cases]
         for at in range(0, len(x), blk):
             fe.push(x[at:at + blk])
-            ys.append(fe.chan_read_iq(cid))
-            fms.append(fe.chan_read_fm(cid, 1.0))
-    y, fm = np.concatenate(ys), np.concatenate(fms)
-    ct, incr = OC.xlating_composite(taps, D, f0, fs)
-    yo, fo = OC.channel_bank(x, D, ct[None, :], np.array([incr]), gains=[1.0])
-    yo, fo = yo[0], fo[0]
-    assert len(y) == len(yo) == n_out
-    rows = []
-    for n in (1000, 10000, 100000, 1000000, n_out):
-        w = slice(n // 2, n)
-        e = rel_rms(y[w], yo[w])
-        # the error is a common rotation: remove the best-fit phase and what is left is the summation-order floor
-        rot = np.vdot(yo[w].astype(np.complex128), y[w].astype(np.complex128))
-        e_rot = rel_rms(y[w] * np.exp(-1j * np.angle(rot)), yo[w])
-        rows.append({"n": n, "iq_rel_rms": e, "common_phase_rad": float(np.angle(rot)), "iq_rel_rms_phase_removed": e_rot,
-                     "fm_rms": rms(fm[w], fo[w])})
-    _dump("r03_iq_drift.json", {"fs": fs, "decim": D, "taps": len(taps), "offset_hz": f0, "outputs": n_out, "rows": rows,
-                               "law": "iq_rel_rms(n) <= 2e-7 + 1.5e-7 * sqrt(n): float32 rotator rounding random walk"})
-    for r in rows:
-        assert r["iq_rel_rms"] <= 2e-7 + 1.5e-7 * math.sqrt(r["n"]), r
-        assert r["iq_rel_rms_phase_removed"] < 2e-6, r        # nothing but a common phase wanders
-        assert r["fm_rms"] < 1e-4, r
-    assert rms(fm[8:], fo[8:]) < 1e-5
+            for j, cid in enumerate(cids):
+                ys[j].append(fe.chan_read_iq(cid))
+                fms[j].append(fe.chan_read_fm(cid, 1.0))
+    out = {"fs": fs, "decim": D, "taps": len(taps), "outputs": n_out, "cases": []}
+    for j, (name, f0) in enumerate(cases):
+        y, fm = np.concatenate(ys[j]), np.concatenate(fms[j])
+        ct, incr = OC.xlating_composite(taps, D, f0, fs)
+        yo, fo = OC.channel_bank(x, D, ct[None, :], np.array([incr]), gains=[1.0])
+        yo, fo = yo[0], fo[0]
+        assert len(y) == len(yo) == n_out
+        rows = []
+        for n in (1000, 10000, 100000, 1000000, n_out):
+            w = slice(n // 2, n)
+            e = rel_rms(y[w], yo[w])
+            # phase of y relative to the oracle over the window: constant + slope, then what is left
+            d = np.angle(y[w].astype(np.complex128) * np.conj(yo[w].astype(np.complex128)))
+            t = np.arange(len(d), dtype=np.float64)
+            wgt = np.abs(yo[w]).astype(np.float64) ** 2
+            A = np.vstack([np.ones_like(t), t - t.mean()]).T * np.sqrt(wgt)[:, None]
+            c0, c1 = np.linalg.lstsq(A, d * np.sqrt(wgt), rcond=None)[0]
+            e_res = rel_rms(y[w] * np.exp(-1j * (c0 + c1 * (t - t.mean()))), yo[w])
+            rows.append({"n": n, "iq_rel_rms": e, "common_phase_rad": float(c0), "phase_slope_rad_per_output": float(c1),
+                         "iq_rel_rms_phase_removed": e_res, "fm_rms": rms(fm[w], fo[w])})
+        out["cases"].append({"case": name, "offset_hz": f0, "incr": [float(incr.real), float(incr.imag)], "rows": rows})
+        for r in rows:
+            assert r["iq_rel_rms_phase_removed"] < 2e-6, (name, r)     # nothing but a common phase wanders
+            assert r["fm_rms"] < 1e-6, (name, r)
+            if name == "generic":
+                assert r["iq_rel_rms"] <= 2e-7 + 1.5e-7 * math.sqrt(r["n"]), (name, r)
+            else:
+                assert r["iq_rel_rms"] <= 2e-7 + 3e-8 * r["n"], (name, r)   # half an ulp per output, worst case
+        assert rms(fm[8:], fo[8:]) < 1e-6
+    out["law"] = ("generic increments: iq_rel_rms(n) <= 2e-7 + 1.5e-7 sqrt(n) (random walk of the float32 iteration); "
+                  "increments within ~1e-6 of a multiple of pi/2 per output (all on-grid channels of a 12.5 kHz plan at "
+                  "D = 800): GNU Radio's iteration absorbs the small component, bound 3e-8 n; always a common phase only")
+    _dump("r03_iq_drift.json", out)

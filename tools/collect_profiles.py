@@ -40,25 +40,28 @@ def short(name):
     return m.group(0) if m else name
 
 
-# ---- timed configuration: PFB traffic
-v = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    v[c], name = counters("gpurun_out/%s_pmc_%s" % (R, c), "pfb_kernel")
-if v["FETCH_SIZE"].get("FETCH_SIZE") is not None and v["WRITE_SIZE"].get("WRITE_SIZE") is not None:
-    fetch = v["FETCH_SIZE"]["FETCH_SIZE"] * 1024 * 2       # KiB -> B, gfx950 x2 correction (MI355X_MICROARCH.md)
-    write = v["WRITE_SIZE"]["WRITE_SIZE"] * 1024
-    B = 1 << 25
-    json.dump({"block": B, "kernel": short(name), "launches_averaged": v["FETCH_SIZE"].get("launches_averaged"),
-               "FETCH_SIZE_KiB_raw": v["FETCH_SIZE"]["FETCH_SIZE"], "WRITE_SIZE_KiB_raw": v["WRITE_SIZE"]["WRITE_SIZE"],
-               "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
-               "algorithmic_bytes_per_launch": 16.0 * B,
-               "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of `rocprofv3 --pmc X --kernel-trace -- python "
-                       "bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras`; KiB units and the gfx950 FETCH_SIZE x2 "
-                       "correction per MI355X_MICROARCH.md; counters sit at the L2<->fabric boundary, so Infinity-Cache "
-                       "hits are included"}, open("profiles/pfb_traffic.json", "w"), indent=1)
-    print("traffic: fetch %.1f MB write %.1f MB (algorithmic %.1f MB)" % (fetch / 1e6, write / 1e6, 16.0 * B / 1e6))
-else:
-    print("traffic: counters missing")
+# ---- timed configurations: PFB traffic (cfg4 -> pfb_traffic.json, cfg5 -> pfb512_traffic.json)
+when = open("gpurun_out/%s_when.txt" % R).read().strip() if os.path.exists("gpurun_out/%s_when.txt" % R) else "?"
+for tag, fname, flag in (("pmc", "pfb_traffic.json", ""), ("pmc5", "pfb512_traffic.json", " --config cfg5")):
+    v = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        v[c], name = counters("gpurun_out/%s_%s_%s" % (R, tag, c), "pfb_kernel")
+    if v["FETCH_SIZE"].get("FETCH_SIZE") is not None and v["WRITE_SIZE"].get("WRITE_SIZE") is not None:
+        fetch = v["FETCH_SIZE"]["FETCH_SIZE"] * 1024 * 2       # KiB -> B, gfx950 x2 correction (MI355X_MICROARCH.md)
+        write = v["WRITE_SIZE"]["WRITE_SIZE"] * 1024
+        B = 1 << 25
+        json.dump({"block": B, "kernel": short(name), "measured": "%s make_profiles run of %s" % (R, when),
+                   "launches_averaged": v["FETCH_SIZE"].get("launches_averaged"),
+                   "FETCH_SIZE_KiB_raw": v["FETCH_SIZE"]["FETCH_SIZE"], "WRITE_SIZE_KiB_raw": v["WRITE_SIZE"]["WRITE_SIZE"],
+                   "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+                   "algorithmic_bytes_per_launch": 16.0 * B,
+                   "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of `rocprofv3 --pmc X --kernel-trace -- python "
+                           "bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-sustained%s`; KiB units and the "
+                           "gfx950 FETCH_SIZE x2 correction per MI355X_MICROARCH.md; counters sit at the L2<->fabric "
+                           "boundary, so Infinity-Cache hits are included" % flag}, open("profiles/" + fname, "w"), indent=1)
+        print("%s: fetch %.1f MB write %.1f MB (algorithmic %.1f MB)" % (fname, fetch / 1e6, write / 1e6, 16.0 * B / 1e6))
+    else:
+        print("%s: counters missing" % fname)
 
 
 def pmc_record(tag, kernel, out, extra):
@@ -77,7 +80,7 @@ def pmc_record(tag, kernel, out, extra):
         print("wrote", out)
 
 
-pmc_record("%s_fir4096" % R, "fir_mfma", "profiles/%s_fir_mfma_pmc.json" % R, {
+pmc_record("%s_fir4096" % R, "fir_mfma_kernel<", "profiles/%s_fir_mfma_pmc.json" % R, {
     "workload": "tools/fir_probe.py C=4096: 4096 reference-shaped channels (D=800, T=2909), 20 Msps, block 2^22",
     "ideal_mfma_instructions": 4096 * 5243 * 2909 * 8 / 2048.0,
     "how_to_read": "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); clock = "
@@ -86,18 +89,28 @@ pmc_record("%s_fir4096" % R, "fir_mfma", "profiles/%s_fir_mfma_pmc.json" % R, {
 pmc_record("%s_pfb512" % R, "pfb_kernel", "profiles/%s_pfb512_traffic.json" % R, {
     "workload": "tools/pfb_probe.py NB=512: 512-bin critically sampled bank (persistent form pfb_kernel_pp), block 2^25; algorithmic 16 B/sample = 536.9 MB",
     "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
+pmc_record("%s_pfb1024" % R, "pfb_kernel", "profiles/%s_pfb1024_traffic.json" % R, {
+    "workload": "tools/pfb_probe.py NB=1024: 1024-bin critically sampled bank (persistent form pfb_kernel_pp), block 2^25; algorithmic 16 B/sample = 536.9 MB",
+    "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
 pmc_record("%s_pfb1600" % R, "pfb5_kernel", "profiles/%s_pfb1600_pmc.json" % R, {
     "workload": "tools/pfb_probe.py NB=1600 BLOCK=2^25: 1600-bin bank, D = 800, 2909 taps; algorithmic 24 B/sample = 805.3 MB",
     "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
 
-src = "gpurun_out/%s_bench.json" % R
-if os.path.exists(src):
-    lines = [l for l in open(src).read().splitlines() if l.startswith("{")]
-    if lines:
-        open("profiles/%s_bench.json" % R, "w").write(lines[-1] + "\n")
+for tag in ("bench", "bench_cfg5", "bench_head_under_rocprof"):
+    src = "gpurun_out/%s_%s.json" % (R, tag)
+    if os.path.exists(src):
+        lines = [l for l in open(src).read().splitlines() if l.startswith("{")]
+        if lines:
+            open("profiles/%s_%s.json" % (R, tag), "w").write(lines[-1] + "\n")
 f = newest("gpurun_out/%s_trace/**/*kernel_stats.csv" % R)
 if f:
     shutil.copy(f, "profiles/%s_bench_kernel_stats.csv" % R)
+f5 = newest("gpurun_out/%s_trace_cfg5/**/*kernel_stats.csv" % R)
+if f5:
+    shutil.copy(f5, "profiles/%s_bench_cfg5_kernel_stats.csv" % R)
+f = newest("gpurun_out/%s_trace_legs/**/*kernel_stats.csv" % R)
+if f:
+    shutil.copy(f, "profiles/%s_bench_legs_kernel_stats.csv" % R)
     rows = [r for r in csv.DictReader(open(f)) if re.search(r"scan|movsum|k_pick|k_prep|k_min|k_tables|k_sort", r["Name"])]
     if rows:
         with open("profiles/%s_scan_kernel_stats.csv" % R, "w", newline="") as fh:

@@ -1,31 +1,41 @@
 #!/bin/bash
-# Regenerate profiles/ for a round on the GPU box:  tools/make_profiles.sh r02
-#   1. bench.py JSON line (full run)
-#   2. rocprofv3 --kernel-trace --stats of the same command (kernel summary CSV, all legs except the CPU baseline)
-#   3. separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over the timed configuration -> profiles/pfb_traffic.json
-#   4. counters of the matrix-core FIR bank at 4096 channels -> profiles/<R>_fir_mfma_pmc.json
-#   5. counters + traffic of the 512-bin and the 1600-bin filterbank -> profiles/<R>_pfb512_traffic.json, <R>_pfb1600_pmc.json
+# Regenerate profiles/ for a round on the GPU box:  tools/make_profiles.sh r03
+#   1. bench.py JSON line (full run, the driver's command) and the cfg5 line
+#   2. rocprofv3 --kernel-trace --stats of the HEADLINE: the same configuration with the untimed legs off
+#      (--no-extras --no-cpu-baseline --no-sustained), so that every filterbank launch in the trace is a 2^25-sample
+#      launch of the timed configuration and the kernel's row equals roofline.avg_launch_ms
+#   3. the same for the untimed legs (all of them except the CPU baseline) -> <R>_bench_legs_kernel_stats.csv
+#   4. separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over the timed configuration -> profiles/pfb_traffic.json, and over
+#      --config cfg5 -> profiles/pfb512_traffic.json
+#   5. counters of the matrix-core FIR bank at 4096 channels -> profiles/<R>_fir_mfma_pmc.json
+#   6. counters + traffic of the 512-, 1024- and 1600-bin filterbanks
 # gpurun merges only gpurun_out/ back: run `python tools/collect_profiles.py <R>` locally afterwards.
 # Counter passes never share a run with trace domains other than --kernel-trace.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 cd "$(dirname "$0")/.."
 ROOT=$PWD
 mkdir -p profiles gpurun_out
 export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 20 --warmup 3"
+date -u +%Y-%m-%dT%H:%MZ > gpurun_out/${R}_when.txt
 
-python bench.py --steps 20 --warmup 3 > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
+python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
+python bench.py --steps 20 --warmup 5 --config cfg5 > gpurun_out/${R}_bench_cfg5.json 2> gpurun_out/${R}_bench_cfg5.err
 
-rm -rf gpurun_out/${R}_trace
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace -- $CMD --no-cpu-baseline --sweep-max 16384 > /dev/null 2>&1)
+HEAD="python $ROOT/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-sustained"
+rm -rf gpurun_out/${R}_trace gpurun_out/${R}_trace_legs gpurun_out/${R}_trace_cfg5
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace -- $HEAD > gpurun_out_head.json 2>/dev/null; cp gpurun_out_head.json $ROOT/gpurun_out/${R}_bench_head_under_rocprof.json)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace_cfg5 -- $HEAD --config cfg5 > /dev/null 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace_legs -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sustained --sweep-max 16384 > /dev/null 2>&1)
 
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf gpurun_out/${R}_pmc_$c
-  (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $ROOT/gpurun_out/${R}_pmc_$c -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1)
+  rm -rf gpurun_out/${R}_pmc_$c gpurun_out/${R}_pmc5_$c
+  (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $ROOT/gpurun_out/${R}_pmc_$c -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-sustained > /dev/null 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $ROOT/gpurun_out/${R}_pmc5_$c -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-sustained --config cfg5 > /dev/null 2>&1)
 done
 
 tools/fir_pmc.sh ${R}_fir4096 C=4096 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb_kernel tools/fir_pmc.sh ${R}_pfb512 NB=512 > /dev/null 2>&1
+PROBE=tools/pfb_probe.py KERNEL=pfb_kernel tools/fir_pmc.sh ${R}_pfb1024 NB=1024 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb5_kernel tools/fir_pmc.sh ${R}_pfb1600 NB=1600 BLOCK=33554432 > /dev/null 2>&1
 echo done
