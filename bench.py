@@ -64,17 +64,18 @@ def proto_taps(native, fs=FS, nb=NB):
     return native.design_low_pass_2(1.0, fs, 0.4 * bw, 0.2 * bw, 60.0, native.WIN_BLACKMAN_HARRIS)
 
 
-def read_sclk_mhz(device=0):
-    """current shader clock from sysfs (pp_dpm_sclk marks the active level with '*'); None when not exposed"""
+def read_sclk_mhz():
+    """current shader clock from sysfs (pp_dpm_sclk marks the active level with '*').  A box exposes every GPU of the
+    node there, idle ones included, and nothing maps a HIP device to its card index without the PCI bus id: the busy
+    GPU is the one with the highest current clock, so report the maximum.  None when nothing is exposed."""
     import glob
     best = None
-    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+    for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
         try:
             for line in open(f):
                 if "*" in line:
-                    best = float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
-            if best is not None:
-                return best
+                    v = float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+                    best = v if best is None else max(best, v)
         except Exception:
             continue
     return best
@@ -455,6 +456,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs (sweep, scan, end-to-end, ...)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained leg")
+    ap.add_argument("--prewarm-seconds", type=float, default=0.5,
+                    help="untimed commits before the warm-up steps: the metric is SUSTAINED throughput, and the chip "
+                         "needs ~100 launches (15 ms) after idling before the filterbank launch settles (the first "
+                         "window of the sustained leg shows it); 0 = none")
     ap.add_argument("--sweep-max", type=int, default=196608, help="largest direct-bank channel count to open")
     args = ap.parse_args()
 
@@ -541,6 +546,12 @@ def main():
             return v
         return fe.allreduce_max(v) if use_rccl else group.max(v)
 
+    tp = time.perf_counter()
+    n_prewarm = 0
+    while time.perf_counter() - tp < args.prewarm_seconds:
+        for _ in range(32):
+            fe.commit(B)
+        n_prewarm += 32
     for _ in range(args.warmup):
         fe.commit(B)
     # HIP events only around the kernel the roofline reports: every timed launch costs two event records on the
@@ -661,6 +672,8 @@ def main():
             "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm": {"seconds": args.prewarm_seconds, "untimed_steps": n_prewarm,
+                        "why": "steady state before the W warm-up steps (metric: sustained); see `sustained`"},
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",

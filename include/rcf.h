@@ -235,7 +235,7 @@ int rcf_source_shift(rcf_t *h, double delta_hz);
  * pfb.channelizer_ccf branch of rc_frontend/receiver.py:242-261.  Output: n_bins streams at fs/decim.
  * Supported shapes (anything else: RCF_EINVAL):
  *   n_bins in {64, 128, 256, 512, 1024}, n_bins / decim in {1, 2}, up to 16 taps per branch
- *   n_bins in {400, 800, 1600, 3200},    n_bins / decim in {1, 2, 4}, up to 4 (decim = n_bins) or 2 taps per branch
+ *   n_bins in {400, 800, 1600, 3200},    n_bins / decim = 1 with up to 4 taps per branch, 2 with up to 2, 4 with 1
  * The second family is what makes the bins the REFERENCE's channels: with the reference's own channel filter
  * (rcf_channel_params: decim = int(fs/cr)/2, low_pass_2(1, fs, cr/2, cr/2, 20, HAMMING)) at fs = 20 Msps,
  * cr = 12.5 kHz -- decim 800, 2909 taps -- a 1600-bin bank is every 12.5 kHz-grid channel and a 3200-bin bank every

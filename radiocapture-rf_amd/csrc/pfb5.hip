@@ -404,7 +404,7 @@ bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s)
 {
     if (p.D <= 0 || p.NB % p.D) return false;
     const int OS = p.NB / p.D;
-    const int PR = p.P <= 1 ? 1 : (p.P <= 2 ? 2 : (p.P <= 4 ? 4 : 0));
+    const int PR = pfb5_padded_p(p.NB, p.D, p.P);
     if (PR == 0) return false;
 #define RCF_PFB5(R_, R3_, OS_, P_)                                  \
     if (p.NB == R_ * R_ * R3_ && OS == OS_ && PR == P_) {            \
@@ -419,10 +419,16 @@ bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s)
     return false;
 }
 
+// rows of the polyphase table the instantiation for (NB / D, P) reads (zero padded by rcf_pfb_open); 0: no kernel.
+// Instantiated: OS = 1 with 4 taps per branch, OS = 2 with 1 or 2, OS = 4 with 1 -- fewer taps run the next larger one.
 int pfb5_padded_p(int NB, int D, int P)
 {
-    (void)NB; (void)D;
-    return P <= 1 ? 1 : (P <= 2 ? 2 : 4);
+    if (D <= 0 || NB % D || P < 1) return 0;
+    const int OS = NB / D;
+    if (OS == 1) return P <= 4 ? 4 : 0;
+    if (OS == 2) return P <= 1 ? 1 : (P <= 2 ? 2 : 0);
+    if (OS == 4) return P <= 1 ? 1 : 0;
+    return 0;
 }
 
 }  // namespace rcfx

@@ -695,7 +695,7 @@ int process_block(rcf_t *h, size_t n)
             std::vector<ChanLaunch> clean, rest, fixups;
             std::vector<Chan *> clean_ch;
             int n_common_of_clean = max_n;
-            if (shared_src && depth == 0 && mfma2_applicable(D, T, h->hist_cap) && !h->no_mfma) {
+            if (shared_src && depth == 0 && mfma2_applicable(D, T, h->hist_cap, h->hist_cap + h->block_cap) && !h->no_mfma) {
                 int64_t k_common = -1;
                 int32_t n_common = 0;
                 for (auto &L : launches)                                   // the range most channels share: the earliest

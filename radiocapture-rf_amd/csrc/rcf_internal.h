@@ -125,9 +125,12 @@ __host__ __device__ inline int bank2_steps(int T)
     return (s + kM2ChunkSteps - 1) / kM2ChunkSteps * kM2ChunkSteps;
 }
 __host__ __device__ inline size_t bank2_group_floats(int T) { return (size_t)bank2_steps(T) * 1024; }
-inline bool mfma2_applicable(int D, int T, size_t hist_cap)
+// buf_samples: hist_cap + block_cap of the wideband buffer -- the kernel addresses it with 32-bit byte offsets of one
+// buffer descriptor, so it must stay under 2 GiB (larger handles keep the vector kernel, which indexes in 64 bits)
+inline bool mfma2_applicable(int D, int T, size_t hist_cap, size_t buf_samples)
 {
-    return D >= 1 && T >= 64 && (size_t)(8 * bank2_steps(T) + 8 + D) <= hist_cap;
+    return D >= 1 && T >= 64 && (size_t)(8 * bank2_steps(T) + 8 + D) <= hist_cap &&
+           (uint64_t)buf_samples * sizeof(float2) < (1ull << 31);
 }
 
 // Work split of one matrix-core launch.  A workgroup is 4 waves x NT tiles of 16 outputs for one group of 32

@@ -37,7 +37,12 @@ fe.timing_enable(True, classes=None if os.environ.get('TIME_ALL') else [native.T
 for _ in range(steps): fe.commit(B)
 ms, n = fe.timing_read(native.T_PFB)
 ms /= n
+extra = ""
+if os.environ.get('TIME_ALL'):
+    d2, n2 = fe.timing_read(native.T_FIR_DERIVED)
+    d3, n3 = fe.timing_read(native.T_DISC)
+    extra = "  derived-FIR %.4f ms/block  disc %.4f ms/block" % (d2 / steps, d3 / steps)
 gbs = (8.0 * B + 8.0 * B * osf) / (ms * 1e-3) / 1e9
 print("NB=%d OS=%d taps=%d remap=%s : %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (
     nb, osf, len(taps),
-    "off" if os.environ.get("RCF_PFB_NOREMAP") else "on", ms, gbs, gbs / 80.0))
+    "off" if os.environ.get("RCF_PFB_NOREMAP") else "on", ms, gbs, gbs / 80.0) + extra + ("  taps=%d" % ntap))
