@@ -112,7 +112,8 @@ int rcf_device(rcf_t *h);
 #define RCF_T_HISTORY      6   /* history carry-over copy */
 #define RCF_T_FIR_MFMA     7   /* the same bank on the FP32 matrix cores (>= 8 channels on one source) */
 #define RCF_T_AUDIO        8   /* analog voice chain (squelch/demod/de-emphasis walk, FIRs, resampler) */
-#define RCF_T_COUNT        9
+#define RCF_T_TAPS         9   /* filterbank taps: tap matrix -> channel rings, rotator + discriminator fused */
+#define RCF_T_COUNT        10
 /* on = 0: off; 1: every class; otherwise a mask with bit (class + 1) set for each class to time -- every timed
  * launch costs two event records on the stream (~10 us of gap), so a throughput run times only what it reports */
 int rcf_timing_enable(rcf_t *h, int on);

@@ -514,6 +514,107 @@ __global__ __launch_bounds__(kThreads) void disc_kernel(const DiscLaunch *__rest
     }
 }
 
+// ---------------------------------------------------------------- filterbank taps: matrix -> channel rings
+// The frame-major banks (pfb5.hip) leave the tapped bins of a launch as a compact frame-major matrix, row r = the
+// bank's frame k_first + r, one column per tap.  A workgroup takes 16 taps x 128 outputs: it reads the rows the way
+// they lie (16 taps = one 128-byte piece of a row), applies each tap's rotator (GNU Radio's increment and / or the
+// source shift: rotate_value(), the FIR bank's epilogue) into LDS, then turns the tile round -- 16 lanes x 2
+// consecutive outputs of ONE tap = two 128-byte lines of that channel's IQ ring and one of its discriminator ring per
+// store -- and writes IQ and the discriminator (which needs the output before: the row above in LDS; rows before the
+// launch come from the ring).  The 128 outputs of a tap are ALIGNED to 32 in the tap's own ring index (every tap has
+// its own k_abs0), so that every store is whole lines: a partial line costs a read-modify-write in the memory system
+// (32-byte pieces measured 4-5x slower than lines).  The price is the 32 extra rows a tile loads.
+constexpr int kTapOut = 128, kTapCols = 16, kTapAlign = 32, kTapLdsRows = kTapOut + kTapAlign + 1,
+              kTapLdsPitch = kTapCols + 1;
+__global__ __launch_bounds__(kThreads) void tap_finalize_kernel(const TapLaunch *__restrict__ taps, int n_taps,
+                                                                const float2 *__restrict__ mat, int pitch, int n_rows,
+                                                                int64_t k_first, uint64_t ring_mask,
+                                                                const float *__restrict__ atan_tab)
+{
+    static_assert(kThreads == kTapCols * 16, "16 x 16 lanes");
+    __shared__ float tab[260];
+    __shared__ float2 ys[kTapLdsRows * kTapLdsPitch];
+    const int tid = threadIdx.x;
+    // grid: x = group of 16 taps (fastest), y = tile of rows -- workgroups dispatched together read neighbouring
+    // 128-byte pieces of the SAME matrix rows (whole rows between them), not one piece from each of 161 rows apart
+    const int s0 = blockIdx.x * kTapCols, r0 = blockIdx.y * kTapOut;
+    const int r_lds0 = r0 - kTapAlign - 1;                   // matrix row of LDS row 0
+    for (int i = tid; i < 257; i += kThreads) tab[i] = atan_tab[i];
+    {
+        const int sl = tid & (kTapCols - 1), rr = tid >> 4;
+        const int slot = s0 + sl;
+        if (slot < n_taps) {
+            const TapLaunch L = taps[slot];
+            const bool idle = L.dangle == 0.0 && L.dlogmag == 0.0 && L.angle0 == 0.0 && L.logmag0 == 0.0;
+            // all of a lane's rows are requested before the first is used (the loop below would otherwise pay one
+            // memory round trip per row: 11 in a row)
+            constexpr int NIT = (kTapLdsRows + 15) / 16;
+            float2 z[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int lr = rr + 16 * it, r = r_lds0 + lr;
+                const int64_t k = k_first + r, n = k - L.k_abs0;
+                z[it] = make_float2(0.f, 0.f);
+                if (lr < kTapLdsRows) {
+                    if (r >= 0 && r < n_rows && k >= L.k_lo && k < L.k_lo + L.n_k && n >= 0)
+                        z[it] = mat[(size_t)r * pitch + slot];
+                    else if (r < 0 && n >= 0)
+                        z[it] = L.iq_ring[(uint64_t)n & ring_mask];   // produced by an earlier launch: already rotated
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int lr = rr + 16 * it, r = r_lds0 + lr;
+                if (lr >= kTapLdsRows) break;
+                const int64_t n = k_first + r - L.k_abs0;
+                float2 v = z[it];
+                if (!idle && r >= 0) v = rotate_value(L, n, v.x, v.y);  // (a zero stays zero: rows outside the tap's range)
+                ys[lr * kTapLdsPitch + sl] = v;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int sl = tid >> 4, q = tid & 15;
+        const int slot = s0 + sl;
+        if (slot >= n_taps) return;
+        const TapLaunch L = taps[slot];
+        const int64_t o = k_first - L.k_abs0;                       // ring index of matrix row 0
+        const int a = (int)((uint64_t)(o + r0) & (kTapAlign - 1));  // this tile's outputs start at row r0 - a
+        auto fm_of = [&](float2 y1, float2 y0) {
+            // volk_32fc_x2_multiply_conjugate_32fc: y1 * conj(y0), unfused (as disc_kernel)
+            const float tr = __fadd_rn(__fmul_rn(y1.x, y0.x), __fmul_rn(y1.y, y0.y));
+            const float ti = __fsub_rn(__fmul_rn(y1.y, y0.x), __fmul_rn(y1.x, y0.y));
+            return fast_atan2f_gr(ti, tr, tab);
+        };
+#pragma unroll
+        for (int j = 0; j < kTapOut / 32; ++j) {
+            const int ra = r0 - a + 2 * (q + 16 * j);               // rows ra, ra + 1 -> ring indices na (even), na + 1
+            const int64_t na = o + ra;
+            const int lr = ra - r_lds0;
+            const bool va = ra >= 0 && ra < n_rows && k_first + ra >= L.k_lo && k_first + ra < L.k_lo + L.n_k && na >= 0;
+            const bool vb = ra + 1 >= 0 && ra + 1 < n_rows && k_first + ra + 1 >= L.k_lo &&
+                            k_first + ra + 1 < L.k_lo + L.n_k && na + 1 >= 0;
+            if (!va && !vb) continue;
+            const float2 ym = na > 0 ? ys[(lr - 1) * kTapLdsPitch + sl] : make_float2(0.f, 0.f);
+            const float2 ya = ys[lr * kTapLdsPitch + sl], yb = ys[(lr + 1) * kTapLdsPitch + sl];
+            const float2 yb0 = na + 1 > 0 ? ya : make_float2(0.f, 0.f);
+            const uint64_t ia = (uint64_t)na & ring_mask;
+            if (va && vb) {                                          // na is even and the ring a power of two: no wrap inside the pair
+                *reinterpret_cast<float4 *>(L.iq_ring + ia) = make_float4(ya.x, ya.y, yb.x, yb.y);
+                *reinterpret_cast<float2 *>(L.fm_ring + ia) = make_float2(fm_of(ya, ym), fm_of(yb, yb0));
+            } else if (va) {
+                L.iq_ring[ia] = ya;
+                L.fm_ring[ia] = fm_of(ya, ym);
+            } else {
+                const uint64_t ib = (uint64_t)(na + 1) & ring_mask;
+                L.iq_ring[ib] = yb;
+                L.fm_ring[ib] = fm_of(yb, yb0);
+            }
+        }
+    }
+}
+
 // P25 symbol filter and friends: a short real FIR over gain * fm (float32, taps in order)
 __global__ __launch_bounds__(kThreads) void fm_fir_kernel(const FmFirLaunch *__restrict__ items, uint64_t ring_mask)
 {
@@ -557,6 +658,16 @@ void launch_fm_fir(const FmFirLaunch *d_items, int n_items, int max_n_k, uint64_
     if (n_items <= 0 || max_n_k <= 0) return;
     hipLaunchKernelGGL(fm_fir_kernel, dim3((max_n_k + kThreads - 1) / kThreads, n_items), dim3(kThreads), 0, s,
                        d_items, ring_mask);
+}
+
+void launch_tap_finalize(const TapLaunch *d_taps, int n_taps, const float2 *tap_mat, int tap_pitch, int n_rows,
+                         int64_t k_first, uint64_t ring_mask, const float *d_atan_table, hipStream_t s)
+{
+    if (n_taps <= 0 || n_rows <= 0) return;
+    hipLaunchKernelGGL(tap_finalize_kernel,
+                       dim3((n_taps + kTapCols - 1) / kTapCols, (n_rows + kTapAlign - 1 + kTapOut - 1) / kTapOut),
+                       dim3(kThreads), 0, s, d_taps, n_taps, tap_mat, tap_pitch, n_rows, k_first, ring_mask,
+                       d_atan_table);
 }
 
 void launch_fm_level(const float *fm_ring, int64_t n_end, int window, float gain, uint64_t ring_mask, float *d_out,

@@ -44,7 +44,6 @@
 #define RCF_EXPLICIT_FMA 1
 #include "fft_core.hpp"
 #include "rcf_internal.h"
-#include "rotator.hpp"
 
 namespace rcfx {
 
@@ -311,35 +310,33 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
         }
     }
     TS(3);
-    // ---- taps first, copy-out last: bins that are open as channels go straight into those channels' rings, through
-    // their rotators (GNU Radio's per-output increment and / or the source shift; an idle rotator is skipped).
-    // One lane per (tap, frame), frames fastest: the F lanes of a tap read the same record (one broadcast request)
-    // and write F x 8 contiguous bytes of the tap's ring; the rotator is rotate_value()'s closed form per output, the
-    // same arithmetic as the FIR bank's epilogue.  The first batch of records is requested before the barrier.
-    // (The first version gave a tap to one lane, which walked the chunk's frames after the copy-out, behind the
-    // acknowledgement of its 20 streaming stores -- vector memory operations of a wavefront return in issue order.)
-    const int tap_items = p.n_taps * F;
-    int64_t tap_w[kTapFields];
-    if (tid < tap_items) {
+    // ---- taps first, copy-out last: bins that are open as channels are copied into the launch's compact tap matrix,
+    // tap_mat[(frame - n_lo) tap_pitch + slot] -- lanes = consecutive slots, so every wavefront store is 512 contiguous
+    // bytes of a row.  Rotators and the discriminator are tap_finalize_kernel's business (fir.hip).  The bin numbers
+    // are requested before the barrier.
+    constexpr int TAP_IT = 5;                                // 5 x 320 slots cover all 1600 bins; 3200 bins loop
+    int tap_bin[TAP_IT];
 #pragma unroll
-        for (int f = 0; f < kTapFields; ++f) tap_w[f] = p.taps[(size_t)f * p.taps_pitch + tid / F];
+    for (int it = 0; it < TAP_IT; ++it) {
+        const int sl = tid + it * kThreads5;
+        tap_bin[it] = sl < p.n_taps ? p.tap_bins[sl] : -1;
     }
     __syncthreads();
     TS(4);
-    for (int it = tid; it < tap_items; it += kThreads5) {
-        const int f = it % F;
-        TapLaunch L;
-        if (it != tid) {
+    if (p.n_taps > 0) {
+        float2 *trow = p.tap_mat + (size_t)fb0 * p.tap_pitch;
 #pragma unroll
-            for (int q = 0; q < kTapFields; ++q) tap_w[q] = p.taps[(size_t)q * p.taps_pitch + it / F];
+        for (int it = 0; it < TAP_IT; ++it) {
+            const int sl = tid + it * kThreads5;
+            if (tap_bin[it] < 0) break;
+            const cf *col = buf + pad5<R>(tap_bin[it]);
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+                if (f < nf) trow[(size_t)f * p.tap_pitch + sl] = col[f * RS];
         }
-        __builtin_memcpy(&L, tap_w, sizeof(L));
-        const int64_t k = n0 - p.n_abs0 + f;                 // the tap's output index = the bank's frame count
-        if (f < nf && k >= L.k_lo && k < L.k_lo + L.n_k && k >= L.k_abs0) {
-            const cf z = buf[f * RS + pad5<R>(L.bin)];
-            const bool idle = L.dangle == 0.0 && L.dlogmag == 0.0 && L.angle0 == 0.0 && L.logmag0 == 0.0;
-            const int64_t n = k - L.k_abs0;
-            L.iq_ring[(uint64_t)n & p.ring_mask] = idle ? z : rotate_value(L, n, z.x, z.y);
+        for (int sl = tid + TAP_IT * kThreads5; sl < p.n_taps; sl += kThreads5) {       // more than 1600 taps (3200 bins)
+            const cf *col = buf + pad5<R>(p.tap_bins[sl]);
+            for (int f = 0; f < nf; ++f) trow[(size_t)f * p.tap_pitch + sl] = col[f * RS];
         }
     }
 

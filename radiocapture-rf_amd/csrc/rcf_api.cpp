@@ -184,6 +184,8 @@ struct rcf {
     unsigned timing_mask = ~0u;
     int mfma_min = 8;             // fewest channels of a class worth a matrix-core launch (RCF_FIR_MFMA_MIN)
     int mfma_nt = 0, mfma_parts = 0;   // RCF_FIR_MFMA_NT / RCF_FIR_MFMA_PARTS: override the launch plan (measurements)
+    float2 *d_tapmat = nullptr;   // filterbank taps: the current launch's compact tap matrix (PfbLaunch::tap_mat)
+    size_t tapmat_cap = 0;        // in float2
     float2 *d_partial = nullptr;  // split-K slabs of the matrix-core bank
     size_t partial_cap = 0;       // in float2
     bool no_mfma = false;         // RCF_FIR_NOMFMA=1: keep the vector-FMA bank kernel (A/B measurements)
@@ -450,7 +452,7 @@ int process_block(rcf_t *h, size_t n)
         size_t need = 4096;
         for (auto &kv : h->chans) {
             const Chan &c = *kv.second;
-            need += 2 * sizeof(ChanLaunch) + sizeof(TapLaunch) + sizeof(DiscLaunch) + 2 + 128;
+            need += 2 * sizeof(ChanLaunch) + sizeof(TapLaunch) + sizeof(DiscLaunch) + 8 + 128;
             if (c.d_sym) need += sizeof(FmFirLaunch);
             if (c.audio) need += sizeof(AudioLaunch);
             max_depth = std::max(max_depth, c.depth);
@@ -493,9 +495,9 @@ int process_block(rcf_t *h, size_t n)
     std::vector<DiscJob> disc_jobs;
     std::vector<FmFirLaunch> symf;     // symbol filters, all channels in one launch
     int symf_max_n = 0;
-    std::vector<TapLaunch> tap_list;   // filterbank taps: stored by the bank's own kernel
-    std::vector<DiscLaunch> tap_discs;
-    int tap_max_n = 0;
+    std::vector<TapLaunch> tap_list;   // filterbank taps: copied out by the bank's kernel, finished by tap_finalize
+    std::vector<int32_t> tap_bins;
+    const TapLaunch *d_tap_list = nullptr;
     std::vector<AudioLaunch> audf;     // analog voice chains, all channels in one set of launches
     int audf_max_n = 0;
     double audf_ratio = 0;
@@ -609,13 +611,13 @@ int process_block(rcf_t *h, size_t n)
                 if (c->is_tap) {                            // written by the filterbank kernel, not by a FIR launch
                     TapLaunch tl{};
                     tl.iq_ring = c->d_iq;
+                    tl.fm_ring = c->d_fm;
                     tl.k_lo = L.k_lo; tl.k_abs0 = L.k_abs0; tl.n_seg0 = L.n_seg0;
                     tl.angle0 = L.angle0; tl.dangle = L.dangle; tl.logmag0 = L.logmag0; tl.dlogmag = L.dlogmag;
                     tl.n_k = L.n_k;
                     tl.bin = c->src - RCF_SRC_PFB_BIN0;
                     tap_list.push_back(tl);
-                    tap_discs.push_back(dl);
-                    tap_max_n = std::max(tap_max_n, (int)cnt);
+                    tap_bins.push_back(tl.bin);
                 } else {
                     launches.push_back(L);
                     launched.push_back(c);
@@ -790,6 +792,7 @@ int process_block(rcf_t *h, size_t n)
                             float2 *np_ = nullptr;
                             RCF_HIP(hipMalloc(&np_, sizeof(float2) * need));
                             bury(h, h->d_partial);
+    bury(h, h->d_tapmat);
                             h->d_partial = np_;
                             h->partial_cap = need;
                         }
@@ -828,22 +831,20 @@ int process_block(rcf_t *h, size_t n)
         }
     }
 
-    if (!tap_list.empty()) {
-        // field-major: row f holds field f of every tap
-        const size_t pitch = (tap_list.size() + 7) & ~size_t(7);
-        std::vector<int64_t> soa((size_t)kTapFields * pitch, 0);
-        for (size_t i = 0; i < tap_list.size(); ++i) {
-            int64_t w[kTapFields];
-            std::memcpy(w, &tap_list[i], sizeof(TapLaunch));
-            for (int f = 0; f < kTapFields; ++f) soa[(size_t)f * pitch + i] = w[f];
+    if (!tap_list.empty() && run_pfb) {
+        const size_t pitch = (tap_list.size() + 15) & ~size_t(15);
+        const size_t need = pitch * (size_t)pl.n_frames;
+        if (need > h->tapmat_cap) {
+            float2 *nm = nullptr;
+            RCF_HIP(hipMalloc(&nm, sizeof(float2) * need));
+            bury(h, h->d_tapmat);
+            h->d_tapmat = nm;
+            h->tapmat_cap = need;
         }
-        if (!ar.put(soa, &pl.taps)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
-        pl.taps_pitch = (int64_t)pitch;
+        if (!ar.put(tap_bins, &pl.tap_bins) || !ar.put(tap_list, &d_tap_list)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+        pl.tap_mat = h->d_tapmat;
+        pl.tap_pitch = (int32_t)pitch;
         pl.n_taps = (int32_t)tap_list.size();
-        DiscJob dj{};
-        dj.n = (int)tap_discs.size(); dj.max_n = tap_max_n;
-        if (!ar.put(tap_discs, &dj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
-        disc_jobs.push_back(dj);
     }
     const FmFirLaunch *d_symf = nullptr;
     if (!symf.empty() && !ar.put(symf, &d_symf)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
@@ -867,6 +868,11 @@ int process_block(rcf_t *h, size_t n)
             launch_fir_bank(j.dev, j.dims, st);
         }
     if (run_pfb) { Timed t(h, RCF_T_PFB); launch_pfb(pl, st); }
+    if (run_pfb && pl.n_taps > 0) {
+        Timed t(h, RCF_T_TAPS);
+        launch_tap_finalize(d_tap_list, pl.n_taps, pl.tap_mat, pl.tap_pitch, pl.n_frames, pl.n_lo - pl.n_abs0,
+                            h->ring_mask, h->d_atan, st);
+    }
     for (size_t d = 1; d < fir_by_depth.size(); ++d)
         for (auto &j : fir_by_depth[d]) { Timed t(h, RCF_T_FIR_DERIVED); launch_fir_bank(j.dev, j.dims, st); }
     for (auto &dj : disc_jobs) {
@@ -1240,6 +1246,7 @@ int rcf_close(rcf_t *h)
     }
     bury(h, h->d_gather);
     bury(h, h->d_partial);
+    bury(h, h->d_tapmat);
     drain_graveyard(h);
     for (auto &kv : h->pools)
         for (void *slab : kv.second.slabs) (void)hipFree(slab);

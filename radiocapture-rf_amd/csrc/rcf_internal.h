@@ -262,26 +262,31 @@ struct PfbLaunch {
     int32_t frame_major;
     int32_t n_taps;
     // frame-major banks: bins that are open as channels (rcf_pfb_tap_open).  The kernel has every bin of the chunk in
-    // LDS when it writes the frames out, so it also puts each tapped bin's new outputs -- through the tap's rotator --
-    // straight into that channel's ring: a tap costs 8 bytes per frame instead of a strided 128-byte line read
-    // per frame in a kernel of its own.  Output index of a tap = frame - n_abs0.
-    // The records are stored FIELD-MAJOR (taps[field * taps_pitch + tap], kTapFields 8-byte fields): one lane
-    // handles one tap, so every field load of a wavefront is one contiguous run (as an array of structs the same
-    // loads touched 64 lines each and cost more than the whole filterbank).
-    const int64_t *taps;
-    int64_t taps_pitch;
+    // LDS when it writes the frames out, so it also copies the tapped bins -- and only those -- into a compact
+    // frame-major matrix of THIS launch's frames, tap_mat[(frame - n_lo) tap_pitch + slot] (slot = position in
+    // tap_bins): whole rows of n_taps x 8 contiguous bytes, like the bins ring itself.  tap_finalize_kernel (fir.hip)
+    // then transposes that matrix tile by tile through LDS into the channels' own rings, 128-byte lines, applying each
+    // tap's rotator and the discriminator on the way.  (Round 2 stored a tap's F frames straight into its ring from
+    // here: 32-byte pieces of lines a megabyte apart -- 0.18 -> 0.64 ms with all 1600 bins tapped; a ring TILED
+    // [16 frames][bin][16] gets the same 32-byte pieces and measures 0.79 ms.)
+    const int32_t *tap_bins;
+    float2 *tap_mat;
+    int32_t tap_pitch;       // row pitch of tap_mat in samples (n_taps rounded up to 16)
+    int32_t pad_;
 };
-struct TapLaunch {           // host-side record; on the device its fields are rows of PfbLaunch::taps
+struct TapLaunch {           // one tapped bin, consumed by tap_finalize_kernel
     float2 *iq_ring;
-    int64_t k_lo, k_abs0;    // as in ChanLaunch
+    float *fm_ring;
+    int64_t k_lo, k_abs0;    // as in ChanLaunch; a tap's output index = the bank's frame count
     int64_t n_seg0;          // rotator model, as in ChanLaunch (rotate_value reads these five)
     double angle0, dangle;
     double logmag0, dlogmag;
     int32_t n_k;
     int32_t bin;
 };
-constexpr int kTapFields = sizeof(TapLaunch) / 8;
-static_assert(sizeof(TapLaunch) % 8 == 0, "TapLaunch is a row of 8-byte fields");
+// mat row r = the bank's frame k_first + r (tap output index); rows [0, n_rows)
+void launch_tap_finalize(const TapLaunch *d_taps, int n_taps, const float2 *tap_mat, int tap_pitch, int n_rows,
+                         int64_t k_first, uint64_t ring_mask, const float *d_atan_table, hipStream_t s);
 bool pfb_supported(int NB, int D, int P);
 int pfb_padded_p(int NB, int D, int P);   // rows the kernel instantiation reads from ptaps (zero padded)
 void launch_pfb(const PfbLaunch &p, hipStream_t s);

@@ -39,7 +39,7 @@ SYMBOLS = [
     "rcf_pfb_tap_leakage",
 ]
 FMT_U8, FMT_S8, FMT_S16 = 1, 2, 3
-T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY, T_FIR_MFMA, T_AUDIO = range(9)
+T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY, T_FIR_MFMA, T_AUDIO, T_TAPS = range(10)
 
 
 class AudioParams(C.Structure):

@@ -41,7 +41,8 @@ extra = ""
 if os.environ.get('TIME_ALL'):
     d2, n2 = fe.timing_read(native.T_FIR_DERIVED)
     d3, n3 = fe.timing_read(native.T_DISC)
-    extra = "  derived-FIR %.4f ms/block  disc %.4f ms/block" % (d2 / steps, d3 / steps)
+    d4, n4 = fe.timing_read(native.T_TAPS)
+    extra = "  derived-FIR %.4f ms/block  disc %.4f ms/block  tap-finalize %.4f ms/block" % (d2 / steps, d3 / steps, d4 / steps)
 gbs = (8.0 * B + 8.0 * B * osf) / (ms * 1e-3) / 1e9
 print("NB=%d OS=%d taps=%d remap=%s : %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (
     nb, osf, len(taps),
