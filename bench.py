@@ -311,6 +311,28 @@ def reference_grid_leg(native, tile, device, B=1 << 25, n_taps=256):
                            "wall_ms_per_block": tap_wall, "realtime_factor_at_20Msps": B / FS / (tap_wall * 1e-3),
                            "pfb_over_untapped": tap_ms / bank_ms})
     fe.close()
+    # the 6.25 kHz grid: 3200 bins, rings of 3.4 GB -- (a) the reference's own 6.25 kHz channel,
+    # channel.py:31-35 at cr = 6250: D = 1600, T = 5819; (b) its 12.5 kHz channel filter on the finer raster, D = 800
+    fine = []
+    for cr, label in ((6250, "channel.py rule at cr = 6250: every bin == one 6.25 kHz reference channel at 12.5 kS/s"),
+                      (12500, "the 12.5 kHz channel filter on the 6.25 kHz raster (oversampled x4), 25 kS/s per bin")):
+        D2, T2 = native.channel_params(FS, cr)
+        taps2 = native.design_low_pass_2(1.0, FS, cr / 2.0, cr / 2.0, 20.0)
+        fe = native.Frontend(FS, 0.0, device=device, block_capacity=B, hist_capacity=1 << 16,
+                             out_capacity=1 << (16 if D2 == 1600 else 17))
+        fe.pfb_open(3200, D2, taps2)
+        for _ in range(2):
+            for at in range(0, B, len(tile)):
+                fe.ingest_write(tile[: min(len(tile), B - at)], at)
+            fe.commit(B)
+        for _ in range(30):
+            fe.commit(B)
+        ms, _, wall = timed(100)
+        fe.close()
+        alg2 = (8.0 + 8.0 * 3200 / D2) * B
+        fine.append({"bins": 3200, "decim": D2, "taps": T2, "what": label, "block_samples": B, "pfb_ms_per_block": ms,
+                     "wall_ms_per_block": wall, "algorithmic_bytes_per_launch": alg2,
+                     "frac_of_hbm_peak": alg2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
     alg = 24.0 * B                                    # 8 B read + 8 * 1600 / 800 B written per input sample
     return {
         "workload": "1600-bin filterbank, decim 800, 2909-tap channel.py prototype (every bin == one reference "
@@ -322,6 +344,7 @@ def reference_grid_leg(native, tile, device, B=1 << 25, n_taps=256):
         "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": alg, "achieved": alg / (bank_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (bank_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "sustained": sustained,
+        "grid_6k25": fine,
         "with_taps": {"note": "tapped bins leave the bank's kernel as a compact frame-major matrix (whole rows); "
                               "tap_finalize_kernel transposes it into the channels' rings with GNU Radio's rotator per tap "
                               "and the discriminator fused in (pfb_ms = the bank incl. the matrix, tap_finalize_ms = that "

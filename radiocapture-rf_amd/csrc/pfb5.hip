@@ -106,8 +106,6 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
 
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<cf *>(p.src.base), 0, (int)(p.src_len * (int64_t)sizeof(cf)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        p.bins_ring, 0, (int)((int64_t)NB * (int64_t)(p.ring_mask + 1) * (int64_t)sizeof(cf)), 0x00020000);
 
     // ---- phase A: branch FIR + first radix-20 pass.  u[t] = sum_q h[NB q + rho_t] x[(n - OS q) D - rho_t],
     // rho_t = j + BPF t; X[f] -> buf[20 j + f]
@@ -346,8 +344,12 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         if (f >= nf) break;
+        // one descriptor per frame row, based at the row itself: the ring (3200 bins x 2^17 frames = 3.4 GB) has no
+        // 2 GiB limit, offsets inside a row stay 32-bit
         const int64_t slot = (int64_t)((uint64_t)(n0 + f - p.n_abs0) & p.ring_mask);
-        const int so = (int)(slot * NB * (int64_t)sizeof(cf));
+        const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.bins_ring + slot * NB, 0, NB * (int)sizeof(cf), 0x00020000);
+        constexpr int so = 0;
         const cf *row = buf + f * RS;
 #pragma unroll
         for (int bb = 0; bb < NB / kThreads5; ++bb) {

@@ -1762,7 +1762,9 @@ int rcf_pfb_open(rcf_t *h, int n_bins, int decim, const float *taps, int ntaps)
     const bool fm = pfb_frame_major(n_bins);
     if (!fm && h->out_cap < (size_t(1) << kPfbTileLog2)) { set_error("output capacity %zu < one ring tile", h->out_cap); return RCF_ECAP; }
     const size_t ring_samples = fm ? (size_t)n_bins * h->out_cap : (size_t)(h->out_cap >> kPfbTileLog2) * (size_t)pfb_tile_pitch(n_bins);
-    if ((uint64_t)ring_samples * sizeof(float2) >= (1ull << 31) ||
+    // 32-bit buffer offsets: the wideband buffer, and the tiled ring of the power-of-two banks (one descriptor for the
+    // whole ring).  The frame-major banks address their ring through one descriptor per frame row: no limit there.
+    if ((!fm && (uint64_t)ring_samples * sizeof(float2) >= (1ull << 31)) ||
         (uint64_t)(h->hist_cap + h->block_cap) * sizeof(float2) >= (1ull << 31)) {
         set_error("PFB rings / wideband buffer exceed the 2 GiB range of 32-bit buffer offsets");
         return RCF_ECAP;

@@ -189,3 +189,40 @@ def test_direct_channel_iq_error_growth_over_a_million_outputs(gpu_required):
                   "increments within ~1e-6 of a multiple of pi/2 per output (all on-grid channels of a 12.5 kHz plan at "
                   "D = 800): GNU Radio's iteration absorbs the small component, bound 3e-8 n; always a common phase only")
     _dump("r03_iq_drift.json", out)
+
+
+def test_pfb3200_ring_beyond_2gib(gpu_required):
+    """the 6.25 kHz-grid bank (3200 bins, rc_frontend/channel.py:31-35 at cr = 6250: D = 1600,
+    T = 5819) with a ring of 2^17 frames = 3.4 GB -- past the 2 GiB range of one buffer descriptor's 32-bit offsets,
+    which rcf_pfb_open used to refuse.  ~94 000 frames are pushed so that the write position passes the 2 GiB mark;
+    the newest frames of six bins must equal, bit for bit, those of a second front-end whose ring is small."""
+    nat = gpu_required
+    fs, nb = 20e6, 3200
+    D, taps = G.channel_params(fs, 6250)
+    assert D == 1600 and len(taps) == 5819
+    rng = np.random.default_rng(77)
+    tile = synth.awgn(rng, 1 << 20)
+    tile += synth.nbfm_carrier(len(tile), fs, 3 * fs / nb + 700.0, 900.0, 2500.0, 1.0).astype(np.complex64)
+    n_push = 144                                             # 144 x 2^20 samples = 94 371 frames x 25.6 KB = 2.4 GB
+    bins = [0, 3, 1599, 1600, 1601, 3199]
+    outs = []
+    for cap in (1 << 17, 1 << 12):
+        with nat.Frontend(fs, block_capacity=1 << 20, out_capacity=cap) as fe:
+            fe.pfb_open(nb, D, taps)
+            for _ in range(n_push):
+                fe.push(tile)
+            assert fe.pfb_produced() == ((n_push << 20) - 1) // D + 1     # frames 0 .. floor((S - 1) / D)
+            outs.append([fe.pfb_read_bin(k)[-2048:] for k in bins])
+    assert (n_push << 20) // D * nb * 8 > (1 << 31)
+    for a, b in zip(*outs):
+        assert len(a) == 2048
+        np.testing.assert_array_equal(a, b)
+    # and the values are the bank's: bin 3 against the float64 exact-phase xlating FIR over the stream's tail, cut on
+    # the stream's decimation grid (S - L a multiple of D) and carrying the absolute frame index's phase
+    S = n_push << 20
+    L = S % D + D * 1200
+    n0 = (S - L) // D
+    tail = np.tile(tile, 2)[-L:]
+    want = G.xlating_fir_exact(tail, D, taps, 3 * fs / nb, fs)[-512:] * np.exp(-2j * np.pi * ((3 * n0 * D) % nb) / nb)
+    got = outs[0][1][-512:]
+    assert rel_rms(got, want) < 2e-5
