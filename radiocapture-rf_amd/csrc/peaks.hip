@@ -27,6 +27,7 @@ constexpr int B1 = 32;      // level-1 block
 constexpr int B2 = 1024;    // level-2 block (32 level-1 blocks)
 
 constexpr int kMinBlocks = 256;
+constexpr int kHeavyCap = 1 << 16;   // peaks k_pick may hand to k_pick_heavy (a spectrum has a handful)
 
 __device__ __forceinline__ float block_min256(float m, float *red)
 {
@@ -120,10 +121,14 @@ struct PickArgs {
     int64_t *out;          // unordered survivors
     int *count;
     int cap;
+    int *heavy;            // peaks whose walks are too long for one thread: finished by k_pick_heavy, one wave each
+    int *heavy_count;
+    int heavy_cap;
 };
+constexpr int kWalkBudget = 48;   // sequential steps a k_pick thread may spend on one peak before handing it over
 
 // min over the stretch from p outward (dir = -1 / +1) up to, not including, the first sample > h
-__device__ double walk_min(const PickArgs &a, int p, double h, int dir)
+__device__ double walk_min(const PickArgs &a, int p, double h, int dir, int &budget)
 {
     const float *x = a.x;
     const float hf_note = 0.f;
@@ -140,6 +145,7 @@ __device__ double walk_min(const PickArgs &a, int p, double h, int dir)
         if (v < m) m = v;
         if (dir < 0 ? (i % B1 == 0) : (i % B1 == B1 - 1)) break;
     }
+    if (--budget < 0) return m;                                  // (the caller discards the value)
     // 2) level-1 blocks up to the level-2 boundary, 3) level-2 blocks, descending when a block holds a higher sample
     int b1 = i / B1 + dir;
     while (b1 >= 0 && b1 < a.n1) {
@@ -150,6 +156,7 @@ __device__ double walk_min(const PickArgs &a, int p, double h, int dir)
                 const double v = (double)a.min2[b2];
                 if (v < m) m = v;
                 b2 += dir;
+                if (--budget < 0) return m;
             }
             if (b2 < 0 || b2 >= a.n2) return m;
             b1 = dir < 0 ? b2 * (B2 / B1) + (B2 / B1) - 1 : b2 * (B2 / B1);
@@ -167,8 +174,112 @@ __device__ double walk_min(const PickArgs &a, int p, double h, int dir)
         const double v = (double)a.min1[b1];
         if (v < m) m = v;
         b1 += dir;
+        if (--budget < 0) return m;
     }
     return m;
+}
+
+// ---- one wavefront per peak: the same quantities as walk_min / the width walks of k_pick, 64 positions per step
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// min over the samples of level-1 block b1 from its near end (seen from the peak) up to, not including, the first
+// sample > h; *stop = such a sample exists.  `from`: first sample to look at (inside the block).
+__device__ __forceinline__ double wave_block_samples(const PickArgs &a, int from, int b1, double h, int dir, bool *stop)
+{
+    const int lane = threadIdx.x & 63;
+    const int lo = b1 * B1, hi = min(lo + B1 - 1, a.n - 1);
+    const int i = from + dir * lane;
+    const bool in = lane < B1 && i >= lo && i <= hi;
+    const double v = in ? (double)a.x[i] : h;
+    const unsigned long long above = __ballot(in && v > h);
+    const int first = above ? __ffsll((long long)above) - 1 : 64;
+    *stop = above != 0;
+    return wave_min(in && lane < first ? v : h);
+}
+
+__device__ double wave_walk_min(const PickArgs &a, int p, double h, int dir)
+{
+    const int lane = threadIdx.x & 63;
+    const int last = a.n - 1;
+    double m = h;
+    int i = p + dir;
+    if (i < 0 || i > last) return m;
+    bool stop;
+    // the rest of the peak's own level-1 block
+    m = fmin(m, wave_block_samples(a, i, i / B1, h, dir, &stop));
+    if (stop) return m;
+    int b1 = i / B1 + dir;
+    constexpr int R21 = B2 / B1;
+    while (b1 >= 0 && b1 < a.n1) {
+        const bool at_l2 = dir < 0 ? (b1 % R21 == R21 - 1) : (b1 % R21 == 0);
+        if (at_l2) {
+            // whole level-2 blocks, 64 per step
+            int b2 = b1 / R21;
+            bool found = false;
+            while (b2 >= 0 && b2 < a.n2) {
+                const int bb = b2 + dir * lane;
+                const bool in = bb >= 0 && bb < a.n2;
+                const bool hit = in && (double)a.max2[bb] > h;
+                const unsigned long long hits = __ballot(hit);
+                const int first = hits ? __ffsll((long long)hits) - 1 : 64;
+                m = fmin(m, wave_min(in && lane < first ? (double)a.min2[bb] : h));
+                if (hits) { b2 += dir * first; found = true; break; }
+                b2 += dir * 64;
+            }
+            if (!found) return m;
+            b1 = dir < 0 ? b2 * R21 + R21 - 1 : b2 * R21;
+        }
+        // level-1 blocks up to the next level-2 boundary (at most 32), one per lane
+        const int left_in_l2 = dir < 0 ? (b1 % R21) + 1 : R21 - (b1 % R21);
+        const int bb = b1 + dir * lane;
+        const bool in = lane < left_in_l2 && bb >= 0 && bb < a.n1;
+        const bool hit = in && (double)a.max1[bb] > h;
+        const unsigned long long hits = __ballot(hit);
+        const int first = hits ? __ffsll((long long)hits) - 1 : 64;
+        m = fmin(m, wave_min(in && lane < first ? (double)a.min1[bb] : h));
+        if (hits) {
+            const int fb = b1 + dir * first;
+            int from = dir < 0 ? fb * B1 + B1 - 1 : fb * B1;
+            if (from > last) from = last;
+            m = fmin(m, wave_block_samples(a, from, fb, h, dir, &stop));
+            return m;                                             // the block holds a sample > h: the walk ends in it
+        }
+        b1 += dir * left_in_l2;
+    }
+    return m;
+}
+
+// first distance d >= 0 from pk (direction dir) at which !(level < x[pk + dir d]) or the array's end is reached
+// (k_pick's width loops), capped: returns bound + 1 when every d <= bound is above the level
+__device__ int wave_width_stop(const PickArgs &a, int pk, double level, int dir, int bound)
+{
+    const int lane = threadIdx.x & 63;
+    const int last = a.n - 1;
+    for (int d0 = 0; d0 <= bound; d0 += 64) {
+        const int d = d0 + lane;
+        const int j = pk + dir * d;
+        const bool in = j >= 0 && j <= last;
+        const bool end = in && (j == (dir < 0 ? 0 : last));
+        const bool st = in && (end || !(level < (double)a.x[j]));
+        const unsigned long long hits = __ballot(st);
+        if (hits) return d0 + __ffsll((long long)hits) - 1;
+    }
+    return bound + 1;
+}
+
+// the decision both kernels share once a peak's two base minima are known
+__device__ __forceinline__ void pick_finish(const PickArgs &a, int pk, double top, double left, double right)
+{
+    const double width = right - left;
+    if (!(a.min_w <= width && width <= a.max_w)) return;
+    if (!(top > *a.mean * 2)) return;
+    const int slot = atomicAdd(a.count, 1);
+    if (slot < a.cap) a.out[slot] = pk;
 }
 
 __global__ __launch_bounds__(256) void k_pick(PickArgs a)
@@ -184,32 +295,77 @@ __global__ __launch_bounds__(256) void k_pick(PickArgs a)
     if (!((double)x[e] < xi)) return;
     const int pk = (i + e - 1) / 2;
     const double top = (double)x[pk];
-    const double lmin = walk_min(a, pk, top, -1);
-    const double rmin = walk_min(a, pk, top, +1);
-    const double prom = top - (lmin > rmin ? lmin : rmin);
-    if (!(prom >= a.prominence)) return;
-    const double level = top - prom * 0.5;
-    // width at half prominence; walks are bounded: a side longer than max_w already fails the window
-    const int bound = (int)fmin(a.max_w + 2.0, (double)a.n);
-    int j = pk;
-    while (j > 0 && level < (double)x[j]) {
-        --j;
-        if (pk - j > bound) return;
+    // Nearly every local maximum of a noisy spectrum is settled within a few samples.  The few that are not -- a
+    // carrier's summit walks hundreds of samples for its width and up to N / 1024 table entries for its bases, every
+    // step a dependent load: 246 us for ONE thread at N = 2^20 -- are handed to k_pick_heavy, one wavefront each.
+    int budget = kWalkBudget;
+    const double lmin = walk_min(a, pk, top, -1, budget);
+    const double rmin = budget >= 0 ? walk_min(a, pk, top, +1, budget) : 0.0;
+    bool heavy = budget < 0;
+    double left = 0.0, right = 0.0;
+    if (!heavy) {
+        const double prom = top - (lmin > rmin ? lmin : rmin);
+        if (!(prom >= a.prominence)) return;
+        const double level = top - prom * 0.5;
+        // width at half prominence; walks are bounded: a side longer than max_w already fails the window
+        const int bound = (int)fmin(a.max_w + 2.0, (double)a.n);
+        int j = pk;
+        while (j > 0 && level < (double)x[j]) {
+            --j;
+            if (pk - j > bound) return;
+            if (--budget < 0) { heavy = true; break; }
+        }
+        if (!heavy) {
+            left = (double)j;
+            if ((double)x[j] < level) left += (level - (double)x[j]) / ((double)x[j + 1] - (double)x[j]);
+            j = pk;
+            while (j < last && level < (double)x[j]) {
+                ++j;
+                if (j - pk > bound) return;
+                if (--budget < 0) { heavy = true; break; }
+            }
+            if (!heavy) {
+                right = (double)j;
+                if ((double)x[j] < level) right -= (level - (double)x[j]) / ((double)x[j - 1] - (double)x[j]);
+            }
+        }
     }
-    double left = (double)j;
-    if ((double)x[j] < level) left += (level - (double)x[j]) / ((double)x[j + 1] - (double)x[j]);
-    j = pk;
-    while (j < last && level < (double)x[j]) {
-        ++j;
-        if (j - pk > bound) return;
+    if (heavy) {
+        const int slot = atomicAdd(a.heavy_count, 1);
+        if (slot < a.heavy_cap) a.heavy[slot] = pk;
+        return;
     }
-    double right = (double)j;
-    if ((double)x[j] < level) right -= (level - (double)x[j]) / ((double)x[j - 1] - (double)x[j]);
-    const double width = right - left;
-    if (!(a.min_w <= width && width <= a.max_w)) return;
-    if (!(top > *a.mean * 2)) return;
-    const int slot = atomicAdd(a.count, 1);
-    if (slot < a.cap) a.out[slot] = pk;
+    pick_finish(a, pk, top, left, right);
+}
+
+// one wavefront per handed-over peak; identical comparisons and float64 arithmetic, 64 positions per step
+__global__ __launch_bounds__(64) void k_pick_heavy(PickArgs a)
+{
+    const int n_heavy = min(*a.heavy_count, a.heavy_cap);
+    for (int it = blockIdx.x; it < n_heavy; it += gridDim.x) {
+        const int pk = a.heavy[it];
+        const float *x = a.x;
+        const double top = (double)x[pk];
+        const double lmin = wave_walk_min(a, pk, top, -1);
+        const double rmin = wave_walk_min(a, pk, top, +1);
+        const double prom = top - (lmin > rmin ? lmin : rmin);      // (every lane holds the same values: the
+        if (!(prom >= a.prominence)) continue;                      //  branches below are wave-uniform)
+        const double level = top - prom * 0.5;
+        const int bound = (int)fmin(a.max_w + 2.0, (double)a.n);
+        const int dl = wave_width_stop(a, pk, level, -1, bound);
+        if (dl > bound) continue;
+        const int dr = wave_width_stop(a, pk, level, +1, bound);
+        if (dr > bound) continue;
+        if ((threadIdx.x & 63) == 0) {
+            int j = pk - dl;
+            double left = (double)j;
+            if ((double)x[j] < level) left += (level - (double)x[j]) / ((double)x[j + 1] - (double)x[j]);
+            j = pk + dr;
+            double right = (double)j;
+            if ((double)x[j] < level) right -= (level - (double)x[j]) / ((double)x[j - 1] - (double)x[j]);
+            pick_finish(a, pk, top, left, right);
+        }
+    }
 }
 
 // ascending sort of min(count, cap) survivors (cap <= 4096), padded with -1 after the valid entries
@@ -240,7 +396,8 @@ __global__ __launch_bounds__(1024) void k_sort(int64_t *buf, const int *count, i
 size_t peaks_workspace_bytes(int n)
 {
     const size_t n1 = (n + B1 - 1) / B1, n2 = (n + B2 - 1) / B2;
-    return sizeof(float) * ((size_t)n + 2 * n1 + 2 * n2 + kMinBlocks + 16) + sizeof(double) * (n2 + 2) + 64;
+    return sizeof(float) * ((size_t)n + 2 * n1 + 2 * n2 + kMinBlocks + 16) + sizeof(double) * (n2 + 2) + 64 +
+           sizeof(int) * (kHeavyCap + 16);
 }
 
 // dev_out: int64[cap] (cap <= 4096); dev_count: int; dev_mean: double -- all inside `ws` after the tables
@@ -257,13 +414,17 @@ void launch_find_peaks(const float *d_spec, int n, double min_w, double max_w, d
     float *max2 = reinterpret_cast<float *>(p);    p += sizeof(float) * n2;
     float *min2 = reinterpret_cast<float *>(p);    p += sizeof(float) * n2;
     float *shift = reinterpret_cast<float *>(p);   p += sizeof(float) * kMinBlocks;
-    int *count = reinterpret_cast<int *>(p);
-    (void)hipMemsetAsync(count, 0, sizeof(int), s);
+    int *count = reinterpret_cast<int *>(p);       p += sizeof(int) * 4;
+    int *heavy_count = count + 1;
+    int *heavy = reinterpret_cast<int *>(p);
+    (void)hipMemsetAsync(count, 0, 2 * sizeof(int), s);
     hipLaunchKernelGGL(k_min, dim3(kMinBlocks), dim3(256), 0, s, d_spec, n, shift);
     hipLaunchKernelGGL(k_prep, dim3(n2), dim3(256), 0, s, d_spec, n, shift, x, max1, min1, part);
     hipLaunchKernelGGL(k_tables, dim3(1), dim3(1024), 0, s, max1, min1, n1, max2, min2, n2, part, n, mean);
-    PickArgs a{x, max1, min1, max2, min2, n, n1, n2, min_w, max_w, prominence, mean, d_out, count, cap};
+    PickArgs a{x, max1, min1, max2, min2, n, n1, n2, min_w, max_w, prominence, mean, d_out, count, cap,
+               heavy, heavy_count, kHeavyCap};
     hipLaunchKernelGGL(k_pick, dim3((n + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_pick_heavy, dim3(1024), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_sort, dim3(1), dim3(1024), 0, s, d_out, count, cap);
     *d_count_out = count;
     *d_mean_out = mean;
