@@ -232,9 +232,11 @@ def xlating_fir_exact(x: np.ndarray, D: int, taps: np.ndarray, f0: float, fs: fl
 # --------------------------------------------------------------------------------------------
 TAN_MAP_RES = f32(0.003921569)
 TAN_MAP_SIZE = 255
-FAST_ATAN_TABLE = np.concatenate([
-    np.arctan(np.arange(256, dtype=np.float64) / 255.0),
-    [math.pi / 4.0]]).astype(f32)           # 257 entries, last one duplicated (GR table layout)
+# GNU Radio ships this table as 257 decimal literals of 7 significant digits (0.000000e+00, 3.921549e-03, ... ,
+# 7.853982e-01, 7.853982e-01): atan(i / 255) PRINTED with %.6e, then read as float -- which is not always the float
+# nearest to atan(i / 255).  Restated the same way (the literals themselves are not available here: parity unpinned).
+FAST_ATAN_TABLE = np.array([float("%.6e" % math.atan(i / 255.0)) for i in range(256)] +
+                           [float("%.6e" % (math.pi / 4.0))], dtype=np.float64).astype(f32)   # last one duplicated
 
 
 def fast_atan2f(y: np.ndarray, x: np.ndarray) -> np.ndarray:

@@ -18,6 +18,7 @@
  * Build: see oracle/Makefile  (gcc -O3 -march=native -fopenmp -shared -fPIC).
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -193,8 +194,12 @@ static int ro_atan_table_ready = 0;
 static void ro_atan_init(void)
 {
     if (ro_atan_table_ready) return;
-    for (int i = 0; i < 256; i++) ro_atan_table[i] = (float)atan((double)i / 255.0);
-    ro_atan_table[256] = (float)(M_PI / 4.0);
+    /* GNU Radio's table is 257 literals of 7 significant digits: atan(i / 255) printed with %.6e (see grspec.py) */
+    char buf[32];
+    for (int i = 0; i < 257; i++) {
+        snprintf(buf, sizeof buf, "%.6e", i < 256 ? atan((double)i / 255.0) : M_PI / 4.0);
+        ro_atan_table[i] = (float)strtod(buf, NULL);
+    }
     ro_atan_table_ready = 1;
 }
 

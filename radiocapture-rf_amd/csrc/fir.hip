@@ -745,8 +745,13 @@ const float *atan_table_host()
 {
     static bool init = false;
     if (!init) {
-        for (int i = 0; i < 256; ++i) g_atan_tab[i] = (float)atan((double)i / 255.0);
-        g_atan_tab[256] = (float)(3.14159265358979323846 / 4.0);
+        // gr::fast_atan2f's table is 257 literals of 7 significant digits -- atan(i / 255) printed with %.6e, the last
+        // one (pi / 4) twice -- not the floats nearest to atan(i / 255): restated the same way
+        char buf[32];
+        for (int i = 0; i < 257; ++i) {
+            snprintf(buf, sizeof buf, "%.6e", i < 256 ? atan((double)i / 255.0) : 3.14159265358979323846 / 4.0);
+            g_atan_tab[i] = (float)strtod(buf, nullptr);
+        }
         init = true;
     }
     return g_atan_tab;
