@@ -47,6 +47,7 @@ class EgressPump:
         # bind when the channel is created, as the reference does (the PUB sink is part of the channel flowgraph,
         # channel.py:36, so a port in use fails channel construction and receiver.py:322-329 picks another)
         tb.bind_port = self.bind_port
+        tb.release_port = self.release_port
 
     def bind_port(self, port):
         """-> True when the channel's socket(s) could be bound on `port`"""
@@ -66,9 +67,22 @@ class EgressPump:
         self.prebound[port] = (iq, fm)
         return True
 
+    def release_port(self, port):
+        """close the sockets bind_port(port) bound when no channel came of it (construction failed, or the channel
+        was destroyed before a pump pass adopted them)"""
+        for s in self.prebound.pop(port, (None, None)):
+            if s is not None:
+                try:
+                    s.close()
+                except Exception:
+                    pass
+
     def pump_once(self):
         with self.tb.access_lock:
             chans = dict(self.tb.channels)
+            live_ports = {ch.port for ch in chans.values() if ch.chan_id is not None}
+            for port in [p for p in self.prebound if p not in live_ports]:   # bound, but the channel is gone
+                self.release_port(port)
         for block_id, ch in chans.items():
             # one channel's failure (destroyed between the snapshot and the read, port already bound, reader error)
             # must not end the pump for everybody else: log, drop that channel's sockets, go on

@@ -36,6 +36,7 @@ class receiver:
         self.last_channel_cleanup = time.time()
         self.scan_mode = bool(getattr(config, "scan_mode", False))
         self.bind_port = None                              # set by the egress pump: port -> bound?
+        self.release_port = None                           # set by the egress pump: close what bind_port(port) bound
         self.fault = None                                  # first data-plane failure (GPU / driver error): healthy() -> False
         self._fed = {}                                     # source_id -> samples delivered
         self._fed_t0 = time.time()
@@ -241,9 +242,14 @@ class receiver:
                     self.log.error("Failed to build channel on port: %s attempt: %s" % (cand, attempt))
                 if port is None:
                     raise Exception("no free egress port")
-                block = channel_mod.channel(frontend, port, channel_rate, source_samp_rate, offset,
-                                            parent_chan=self.sources[source_id].get("parent_chan"),
-                                            pfb=self.sources[source_id].get("pfb"))
+                try:
+                    block = channel_mod.channel(frontend, port, channel_rate, source_samp_rate, offset,
+                                                parent_chan=self.sources[source_id].get("parent_chan"),
+                                                pfb=self.sources[source_id].get("pfb"))
+                except Exception:
+                    if self.release_port is not None:      # the sockets bound above have no channel: close them
+                        self.release_port(port)
+                    raise
                 block.source_id = source_id
                 block.block_id = "%s" % uuid.uuid4()
                 self.channels[block.block_id] = block

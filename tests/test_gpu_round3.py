@@ -231,3 +231,42 @@ def test_pfb3200_ring_beyond_2gib(gpu_required):
     want = G.xlating_fir_exact(tail, D, taps, 3 * fs / nb, fs)[-512:] * np.exp(-2j * np.pi * ((3 * n0 * D) % nb) / nb)
     got = outs[0][1][-512:]
     assert rel_rms(got, want) < 2e-5
+
+
+def test_matrix_core_bank_uneven_cuts_agree_to_summation_order(gpu_required):
+    """the matrix-core bank picks its split-K plan (tap parts) per launch from the channel count and the
+    block's output count (rcf_internal.h mfma_plan), and freshly opened channels' first outputs come from the vector
+    kernel -- so a channel's float32 summation ORDER, hence its last bits, depends on how the stream is cut.  The
+    filterbank kernels are bit-identical under any cut (test_pfb1600_all_bins_and_cut_invariance); the direct bank
+    is cut-invariant only up to that order: <= 2e-6 relative here, far inside the parity bars (IQ 1e-5, fm 1e-4),
+    and both cuts hold those bars against the oracle."""
+    nat = gpu_required
+    fs = 20e6
+    D, taps = G.channel_params(fs, 12500)
+    rng = np.random.default_rng(91)
+    n_out = 700
+    x = synth.awgn(rng, D * n_out).astype(np.complex128)
+    offs = [((k * 77 + 5) % 1500 - 750) * 12500.0 + 312.5 for k in range(256)]
+    for f in offs[:8]:
+        x += synth.nbfm_carrier(len(x), fs, f, 1000.0, 2500.0, synth.snr_amp(30.0, 12500.0, fs))
+    x = x.astype(np.complex64)
+    outs = []
+    for cuts in ([len(x)], [D * 100 + 7, D * 131 + 500, D * 450, len(x)]):
+        with nat.Frontend(fs, block_capacity=len(x)) as fe:
+            ids = [fe.chan_open(12500, f) for f in offs]
+            at = 0
+            for c in cuts:
+                fe.push(x[at:c])
+                at = c
+            outs.append([(fe.chan_read_iq(i), fe.chan_read_fm(i, 1.0)) for i in ids])
+    worst_iq = worst_fm = 0.0
+    for (y1, f1), (y2, f2) in zip(*outs):
+        assert len(y1) == len(y2) == n_out
+        worst_iq = max(worst_iq, rel_rms(y1, y2))
+        worst_fm = max(worst_fm, rms(f1, f2))
+    assert worst_iq < 2e-6 and worst_fm < 1e-5, (worst_iq, worst_fm)
+    for j in range(0, 8):
+        ct, incr = OC.xlating_composite(taps, D, offs[j], fs)
+        yo, fo = OC.channel_bank(x, D, ct[None, :], np.array([incr]), gains=[1.0])
+        for y, fm in (outs[0][j], outs[1][j]):
+            assert rel_rms(y, yo[0]) < 1e-5 and rms(fm, fo[0]) < 1e-4

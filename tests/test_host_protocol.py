@@ -447,6 +447,22 @@ def test_tap_leakage_matches_the_float32_phase_model():
         native.pfb_tap_leakage(fs, nb, taps, nb)
 
 
+def test_failed_channel_construction_releases_its_egress_port():
+    """receiver binds the channel's egress port before building the channel (as the reference's channel
+    flowgraph does, channel.py:36); when the build then fails the port must be handed back."""
+    cfg = types.SimpleNamespace(sources={0: dict(type="synthetic", center_freq=855000000, samp_rate=2400000)},
+                                frontend_mode="xlat")
+    tb = receiver.receiver(cfg, frontend_factory=StubFrontend)
+    bound, released = [], []
+    tb.bind_port = lambda port: bound.append(port) or True
+    tb.release_port = released.append
+    with pytest.raises(Exception):
+        tb.connect_channel(7, 855000000)                    # int(2.4e6 / 7) / 2 is not a decimation: the open fails
+    assert len(bound) == 1 and released == bound and not tb.channels
+    bid, port = tb.connect_channel(12500, 855012500)        # and the receiver still works
+    assert bid in tb.channels and released == bound[:1] and bound[-1] == port
+
+
 def test_rep_loop_survives_handler_errors_and_egress_isolates_channels():
     """a malformed request must not end serve_zmq (the reference's loop catches and keeps serving,
     receiver.py:686-699); one channel's egress failure must not stop the pump for the others."""
@@ -524,6 +540,13 @@ def test_rep_loop_survives_handler_errors_and_egress_isolates_channels():
                                 bind_port=None)
     pump = egress.EgressPump(tbx, socket_factory=factory)
     assert tbx.bind_port is not None and tbx.bind_port(12345) is False and tbx.bind_port(23456) is True
+    # a port that was bound but never got a channel (construction failed after bind_port) is released
+    # explicitly by the receiver, or swept by the next pump pass -- not held for the life of the process
+    assert 23456 in pump.prebound and tbx.release_port is not None
+    assert tbx.bind_port(34567) is True
+    tbx.release_port(34567)
+    assert socks[34567].closed and 34567 not in pump.prebound
     pump.pump_once()
+    assert socks[23456].closed and not pump.prebound          # no live channel on 23456: swept
     pump.pump_once()
     assert pump.errors == 2 and socks[22222].sent == 64 and pump.bytes_out == 64
