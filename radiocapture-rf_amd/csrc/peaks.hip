@@ -105,11 +105,21 @@ __global__ __launch_bounds__(1024) void k_tables(const float *__restrict__ max1,
         max2[b] = mx;
         min2[b] = mn;
     }
-    if (threadIdx.x == 0) {
-        double a = 0.0;
-        for (int i = 0; i < n2; ++i) a += part[i];
-        *mean_out = a / (double)n;
+    // ordered final sum: the partials go to LDS in one round trip (one thread reading them from global memory paid a
+    // memory latency per element: 76 us at n2 = 1024), then ONE thread adds them in index order
+    __shared__ double ps[1024];
+    double a = 0.0;
+    for (int base = 0; base < n2; base += 1024) {
+        const int i = base + threadIdx.x;
+        __syncthreads();
+        ps[threadIdx.x] = i < n2 ? part[i] : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int cnt = min(1024, n2 - base);
+            for (int q = 0; q < cnt; ++q) a += ps[q];
+        }
     }
+    if (threadIdx.x == 0) *mean_out = a / (double)n;
 }
 
 struct PickArgs {
@@ -125,7 +135,7 @@ struct PickArgs {
     int *heavy_count;
     int heavy_cap;
 };
-constexpr int kWalkBudget = 48;   // sequential steps a k_pick thread may spend on one peak before handing it over
+constexpr int kWalkBudget = 16;   // sequential steps a k_pick thread may spend on one peak before handing it over
 
 // min over the stretch from p outward (dir = -1 / +1) up to, not including, the first sample > h
 __device__ double walk_min(const PickArgs &a, int p, double h, int dir, int &budget)
@@ -373,11 +383,13 @@ __global__ __launch_bounds__(1024) void k_sort(int64_t *buf, const int *count, i
 {
     __shared__ int64_t s[4096];
     const int n = min(*count, cap);
+    int m = 2;                                             // sort only the power of two that holds the survivors:
+    while (m < n) m <<= 1;                                 // a dozen peaks are 10 compare stages, not 78
     for (int i = threadIdx.x; i < 4096; i += 1024) s[i] = i < n ? buf[i] : INT64_MAX;
     __syncthreads();
-    for (int k = 2; k <= 4096; k <<= 1)
+    for (int k = 2; k <= m; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < 4096; i += 1024) {
+            for (int i = threadIdx.x; i < m; i += 1024) {
                 const int l = i ^ j;
                 if (l > i) {
                     const bool up = (i & k) == 0;
