@@ -142,7 +142,7 @@ inline bool mfma2_applicable(int D, int T, size_t hist_cap, size_t buf_samples)
 // The plan depends on the launch (channel count, outputs in the block): with parts > 1 a channel's taps are summed
 // in `parts` float32 chains that are then added in order, so the LAST BITS of the bank's outputs depend on how the
 // stream is cut into blocks (and freshly opened channels get their first outputs from the vector kernel's order).
-// Deterministic for a given sequence of commits; cut-invariant to ~1e-6 relative, not bit for bit
+// Deterministic for a given sequence of commits; cut-invariant to ~1e-6 relative (5e-6 on noise-only channels), not bit for bit
 // (tests/test_gpu_round3.py::test_matrix_core_bank_uneven_cuts_agree_to_summation_order) -- unlike the filterbanks.
 struct MfmaPlan { int nt, parts; };
 inline MfmaPlan mfma_plan(int n_chans, int n_k, int T, int force_nt = 0, int force_parts = 0)
