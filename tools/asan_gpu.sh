@@ -11,8 +11,8 @@ mkdir -p gpurun_out
   echo "# ASan runtime: $RT"
   RCF_LIBRCF=$PWD/radiocapture-rf_amd/rcf/librcf_asan.so LD_PRELOAD=$RT \
   ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 \
-  timeout 1500 python -m pytest tests/test_gpu_round2.py tests/test_gpu_parity.py tests/test_gpu_end_to_end.py -m gpu -x -q \
-      -k "threads or churn or arena or pinned or chunked or mid_stream or ring_wrap or retune or create_channel or pfb_mode or source_offset" 2>&1 | tail -25
+  timeout 1500 python -m pytest tests/test_gpu_round2.py tests/test_gpu_round3.py tests/test_gpu_parity.py tests/test_gpu_end_to_end.py -m gpu -x -q \
+      -k "threads or churn or arena or pinned or chunked or mid_stream or ring_wrap or retune or create_channel or pfb_mode or source_offset or tap or uneven or 3200" 2>&1 | tail -25
   echo "# exit: $?"
 } > $OUT 2>&1
 cat $OUT
