@@ -274,3 +274,54 @@ def test_matrix_core_bank_uneven_cuts_agree_to_summation_order(gpu_required):
         yo, fo = OC.channel_bank(x, D, ct[None, :], np.array([incr]), gains=[1.0])
         for y, fm in (outs[0][j], outs[1][j]):
             assert rel_rms(y, yo[0]) < 1e-5 and rms(fm, fo[0]) < 1e-4
+
+
+def test_cfg5_per_gpu_shape_bank_scan_and_gather(gpu_required):
+    """BASELINE configs[4], the part one GPU runs (bench.py --config cfg5): a 25 Msps spectrum slice through the 512-bin
+    critically sampled bank (prototype by the reference's low_pass_2 rule: 6983 taps) WHILE the N = 2^20 / 1000-frame /
+    100-average scan (fft_vector.py:31-60) runs on the same stream, then the peak pick (fft_peak_detection.py:38-73)
+    and the gather of the rank's peak frequencies.  Bins against the float64 exact-phase bank, peak indices bit-exact
+    against the oracle chain, frequencies through the world-of-one all-gather."""
+    from oracle import peaks as P
+    from rcf import multigpu
+    nat = gpu_required
+    fs, nb, N, U, F, L, fc = 25e6, 512, 1 << 20, 16, 1000, 100, 851e6
+    bw = fs / nb
+    taps = nat.design_low_pass_2(1.0, fs, 0.4 * bw, 0.2 * bw, 60.0, nat.WIN_BLACKMAN_HARRIS)
+    assert len(taps) == 6983
+    rng = np.random.default_rng(5000)
+    centres = [40000 + 80000 * i + int(rng.integers(-3000, 3000)) for i in range(12)]
+    carriers = [(c, float(rng.uniform(4000, 9000)), 45.0) for c in centres]
+    tile = synth.scan_stream(fs, N, U, carriers, seed=5000)
+    bins = [0, 1, 37, 255, 256, 257, 511]
+    with nat.Frontend(fs, fc, block_capacity=N * U, hist_capacity=N, out_capacity=1 << 16) as fe:
+        fe.pfb_open(nb, nb, taps)
+        fe.ingest_write(tile, 0)
+        fe.commit(N * U)
+        fe.ingest_write(tile, 0)                     # both ping-pong buffers hold the periodic tile
+        fe.scan_start(N, F, L)
+        while fe.scan_frames_done() < F:
+            fe.commit(N * U)
+        spec = fe.scan_result()
+        lines_dev, _, _ = fe.scan_find_peaks(cap=1024)
+        got = {k: fe.pfb_read_bin(k)[-256:] for k in bins}
+        n_frames_total = fe.pfb_produced()
+        freqs = [nat.peak_frequency(int(i), fs, N, fc) for i in lines_dev]
+        gathered = multigpu.allgather_peaks(fe, freqs)
+    # the bank: the stream is the tile repeated; the newest 256 frames of a bin against the exact bank over the tail
+    S = n_frames_total * nb
+    assert S % len(tile) == 0
+    tail = np.tile(tile, 2)[-(256 + 16) * nb:]
+    for k in bins:
+        f0 = k * fs / nb if k < nb // 2 else (k - nb) * fs / nb
+        want = G.xlating_fir_exact(tail, nb, taps, f0, fs)[-256:]
+        scale = np.sqrt(np.mean(np.abs(want) ** 2))
+        assert np.sqrt(np.mean(np.abs(got[k] - want) ** 2)) / max(scale, 1e-6) < 2e-5, k
+    # the scan, armed after one committed tile: frame f is tile frame f % 16
+    frames = [OC.scan_chain(tile[u * N:(u + 1) * N], N, 1, 1) for u in range(U)]
+    want = G.scan_chain_periodic(frames, F, L)
+    assert np.sqrt(np.mean((spec - want) ** 2)) < 5e-3
+    l_want, _ = P.peak_detect_scipy(want, fs, fc)
+    np.testing.assert_array_equal(lines_dev, l_want)
+    assert len(l_want) == 12
+    assert sorted(int(v) for v in gathered) == sorted(int(nat.peak_frequency(int(i), fs, N, fc)) for i in l_want)
