@@ -59,7 +59,7 @@ SCAN_CEILING_NOTE = ("a 1M-point FFT cannot live in LDS: the four-step form move
 
 def proto_taps(native, fs=FS, nb=NB):
     # SURVEY 8(d) cfg2 prototype by the reference's own low_pass_2 rule: fc = 0.4 bin, tw = 0.2 bin,
-    # 60 dB, Blackman-Harris -> 3491 taps (13.6 per branch) at 256 bins, 6983 at 512
+    # 60 dB, Blackman-Harris -> 3491 taps (13.6 per branch) at 256 bins, 6981 at 512
     bw = fs / nb
     return native.design_low_pass_2(1.0, fs, 0.4 * bw, 0.2 * bw, 60.0, native.WIN_BLACKMAN_HARRIS)
 
@@ -689,7 +689,7 @@ def main():
             except Exception:
                 traffic = None
         if cfg5:
-            workload = ("BASELINE configs[4], per-GPU shape: 512-bin critically-sampled PFB (6983-tap prototype) over "
+            workload = ("BASELINE configs[4], per-GPU shape: 512-bin critically-sampled PFB (6981-tap prototype) over "
                         "one 25 Msps cf32 spectrum slice per GPU (x8 = 4096 channels at 200 Msps), N=2^20 scan of the "
                         "slice + <=1024 peaks per rank into the all-gather outside the timed region")
             kname = "pfb_kernel_pp<512,1,14,...> (persistent form)"

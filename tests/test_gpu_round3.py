@@ -278,7 +278,7 @@ def test_matrix_core_bank_uneven_cuts_agree_to_summation_order(gpu_required):
 
 def test_cfg5_per_gpu_shape_bank_scan_and_gather(gpu_required):
     """BASELINE configs[4], the part one GPU runs (bench.py --config cfg5): a 25 Msps spectrum slice through the 512-bin
-    critically sampled bank (prototype by the reference's low_pass_2 rule: 6983 taps) WHILE the N = 2^20 / 1000-frame /
+    critically sampled bank (prototype by the reference's low_pass_2 rule: 6981 taps) WHILE the N = 2^20 / 1000-frame /
     100-average scan (fft_vector.py:31-60) runs on the same stream, then the peak pick (fft_peak_detection.py:38-73)
     and the gather of the rank's peak frequencies.  Bins against the float64 exact-phase bank, peak indices bit-exact
     against the oracle chain, frequencies through the world-of-one all-gather."""
@@ -288,7 +288,7 @@ def test_cfg5_per_gpu_shape_bank_scan_and_gather(gpu_required):
     fs, nb, N, U, F, L, fc = 25e6, 512, 1 << 20, 16, 1000, 100, 851e6
     bw = fs / nb
     taps = nat.design_low_pass_2(1.0, fs, 0.4 * bw, 0.2 * bw, 60.0, nat.WIN_BLACKMAN_HARRIS)
-    assert len(taps) == 6983
+    assert len(taps) == 6981
     rng = np.random.default_rng(5000)
     centres = [40000 + 80000 * i + int(rng.integers(-3000, 3000)) for i in range(12)]
     carriers = [(c, float(rng.uniform(4000, 9000)), 45.0) for c in centres]
