@@ -94,6 +94,17 @@ int rcf_open(int device, double samp_rate, double center_freq, rcf_t **out);
 int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_capacity,
                 size_t hist_capacity, size_t out_capacity, rcf_t **out);
 int rcf_close(rcf_t *h);
+/* How the channels' rotators run (freq_xlating_fir_filter_ccc's gr::blocks::rotator, rc_frontend/channel.py:35).
+ * exact = 0 (default): GNU Radio's float32 increment in closed form (float64 model) -- any block size at full speed;
+ *   the IQ stream is GNU Radio's up to a slowly turning common phase (7.7e-6 .. 4.3e-4 rad after 10^6 outputs),
+ *   discriminator and magnitudes are not affected.
+ * exact != 0: GNU Radio's own recurrence, phase *= incr in float32 with the renormalisation every 512 calls, iterated
+ *   per channel on the device before each block's FIR launches: the IQ stream then carries GNU Radio's phase output for
+ *   output at any stream length.  Sequential by nature (~4 ns per output and channel per block): meant for real-time
+ *   block sizes.  Plain channels only -- filterbank bin taps keep the closed form (their rotator also carries the
+ *   bank's own phases).  Must be called before the first channel is opened (RCF_ESTATE otherwise); the environment
+ *   variable RCF_ROTATOR=exact sets it at rcf_open. */
+int rcf_set_rotator(rcf_t *h, int exact);
 /* wait until everything queued on the handle's stream has finished */
 int rcf_sync(rcf_t *h);
 /* the handle's hipStream_t, for callers that time the kernels with HIP events */

@@ -514,6 +514,47 @@ __global__ __launch_bounds__(kThreads) void disc_kernel(const DiscLaunch *__rest
     }
 }
 
+// ---------------------------------------------------------------- exact rotator (rcf_set_rotator)
+// gr::blocks::rotator as freq_xlating_fir_filter_ccc drives it, one lane per channel, the block's outputs in order:
+//   y = v * phase;  phase *= incr;  if (++counter % 512 == 0) phase /= |phase|       (float32, unfused)
+// The kernel only TABULATES phase per output (the multiply happens in the FIR kernels' epilogues, rotate_value): the
+// sequence does not depend on the data.  Sequential by nature -- ~4 ns per output and channel -- which is why it is an
+// option: at real-time block sizes (thousands of outputs) it hides behind the FIR launch it precedes; at the bench's
+// 10^4 x real time it would not.  |phase| as glibc's hypotf computes it: sqrt of the exact double sum, rounded twice.
+__global__ __launch_bounds__(64) void rot_fill_kernel(const RotFill *__restrict__ items, int n_items, uint64_t ring_mask)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_items) return;
+    const RotFill it = items[i];
+    float pr = it.state[0], pi = it.state[1];
+    unsigned cnt = __float_as_uint(it.state[2]);
+    const float ir = it.incr_re, ii = it.incr_im;
+    // runs between two renormalisations (every 512th call) are plain loops: nothing but the recurrence and a store
+    int j = 0;
+    while (j < it.n_k) {
+        const int run = min(it.n_k - j, 512 - (int)(cnt & 511u));
+        uint64_t at = (uint64_t)(it.n_from + j);
+#pragma unroll 8
+        for (int q = 0; q < run; ++q) {
+            it.ring[(at + q) & ring_mask] = make_float2(pr, pi);
+            const float nr = __fsub_rn(__fmul_rn(pr, ir), __fmul_rn(pi, ii));
+            const float ni = __fadd_rn(__fmul_rn(pr, ii), __fmul_rn(pi, ir));
+            pr = nr;
+            pi = ni;
+        }
+        cnt += (unsigned)run;
+        j += run;
+        if ((cnt & 511u) == 0) {
+            const float mag = (float)sqrt((double)pr * (double)pr + (double)pi * (double)pi);
+            pr = __fdiv_rn(pr, mag);
+            pi = __fdiv_rn(pi, mag);
+        }
+    }
+    it.state[0] = pr;
+    it.state[1] = pi;
+    it.state[2] = __uint_as_float(cnt);
+}
+
 // ---------------------------------------------------------------- filterbank taps: matrix -> channel rings
 // The frame-major banks (pfb5.hip) leave the tapped bins of a launch as a compact frame-major matrix, row r = the
 // bank's frame k_first + r, one column per tap.  A workgroup takes 16 taps x 128 outputs: it reads the rows the way
@@ -658,6 +699,12 @@ void launch_fm_fir(const FmFirLaunch *d_items, int n_items, int max_n_k, uint64_
     if (n_items <= 0 || max_n_k <= 0) return;
     hipLaunchKernelGGL(fm_fir_kernel, dim3((max_n_k + kThreads - 1) / kThreads, n_items), dim3(kThreads), 0, s,
                        d_items, ring_mask);
+}
+
+void launch_rot_fill(const RotFill *d_items, int n_items, uint64_t ring_mask, hipStream_t s)
+{
+    if (n_items <= 0) return;
+    hipLaunchKernelGGL(rot_fill_kernel, dim3((n_items + 63) / 64), dim3(64), 0, s, d_items, n_items, ring_mask);
 }
 
 void launch_tap_finalize(const TapLaunch *d_taps, int n_taps, const float2 *tap_mat, int tap_pitch, int n_rows,

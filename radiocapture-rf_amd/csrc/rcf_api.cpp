@@ -88,6 +88,9 @@ struct Chan {
         int64_t rd = 0;                 // audio samples handed to the reader
     };
     std::unique_ptr<Audio> audio;
+    // exact rotator (rcf_set_rotator): phase ring + {phase, counter} state, one pool slice; incr = what GNU Radio iterates
+    float2 *d_rot = nullptr;
+    float incr[2] = {1.f, 0.f};
     // rotator model
     double extra_dangle = 0, extra_dlogmag = 0;   // added to the increment's own angle / log magnitude (filterbank taps)
     double dangle = 0, dlogmag = 0;
@@ -184,6 +187,7 @@ struct rcf {
     unsigned timing_mask = ~0u;
     int mfma_min = 8;             // fewest channels of a class worth a matrix-core launch (RCF_FIR_MFMA_MIN)
     int mfma_nt = 0, mfma_parts = 0;   // RCF_FIR_MFMA_NT / RCF_FIR_MFMA_PARTS: override the launch plan (measurements)
+    bool exact_rot = false;       // rcf_set_rotator / RCF_ROTATOR=exact: channels iterate GNU Radio's float32 rotator
     float2 *d_tapmat = nullptr;   // filterbank taps: the current launch's compact tap matrix (PfbLaunch::tap_mat)
     size_t tapmat_cap = 0;        // in float2
     float2 *d_partial = nullptr;  // split-K slabs of the matrix-core bank
@@ -338,6 +342,8 @@ int upload_composite(rcf_t *h, Chan *c)
     c->d_ctaps = fresh;
     c->taps_version = ++h->taps_clock;
     // GR iterates phase *= incr in float32; model it by the increment's actual angle and magnitude
+    c->incr[0] = incr[0];
+    c->incr[1] = incr[1];
     c->dangle = std::atan2((double)incr[1], (double)incr[0]) + c->extra_dangle;
     c->dlogmag = std::log(std::hypot((double)incr[0], (double)incr[1])) + c->extra_dlogmag;
     return RCF_OK;
@@ -377,9 +383,21 @@ int new_channel(rcf_t *h, int src, int D, const float *taps, int T, double offse
     c->d_iq = static_cast<float2 *>(pool_get(h, ring_slice));
     if (!c->d_iq) return RCF_ENOMEM;
     c->d_fm = reinterpret_cast<float *>(c->d_iq + h->out_cap);
+    if (h->exact_rot) {
+        const size_t rot_slice = slice_round(sizeof(float2) * h->out_cap + 256);
+        c->d_rot = static_cast<float2 *>(pool_get(h, rot_slice));
+        if (!c->d_rot) { h->pools[ring_slice].free_.push_back(c->d_iq); return RCF_ENOMEM; }
+        const float st0[4] = {1.0f, 0.0f, 0.0f, 0.0f};       // phase 1 + 0j, counter 0 (bit pattern of 0.0f)
+        if (!hip_ok(hipMemcpy(c->d_rot + h->out_cap, st0, sizeof(st0), hipMemcpyHostToDevice), "hipMemcpy(rotator state)")) {
+            h->pools[rot_slice].free_.push_back(c->d_rot);
+            h->pools[ring_slice].free_.push_back(c->d_iq);
+            return RCF_EHIP;
+        }
+    }
     int rc = upload_composite(h, c.get());
     if (rc != RCF_OK) {
         h->pools[ring_slice].free_.push_back(c->d_iq);      // never seen by the stream: straight back
+        if (c->d_rot) h->pools[slice_round(sizeof(float2) * h->out_cap + 256)].free_.push_back(c->d_rot);
         return rc;
     }
     c->id = h->next_id++;
@@ -392,6 +410,8 @@ void free_channel(rcf_t *h, Chan *c)
 {
     bury(h, c->d_ctaps, slice_round(sizeof(float2) * (size_t)c->T));
     bury(h, c->d_iq, slice_round(12 * h->out_cap));       // d_fm lives in the same slice
+    bury(h, c->d_rot, slice_round(sizeof(float2) * h->out_cap + 256));
+    c->d_rot = nullptr;
     bury(h, c->d_sym);
     bury(h, c->d_symtaps);
     if (c->audio) { bury(h, c->audio->d_state); bury(h, c->audio->d_rings); bury(h, c->audio->d_taps); c->audio.reset(); }
@@ -452,7 +472,7 @@ int process_block(rcf_t *h, size_t n)
         size_t need = 4096;
         for (auto &kv : h->chans) {
             const Chan &c = *kv.second;
-            need += 2 * sizeof(ChanLaunch) + sizeof(TapLaunch) + sizeof(DiscLaunch) + 8 + 128;
+            need += 2 * sizeof(ChanLaunch) + sizeof(TapLaunch) + sizeof(DiscLaunch) + sizeof(RotFill) + 8 + 128;
             if (c.d_sym) need += sizeof(FmFirLaunch);
             if (c.audio) need += sizeof(AudioLaunch);
             max_depth = std::max(max_depth, c.depth);
@@ -495,6 +515,7 @@ int process_block(rcf_t *h, size_t n)
     std::vector<DiscJob> disc_jobs;
     std::vector<FmFirLaunch> symf;     // symbol filters, all channels in one launch
     int symf_max_n = 0;
+    std::vector<RotFill> rot_fills;    // exact rotator: one record per launched channel, one launch before the FIRs
     std::vector<TapLaunch> tap_list;   // filterbank taps: copied out by the bank's kernel, finished by tap_finalize
     std::vector<int32_t> tap_bins;
     const TapLaunch *d_tap_list = nullptr;
@@ -603,6 +624,19 @@ int process_block(rcf_t *h, size_t n)
                 L.logmag0 = c->logmag0;
                 L.dlogmag = c->dlogmag;
                 L.n_k = (int32_t)cnt;
+                // exact rotator: plain channels only (a filterbank tap's rotator carries the bank's own phases too)
+                if (c->d_rot && !c->is_tap && c->extra_dangle == 0.0 && c->extra_dlogmag == 0.0) {
+                    L.rot_ring = c->d_rot;
+                    L.rot_mask = h->ring_mask;
+                    RotFill rf{};
+                    rf.ring = c->d_rot;
+                    rf.state = reinterpret_cast<float *>(c->d_rot + h->out_cap);
+                    rf.n_from = k_lo - c->k_abs0;
+                    rf.n_k = (int32_t)cnt;
+                    rf.incr_re = c->incr[0];
+                    rf.incr_im = c->incr[1];
+                    rot_fills.push_back(rf);
+                }
                 DiscLaunch dl{};
                 dl.iq_ring = c->d_iq;
                 dl.fm_ring = c->d_fm;
@@ -846,6 +880,8 @@ int process_block(rcf_t *h, size_t n)
         pl.tap_pitch = (int32_t)pitch;
         pl.n_taps = (int32_t)tap_list.size();
     }
+    const RotFill *d_rot_fills = nullptr;
+    if (!rot_fills.empty() && !ar.put(rot_fills, &d_rot_fills)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
     const FmFirLaunch *d_symf = nullptr;
     if (!symf.empty() && !ar.put(symf, &d_symf)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
     const AudioLaunch *d_audf = nullptr;
@@ -858,6 +894,7 @@ int process_block(rcf_t *h, size_t n)
         h->arena_used[a] = true;
         h->arena_cur ^= 1;
     }
+    if (d_rot_fills) launch_rot_fill(d_rot_fills, (int)rot_fills.size(), h->ring_mask, st);
     if (!fir_by_depth.empty())
         for (auto &j : fir_by_depth[0]) {
             if (j.repack) {
@@ -1196,6 +1233,7 @@ int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_c
     h->ring_mask = (uint64_t)h->out_cap - 1;
     {
         if (const char *nm = getenv("RCF_FIR_NOMFMA")) h->no_mfma = atoi(nm) != 0;
+        if (const char *rm = getenv("RCF_ROTATOR")) h->exact_rot = std::strcmp(rm, "exact") == 0;
     if (const char *nm = getenv("RCF_FIR_MFMA_MIN")) h->mfma_min = std::max(1, atoi(nm));
         if (const char *nm = getenv("RCF_FIR_MFMA_NT")) h->mfma_nt = atoi(nm);
         if (const char *nm = getenv("RCF_FIR_MFMA_PARTS")) h->mfma_parts = atoi(nm);
@@ -1295,6 +1333,15 @@ int rcf_timing_read(rcf_t *h, int what, double *total_ms, int64_t *launches, int
     if (total_ms) *total_ms = h->time_ms[what];
     if (launches) *launches = h->time_n[what];
     if (reset) { h->time_ms[what] = 0; h->time_n[what] = 0; }
+    return RCF_OK;
+}
+
+int rcf_set_rotator(rcf_t *h, int exact)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->chans.empty()) { set_error("rcf_set_rotator: channels are already open"); return RCF_ESTATE; }
+    h->exact_rot = exact != 0;
     return RCF_OK;
 }
 

@@ -98,7 +98,22 @@ struct ChanLaunch {
     int32_t n_k;             // outputs to produce
     int32_t pad_;
     float *fm_ring;          // discriminator ring (written by the fused small-T kernel only)
+    // exact rotator (rcf_set_rotator): GNU Radio's phase for output n = k - k_abs0, iterated in float32 by
+    // rot_fill_kernel before the block's FIR launches; nullptr = the closed form above
+    const float2 *rot_ring;
+    uint64_t rot_mask;
+    static constexpr bool kHasRotRing = true;
 };
+// one channel's share of rot_fill_kernel: phases of outputs [n_from, n_from + n_k) into the ring, state carried on
+struct RotFill {
+    float2 *ring;
+    float *state;            // {phase.re, phase.im, call counter (uint32 bits)}: the phase the NEXT output gets
+    int64_t n_from;
+    int32_t n_k;
+    float incr_re, incr_im;  // float32(cos a, sin a), a = float32(-fwT0 * D): what GNU Radio iterates
+    int32_t pad_;
+};
+void launch_rot_fill(const RotFill *d_items, int n_items, uint64_t ring_mask, hipStream_t s);
 
 // outputs per workgroup of the small-T kernel (tile of KB D + T samples within ~26 KB of LDS, two outputs per
 // thread minus the recomputed predecessor); 0 = not applicable
@@ -288,6 +303,7 @@ struct TapLaunch {           // one tapped bin, consumed by tap_finalize_kernel
     double logmag0, dlogmag;
     int32_t n_k;
     int32_t bin;
+    static constexpr bool kHasRotRing = false;
 };
 // mat row r = the bank's frame k_first + r (tap output index); rows [0, n_rows)
 void launch_tap_finalize(const TapLaunch *d_taps, int n_taps, const float2 *tap_mat, int tap_pitch, int n_rows,

@@ -46,15 +46,28 @@ __device__ __forceinline__ void sincos_fast(double a, double &sn, double &cs)
 template <class LT>
 __device__ __forceinline__ float2 rotate_value(const LT &L, int64_t n, float vr, float vi)
 {
-    const int64_t dk = n - L.n_seg0;
-    const int64_t r512 = n & ~(int64_t)511;
-    const double ang = L.angle0 + (double)dk * L.dangle;
-    const double lm = (r512 > L.n_seg0) ? (double)(n - r512) * L.dlogmag : L.logmag0 + (double)dk * L.dlogmag;
-    double sn, cs;
-    sincos_fast(ang, sn, cs);
-    // |lm| is a few hundred times log|incr| ~ 1e-7: four series terms are exact to double rounding
-    const double mag = fabs(lm) < 1e-3 ? 1.0 + lm * (1.0 + lm * (0.5 + lm * (1.0 / 6.0))) : exp(lm);
-    const float pr = (float)(mag * cs), pi = (float)(mag * sn);
+    float pr = 1.f, pi = 0.f;
+    bool have = false;
+    if constexpr (LT::kHasRotRing) {
+        if (L.rot_ring) {                                 // exact mode: the phase GNU Radio's iteration holds at output n
+            const float2 p = L.rot_ring[(uint64_t)n & L.rot_mask];
+            pr = p.x;
+            pi = p.y;
+            have = true;
+        }
+    }
+    if (!have) {
+        const int64_t dk = n - L.n_seg0;
+        const int64_t r512 = n & ~(int64_t)511;
+        const double ang = L.angle0 + (double)dk * L.dangle;
+        const double lm = (r512 > L.n_seg0) ? (double)(n - r512) * L.dlogmag : L.logmag0 + (double)dk * L.dlogmag;
+        double sn, cs;
+        sincos_fast(ang, sn, cs);
+        // |lm| is a few hundred times log|incr| ~ 1e-7: four series terms are exact to double rounding
+        const double mag = fabs(lm) < 1e-3 ? 1.0 + lm * (1.0 + lm * (0.5 + lm * (1.0 / 6.0))) : exp(lm);
+        pr = (float)(mag * cs);
+        pi = (float)(mag * sn);
+    }
     // rotator::rotate(): z = in * phase, float32 complex multiply, unfused
     float2 y;
     y.x = __fsub_rn(__fmul_rn(vr, pr), __fmul_rn(vi, pi));

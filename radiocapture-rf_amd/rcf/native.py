@@ -36,7 +36,7 @@ SYMBOLS = [
     "rcf_chan_audio_close", "rcf_chan_audio_produced", "rcf_chan_read_audio",
     "rcf_host_alloc", "rcf_host_free", "rcf_comm_unique_id", "rcf_comm_init", "rcf_comm_destroy", "rcf_comm_size",
     "rcf_allgather_peaks", "rcf_allreduce_max", "rcf_pfb_tap_open", "rcf_pfb_shape_supported",
-    "rcf_pfb_tap_leakage",
+    "rcf_pfb_tap_leakage", "rcf_set_rotator",
 ]
 FMT_U8, FMT_S8, FMT_S16 = 1, 2, 3
 T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY, T_FIR_MFMA, T_AUDIO, T_TAPS = range(10)
@@ -77,6 +77,7 @@ def lib():
         "rcf_open": (C.c_int, [C.c_int, C.c_double, C.c_double, C.POINTER(vp)]),
         "rcf_open_ex": (C.c_int, [C.c_int, C.c_double, C.c_double, sz, sz, sz, C.POINTER(vp)]),
         "rcf_close": (C.c_int, [vp]),
+        "rcf_set_rotator": (C.c_int, [vp, C.c_int]),
         "rcf_sync": (C.c_int, [vp]),
         "rcf_stream": (vp, [vp]),
         "rcf_device": (C.c_int, [vp]),
@@ -308,6 +309,10 @@ class Frontend:
 
     def __exit__(self, *a):
         self.close()
+
+    def set_rotator(self, exact=True):
+        """exact: iterate GNU Radio's float32 rotator per channel (rcf_set_rotator); before the first channel"""
+        _check(lib().rcf_set_rotator(self._h, 1 if exact else 0))
 
     def sync(self):
         _check(lib().rcf_sync(self._h))

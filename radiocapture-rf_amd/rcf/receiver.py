@@ -55,6 +55,11 @@ class receiver:
         for source in sorted(self.realsources):
             src = self.realsources[source]
             fe = frontend_factory(float(src["samp_rate"]), float(src["center_freq"]), device)
+            # config.rotator = 'exact': the channels iterate GNU Radio's float32 rotator (rcf_set_rotator) -- the IQ
+            # egress then carries GNU Radio's phase at any stream length, for ~30 ns per output and channel per block;
+            # default 'fast' = its closed form (the discriminator cannot tell them apart)
+            if getattr(config, "rotator", "fast") == "exact":
+                fe.set_rotator(True)
             if getattr(config, "receiver_split2", False):
                 # receiver.py:205-237: each source becomes two half-rate sources, centre -/+ fs/4, through
                 # freq_xlating_fir_filter_ccc(2, firdes.low_pass(1, fs, fs/4, fs/8), -/+fs/4, fs).

@@ -447,6 +447,26 @@ def test_tap_leakage_matches_the_float32_phase_model():
         native.pfb_tap_leakage(fs, nb, taps, nb)
 
 
+def test_receiver_rotator_config_reaches_the_front_end():
+    """config.rotator = 'exact' -> rcf_set_rotator on every source's front-end before any channel exists"""
+    class Fe(StubFrontend):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.rotator = None
+
+        def set_rotator(self, exact=True):
+            assert not self.chans
+            self.rotator = exact
+
+    cfg = types.SimpleNamespace(sources={0: dict(type="synthetic", center_freq=855000000, samp_rate=2400000)},
+                                frontend_mode="xlat", rotator="exact")
+    tb = receiver.receiver(cfg, frontend_factory=Fe)
+    assert StubFrontend.instances[-1].rotator is True
+    cfg.rotator = "fast"
+    tb = receiver.receiver(cfg, frontend_factory=Fe)
+    assert StubFrontend.instances[-1].rotator is None
+
+
 def test_failed_channel_construction_releases_its_egress_port():
     """receiver binds the channel's egress port before building the channel (as the reference's channel
     flowgraph does, channel.py:36); when the build then fails the port must be handed back."""
