@@ -388,3 +388,31 @@ def test_exact_rotator_carries_gnuradio_phase_for_a_million_outputs(gpu_required
             assert rows[-1]["iq_rel_rms"] < 2e-7, (name, rows[-1])       # measured 4.5e-8 .. 5.6e-8 at every n
         out.append({"case": name, "rows": rows})
     _dump("r03_iq_exact_rotator.json", {"outputs": n_out, "retune_of_case_0_at_output": k_retune, "cases": out})
+
+
+def test_pfb3200_two_thousand_taps_equal_their_bins(gpu_required):
+    """More taps than one pass of the bank's tap copy covers (5 x 320 slots): 2000 of the 3200 bins of the 6.25 kHz-grid
+    bank opened as channels with idle rotators -- every tap stream must be its bin bit for bit, through two ragged
+    pushes (tap matrix rows of 2000 x 8 bytes, tap_finalize tiles at both launches' edges)."""
+    nat = gpu_required
+    fs, nb = 20e6, 3200
+    D, taps = G.channel_params(fs, 12500)                    # D = 800: OS = 4, one tap per branch
+    rng = np.random.default_rng(123)
+    n_frames = 150
+    x = synth.awgn(rng, D * n_frames + 333)
+    picks = [(7 * i + 3) % nb for i in range(2000)]
+    assert len(set(picks)) == 2000
+    with nat.Frontend(fs, block_capacity=len(x), out_capacity=1 << 10) as fe:
+        fe.pfb_open(nb, D, taps)
+        ids = [fe.pfb_tap_open(k, gr_phase=False) for k in picks]
+        cut = D * 61 + 17
+        fe.push(x[:cut])
+        fe.push(x[cut:])
+        n_out = fe.pfb_produced()
+        for j in (0, 1, 319, 320, 1599, 1600, 1601, 1999):
+            y = fe.chan_read_iq(ids[j])
+            b = fe.pfb_read_bin(picks[j])
+            assert len(y) == len(b) == n_out
+            np.testing.assert_array_equal(y, b)
+            fm = fe.chan_read_fm(ids[j], 1.0)
+            np.testing.assert_array_equal(fm, G.quadrature_demod_cf(b.astype(np.complex64), 1.0))
