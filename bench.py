@@ -488,6 +488,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs (sweep, scan, end-to-end, ...)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained leg")
+    ap.add_argument("--time-every", type=int, default=4,
+                    help="HIP events around every n-th filterbank launch of the timed region (1 = all of them)")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5,
                     help="untimed commits before the warm-up steps: the metric is SUSTAINED throughput, and the chip "
                          "needs ~100 launches (15 ms) after idling before the filterbank launch settles (the first "
@@ -588,7 +590,10 @@ def main():
         fe.commit(B)
     # HIP events only around the kernel the roofline reports: every timed launch costs two event records on the
     # stream (~10 us of inter-kernel gap each), which would otherwise be charged to `value`
+    # ... and only every 4th filterbank launch of the timed region: an event record is a barrier packet, ~6 us of
+    # queue gap each (rocprof trace, tools/gap_probe.py), 12 us per bracketed launch of a 0.13 ms step
     fe.timing_enable(True, classes=[native.T_PFB])
+    fe.timing_stride(args.time_every)
     for w in range(native.T_HISTORY + 1):
         fe.timing_read(w, reset=True)
     barrier_max()
@@ -600,6 +605,7 @@ def main():
     elapsed = barrier_max(t1 - t0)
 
     pfb_ms, pfb_n = fe.timing_read(native.T_PFB)
+    fe.timing_stride(1)
     # the FM channels' newest outputs, for the parity check against the oracle (done in the cpu_baseline leg)
     fm_check = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and chans:
@@ -725,7 +731,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_launch_ms": avg_pfb_s * 1e3, "launches": pfb_n,
+                "avg_launch_ms": avg_pfb_s * 1e3, "launches": pfb_n, "timed_every": args.time_every,
                 "avg_launch_ms_slowest_rank": pfb_avg_ms_max,
                 "frac_slowest_rank": alg_bytes / (pfb_avg_ms_max * 1e-3) / 1e9 / HBM_PEAK_GBS if pfb_avg_ms_max > 0 else 0.0,
             },

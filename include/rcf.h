@@ -128,6 +128,10 @@ int rcf_device(rcf_t *h);
 /* on = 0: off; 1: every class; otherwise a mask with bit (class + 1) set for each class to time -- every timed
  * launch costs two event records on the stream (~10 us of gap), so a throughput run times only what it reports */
 int rcf_timing_enable(rcf_t *h, int on);
+/* events around every `every`-th launch of a timed class only (default 1 = every launch).  An event record is a
+ * barrier packet: ~6 us of queue gap each on MI355X, two per timed launch -- at a 0.13 ms step that is 9 % of the
+ * throughput being measured; a stride keeps the per-launch durations live and the stream nearly undisturbed. */
+int rcf_timing_stride(rcf_t *h, int every);
 /* accumulated milliseconds and launch count of one class since the last reset (syncs the stream) */
 int rcf_timing_read(rcf_t *h, int what, double *total_ms, int64_t *launches, int reset);
 

@@ -60,7 +60,26 @@ __global__ __launch_bounds__(256) void gather_view_kernel(StreamView v, int64_t 
     if (i < n) dst[i] = v.base[v.at(first + (int64_t)i)];
 }
 
+// plain 8-byte-granular copy.  The per-block schedule used hipMemcpyAsync for its two small copies (launch records
+// host -> device, history tail device -> device); the runtime puts each of those behind ~6 us of queue gap, while a
+// kernel follows the kernel before it with none (rocprof trace of the timed configuration: 136.8 us per step of which
+// 12 us were those two gaps).  n8 = number of 8-byte words; src may be pinned host memory.
+__global__ __launch_bounds__(256) void copy8_kernel(unsigned long long *__restrict__ dst,
+                                                    const unsigned long long *__restrict__ src, size_t n8)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 }  // namespace
+
+void launch_copy8(void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    const size_t n8 = (bytes + 7) / 8;
+    if (n8 == 0) return;
+    const size_t blocks = std::min<size_t>((n8 + 255) / 256, 2048);
+    hipLaunchKernelGGL(copy8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<unsigned long long *>(dst),
+                       static_cast<const unsigned long long *>(src), n8);
+}
 
 void launch_gather_view(const StreamView &v, int64_t first, float2 *dst, size_t n, hipStream_t s)
 {

@@ -150,10 +150,15 @@ struct rcf {
     // launch-parameter arenas (pinned host + device), double buffered
     size_t arena_cap = 8u << 20;
     unsigned char *h_arena[2] = {nullptr, nullptr};
+    unsigned char *h_arena_dev[2] = {nullptr, nullptr};   // the same pinned memory as the device sees it
+    bool copy_kernels = true;     // RCF_COPY_KERNELS=0: hipMemcpyAsync for the launch records and the history (A/B)
     unsigned char *d_arena[2] = {nullptr, nullptr};
     hipEvent_t arena_ev[2] = {nullptr, nullptr};
     bool arena_used[2] = {false, false};
     int arena_cur = 0;
+    size_t arena_fill = 0;        // bytes of the current arena taken by earlier commits (records are appended: the event
+                                  // that guards an arena's reuse is recorded when it is LEFT, not once per commit --
+                                  // every hipEventRecord costs ~6 us of queue gap, rocprof trace of the timed configuration)
     std::map<int, std::unique_ptr<Chan>> chans;
     int next_id = 1;
     Pfb pfb;
@@ -176,6 +181,10 @@ struct rcf {
     hipEvent_t buf_done[2] = {nullptr, nullptr};   // the kernels that read d_buf[i] have finished
     hipEvent_t copy_ev = nullptr, raw_done = nullptr;
     bool buf_done_set[2] = {false, false};
+    bool buf_dirty[2] = {false, false};   // kernels that read d_buf[i] were queued after buf_done[i] was last recorded
+    bool eager_buf_done = false;          // a handle that is fed by rcf_push_iq records buf_done after every block (the
+                                          // next block's copy overlaps this block's kernels); one fed in place
+                                          // (rcf_ingest_ptr / rcf_commit) has no copy to order and records nothing
     bool raw_done_set = false;
     // RCCL communicator for the peak-list all-gather (rcf_comm_init); librccl is dlopen'ed on first use
     void *comm = nullptr;
@@ -196,6 +205,8 @@ struct rcf {
     struct TimeRec { int what; hipEvent_t a, b; };
     std::vector<TimeRec> time_pending;
     std::vector<hipEvent_t> time_pool;
+    unsigned timing_stride = 1;   // rcf_timing_stride: events around every n-th launch of a class only
+    unsigned time_seen[RCF_T_COUNT] = {0};
     double time_ms[RCF_T_COUNT] = {0};
     int64_t time_n[RCF_T_COUNT] = {0};
     std::mutex mu;
@@ -262,7 +273,10 @@ struct Timed {   // RAII: brackets the launches issued in its scope with two eve
     rcf_t *h; int what; hipEvent_t a = nullptr;
     Timed(rcf_t *h_, int what_) : h(h_), what(what_)
     {
-        if (h->timing && (h->timing_mask >> what & 1u)) { a = time_event(h); (void)hipEventRecord(a, h->stream); }
+        if (h->timing && (h->timing_mask >> what & 1u) && (h->time_seen[what]++ % h->timing_stride) == 0) {
+            a = time_event(h);
+            (void)hipEventRecord(a, h->stream);
+        }
     }
     ~Timed()
     {
@@ -463,6 +477,7 @@ int process_block(rcf_t *h, size_t n)
     // host's schedule time).
     std::unordered_map<int, size_t> reach_x;                // source id (channel id / RCF_SRC_PFB_BIN0) -> samples
     int max_depth = 0;
+    size_t arena_need = 0;
 
     // arena for this commit: sized for every channel's launch records before anything is scheduled, so the
     // schedule below cannot run out half way (it mutates channel state as it goes)
@@ -483,6 +498,7 @@ int process_block(rcf_t *h, size_t n)
             }
         }
         need += 64 * (h->chans.size() / 4 + 64);              // per-class alignment slack
+        arena_need = need;
         if (need > h->arena_cap) {
             RCF_HIP(hipStreamSynchronize(h->stream));
             size_t cap = h->arena_cap;
@@ -496,13 +512,26 @@ int process_block(rcf_t *h, size_t n)
                 h->h_arena[i] = nh;
                 h->d_arena[i] = nd;
                 h->arena_used[i] = false;
+                void *dv = nullptr;
+                h->h_arena_dev[i] = hipHostGetDevicePointer(&dv, nh, 0) == hipSuccess ? static_cast<unsigned char *>(dv) : nullptr;
+                if (!h->h_arena_dev[i]) h->copy_kernels = false;
             }
             h->arena_cap = cap;
+            h->arena_fill = 0;
         }
     }
+    if (h->arena_fill + arena_need > h->arena_cap) {
+        // this arena is full: everything queued so far may still read it -- one event now guards its reuse -- and the
+        // other one must have been drained
+        RCF_HIP(hipEventRecord(h->arena_ev[h->arena_cur], h->stream));
+        h->arena_used[h->arena_cur] = true;
+        h->arena_cur ^= 1;
+        h->arena_fill = 0;
+        if (h->arena_used[h->arena_cur]) RCF_HIP(hipEventSynchronize(h->arena_ev[h->arena_cur]));
+    }
     const int a = h->arena_cur;
-    if (h->arena_used[a]) RCF_HIP(hipEventSynchronize(h->arena_ev[a]));
-    Arena ar{h->h_arena[a], h->d_arena[a], 0, h->arena_cap};
+    const size_t arena_base = h->arena_fill;
+    Arena ar{h->h_arena[a], h->d_arena[a], arena_base, h->arena_cap};
 
     struct FirJob {
         FirLaunchDims dims; const ChanLaunch *dev; bool repack; const unsigned char *dirty;
@@ -888,11 +917,11 @@ int process_block(rcf_t *h, size_t n)
     if (!audf.empty() && !ar.put(audf, &d_audf)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
 
     // ---- upload all launch parameters in one copy, then launch in dependency order
-    if (ar.used) {
-        RCF_HIP(hipMemcpyAsync(ar.d, ar.h, ar.used, hipMemcpyHostToDevice, st));
-        RCF_HIP(hipEventRecord(h->arena_ev[a], st));
-        h->arena_used[a] = true;
-        h->arena_cur ^= 1;
+    if (ar.used > arena_base) {
+        const size_t from = arena_base & ~size_t(63), bytes = ((ar.used + 63) & ~size_t(63)) - from;
+        if (h->copy_kernels) launch_copy8(ar.d + from, h->h_arena_dev[a] + from, bytes, st);
+        else RCF_HIP(hipMemcpyAsync(ar.d + from, ar.h + from, bytes, hipMemcpyHostToDevice, st));
+        h->arena_fill = (ar.used + 63) & ~size_t(63);
     }
     if (d_rot_fills) launch_rot_fill(d_rot_fills, (int)rot_fills.size(), h->ring_mask, st);
     if (!fir_by_depth.empty())
@@ -959,11 +988,17 @@ int process_block(rcf_t *h, size_t n)
     const int other = h->cur ^ 1;
     {
         Timed t(h, RCF_T_HISTORY);
-        RCF_HIP(hipMemcpyAsync(h->d_buf[other], h->d_buf[h->cur] + n, sizeof(float2) * h->hist_cap,
-                               hipMemcpyDeviceToDevice, st));
+        if (h->copy_kernels) launch_copy8(h->d_buf[other], h->d_buf[h->cur] + n, sizeof(float2) * h->hist_cap, st);
+        else RCF_HIP(hipMemcpyAsync(h->d_buf[other], h->d_buf[h->cur] + n, sizeof(float2) * h->hist_cap,
+                                    hipMemcpyDeviceToDevice, st));
     }
-    RCF_HIP(hipEventRecord(h->buf_done[h->cur], st));        // everything that reads this buffer is queued
-    h->buf_done_set[h->cur] = true;
+    if (h->eager_buf_done) {
+        RCF_HIP(hipEventRecord(h->buf_done[h->cur], st));    // everything that reads this buffer is queued
+        h->buf_done_set[h->cur] = true;
+        h->buf_dirty[h->cur] = false;
+    } else {
+        h->buf_dirty[h->cur] = true;
+    }
     h->cur = other;
     h->total_in = S1;
     RCF_HIP(hipGetLastError());
@@ -1234,6 +1269,7 @@ int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_c
     {
         if (const char *nm = getenv("RCF_FIR_NOMFMA")) h->no_mfma = atoi(nm) != 0;
         if (const char *rm = getenv("RCF_ROTATOR")) h->exact_rot = std::strcmp(rm, "exact") == 0;
+        if (const char *ck = getenv("RCF_COPY_KERNELS")) h->copy_kernels = h->copy_kernels && atoi(ck) != 0;
     if (const char *nm = getenv("RCF_FIR_MFMA_MIN")) h->mfma_min = std::max(1, atoi(nm));
         if (const char *nm = getenv("RCF_FIR_MFMA_NT")) h->mfma_nt = atoi(nm);
         if (const char *nm = getenv("RCF_FIR_MFMA_PARTS")) h->mfma_parts = atoi(nm);
@@ -1246,6 +1282,11 @@ int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_c
         RCF_HIP(hipMemsetAsync(h->d_buf[i], 0, sizeof(float2) * buf_samples, h->stream));
         RCF_HIP(hipHostMalloc(&h->h_arena[i], h->arena_cap, hipHostMallocDefault));
         RCF_HIP(hipMalloc(&h->d_arena[i], h->arena_cap));
+        {
+            void *dv = nullptr;
+            h->h_arena_dev[i] = hipHostGetDevicePointer(&dv, h->h_arena[i], 0) == hipSuccess ? static_cast<unsigned char *>(dv) : nullptr;
+            if (!h->h_arena_dev[i]) h->copy_kernels = false;
+        }
         RCF_HIP(hipEventCreateWithFlags(&h->arena_ev[i], hipEventDisableTiming));
     }
     RCF_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
@@ -1323,6 +1364,15 @@ int rcf_timing_enable(rcf_t *h, int on)
     return RCF_OK;
 }
 
+int rcf_timing_stride(rcf_t *h, int every)
+{
+    if (!h || every < 1) { set_error("bad timing stride"); return RCF_EINVAL; }
+    std::lock_guard<std::mutex> g(h->mu);
+    h->timing_stride = (unsigned)every;
+    for (unsigned &v : h->time_seen) v = 0;
+    return RCF_OK;
+}
+
 int rcf_timing_read(rcf_t *h, int what, double *total_ms, int64_t *launches, int reset)
 {
     if (!h || what < 0 || what >= RCF_T_COUNT) { set_error("bad timing class"); return RCF_EINVAL; }
@@ -1360,6 +1410,12 @@ int rcf_push_iq(rcf_t *h, const float *iq, size_t n)
     if (n > h->block_cap) { set_error("push of %zu samples exceeds block capacity %zu", n, h->block_cap); return RCF_ECAP; }
     std::lock_guard<std::mutex> g(h->mu);
     if (set_dev(h)) return RCF_EHIP;
+    h->eager_buf_done = true;
+    if (h->buf_dirty[h->cur]) {                               // blocks committed in place read this buffer since
+        RCF_HIP(hipEventRecord(h->buf_done[h->cur], h->stream));
+        h->buf_done_set[h->cur] = true;
+        h->buf_dirty[h->cur] = false;
+    }
     if (h->buf_done_set[h->cur]) RCF_HIP(hipStreamWaitEvent(h->copy_stream, h->buf_done[h->cur], 0));
     RCF_HIP(hipMemcpyAsync(h->d_buf[h->cur] + h->hist_cap, iq, sizeof(float2) * n, hipMemcpyHostToDevice,
                            h->copy_stream));

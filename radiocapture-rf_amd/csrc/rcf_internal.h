@@ -316,6 +316,8 @@ bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s);
 inline bool pfb_frame_major(int NB) { return NB % 25 == 0; }
 // dst[i] = view sample (first + i), i < n (one bin's samples out of a bank ring; ingest.hip)
 void launch_gather_view(const StreamView &v, int64_t first, float2 *dst, size_t n, hipStream_t s);
+// dst[0, bytes) = src[0, bytes), both 8-byte aligned, bytes rounded up to 8; src may be pinned (device-mapped) host memory
+void launch_copy8(void *dst, const void *src, size_t bytes, hipStream_t s);
 int pfb5_padded_p(int NB, int D, int P);
 
 // ---------------------------------------------------------------- scan

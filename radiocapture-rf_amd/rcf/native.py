@@ -36,7 +36,7 @@ SYMBOLS = [
     "rcf_chan_audio_close", "rcf_chan_audio_produced", "rcf_chan_read_audio",
     "rcf_host_alloc", "rcf_host_free", "rcf_comm_unique_id", "rcf_comm_init", "rcf_comm_destroy", "rcf_comm_size",
     "rcf_allgather_peaks", "rcf_allreduce_max", "rcf_pfb_tap_open", "rcf_pfb_shape_supported",
-    "rcf_pfb_tap_leakage", "rcf_set_rotator",
+    "rcf_pfb_tap_leakage", "rcf_set_rotator", "rcf_timing_stride",
 ]
 FMT_U8, FMT_S8, FMT_S16 = 1, 2, 3
 T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY, T_FIR_MFMA, T_AUDIO, T_TAPS = range(10)
@@ -126,6 +126,7 @@ def lib():
                                      C.POINTER(i64), C.POINTER(C.c_double)]),
         "rcf_peak_frequency": (i64, [i64, C.c_double, i64, C.c_double]),
         "rcf_timing_enable": (C.c_int, [vp, C.c_int]),
+        "rcf_timing_stride": (C.c_int, [vp, C.c_int]),
         "rcf_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(i64), C.c_int]),
         "rcf_scan_find_peaks": (C.c_int, [vp, C.c_double, C.POINTER(i64), i64, C.POINTER(i64),
                                           C.POINTER(C.c_double), C.POINTER(vp)]),
@@ -358,6 +359,10 @@ class Frontend:
             for c in classes:
                 v |= 1 << (int(c) + 1)
         _check(lib().rcf_timing_enable(self._h, v))
+
+    def timing_stride(self, every=1):
+        """time only every `every`-th launch of each timed class (an event pair costs ~12 us of queue gap)"""
+        _check(lib().rcf_timing_stride(self._h, int(every)))
 
     def timing_read(self, what, reset=True):
         ms, n = C.c_double(), C.c_int64()
