@@ -586,17 +586,16 @@ def main():
         for _ in range(32):
             fe.commit(B)
         n_prewarm += 32
-    for _ in range(args.warmup):
-        fe.commit(B)
-    # HIP events only around the kernel the roofline reports: every timed launch costs two event records on the
-    # stream (~10 us of inter-kernel gap each), which would otherwise be charged to `value`
-    # ... and only every 4th filterbank launch of the timed region: an event record is a barrier packet, ~6 us of
-    # queue gap each (rocprof trace, tools/gap_probe.py), 12 us per bracketed launch of a 0.13 ms step
+    # HIP events only around the kernel the roofline reports, and only around every 4th launch of it: an event record
+    # is a barrier packet, ~6 us of queue gap each (rocprof trace, tools/gap_probe.py), 12 us per bracketed launch of
+    # a 0.13 ms step that would otherwise be charged to `value`.  Switched on BEFORE the warm-up steps, so that nothing
+    # but the barrier and one counter reset lies between them and the timed region.
     fe.timing_enable(True, classes=[native.T_PFB])
     fe.timing_stride(args.time_every)
-    for w in range(native.T_HISTORY + 1):
-        fe.timing_read(w, reset=True)
+    for _ in range(args.warmup):
+        fe.commit(B)
     barrier_max()
+    fe.timing_read(native.T_PFB, reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fe.commit(B)

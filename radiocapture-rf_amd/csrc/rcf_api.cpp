@@ -273,7 +273,7 @@ struct Timed {   // RAII: brackets the launches issued in its scope with two eve
     rcf_t *h; int what; hipEvent_t a = nullptr;
     Timed(rcf_t *h_, int what_) : h(h_), what(what_)
     {
-        if (h->timing && (h->timing_mask >> what & 1u) && (h->time_seen[what]++ % h->timing_stride) == 0) {
+        if (h->timing && (h->timing_mask >> what & 1u) && (h->time_seen[what]++ % h->timing_stride) == h->timing_stride - 1) {   // the LAST of each group: never the first launch after a sync
             a = time_event(h);
             (void)hipEventRecord(a, h->stream);
         }
