@@ -17,6 +17,9 @@
 // reference's left-to-right sum bit for bit whenever the additions are exact, which holds for these
 // spectra (float32 values sharing a 2^-18 grid, total < 2^33); otherwise it differs in the last bits
 // and only a peak within 1e-13 (relative) of the 2*mean gate could be affected.
+#include <algorithm>
+#include <cstdlib>
+
 #include "rcf_internal.h"
 
 namespace rcfx {
@@ -308,44 +311,48 @@ __global__ __launch_bounds__(256) void k_pick(PickArgs a)
     // Nearly every local maximum of a noisy spectrum is settled within a few samples.  The few that are not -- a
     // carrier's summit walks hundreds of samples for its width and up to N / 1024 table entries for its bases, every
     // step a dependent load: 246 us for ONE thread at N = 2^20 -- are handed to k_pick_heavy, one wavefront each.
-    int budget = kWalkBudget;
-    const double lmin = walk_min(a, pk, top, -1, budget);
-    const double rmin = budget >= 0 ? walk_min(a, pk, top, +1, budget) : 0.0;
-    bool heavy = budget < 0;
-    double left = 0.0, right = 0.0;
-    if (!heavy) {
-        const double prom = top - (lmin > rmin ? lmin : rmin);
-        if (!(prom >= a.prominence)) return;
-        const double level = top - prom * 0.5;
-        // width at half prominence; walks are bounded: a side longer than max_w already fails the window
-        const int bound = (int)fmin(a.max_w + 2.0, (double)a.n);
-        int j = pk;
-        while (j > 0 && level < (double)x[j]) {
-            --j;
-            if (pk - j > bound) return;
-            if (--budget < 0) { heavy = true; break; }
-        }
+    // (second attempt, without a budget: only when the hand-over list is full -- nothing is ever dropped)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int budget = attempt ? 0x7fffffff : kWalkBudget;
+        const double lmin = walk_min(a, pk, top, -1, budget);
+        const double rmin = budget >= 0 ? walk_min(a, pk, top, +1, budget) : 0.0;
+        bool heavy = budget < 0;
+        double left = 0.0, right = 0.0;
         if (!heavy) {
-            left = (double)j;
-            if ((double)x[j] < level) left += (level - (double)x[j]) / ((double)x[j + 1] - (double)x[j]);
-            j = pk;
-            while (j < last && level < (double)x[j]) {
-                ++j;
-                if (j - pk > bound) return;
+            const double prom = top - (lmin > rmin ? lmin : rmin);
+            if (!(prom >= a.prominence)) return;
+            const double level = top - prom * 0.5;
+            // width at half prominence; walks are bounded: a side longer than max_w already fails the window
+            const int bound = (int)fmin(a.max_w + 2.0, (double)a.n);
+            int j = pk;
+            while (j > 0 && level < (double)x[j]) {
+                --j;
+                if (pk - j > bound) return;
                 if (--budget < 0) { heavy = true; break; }
             }
             if (!heavy) {
-                right = (double)j;
-                if ((double)x[j] < level) right -= (level - (double)x[j]) / ((double)x[j - 1] - (double)x[j]);
+                left = (double)j;
+                if ((double)x[j] < level) left += (level - (double)x[j]) / ((double)x[j + 1] - (double)x[j]);
+                j = pk;
+                while (j < last && level < (double)x[j]) {
+                    ++j;
+                    if (j - pk > bound) return;
+                    if (--budget < 0) { heavy = true; break; }
+                }
+                if (!heavy) {
+                    right = (double)j;
+                    if ((double)x[j] < level) right -= (level - (double)x[j]) / ((double)x[j - 1] - (double)x[j]);
+                }
             }
         }
-    }
-    if (heavy) {
-        const int slot = atomicAdd(a.heavy_count, 1);
-        if (slot < a.heavy_cap) a.heavy[slot] = pk;
+        if (heavy) {
+            const int slot = atomicAdd(a.heavy_count, 1);
+            if (slot < a.heavy_cap) { a.heavy[slot] = pk; return; }
+            continue;                                            // list full: finish it here, sequentially
+        }
+        pick_finish(a, pk, top, left, right);
         return;
     }
-    pick_finish(a, pk, top, left, right);
 }
 
 // one wavefront per handed-over peak; identical comparisons and float64 arithmetic, 64 positions per step
@@ -433,8 +440,10 @@ void launch_find_peaks(const float *d_spec, int n, double min_w, double max_w, d
     hipLaunchKernelGGL(k_min, dim3(kMinBlocks), dim3(256), 0, s, d_spec, n, shift);
     hipLaunchKernelGGL(k_prep, dim3(n2), dim3(256), 0, s, d_spec, n, shift, x, max1, min1, part);
     hipLaunchKernelGGL(k_tables, dim3(1), dim3(1024), 0, s, max1, min1, n1, max2, min2, n2, part, n, mean);
+    int heavy_cap = kHeavyCap;
+    if (const char *e = getenv("RCF_PEAKS_HEAVY_CAP")) heavy_cap = std::max(0, std::min(kHeavyCap, atoi(e)));   // tests: overflow path
     PickArgs a{x, max1, min1, max2, min2, n, n1, n2, min_w, max_w, prominence, mean, d_out, count, cap,
-               heavy, heavy_count, kHeavyCap};
+               heavy, heavy_count, heavy_cap};
     hipLaunchKernelGGL(k_pick, dim3((n + 255) / 256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_pick_heavy, dim3(1024), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_sort, dim3(1), dim3(1024), 0, s, d_out, count, cap);

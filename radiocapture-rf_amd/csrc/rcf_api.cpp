@@ -855,7 +855,6 @@ int process_block(rcf_t *h, size_t n)
                             float2 *np_ = nullptr;
                             RCF_HIP(hipMalloc(&np_, sizeof(float2) * need));
                             bury(h, h->d_partial);
-    bury(h, h->d_tapmat);
                             h->d_partial = np_;
                             h->partial_cap = need;
                         }

@@ -416,3 +416,35 @@ def test_pfb3200_two_thousand_taps_equal_their_bins(gpu_required):
             np.testing.assert_array_equal(y, b)
             fm = fe.chan_read_fm(ids[j], 1.0)
             np.testing.assert_array_equal(fm, G.quadrature_demod_cf(b.astype(np.complex64), 1.0))
+
+
+def test_peak_picker_heavy_list_overflow_drops_nothing(gpu_required):
+    """k_pick hands peaks with long walks to k_pick_heavy through a bounded list; when the list is full the thread
+    finishes its peak itself.  With the list capped at 0 and at 3 entries (RCF_PEAKS_HEAVY_CAP) the device picker must
+    still return scipy's indices on the reference-sized scan spectrum and on a 2^17-bin one."""
+    from oracle import peaks as P
+    nat = gpu_required
+    for N, fs, seed in ((16384, 2.4e6, 3004), (1 << 17, 12.5e6, 3005)):
+        centres = [N // 7 + (N // 7) * i for i in range(5)]
+        carriers = [(c, 8000.0, 45.0) for c in centres]         # occupied widths inside find_peaks' 3-30 kHz window
+        U, F, L = 8, 120, 100
+        tile = synth.scan_stream(fs, N, U, carriers, seed=seed)
+        results = []
+        for cap in (None, "0", "3"):
+            if cap is None:
+                os.environ.pop("RCF_PEAKS_HEAVY_CAP", None)
+            else:
+                os.environ["RCF_PEAKS_HEAVY_CAP"] = cap
+            try:
+                with nat.Frontend(fs, 855e6, block_capacity=len(tile), hist_capacity=max(N, 1 << 16)) as fe:
+                    fe.scan_start(N, F, L)
+                    while fe.scan_frames_done() < F:
+                        fe.push(tile)
+                    spec = fe.scan_result()
+                    lines, mean, _ = fe.scan_find_peaks(cap=4096)
+            finally:
+                os.environ.pop("RCF_PEAKS_HEAVY_CAP", None)
+            want, _ = P.peak_detect_scipy(spec, fs, 855e6)
+            np.testing.assert_array_equal(lines, want)
+            results.append(lines)
+        assert len(results[0]) == 5
