@@ -4,6 +4,7 @@
 #   make -C radiocapture-rf_amd/csrc asan      (here: the .so travels with the snapshot)
 #   gpurun -- tools/asan_gpu.sh                -> gpurun_out/asan_gpu.txt
 cd "$(dirname "$0")/.."
+make -C radiocapture-rf_amd/csrc asan -j8 -s > /dev/null 2>&1     # never run a stale host layer (it must export every symbol native.py binds)
 RT=$(gcc -print-file-name=libasan.so)
 OUT=gpurun_out/asan_gpu.txt
 mkdir -p gpurun_out
