@@ -463,11 +463,20 @@ int choose_kt(int D, int T)
 }
 
 // ------------------------------------------------------------------ the per-block schedule
-int process_block(rcf_t *h, size_t n)
-{
-    const int64_t S0 = h->total_in, S1 = S0 + (int64_t)n;
-    hipStream_t st = h->stream;
-    if (h->graveyard.size() > 512) drain_graveyard(h);     // bounded even if nobody ever syncs or reads
+// Everything one commit schedules is built on the host first (a BlockPlan: launch records in the pinned arena, jobs per
+// dependency depth), then uploaded with one copy and launched in dependency order.  process_block() is the sequence;
+// the plan_*() functions below each build one part of it.
+struct FirJob {
+    FirLaunchDims dims; const ChanLaunch *dev; bool repack; const unsigned char *dirty;
+    // bank-matrix cache entry to mark current once the pack launch has been queued (not before: an error
+    // return in between must not leave a key that claims a matrix nobody built)
+    rcf::BankCache *bc; std::vector<std::pair<int, uint64_t>> key;
+};
+struct DiscJob { const DiscLaunch *dev; int n; int max_n; };
+
+struct BlockPlan {
+    int64_t S0 = 0, S1 = 0;            // the block's samples [S0, S1)
+    size_t n = 0;
 
     // how far back every consumer of a ring reaches beyond the block's new samples (a block's writes must not
     // overwrite what the same block's readers still need): derived channels T - 1 + D of source output, the
@@ -478,9 +487,53 @@ int process_block(rcf_t *h, size_t n)
     std::unordered_map<int, size_t> reach_x;                // source id (channel id / RCF_SRC_PFB_BIN0) -> samples
     int max_depth = 0;
     size_t arena_need = 0;
+    int a = 0;                         // arena in use, and where this commit's records start in it
+    size_t arena_base = 0;
+    Arena ar{nullptr, nullptr, 0, 0};
+    uint64_t serial = 0;               // Chan::blk_before / blk_after of this block carry it
+    std::vector<std::vector<FirJob>> fir_by_depth;
+    std::vector<DiscJob> disc_jobs;
+    std::vector<FmFirLaunch> symf;     // symbol filters, all channels in one launch
+    int symf_max_n = 0;
+    std::vector<RotFill> rot_fills;    // exact rotator: one record per launched channel, one launch before the FIRs
+    std::vector<TapLaunch> tap_list;   // filterbank taps: copied out by the bank's kernel, finished by tap_finalize
+    std::vector<int32_t> tap_bins;
+    std::vector<AudioLaunch> audf;     // analog voice chains, all channels in one set of launches
+    int audf_max_n = 0;
+    double audf_ratio = 0;
+    int audf_num = 1, audf_den = 1;
+    PfbLaunch pl{};
+    bool run_pfb = false;
+    const TapLaunch *d_tap_list = nullptr;
+    const RotFill *d_rot_fills = nullptr;
+    const FmFirLaunch *d_symf = nullptr;
+    const AudioLaunch *d_audf = nullptr;
 
-    // arena for this commit: sized for every channel's launch records before anything is scheduled, so the
-    // schedule below cannot run out half way (it mutates channel state as it goes)
+    size_t reach(int id) const
+    {
+        if (reach_x.empty()) return 1;
+        auto it = reach_x.find(id);
+        return it == reach_x.end() ? (size_t)1 : std::max<size_t>(1, it->second);
+    }
+};
+
+// channels of one (depth, D, T) class collected for launching
+struct ClassPlan {
+    std::vector<ChanLaunch> launches;
+    std::vector<Chan *> launched;
+    std::vector<DiscLaunch> discs;
+    int max_n = 0;
+    bool shared_src = true;
+};
+
+// arena for this commit: sized for every channel's launch records before anything is scheduled, so the schedule
+// cannot run out half way (it mutates channel state as it goes); also the consumers' reach and the deepest chain
+int plan_arena(rcf_t *h, BlockPlan &bp)
+{
+    auto &reach_x = bp.reach_x;
+    int &max_depth = bp.max_depth;
+    size_t &arena_need = bp.arena_need;
+
     {
         // (one pass over the channel map for everything that needs one: at 196608 channels each pass is ~8 ms of
         // pointer chasing)
@@ -529,39 +582,21 @@ int process_block(rcf_t *h, size_t n)
         h->arena_fill = 0;
         if (h->arena_used[h->arena_cur]) RCF_HIP(hipEventSynchronize(h->arena_ev[h->arena_cur]));
     }
-    const int a = h->arena_cur;
-    const size_t arena_base = h->arena_fill;
-    Arena ar{h->h_arena[a], h->d_arena[a], arena_base, h->arena_cap};
+    bp.a = h->arena_cur;
+    bp.arena_base = h->arena_fill;
+    bp.ar = Arena{h->h_arena[bp.a], h->d_arena[bp.a], bp.arena_base, h->arena_cap};
+    return RCF_OK;
+}
 
-    struct FirJob {
-        FirLaunchDims dims; const ChanLaunch *dev; bool repack; const unsigned char *dirty;
-        // bank-matrix cache entry to mark current once the pack launch has been queued (not before: an error
-        // return in between must not leave a key that claims a matrix nobody built)
-        rcf::BankCache *bc; std::vector<std::pair<int, uint64_t>> key;
-    };
-    struct DiscJob { const DiscLaunch *dev; int n; int max_n; };
-    std::vector<std::vector<FirJob>> fir_by_depth;
-    std::vector<DiscJob> disc_jobs;
-    std::vector<FmFirLaunch> symf;     // symbol filters, all channels in one launch
-    int symf_max_n = 0;
-    std::vector<RotFill> rot_fills;    // exact rotator: one record per launched channel, one launch before the FIRs
-    std::vector<TapLaunch> tap_list;   // filterbank taps: copied out by the bank's kernel, finished by tap_finalize
-    std::vector<int32_t> tap_bins;
-    const TapLaunch *d_tap_list = nullptr;
-    std::vector<AudioLaunch> audf;     // analog voice chains, all channels in one set of launches
-    int audf_max_n = 0;
-    double audf_ratio = 0;
-    int audf_num = 1, audf_den = 1;
+// the filterbank's share of the block (derived channels need its new range)
+int plan_pfb(rcf_t *h, BlockPlan &bp)
+{
+    const int64_t S0 = bp.S0, S1 = bp.S1;
+    const size_t n = bp.n;
+    auto &reach_x = bp.reach_x;
+    PfbLaunch &pl = bp.pl;
+    bool &run_pfb = bp.run_pfb;
 
-    auto reach = [&](int id) -> size_t {
-        if (reach_x.empty()) return 1;
-        auto it = reach_x.find(id);
-        return it == reach_x.end() ? (size_t)1 : std::max<size_t>(1, it->second);
-    };
-
-    // ---- PFB bookkeeping first (derived channels need its new range)
-    PfbLaunch pl{};
-    bool run_pfb = false;
     if (h->pfb.open) {
         Pfb &p = h->pfb;
         const int64_t n_lo = std::max(ceil_div(S0, p.D), p.n_abs0);
@@ -594,304 +629,342 @@ int process_block(rcf_t *h, size_t n)
             p.produced = n_hi - p.n_abs0 + 1;
         }
     }
+    return RCF_OK;
+}
 
-    // ---- channels, by depth then by (D, T) class
-    fir_by_depth.resize(max_depth + 1);
-    const uint64_t serial = ++h->blk_serial;               // Chan::blk_before / blk_after of this block carry it
-    for (int depth = 0; depth <= max_depth; ++depth) {
-        std::map<std::pair<int, int>, std::vector<Chan *>> classes;
-        for (auto &kv : h->chans)
-            if (kv.second->depth == depth) classes[{kv.second->D, kv.second->T}].push_back(kv.second.get());
-        for (auto &cls : classes) {
-            const int D = cls.first.first, T = cls.first.second;
-            std::vector<ChanLaunch> launches;
-            std::vector<Chan *> launched;
-            std::vector<DiscLaunch> discs;
-            launches.reserve(cls.second.size());
-            launched.reserve(cls.second.size());
-            discs.reserve(cls.second.size());
-            int max_n = 0;
-            bool shared_src = true;
-            for (Chan *c : cls.second) {
-                SrcRange sr{};
-                if (c->src >= 0 && c->src < RCF_SRC_PFB_BIN0) {
-                    auto it = h->chans.find(c->src);
-                    if (it == h->chans.end()) continue;            // source closed: channel starves
-                    const Chan &sc_ = *it->second;
-                    const bool fresh = sc_.blk_serial == serial;
-                    sr.view.base = sc_.d_iq;
-                    sr.view.mask = h->ring_mask;
-                    sr.view.origin = 0;
-                    sr.view.stride = 1;
-                    sr.p0 = fresh ? sc_.blk_before : sc_.produced;
-                    sr.p1 = fresh ? sc_.blk_after : sc_.produced;
-                } else if (!source_range(h, c->src, S0, S1, &sr)) {
-                    continue;
-                }
-                if (c->src >= 0) shared_src = false;
-                const int64_t k_lo = std::max(ceil_div(sr.p0, D), c->k_abs0);
-                const int64_t k_hi = floor_div(sr.p1 - 1, D);
-                const int64_t before = c->produced;
-                if (sr.p1 <= sr.p0 || k_hi < k_lo) { c->blk_serial = serial; c->blk_before = c->blk_after = before; continue; }
-                const int64_t cnt = k_hi - k_lo + 1;
-                if ((size_t)cnt + reach(c->id) > h->out_cap) {
-                    set_error("block yields %lld outputs (+%zu of history its consumers need) > ring capacity %zu",
-                              (long long)cnt, reach(c->id), h->out_cap);
-                    return RCF_ECAP;
-                }
-                ChanLaunch L{};
-                L.ctaps = c->d_ctaps;
-                L.fm_ring = c->d_fm;
-                L.iq_ring = c->d_iq;
-                L.src = sr.view;
-                L.k_lo = k_lo;
-                L.k_abs0 = c->k_abs0;
-                L.start_sample = c->start_sample;
-                L.n_seg0 = c->n_seg0;
-                L.angle0 = (double)c->angle0;
-                L.dangle = c->dangle;
-                L.logmag0 = c->logmag0;
-                L.dlogmag = c->dlogmag;
-                L.n_k = (int32_t)cnt;
-                // exact rotator: plain channels only (a filterbank tap's rotator carries the bank's own phases too)
-                if (c->d_rot && !c->is_tap && c->extra_dangle == 0.0 && c->extra_dlogmag == 0.0) {
-                    L.rot_ring = c->d_rot;
-                    L.rot_mask = h->ring_mask;
-                    RotFill rf{};
-                    rf.ring = c->d_rot;
-                    rf.state = reinterpret_cast<float *>(c->d_rot + h->out_cap);
-                    rf.n_from = k_lo - c->k_abs0;
-                    rf.n_k = (int32_t)cnt;
-                    rf.incr_re = c->incr[0];
-                    rf.incr_im = c->incr[1];
-                    rot_fills.push_back(rf);
-                }
-                DiscLaunch dl{};
-                dl.iq_ring = c->d_iq;
-                dl.fm_ring = c->d_fm;
-                dl.n_lo = k_lo - c->k_abs0;
-                dl.n_k = (int32_t)cnt;
-                if (c->is_tap) {                            // written by the filterbank kernel, not by a FIR launch
-                    TapLaunch tl{};
-                    tl.iq_ring = c->d_iq;
-                    tl.fm_ring = c->d_fm;
-                    tl.k_lo = L.k_lo; tl.k_abs0 = L.k_abs0; tl.n_seg0 = L.n_seg0;
-                    tl.angle0 = L.angle0; tl.dangle = L.dangle; tl.logmag0 = L.logmag0; tl.dlogmag = L.dlogmag;
-                    tl.n_k = L.n_k;
-                    tl.bin = c->src - RCF_SRC_PFB_BIN0;
-                    tap_list.push_back(tl);
-                    tap_bins.push_back(tl.bin);
-                } else {
-                    launches.push_back(L);
-                    launched.push_back(c);
-                    discs.push_back(dl);
-                    max_n = std::max(max_n, (int)cnt);
-                }
-                if (c->d_sym) {
-                    FmFirLaunch fl{};
-                    fl.fm_ring = c->d_fm;
-                    fl.sym_ring = c->d_sym;
-                    fl.taps = c->d_symtaps;
-                    fl.gain = c->sym_gain;
-                    fl.ntaps = c->sym_ntaps;
-                    fl.n_lo = std::max(dl.n_lo, c->sym_from);
-                    fl.n_first = c->sym_from;
-                    fl.n_k = (int32_t)(dl.n_lo + dl.n_k - fl.n_lo);
-                    if (fl.n_k > 0) symf.push_back(fl);
-                    symf_max_n = std::max(symf_max_n, (int)cnt);
-                }
-                if (c->audio) {
-                    Chan::Audio &au = *c->audio;
-                    AudioLaunch al{};
-                    al.iq_ring = c->d_iq;
-                    al.st = au.d_state;
-                    al.a_ring = au.d_rings;
-                    al.l_ring = au.d_rings + h->out_cap;
-                    al.h_ring = au.d_rings + 2 * h->out_cap;
-                    al.o_ring = au.d_rings + 3 * h->out_cap;
-                    al.c_ring = reinterpret_cast<float2 *>(au.d_rings + 4 * h->out_cap);
-                    al.lpf = au.d_taps;
-                    al.hpf = au.d_taps + au.n_lpf;
-                    al.rs = au.d_taps + au.n_lpf + au.n_hpf;
-                    al.n_lo = std::max(dl.n_lo, au.from);
-                    al.n_k = (int32_t)(dl.n_lo + dl.n_k - al.n_lo);
-                    al.n_lpf = au.n_lpf; al.n_hpf = au.n_hpf; al.nt_rs = au.nt_rs;
-                    al.interp = au.interp; al.decim = au.decim;
-                    al.gain = au.gain;
-                    al.thr = au.thr; al.alpha = au.alpha; al.b0 = au.b0; al.b1 = au.b1; al.fb1 = au.fb1;
-                    if (al.n_k > 0) {
-                        const size_t reach = (size_t)std::max(std::max(au.n_lpf, au.n_hpf), au.nt_rs);
-                        if ((size_t)al.n_k + reach > h->out_cap) {
-                            set_error("block yields %d channel samples: audio rings of %zu too small", al.n_k, h->out_cap);
-                            return RCF_ECAP;
-                        }
-                        audf.push_back(al);
-                        audf_max_n = std::max(audf_max_n, (int)al.n_k);
-                        if ((double)au.interp / au.decim > audf_ratio) {
-                            audf_ratio = (double)au.interp / au.decim; audf_num = au.interp; audf_den = au.decim;
-                        }
-                    }
-                }
-                // advance channel state: rebase the rotator model at the next output index
-                const int64_t n_next = k_hi - c->k_abs0 + 1;
-                const int64_t r512 = n_next & ~(int64_t)511;
-                const long double adv = (long double)(n_next - c->n_seg0) * (long double)c->dangle;
-                c->logmag0 = (r512 > c->n_seg0) ? (double)(n_next - r512) * c->dlogmag
-                                                : c->logmag0 + (double)(n_next - c->n_seg0) * c->dlogmag;
-                c->angle0 = fmodl(c->angle0 + adv, (long double)kTwoPi);
-                c->n_seg0 = n_next;
-                c->produced = n_next;
-                c->blk_serial = serial; c->blk_before = before; c->blk_after = n_next;
+// one channel's launch records (FIR / tap, discriminator, symbol filter, voice chain, exact rotator) and the advance of
+// its state.  Returns RCF_OK also when the channel has nothing to do in this block.
+int plan_channel(rcf_t *h, BlockPlan &bp, ClassPlan &cp, Chan *c, int D)
+{
+    const int64_t S0 = bp.S0, S1 = bp.S1;
+    const uint64_t serial = bp.serial;
+    auto &launches = cp.launches;
+    auto &launched = cp.launched;
+    auto &discs = cp.discs;
+    int &max_n = cp.max_n;
+    bool &shared_src = cp.shared_src;
+    auto &rot_fills = bp.rot_fills;
+    auto &tap_list = bp.tap_list;
+    auto &tap_bins = bp.tap_bins;
+    auto &symf = bp.symf;
+    int &symf_max_n = bp.symf_max_n;
+    auto &audf = bp.audf;
+    int &audf_max_n = bp.audf_max_n;
+    double &audf_ratio = bp.audf_ratio;
+    int &audf_num = bp.audf_num, &audf_den = bp.audf_den;
+    auto reach = [&](int id) { return bp.reach(id); };
+
+    SrcRange sr{};
+    if (c->src >= 0 && c->src < RCF_SRC_PFB_BIN0) {
+        auto it = h->chans.find(c->src);
+        if (it == h->chans.end()) return RCF_OK;            // source closed: channel starves
+        const Chan &sc_ = *it->second;
+        const bool fresh = sc_.blk_serial == serial;
+        sr.view.base = sc_.d_iq;
+        sr.view.mask = h->ring_mask;
+        sr.view.origin = 0;
+        sr.view.stride = 1;
+        sr.p0 = fresh ? sc_.blk_before : sc_.produced;
+        sr.p1 = fresh ? sc_.blk_after : sc_.produced;
+    } else if (!source_range(h, c->src, S0, S1, &sr)) {
+        return RCF_OK;
+    }
+    if (c->src >= 0) shared_src = false;
+    const int64_t k_lo = std::max(ceil_div(sr.p0, D), c->k_abs0);
+    const int64_t k_hi = floor_div(sr.p1 - 1, D);
+    const int64_t before = c->produced;
+    if (sr.p1 <= sr.p0 || k_hi < k_lo) { c->blk_serial = serial; c->blk_before = c->blk_after = before; return RCF_OK; }
+    const int64_t cnt = k_hi - k_lo + 1;
+    if ((size_t)cnt + reach(c->id) > h->out_cap) {
+        set_error("block yields %lld outputs (+%zu of history its consumers need) > ring capacity %zu",
+                  (long long)cnt, reach(c->id), h->out_cap);
+        return RCF_ECAP;
+    }
+    ChanLaunch L{};
+    L.ctaps = c->d_ctaps;
+    L.fm_ring = c->d_fm;
+    L.iq_ring = c->d_iq;
+    L.src = sr.view;
+    L.k_lo = k_lo;
+    L.k_abs0 = c->k_abs0;
+    L.start_sample = c->start_sample;
+    L.n_seg0 = c->n_seg0;
+    L.angle0 = (double)c->angle0;
+    L.dangle = c->dangle;
+    L.logmag0 = c->logmag0;
+    L.dlogmag = c->dlogmag;
+    L.n_k = (int32_t)cnt;
+    // exact rotator: plain channels only (a filterbank tap's rotator carries the bank's own phases too)
+    if (c->d_rot && !c->is_tap && c->extra_dangle == 0.0 && c->extra_dlogmag == 0.0) {
+        L.rot_ring = c->d_rot;
+        L.rot_mask = h->ring_mask;
+        RotFill rf{};
+        rf.ring = c->d_rot;
+        rf.state = reinterpret_cast<float *>(c->d_rot + h->out_cap);
+        rf.n_from = k_lo - c->k_abs0;
+        rf.n_k = (int32_t)cnt;
+        rf.incr_re = c->incr[0];
+        rf.incr_im = c->incr[1];
+        rot_fills.push_back(rf);
+    }
+    DiscLaunch dl{};
+    dl.iq_ring = c->d_iq;
+    dl.fm_ring = c->d_fm;
+    dl.n_lo = k_lo - c->k_abs0;
+    dl.n_k = (int32_t)cnt;
+    if (c->is_tap) {                            // written by the filterbank kernel, not by a FIR launch
+        TapLaunch tl{};
+        tl.iq_ring = c->d_iq;
+        tl.fm_ring = c->d_fm;
+        tl.k_lo = L.k_lo; tl.k_abs0 = L.k_abs0; tl.n_seg0 = L.n_seg0;
+        tl.angle0 = L.angle0; tl.dangle = L.dangle; tl.logmag0 = L.logmag0; tl.dlogmag = L.dlogmag;
+        tl.n_k = L.n_k;
+        tl.bin = c->src - RCF_SRC_PFB_BIN0;
+        tap_list.push_back(tl);
+        tap_bins.push_back(tl.bin);
+    } else {
+        launches.push_back(L);
+        launched.push_back(c);
+        discs.push_back(dl);
+        max_n = std::max(max_n, (int)cnt);
+    }
+    if (c->d_sym) {
+        FmFirLaunch fl{};
+        fl.fm_ring = c->d_fm;
+        fl.sym_ring = c->d_sym;
+        fl.taps = c->d_symtaps;
+        fl.gain = c->sym_gain;
+        fl.ntaps = c->sym_ntaps;
+        fl.n_lo = std::max(dl.n_lo, c->sym_from);
+        fl.n_first = c->sym_from;
+        fl.n_k = (int32_t)(dl.n_lo + dl.n_k - fl.n_lo);
+        if (fl.n_k > 0) symf.push_back(fl);
+        symf_max_n = std::max(symf_max_n, (int)cnt);
+    }
+    if (c->audio) {
+        Chan::Audio &au = *c->audio;
+        AudioLaunch al{};
+        al.iq_ring = c->d_iq;
+        al.st = au.d_state;
+        al.a_ring = au.d_rings;
+        al.l_ring = au.d_rings + h->out_cap;
+        al.h_ring = au.d_rings + 2 * h->out_cap;
+        al.o_ring = au.d_rings + 3 * h->out_cap;
+        al.c_ring = reinterpret_cast<float2 *>(au.d_rings + 4 * h->out_cap);
+        al.lpf = au.d_taps;
+        al.hpf = au.d_taps + au.n_lpf;
+        al.rs = au.d_taps + au.n_lpf + au.n_hpf;
+        al.n_lo = std::max(dl.n_lo, au.from);
+        al.n_k = (int32_t)(dl.n_lo + dl.n_k - al.n_lo);
+        al.n_lpf = au.n_lpf; al.n_hpf = au.n_hpf; al.nt_rs = au.nt_rs;
+        al.interp = au.interp; al.decim = au.decim;
+        al.gain = au.gain;
+        al.thr = au.thr; al.alpha = au.alpha; al.b0 = au.b0; al.b1 = au.b1; al.fb1 = au.fb1;
+        if (al.n_k > 0) {
+            const size_t reach = (size_t)std::max(std::max(au.n_lpf, au.n_hpf), au.nt_rs);
+            if ((size_t)al.n_k + reach > h->out_cap) {
+                set_error("block yields %d channel samples: audio rings of %zu too small", al.n_k, h->out_cap);
+                return RCF_ECAP;
             }
-            if (launches.empty()) continue;
-            FirJob job{};
-            job.dims.D = D; job.dims.T = T; job.dims.KT = choose_kt(D, T);
-            job.dims.chans_per_wg = shared_src ? 16 : 1;
-            job.dims.max_n_k = max_n;
-            job.dims.ring_mask = h->ring_mask;
-            job.dims.atan_tab = h->d_atan;
-            // Matrix-core path: channels on one shared source with one common output range.  A channel that was just
-            // opened still has outputs whose taps reach before its start (GR zero history) -- at most ceil((T-1)/D)
-            // of them, four for the reference's shapes.  It joins the matrix-core launch anyway (which computes those
-            // few outputs from real history, i.e. wrongly) and a vector-kernel launch AFTER it on the same stream
-            // rewrites just those outputs with the per-tap mask: opening 16384 channels at once used to put one
-            // whole block (70 ms) on the vector kernel.  Channels that start later inside the block keep the vector
-            // kernel for that block.
-            std::vector<ChanLaunch> clean, rest, fixups;
-            std::vector<Chan *> clean_ch;
-            int n_common_of_clean = max_n;
-            if (shared_src && depth == 0 && mfma2_applicable(D, T, h->hist_cap, h->hist_cap + h->block_cap) && !h->no_mfma) {
-                int64_t k_common = -1;
-                int32_t n_common = 0;
-                for (auto &L : launches)                                   // the range most channels share: the earliest
-                    if (k_common < 0 || L.k_lo < k_common) { k_common = L.k_lo; n_common = L.n_k; }
-                n_common_of_clean = n_common;
-                size_t n_ok = 0;
-                for (const ChanLaunch &L : launches) n_ok += (L.k_lo == k_common && L.n_k == n_common) ? 1 : 0;
-                if (n_ok == launches.size()) {              // the steady state: the whole class, no record copied
-                    clean.swap(launches);
-                    clean_ch.swap(launched);
-                } else {
-                    clean.reserve(n_ok);
-                    clean_ch.reserve(n_ok);
-                    for (size_t i = 0; i < launches.size(); ++i) {
-                        const ChanLaunch &L = launches[i];
-                        const bool ok = L.k_lo == k_common && L.n_k == n_common;
-                        if (!ok) { rest.push_back(L); continue; }
-                        clean.push_back(L);
-                        clean_ch.push_back(launched[i]);
-                    }
-                }
-                for (const ChanLaunch &L : clean)
-                    if (L.k_lo * D - L.start_sample < (int64_t)(T - 1)) {
-                        // outputs k with k D - (T-1) < start: k < ceil((start + T - 1) / D)
-                        const int64_t k_end = ceil_div(L.start_sample + (int64_t)(T - 1), D);
-                        ChanLaunch F = L;
-                        F.n_k = (int32_t)std::min<int64_t>(L.n_k, std::max<int64_t>(0, k_end - L.k_lo));
-                        if (F.n_k > 0) fixups.push_back(F);
-                    }
-                // (no size limit on a class: every group of 32 channels has its own tap slab)
-                if ((int)clean.size() < h->mfma_min) {
-                    rest.insert(rest.end(), clean.begin(), clean.end());   // (order within a vector launch is free)
-                    clean.clear();
-                    clean_ch.clear();
-                    fixups.clear();
-                }
-            } else {
-                rest.swap(launches);
-            }
-            if (!clean.empty()) {
-                FirJob mj = job;
-                mj.bc = nullptr;
-                rcf::BankCache &bc = h->banks[cls.first];
-                std::vector<std::pair<int, uint64_t>> key;
-                key.reserve(clean_ch.size());
-                for (Chan *c : clean_ch) key.push_back({c->id, c->taps_version});
-                mj.repack = key != bc.key;
-                mj.dirty = nullptr;
-                if (mj.repack) {
-                    // + one chunk of slack: the kernel prefetches one chunk past a group's last
-                    const size_t need = (size_t)((clean.size() + kM2Group - 1) / kM2Group) * bank2_group_floats(T) +
-                                        (size_t)kM2ChunkSteps * 1024;
-                    bool fresh = false;
-                    if (need > bc.cap) {
-                        // grow with headroom: a class that gains channels one by one must not reallocate each time
-                        const size_t want = std::max(need, bc.cap + bc.cap / 2);
-                        float *nd = nullptr;
-                        RCF_HIP(hipMalloc(&nd, sizeof(float) * want));
-                        bury(h, bc.d);
-                        bc.d = nd;
-                        bc.cap = want;
-                        fresh = true;
-                    }
-                    if (!fresh) {
-                        // rebuild only the groups of 32 whose membership or taps changed
-                        const size_t ng = (clean.size() + kM2Group - 1) / kM2Group;
-                        std::vector<unsigned char> dirty(ng, 0);
-                        for (size_t i = 0; i < key.size(); ++i)
-                            if (i >= bc.key.size() || bc.key[i] != key[i]) dirty[i / kM2Group] = 1;
-                        if (bc.key.size() > key.size())                      // the class shrank: its last group lost rows
-                            dirty[ng - 1] = 1;
-                        if (!ar.put(dirty, &mj.dirty)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
-                    }
-                    bc.key.clear();                           // stale until the pack launch below is queued
-                    mj.bc = &bc;
-                    mj.key = key;
-                }
-                mj.dims.n_chans = (int)clean.size();
-                mj.dims.mfma = 1;
-                mj.dims.chans_per_wg = 128;
-                mj.dims.bank = bc.d;
-                mj.dims.max_n_k = n_common_of_clean;
-                mj.dims.src_len = (int64_t)(h->hist_cap + n);
-                {
-                    const MfmaPlan plan = mfma_plan((int)clean.size(), n_common_of_clean, T, h->mfma_nt, h->mfma_parts);
-                    mj.dims.mfma_nt = plan.nt;
-                    mj.dims.mfma_parts = plan.parts;
-                    mj.dims.partial = nullptr;
-                    if (plan.parts > 1) {
-                        const size_t need = (size_t)plan.parts * clean.size() * (size_t)n_common_of_clean;
-                        if (need > h->partial_cap) {
-                            float2 *np_ = nullptr;
-                            RCF_HIP(hipMalloc(&np_, sizeof(float2) * need));
-                            bury(h, h->d_partial);
-                            h->d_partial = np_;
-                            h->partial_cap = need;
-                        }
-                        mj.dims.partial = h->d_partial;
-                    }
-                }
-                if (!ar.put(clean, &mj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
-                fir_by_depth[depth].push_back(mj);
-            }
-            if (!fixups.empty()) {                          // queued behind the matrix-core launch: see above
-                FirJob fj = job;
-                fj.bc = nullptr;
-                fj.repack = false;
-                fj.dirty = nullptr;
-                fj.dims.n_chans = (int)fixups.size();
-                fj.dims.max_n_k = 0;
-                for (auto &F : fixups) fj.dims.max_n_k = std::max(fj.dims.max_n_k, (int)F.n_k);
-                fj.dims.small = 0;
-                fj.dims.mfma = 0;
-                fj.dims.chans_per_wg = 1;                   // per-channel n_k differ: one channel per workgroup
-                if (!ar.put(fixups, &fj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
-                fir_by_depth[depth].push_back(fj);
-            }
-            if (!rest.empty()) {
-                job.dims.n_chans = (int)rest.size();
-                job.dims.small = (!shared_src && fir_small_outputs(D, T) > 0) ? 1 : 0;
-                if (!ar.put(rest, &job.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
-                fir_by_depth[depth].push_back(job);
-            }
-            if (!(job.dims.small && clean.empty())) {   // the small-T kernel writes the discriminator ring itself
-                DiscJob dj{};
-                dj.n = (int)discs.size(); dj.max_n = max_n;
-                if (!ar.put(discs, &dj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
-                disc_jobs.push_back(dj);
+            audf.push_back(al);
+            audf_max_n = std::max(audf_max_n, (int)al.n_k);
+            if ((double)au.interp / au.decim > audf_ratio) {
+                audf_ratio = (double)au.interp / au.decim; audf_num = au.interp; audf_den = au.decim;
             }
         }
     }
+    // advance channel state: rebase the rotator model at the next output index
+    const int64_t n_next = k_hi - c->k_abs0 + 1;
+    const int64_t r512 = n_next & ~(int64_t)511;
+    const long double adv = (long double)(n_next - c->n_seg0) * (long double)c->dangle;
+    c->logmag0 = (r512 > c->n_seg0) ? (double)(n_next - r512) * c->dlogmag
+                                    : c->logmag0 + (double)(n_next - c->n_seg0) * c->dlogmag;
+    c->angle0 = fmodl(c->angle0 + adv, (long double)kTwoPi);
+    c->n_seg0 = n_next;
+    c->produced = n_next;
+    c->blk_serial = serial; c->blk_before = before; c->blk_after = n_next;
+    return RCF_OK;
+}
+
+// the launches of one (depth, D, T) class: matrix-core job (+ zero-history fix-ups), vector job, discriminator job
+int plan_class_jobs(rcf_t *h, BlockPlan &bp, ClassPlan &cp, int depth, std::pair<int, int> cls_key)
+{
+    const int D = cls_key.first, T = cls_key.second;
+    const size_t n = bp.n;
+    Arena &ar = bp.ar;
+    auto &fir_by_depth = bp.fir_by_depth;
+    auto &disc_jobs = bp.disc_jobs;
+    auto &launches = cp.launches;
+    auto &launched = cp.launched;
+    auto &discs = cp.discs;
+    const int max_n = cp.max_n;
+    const bool shared_src = cp.shared_src;
+
+    if (launches.empty()) return RCF_OK;
+    FirJob job{};
+    job.dims.D = D; job.dims.T = T; job.dims.KT = choose_kt(D, T);
+    job.dims.chans_per_wg = shared_src ? 16 : 1;
+    job.dims.max_n_k = max_n;
+    job.dims.ring_mask = h->ring_mask;
+    job.dims.atan_tab = h->d_atan;
+    // Matrix-core path: channels on one shared source with one common output range.  A channel that was just
+    // opened still has outputs whose taps reach before its start (GR zero history) -- at most ceil((T-1)/D)
+    // of them, four for the reference's shapes.  It joins the matrix-core launch anyway (which computes those
+    // few outputs from real history, i.e. wrongly) and a vector-kernel launch AFTER it on the same stream
+    // rewrites just those outputs with the per-tap mask: opening 16384 channels at once used to put one
+    // whole block (70 ms) on the vector kernel.  Channels that start later inside the block keep the vector
+    // kernel for that block.
+    std::vector<ChanLaunch> clean, rest, fixups;
+    std::vector<Chan *> clean_ch;
+    int n_common_of_clean = max_n;
+    if (shared_src && depth == 0 && mfma2_applicable(D, T, h->hist_cap, h->hist_cap + h->block_cap) && !h->no_mfma) {
+        int64_t k_common = -1;
+        int32_t n_common = 0;
+        for (auto &L : launches)                                   // the range most channels share: the earliest
+            if (k_common < 0 || L.k_lo < k_common) { k_common = L.k_lo; n_common = L.n_k; }
+        n_common_of_clean = n_common;
+        size_t n_ok = 0;
+        for (const ChanLaunch &L : launches) n_ok += (L.k_lo == k_common && L.n_k == n_common) ? 1 : 0;
+        if (n_ok == launches.size()) {              // the steady state: the whole class, no record copied
+            clean.swap(launches);
+            clean_ch.swap(launched);
+        } else {
+            clean.reserve(n_ok);
+            clean_ch.reserve(n_ok);
+            for (size_t i = 0; i < launches.size(); ++i) {
+                const ChanLaunch &L = launches[i];
+                const bool ok = L.k_lo == k_common && L.n_k == n_common;
+                if (!ok) { rest.push_back(L); continue; }
+                clean.push_back(L);
+                clean_ch.push_back(launched[i]);
+            }
+        }
+        for (const ChanLaunch &L : clean)
+            if (L.k_lo * D - L.start_sample < (int64_t)(T - 1)) {
+                // outputs k with k D - (T-1) < start: k < ceil((start + T - 1) / D)
+                const int64_t k_end = ceil_div(L.start_sample + (int64_t)(T - 1), D);
+                ChanLaunch F = L;
+                F.n_k = (int32_t)std::min<int64_t>(L.n_k, std::max<int64_t>(0, k_end - L.k_lo));
+                if (F.n_k > 0) fixups.push_back(F);
+            }
+        // (no size limit on a class: every group of 32 channels has its own tap slab)
+        if ((int)clean.size() < h->mfma_min) {
+            rest.insert(rest.end(), clean.begin(), clean.end());   // (order within a vector launch is free)
+            clean.clear();
+            clean_ch.clear();
+            fixups.clear();
+        }
+    } else {
+        rest.swap(launches);
+    }
+    if (!clean.empty()) {
+        FirJob mj = job;
+        mj.bc = nullptr;
+        rcf::BankCache &bc = h->banks[cls_key];
+        std::vector<std::pair<int, uint64_t>> key;
+        key.reserve(clean_ch.size());
+        for (Chan *c : clean_ch) key.push_back({c->id, c->taps_version});
+        mj.repack = key != bc.key;
+        mj.dirty = nullptr;
+        if (mj.repack) {
+            // + one chunk of slack: the kernel prefetches one chunk past a group's last
+            const size_t need = (size_t)((clean.size() + kM2Group - 1) / kM2Group) * bank2_group_floats(T) +
+                                (size_t)kM2ChunkSteps * 1024;
+            bool fresh = false;
+            if (need > bc.cap) {
+                // grow with headroom: a class that gains channels one by one must not reallocate each time
+                const size_t want = std::max(need, bc.cap + bc.cap / 2);
+                float *nd = nullptr;
+                RCF_HIP(hipMalloc(&nd, sizeof(float) * want));
+                bury(h, bc.d);
+                bc.d = nd;
+                bc.cap = want;
+                fresh = true;
+            }
+            if (!fresh) {
+                // rebuild only the groups of 32 whose membership or taps changed
+                const size_t ng = (clean.size() + kM2Group - 1) / kM2Group;
+                std::vector<unsigned char> dirty(ng, 0);
+                for (size_t i = 0; i < key.size(); ++i)
+                    if (i >= bc.key.size() || bc.key[i] != key[i]) dirty[i / kM2Group] = 1;
+                if (bc.key.size() > key.size())                      // the class shrank: its last group lost rows
+                    dirty[ng - 1] = 1;
+                if (!ar.put(dirty, &mj.dirty)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+            }
+            bc.key.clear();                           // stale until the pack launch below is queued
+            mj.bc = &bc;
+            mj.key = key;
+        }
+        mj.dims.n_chans = (int)clean.size();
+        mj.dims.mfma = 1;
+        mj.dims.chans_per_wg = 128;
+        mj.dims.bank = bc.d;
+        mj.dims.max_n_k = n_common_of_clean;
+        mj.dims.src_len = (int64_t)(h->hist_cap + n);
+        {
+            const MfmaPlan plan = mfma_plan((int)clean.size(), n_common_of_clean, T, h->mfma_nt, h->mfma_parts);
+            mj.dims.mfma_nt = plan.nt;
+            mj.dims.mfma_parts = plan.parts;
+            mj.dims.partial = nullptr;
+            if (plan.parts > 1) {
+                const size_t need = (size_t)plan.parts * clean.size() * (size_t)n_common_of_clean;
+                if (need > h->partial_cap) {
+                    float2 *np_ = nullptr;
+                    RCF_HIP(hipMalloc(&np_, sizeof(float2) * need));
+                    bury(h, h->d_partial);
+                    h->d_partial = np_;
+                    h->partial_cap = need;
+                }
+                mj.dims.partial = h->d_partial;
+            }
+        }
+        if (!ar.put(clean, &mj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+        fir_by_depth[depth].push_back(mj);
+    }
+    if (!fixups.empty()) {                          // queued behind the matrix-core launch: see above
+        FirJob fj = job;
+        fj.bc = nullptr;
+        fj.repack = false;
+        fj.dirty = nullptr;
+        fj.dims.n_chans = (int)fixups.size();
+        fj.dims.max_n_k = 0;
+        for (auto &F : fixups) fj.dims.max_n_k = std::max(fj.dims.max_n_k, (int)F.n_k);
+        fj.dims.small = 0;
+        fj.dims.mfma = 0;
+        fj.dims.chans_per_wg = 1;                   // per-channel n_k differ: one channel per workgroup
+        if (!ar.put(fixups, &fj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+        fir_by_depth[depth].push_back(fj);
+    }
+    if (!rest.empty()) {
+        job.dims.n_chans = (int)rest.size();
+        job.dims.small = (!shared_src && fir_small_outputs(D, T) > 0) ? 1 : 0;
+        if (!ar.put(rest, &job.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+        fir_by_depth[depth].push_back(job);
+    }
+    if (!(job.dims.small && clean.empty())) {   // the small-T kernel writes the discriminator ring itself
+        DiscJob dj{};
+        dj.n = (int)discs.size(); dj.max_n = max_n;
+        if (!ar.put(discs, &dj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+        disc_jobs.push_back(dj);
+    }
+    return RCF_OK;
+}
+
+// filterbank taps (matrix + records) and the records that go out as one launch each
+int plan_tail(rcf_t *h, BlockPlan &bp)
+{
+    Arena &ar = bp.ar;
+    auto &tap_list = bp.tap_list;
+    auto &tap_bins = bp.tap_bins;
+    auto &rot_fills = bp.rot_fills;
+    auto &symf = bp.symf;
+    auto &audf = bp.audf;
+    PfbLaunch &pl = bp.pl;
+    const bool run_pfb = bp.run_pfb;
+    const TapLaunch *&d_tap_list = bp.d_tap_list;
+    const RotFill *&d_rot_fills = bp.d_rot_fills;
+    const FmFirLaunch *&d_symf = bp.d_symf;
+    const AudioLaunch *&d_audf = bp.d_audf;
 
     if (!tap_list.empty() && run_pfb) {
         const size_t pitch = (tap_list.size() + 15) & ~size_t(15);
@@ -908,14 +981,32 @@ int process_block(rcf_t *h, size_t n)
         pl.tap_pitch = (int32_t)pitch;
         pl.n_taps = (int32_t)tap_list.size();
     }
-    const RotFill *d_rot_fills = nullptr;
     if (!rot_fills.empty() && !ar.put(rot_fills, &d_rot_fills)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
-    const FmFirLaunch *d_symf = nullptr;
     if (!symf.empty() && !ar.put(symf, &d_symf)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
-    const AudioLaunch *d_audf = nullptr;
     if (!audf.empty() && !ar.put(audf, &d_audf)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+    return RCF_OK;
+}
 
-    // ---- upload all launch parameters in one copy, then launch in dependency order
+// upload all launch parameters in one copy, then launch in dependency order
+int launch_plan(rcf_t *h, BlockPlan &bp)
+{
+    hipStream_t st = h->stream;
+    Arena &ar = bp.ar;
+    const int a = bp.a;
+    const size_t arena_base = bp.arena_base;
+    auto &fir_by_depth = bp.fir_by_depth;
+    auto &disc_jobs = bp.disc_jobs;
+    auto &symf = bp.symf;
+    auto &audf = bp.audf;
+    auto &rot_fills = bp.rot_fills;
+    const PfbLaunch &pl = bp.pl;
+    const bool run_pfb = bp.run_pfb;
+    const TapLaunch *d_tap_list = bp.d_tap_list;
+    const RotFill *d_rot_fills = bp.d_rot_fills;
+    const FmFirLaunch *d_symf = bp.d_symf;
+    const AudioLaunch *d_audf = bp.d_audf;
+    const int symf_max_n = bp.symf_max_n, audf_max_n = bp.audf_max_n, audf_num = bp.audf_num, audf_den = bp.audf_den;
+
     if (ar.used > arena_base) {
         const size_t from = arena_base & ~size_t(63), bytes = ((ar.used + 63) & ~size_t(63)) - from;
         if (h->copy_kernels) launch_copy8(ar.d + from, h->h_arena_dev[a] + from, bytes, st);
@@ -952,8 +1043,15 @@ int process_block(rcf_t *h, size_t n)
         Timed t(h, RCF_T_AUDIO);
         launch_audio(d_audf, (int)audf.size(), audf_max_n, audf_num, audf_den, h->ring_mask, h->d_atan, st);
     }
+    return RCF_OK;
+}
 
-    // ---- scan
+// the scan's share of the block: every frame that is complete now
+int run_scan(rcf_t *h, const BlockPlan &bp)
+{
+    hipStream_t st = h->stream;
+    const int64_t S0 = bp.S0, S1 = bp.S1;
+
     Scan &sc = h->scan;
     if (sc.armed && !sc.done) {
         int64_t avail = (S1 - sc.start_sample) / sc.N;
@@ -982,8 +1080,16 @@ int process_block(rcf_t *h, size_t n)
         }
         if (sc.frames_done >= sc.n_frames) sc.done = true;
     }
+    return RCF_OK;
+}
 
-    // ---- history for the next block, flip buffers
+// history for the next block, flip buffers
+int finish_block(rcf_t *h, const BlockPlan &bp)
+{
+    hipStream_t st = h->stream;
+    const size_t n = bp.n;
+    const int64_t S1 = bp.S1;
+
     const int other = h->cur ^ 1;
     {
         Timed t(h, RCF_T_HISTORY);
@@ -1002,6 +1108,39 @@ int process_block(rcf_t *h, size_t n)
     h->total_in = S1;
     RCF_HIP(hipGetLastError());
     return RCF_OK;
+}
+
+int process_block(rcf_t *h, size_t n)
+{
+    if (h->graveyard.size() > 512) drain_graveyard(h);     // bounded even if nobody ever syncs or reads
+    BlockPlan bp;
+    bp.S0 = h->total_in;
+    bp.S1 = bp.S0 + (int64_t)n;
+    bp.n = n;
+    int rc = plan_arena(h, bp);
+    if (rc == RCF_OK) rc = plan_pfb(h, bp);
+    if (rc != RCF_OK) return rc;
+    // channels, by depth then by (D, T) class
+    bp.fir_by_depth.resize(bp.max_depth + 1);
+    bp.serial = ++h->blk_serial;
+    for (int depth = 0; depth <= bp.max_depth; ++depth) {
+        std::map<std::pair<int, int>, std::vector<Chan *>> classes;
+        for (auto &kv : h->chans)
+            if (kv.second->depth == depth) classes[{kv.second->D, kv.second->T}].push_back(kv.second.get());
+        for (auto &cls : classes) {
+            ClassPlan cp;
+            cp.launches.reserve(cls.second.size());
+            cp.launched.reserve(cls.second.size());
+            cp.discs.reserve(cls.second.size());
+            for (Chan *c : cls.second)
+                if ((rc = plan_channel(h, bp, cp, c, cls.first.first)) != RCF_OK) return rc;
+            if ((rc = plan_class_jobs(h, bp, cp, depth, cls.first)) != RCF_OK) return rc;
+        }
+    }
+    if ((rc = plan_tail(h, bp)) != RCF_OK) return rc;
+    if ((rc = launch_plan(h, bp)) != RCF_OK) return rc;
+    if ((rc = run_scan(h, bp)) != RCF_OK) return rc;
+    return finish_block(h, bp);
 }
 
 int64_t ring_read(rcf_t *h, const void *ring, size_t elem, int64_t produced, int64_t *cursor, void *out,
