@@ -72,6 +72,28 @@ __global__ __launch_bounds__(256) void copy8_kernel(unsigned long long *__restri
 
 }  // namespace
 
+// two such copies in one launch (the block's launch records and its history tail: one launch less per block)
+static __global__ __launch_bounds__(256) void copy8x2_kernel(unsigned long long *__restrict__ d0, const unsigned long long *__restrict__ s0,
+                                                      size_t n0, unsigned long long *__restrict__ d1,
+                                                      const unsigned long long *__restrict__ s1, size_t n1)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n0 + n1; i += stride) {
+        if (i < n0) d0[i] = s0[i];
+        else d1[i - n0] = s1[i - n0];
+    }
+}
+
+void launch_copy8x2(void *d0, const void *s0, size_t bytes0, void *d1, const void *s1, size_t bytes1, hipStream_t s)
+{
+    const size_t n0 = (bytes0 + 7) / 8, n1 = (bytes1 + 7) / 8;
+    if (n0 + n1 == 0) return;
+    const size_t blocks = std::min<size_t>((n0 + n1 + 255) / 256, 2048);
+    hipLaunchKernelGGL(copy8x2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<unsigned long long *>(d0),
+                       static_cast<const unsigned long long *>(s0), n0, static_cast<unsigned long long *>(d1),
+                       static_cast<const unsigned long long *>(s1), n1);
+}
+
 void launch_copy8(void *dst, const void *src, size_t bytes, hipStream_t s)
 {
     const size_t n8 = (bytes + 7) / 8;

@@ -508,6 +508,7 @@ struct BlockPlan {
     const RotFill *d_rot_fills = nullptr;
     const FmFirLaunch *d_symf = nullptr;
     const AudioLaunch *d_audf = nullptr;
+    bool history_done = false;         // launch_plan copied the history tail together with the launch records
 
     size_t reach(int id) const
     {
@@ -1007,11 +1008,24 @@ int launch_plan(rcf_t *h, BlockPlan &bp)
     const AudioLaunch *d_audf = bp.d_audf;
     const int symf_max_n = bp.symf_max_n, audf_max_n = bp.audf_max_n, audf_num = bp.audf_num, audf_den = bp.audf_den;
 
-    if (ar.used > arena_base) {
-        const size_t from = arena_base & ~size_t(63), bytes = ((ar.used + 63) & ~size_t(63)) - from;
-        if (h->copy_kernels) launch_copy8(ar.d + from, h->h_arena_dev[a] + from, bytes, st);
-        else RCF_HIP(hipMemcpyAsync(ar.d + from, ar.h + from, bytes, hipMemcpyHostToDevice, st));
-        h->arena_fill = (ar.used + 63) & ~size_t(63);
+    {
+        // the block's launch records host -> device, and -- in the same launch -- its history tail behind the OTHER input
+        // buffer's block (nothing in this block reads that place, and the kernels that did read it are earlier in
+        // the stream): one small launch per block instead of two
+        const size_t from = arena_base & ~size_t(63);
+        const size_t bytes = ar.used > arena_base ? ((ar.used + 63) & ~size_t(63)) - from : 0;
+        static const bool merge = [] { const char *e = getenv("RCF_COPY_MERGE"); return !e || atoi(e) != 0; }();   // A/B
+        if (h->copy_kernels && !merge) {
+            if (bytes) launch_copy8(ar.d + from, h->h_arena_dev[a] + from, bytes, st);
+        } else if (h->copy_kernels) {
+            Timed t(h, RCF_T_HISTORY);
+            launch_copy8x2(ar.d + from, h->h_arena_dev[a] + from, bytes, h->d_buf[h->cur ^ 1], h->d_buf[h->cur] + bp.n,
+                           sizeof(float2) * h->hist_cap, st);
+            bp.history_done = true;
+        } else if (bytes) {
+            RCF_HIP(hipMemcpyAsync(ar.d + from, ar.h + from, bytes, hipMemcpyHostToDevice, st));
+        }
+        if (bytes) h->arena_fill = (ar.used + 63) & ~size_t(63);
     }
     if (d_rot_fills) launch_rot_fill(d_rot_fills, (int)rot_fills.size(), h->ring_mask, st);
     if (!fir_by_depth.empty())
@@ -1091,7 +1105,7 @@ int finish_block(rcf_t *h, const BlockPlan &bp)
     const int64_t S1 = bp.S1;
 
     const int other = h->cur ^ 1;
-    {
+    if (!bp.history_done) {
         Timed t(h, RCF_T_HISTORY);
         if (h->copy_kernels) launch_copy8(h->d_buf[other], h->d_buf[h->cur] + n, sizeof(float2) * h->hist_cap, st);
         else RCF_HIP(hipMemcpyAsync(h->d_buf[other], h->d_buf[h->cur] + n, sizeof(float2) * h->hist_cap,

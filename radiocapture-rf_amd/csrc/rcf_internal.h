@@ -318,6 +318,7 @@ inline bool pfb_frame_major(int NB) { return NB % 25 == 0; }
 void launch_gather_view(const StreamView &v, int64_t first, float2 *dst, size_t n, hipStream_t s);
 // dst[0, bytes) = src[0, bytes), both 8-byte aligned, bytes rounded up to 8; src may be pinned (device-mapped) host memory
 void launch_copy8(void *dst, const void *src, size_t bytes, hipStream_t s);
+void launch_copy8x2(void *d0, const void *s0, size_t bytes0, void *d1, const void *s1, size_t bytes1, hipStream_t s);
 int pfb5_padded_p(int NB, int D, int P);
 
 // ---------------------------------------------------------------- scan
