@@ -13,6 +13,8 @@
 //   (fully coalesced); the un-permute k = k1 + N1 k2 and the fftshift happen once, on the emitted vector.
 // HBM traffic per sample: 8 (read) + 8 (scratch write) + 8 (scratch read) + 4 (write) = 28 B against
 // 12 B algorithmic -- the four-step ceiling stated in SURVEY.md 8(d) (~43 % of the algorithmic roofline).
+#include <cstdlib>
+
 #include "fft_core.hpp"
 #include "rcf_internal.h"
 
@@ -155,9 +157,12 @@ void launch_scan4_fft(const ScanLaunch &p, hipStream_t s)
     const cf *tw2 = p.tw + a.N1;
     a.tlo = tw2 + a.N2;
     a.thi = a.tlo + 1024;
-    // 16 columns per workgroup = one 128-byte line per row, 35 KB of LDS, four workgroups per CU (32 columns:
-    // 256-byte runs but two workgroups per CU -- measured 4 % faster, not worth the second instantiation)
+    // N1 = 256: 32 columns per workgroup = 256-byte runs per row on both sides, 72 KB of LDS, two workgroups per CU --
+    // 2.7 % faster than 16 columns (128-byte runs, 37 KB, four per CU): 6.61 -> 6.43 ms per 1000 frames at N = 2^20
+    // (RCF_SCAN_CW32=0 keeps the 16-column form)
+    static const bool cw32 = [] { const char *e = getenv("RCF_SCAN_CW32"); return !e || atoi(e) != 0; }();
     if (a.N1 == 128) launch_cols<128, 16>(a, s);
+    else if (cw32)   launch_cols<256, 32>(a, s);
     else             launch_cols<256, 16>(a, s);
     launch_scan4_rows(p, tw2, a.N1, a.N2, s);
 }
