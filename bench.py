@@ -591,7 +591,8 @@ def main():
     # a 0.13 ms step that would otherwise be charged to `value`.  Switched on BEFORE the warm-up steps, so that nothing
     # but the barrier and one counter reset lies between them and the timed region.
     fe.timing_enable(True, classes=[native.T_PFB])
-    fe.timing_stride(args.time_every)
+    time_every = args.time_every if args.steps >= 2 * args.time_every else 1     # a short run times every launch
+    fe.timing_stride(time_every)
     for _ in range(args.warmup):
         fe.commit(B)
     barrier_max()
@@ -730,7 +731,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_launch_ms": avg_pfb_s * 1e3, "launches": pfb_n, "timed_every": args.time_every,
+                "avg_launch_ms": avg_pfb_s * 1e3, "launches": pfb_n, "timed_every": time_every,
                 "avg_launch_ms_slowest_rank": pfb_avg_ms_max,
                 "frac_slowest_rank": alg_bytes / (pfb_avg_ms_max * 1e-3) / 1e9 / HBM_PEAK_GBS if pfb_avg_ms_max > 0 else 0.0,
             },
