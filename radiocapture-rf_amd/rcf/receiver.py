@@ -55,10 +55,12 @@ class receiver:
         for source in sorted(self.realsources):
             src = self.realsources[source]
             fe = frontend_factory(float(src["samp_rate"]), float(src["center_freq"]), device)
-            # config.rotator = 'exact': the channels iterate GNU Radio's float32 rotator (rcf_set_rotator) -- the IQ
-            # egress then carries GNU Radio's phase at any stream length, for ~30 ns per output and channel per block;
-            # default 'fast' = its closed form (the discriminator cannot tell them apart)
-            if getattr(config, "rotator", "fast") == "exact":
+            # The channels of a receiver iterate GNU Radio's own float32 rotator (rcf_set_rotator): the IQ egress then
+            # carries GNU Radio's phase at any stream length, for ~30 ns per output and channel per block -- under 1 %
+            # of a block at real-time rates, which is what a receiver runs at.  config.rotator = 'fast' selects the
+            # closed form instead (the C ABI's own default, what bench.py measures at 10^4 x real time; the
+            # discriminator cannot tell the two apart, the IQ stream differs by a slowly turning common phase).
+            if getattr(config, "rotator", "exact") == "exact" and hasattr(fe, "set_rotator"):
                 fe.set_rotator(True)
             if getattr(config, "receiver_split2", False):
                 # receiver.py:205-237: each source becomes two half-rate sources, centre -/+ fs/4, through

@@ -448,7 +448,8 @@ def test_tap_leakage_matches_the_float32_phase_model():
 
 
 def test_receiver_rotator_config_reaches_the_front_end():
-    """config.rotator = 'exact' -> rcf_set_rotator on every source's front-end before any channel exists"""
+    """a receiver's channels iterate GNU Radio's rotator (rcf_set_rotator on every source's front-end, before any
+    channel exists) unless config.rotator = 'fast'"""
     class Fe(StubFrontend):
         def __init__(self, *a, **k):
             super().__init__(*a, **k)
@@ -459,12 +460,16 @@ def test_receiver_rotator_config_reaches_the_front_end():
             self.rotator = exact
 
     cfg = types.SimpleNamespace(sources={0: dict(type="synthetic", center_freq=855000000, samp_rate=2400000)},
-                                frontend_mode="xlat", rotator="exact")
-    tb = receiver.receiver(cfg, frontend_factory=Fe)
+                                frontend_mode="xlat")
+    receiver.receiver(cfg, frontend_factory=Fe)
+    assert StubFrontend.instances[-1].rotator is True
+    cfg.rotator = "exact"
+    receiver.receiver(cfg, frontend_factory=Fe)
     assert StubFrontend.instances[-1].rotator is True
     cfg.rotator = "fast"
-    tb = receiver.receiver(cfg, frontend_factory=Fe)
+    receiver.receiver(cfg, frontend_factory=Fe)
     assert StubFrontend.instances[-1].rotator is None
+    receiver.receiver(cfg, frontend_factory=StubFrontend)          # a front-end without the knob is left alone
 
 
 def test_failed_channel_construction_releases_its_egress_port():
