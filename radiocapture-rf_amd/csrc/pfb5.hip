@@ -56,6 +56,21 @@ constexpr int kThreads5 = 320;
 // padded extent of one frame in LDS: pad5(NB - 1) + 1
 constexpr int pfb5_row_stride(int NB, int R) { return NB + NB / R - 1; }
 
+// LDS of one workgroup, in complex samples: the F padded frame rows of the FFT -- or, where the chunk's input window is
+// larger than that but still fits TWO workgroups per CU (64 granules of 1280 bytes each), the window: staging it is
+// worth more than the third workgroup (3200 bins, D = 1600: window 8000 samples = 64 KB against 53.7 KB of rows)
+constexpr int pfb5_win(int NB, int F, int OS, int P) { return (F - 1 + OS * (P - 1)) * (NB / OS) + NB; }
+constexpr int pfb5_win_rounds(int win) { return (win + 1 + 2 * kThreads5 - 1) / (2 * kThreads5) * (2 * kThreads5); }   // DMA rounds of 640 samples
+constexpr int pfb5_buf(int NB, int R, int F, int OS, int P)
+{
+    const int rows = F * pfb5_row_stride(NB, R), win = pfb5_win_rounds(pfb5_win(NB, F, OS, P));
+    if (!(win > rows && (size_t)win * 8 <= (size_t)64 * 1280)) return rows;
+    // ... and behind the window as many whole rows of the prototype as the two-workgroup budget still holds
+    int extra = (int)(((size_t)64 * 1280 - (size_t)win * 8) / ((size_t)NB * 4));
+    if (extra > P) extra = P;
+    return win + extra * (NB / 2);
+}
+
 // padded index: one spare complex after every R
 template <int R> __device__ __forceinline__ constexpr int pad5(int i) { return i + i / R; }
 
@@ -80,7 +95,9 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
     // of 1280 bytes (tools/occ_probe.hip: 53760 bytes -> three workgroups per CU, 53776 -> two), and F (extent + 2)
     // complex -- the stride this kernel had first -- is 53792 bytes: 32 bytes too many for the third workgroup.
     constexpr int RS = pfb5_row_stride(NB, R);
+    constexpr int BUF = pfb5_buf(NB, R, F, OS, P);       // complex samples of LDS (>= F RS)
     static_assert((size_t)F * RS * sizeof(cf) <= 42 * 1280, "three workgroups per CU need <= 42 LDS granules each");
+    static_assert((size_t)BUF * sizeof(cf) <= 64 * 1280, "at least two workgroups per CU");
     static_assert(R == 20 && F * BPF == kThreads5, "one butterfly per thread and pass");
     static_assert(OS == 1 || OS == 2 || OS == 4, "bin phase factor must be a power of -j");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -116,7 +133,7 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
     // FIR reads LDS (consecutive lanes = consecutive samples, conflict free).  Shapes whose window does not fit
     // (OS = 1 with 4 taps per branch) keep the direct form.
     constexpr int WIN = (F - 1 + OS * (P - 1)) * D + NB;
-    constexpr bool STAGE = WIN <= F * RS;
+    constexpr bool STAGE = WIN <= BUF;
     {
         const int frame = tid / BPF, j = tid % BPF;
         const int64_t n = n0 + frame;
@@ -136,7 +153,7 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
                 // aligned; rounds past its end read zeros (descriptor range) into LDS nobody looks at.
                 constexpr int PER = kThreads5 * 2;                            // samples per round of the workgroup
                 constexpr int NLD = (WIN + 1 + PER - 1) / PER;
-                static_assert((size_t)NLD * PER * sizeof(cf) <= (size_t)F * RS * sizeof(cf), "window rounds fit the buffer");
+                static_assert((size_t)NLD * PER * sizeof(cf) <= (size_t)BUF * sizeof(cf), "window rounds fit the buffer");
                 odd = (int)((m_lo - p.src.origin) & 1);
                 const int vo0 = (int)((m_lo - odd - p.src.origin) * (int64_t)sizeof(cf)) + tid * 16;
                 unsigned char *lds_wave = reinterpret_cast<unsigned char *>(buf) + (tid >> 6) * (64 * 16);
@@ -151,7 +168,7 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
                 // consecutive floats); the rest still comes from L2.
                 constexpr int WIN_BYTES = NLD * PER * (int)sizeof(cf);
                 constexpr int HROW = NB * (int)sizeof(float);
-                constexpr int HQ_ = ((int)(F * RS * sizeof(cf)) - WIN_BYTES) / HROW;
+                constexpr int HQ_ = ((int)(BUF * sizeof(cf)) - WIN_BYTES) / HROW;
                 constexpr int HQ = HQ_ > P ? P : HQ_;                         // rows of h staged in LDS
                 if constexpr (HQ > 0) {
                     const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -386,7 +403,7 @@ void launch5(const PfbLaunch &p, hipStream_t s)
 {
     constexpr int NB = R * R * R3, F = 16 / R3;
     const int n_wg = (p.n_frames + F - 1) / F;
-    const size_t lds = (size_t)F * pfb5_row_stride(NB, R) * sizeof(cf);
+    const size_t lds = (size_t)pfb5_buf(NB, R, F, OS, P) * sizeof(cf);
     static DynLdsAttr attr_f, attr_t;
     attr_f.ensure(reinterpret_cast<const void *>(pfb5_kernel<R, R3, OS, P, false>), lds);
     attr_t.ensure(reinterpret_cast<const void *>(pfb5_kernel<R, R3, OS, P, true>), lds);
