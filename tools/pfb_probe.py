@@ -8,7 +8,7 @@ from rcf import native
 
 nb = int(os.environ.get("NB", 256)); osf = int(os.environ.get("OS", 1))
 B = int(os.environ.get("BLOCK", 1 << 25)); steps = int(os.environ.get("STEPS", 10))
-fs = 20e6
+fs = float(os.environ.get("FS", 20e6))
 D = nb // osf
 bw = fs / nb
 if nb % 25 == 0:
