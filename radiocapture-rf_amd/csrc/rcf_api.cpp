@@ -60,7 +60,8 @@ struct Chan {
     int src = -1;                 // -1 wideband; RCF_SRC_PFB_BIN0 + bin; else source channel id
     int D = 0, T = 0;
     double src_rate = 0, offset_hz = 0;
-    bool is_tap = false;          // a bin of a frame-major filterbank open as a channel: filled by the bank's kernel
+    bool is_tap = false;          // a bin of a frame-major filterbank open as a channel: the bank's kernel copies it
+                                  // into the launch's tap matrix, tap_finalize_kernel fills the rings
     std::vector<float> proto;     // prototype taps (host)
     float2 *d_ctaps = nullptr;
     uint64_t taps_version = 0;    // bumped whenever d_ctaps changes (bank-matrix cache key)
@@ -713,7 +714,7 @@ int plan_channel(rcf_t *h, BlockPlan &bp, ClassPlan &cp, Chan *c, int D)
     dl.fm_ring = c->d_fm;
     dl.n_lo = k_lo - c->k_abs0;
     dl.n_k = (int32_t)cnt;
-    if (c->is_tap) {                            // written by the filterbank kernel, not by a FIR launch
+    if (c->is_tap) {                            // served through the tap matrix, not by a FIR launch
         TapLaunch tl{};
         tl.iq_ring = c->d_iq;
         tl.fm_ring = c->d_fm;
