@@ -31,9 +31,14 @@
 //     the other powers by binary powering in registers.
 //   * the finish writes its bins back in place (bin b at position b, bin phase factor e^{-j 2 pi k n D / NB} = a
 //     power of -j applied), one more barrier, then the chunk leaves as WHOLE FRAMES: the output is a frame-major ring
-//     bins_ring[(n & mask) NB + k] and every wavefront store is 512 contiguous bytes.  (Per-bin rings, as pfb.hip
-//     writes them, would get 32- or 16-byte pieces from a 4- or 2-frame chunk: measured 2x slower than the whole
-//     rest of the kernel, nt or not.)  Consumers read one bin with stride NB (StreamView.stride).
+//     bins_ring[(n & mask) NB + k] and every wavefront store is 512 contiguous bytes.  (Per-bin lines would get 32- or
+//     16-byte pieces from a 4- or 2-frame chunk: per-bin rings measured 2x slower than the whole rest of the kernel, nt
+//     or not; pfb.hip's 16-frame tiles, where those pieces are dense, 4.6x slower than this -- a store that does not
+//     fill its 128-byte line is a read-modify-write further down.)  Consumers read one bin with stride NB
+//     (StreamView.stride); bins open as channels leave through the tap matrix below.
+//   * shapes whose input window is larger than the F frame rows (3200 bins at D = 1600, 800 bins at OS = 1) take the
+//     window's size of LDS instead and run two workgroups per CU (pfb5_buf): staging the window is worth more than
+//     the third workgroup (0.445 -> 0.48, 0.37 -> 0.49 of the HBM peak).
 // Bound: HBM.  Algorithmic bytes per input sample = 8 (read) + 8 NB / D (written) = 24 at OS = 2, 40 at OS = 4.
 // Build notes: no SLP vectoriser (packed v_pk_*_f32 arithmetic issues slower than the scalar pair on gfx950: 0.137 ->
 // 0.111 ms), no implicit contraction (instantiations must round alike) with the FMAs of the complex products spelled
