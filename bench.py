@@ -739,7 +739,7 @@ def main():
                 "pfb": pfb_ms / max(pfb_n, 1),
                 "stage2_fir_with_fused_discriminator": fir2_ms / max(n_extra, 1),
                 "separate_discriminator_launches": disc_ms / max(n_extra, 1),
-                "history_copy": hist_ms / max(n_extra, 1),
+                "launch_records_and_history_copy": hist_ms / max(n_extra, 1),
             },
         }
         if sustained is not None:
