@@ -96,6 +96,37 @@ pmc_record("%s_pfb1600" % R, "pfb5_kernel", "profiles/%s_pfb1600_pmc.json" % R, 
     "workload": "tools/pfb_probe.py NB=1600 BLOCK=2^25: 1600-bin bank, D = 800, 2909 taps; algorithmic 24 B/sample = 805.3 MB",
     "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
 
+# ---- shader clock of the filterbank launches over the sustained leg (first / last 100 dispatches)
+def clock_series(d, kernel):
+    cnt, dur = {}, {}
+    f = newest(os.path.join(d, "**", "*counter_collection.csv"))
+    if f:
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"] and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                cnt[int(r["Dispatch_Id"])] = cnt.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+    f = newest(os.path.join(d, "**", "*kernel_trace.csv"))
+    if f:
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"]:
+                dur[int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    ids = sorted(i for i in cnt if i in dur and dur[i] > 0)
+    return [(cnt[i] / 8.0 / dur[i] / 1e3, dur[i]) for i in ids]      # (GHz, us)
+
+
+ser = clock_series("gpurun_out/%s_pmc_clock" % R, "pfb_kernel_os<256")
+if len(ser) > 400:
+    w = lambda xs: sum(xs) / len(xs)
+    json.dump({"kernel": "pfb_kernel_os<256, 1, 14, 4, false>", "dispatches": len(ser),
+               "clock_ghz_first_100": w([c for c, _ in ser[:100]]), "clock_ghz_last_100": w([c for c, _ in ser[-100:]]),
+               "kernel_us_first_100_under_pmc": w([u for _, u in ser[:100]]),
+               "kernel_us_last_100_under_pmc": w([u for _, u in ser[-100:]]),
+               "how": "rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace over `bench.py --steps 20 --warmup 5 --no-extras "
+                      "--no-cpu-baseline` (prewarm + timed region + the 2 s sustained leg); clock = GRBM_GUI_ACTIVE / 8 XCDs / "
+                      "dispatch duration; durations under counter collection are longer than un-profiled ones"},
+              open("profiles/%s_sustained_clock.json" % R, "w"), indent=1)
+    print("clock: first 100 %.3f GHz, last 100 %.3f GHz over %d dispatches" % (
+        w([c for c, _ in ser[:100]]), w([c for c, _ in ser[-100:]]), len(ser)))
+
 for tag in ("bench", "bench_cfg5", "bench_head_under_rocprof"):
     src = "gpurun_out/%s_%s.json" % (R, tag)
     if os.path.exists(src):

@@ -34,6 +34,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $ROOT/gpurun_out/${R}_pmc5_$c -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-sustained --config cfg5 > /dev/null 2>&1)
 done
 
+# shader clock over the sustained leg: GRBM_GUI_ACTIVE per filterbank dispatch (8 XCDs) / its duration
+rm -rf gpurun_out/${R}_pmc_clock
+(cd /tmp && timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $ROOT/gpurun_out/${R}_pmc_clock -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > /dev/null 2>&1)
+
 tools/fir_pmc.sh ${R}_fir4096 C=4096 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb_kernel tools/fir_pmc.sh ${R}_pfb512 NB=512 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb_kernel tools/fir_pmc.sh ${R}_pfb1024 NB=1024 > /dev/null 2>&1
