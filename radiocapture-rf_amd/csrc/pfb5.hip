@@ -335,16 +335,19 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
     // bytes of a row.  Rotators and the discriminator are tap_finalize_kernel's business (fir.hip).  The bin numbers
     // are requested before the barrier.
     constexpr int TAP_IT = 5;                                // 5 x 320 slots cover all 1600 bins; 3200 bins loop
+    // slots below tap_first are whole aligned runs of 16 bins: tap_finalize reads those from the ring this kernel
+    // writes anyway, and nothing is copied for them here
+    const int n_mat = p.n_taps - p.tap_first;
     int tap_bin[TAP_IT];
 #pragma unroll
     for (int it = 0; it < TAP_IT; ++it) {
         const int sl = tid + it * kThreads5;
-        tap_bin[it] = sl < p.n_taps ? p.tap_bins[sl] : -1;
+        tap_bin[it] = sl < n_mat ? p.tap_bins[p.tap_first + sl] : -1;
     }
     __syncthreads();
     TS(4);
-    if (p.n_taps > 0) {
-        float2 *trow = p.tap_mat + (size_t)fb0 * p.tap_pitch;
+    if (n_mat > 0) {
+        float2 *trow = p.tap_mat + (size_t)fb0 * p.tap_pitch + p.tap_first;
 #pragma unroll
         for (int it = 0; it < TAP_IT; ++it) {
             const int sl = tid + it * kThreads5;
@@ -354,8 +357,8 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
             for (int f = 0; f < F; ++f)
                 if (f < nf) trow[(size_t)f * p.tap_pitch + sl] = col[f * RS];
         }
-        for (int sl = tid + TAP_IT * kThreads5; sl < p.n_taps; sl += kThreads5) {       // more than 1600 taps (3200 bins)
-            const cf *col = buf + pad5<R>(p.tap_bins[sl]);
+        for (int sl = tid + TAP_IT * kThreads5; sl < n_mat; sl += kThreads5) {          // more than 1600 taps (3200 bins)
+            const cf *col = buf + pad5<R>(p.tap_bins[p.tap_first + sl]);
             for (int f = 0; f < nf; ++f) trow[(size_t)f * p.tap_pitch + sl] = col[f * RS];
         }
     }

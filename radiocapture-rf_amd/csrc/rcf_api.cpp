@@ -506,6 +506,9 @@ struct BlockPlan {
     PfbLaunch pl{};
     bool run_pfb = false;
     const TapLaunch *d_tap_list = nullptr;
+    const int32_t *d_group_bin0 = nullptr;   // per group of 16 tap slots: first bin of a run read straight from the ring, or -1
+    std::vector<int32_t> tap_first_of_bin;
+    std::vector<TapLaunch> tap_ordered;
     const RotFill *d_rot_fills = nullptr;
     const FmFirLaunch *d_symf = nullptr;
     const AudioLaunch *d_audf = nullptr;
@@ -542,7 +545,7 @@ int plan_arena(rcf_t *h, BlockPlan &bp)
         size_t need = 4096;
         for (auto &kv : h->chans) {
             const Chan &c = *kv.second;
-            need += 2 * sizeof(ChanLaunch) + sizeof(TapLaunch) + sizeof(DiscLaunch) + sizeof(RotFill) + 8 + 128;
+            need += 2 * sizeof(ChanLaunch) + sizeof(TapLaunch) + sizeof(DiscLaunch) + sizeof(RotFill) + 12 + 128;
             if (c.d_sym) need += sizeof(FmFirLaunch);
             if (c.audio) need += sizeof(AudioLaunch);
             max_depth = std::max(max_depth, c.depth);
@@ -978,7 +981,38 @@ int plan_tail(rcf_t *h, BlockPlan &bp)
             h->d_tapmat = nm;
             h->tapmat_cap = need;
         }
-        if (!ar.put(tap_bins, &pl.tap_bins) || !ar.put(tap_list, &d_tap_list)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+        // Slot order: first every aligned run of 16 bins that is tapped completely (tap_finalize reads those from the
+        // bank's ring: PfbLaunch::tap_first), then the remaining taps, which go through the matrix.
+        const int NB = pl.NB;
+        auto &first = bp.tap_first_of_bin;
+        first.assign((size_t)NB, -1);
+        for (size_t i = 0; i < tap_list.size(); ++i)
+            if (first[tap_list[i].bin] < 0) first[tap_list[i].bin] = (int32_t)i;
+        auto &ordered = bp.tap_ordered;
+        ordered.clear();
+        ordered.reserve(tap_list.size());
+        std::vector<int32_t> group_bin0;
+        group_bin0.reserve(pitch / 16);
+        for (int b0 = 0; b0 + 16 <= NB; b0 += 16) {
+            bool full = true;
+            for (int j = 0; j < 16 && full; ++j) full = first[b0 + j] >= 0;
+            if (!full) continue;
+            for (int j = 0; j < 16; ++j) {
+                ordered.push_back(tap_list[first[b0 + j]]);
+                tap_list[first[b0 + j]].bin = -1;               // taken
+            }
+            group_bin0.push_back(b0);
+        }
+        pl.tap_first = (int32_t)ordered.size();
+        for (const TapLaunch &t : tap_list)
+            if (t.bin >= 0) ordered.push_back(t);
+        tap_list.swap(ordered);
+        group_bin0.resize(pitch / 16, -1);
+        for (size_t i = 0; i < tap_list.size(); ++i) tap_bins[i] = tap_list[i].bin;
+        if (!ar.put(tap_bins, &pl.tap_bins) || !ar.put(tap_list, &d_tap_list) || !ar.put(group_bin0, &bp.d_group_bin0)) {
+            set_error("launch arena exhausted");
+            return RCF_ENOMEM;
+        }
         pl.tap_mat = h->d_tapmat;
         pl.tap_pitch = (int32_t)pitch;
         pl.n_taps = (int32_t)tap_list.size();
@@ -1042,7 +1076,7 @@ int launch_plan(rcf_t *h, BlockPlan &bp)
     if (run_pfb && pl.n_taps > 0) {
         Timed t(h, RCF_T_TAPS);
         launch_tap_finalize(d_tap_list, pl.n_taps, pl.tap_mat, pl.tap_pitch, pl.n_frames, pl.n_lo - pl.n_abs0,
-                            h->ring_mask, h->d_atan, st);
+                            h->ring_mask, h->d_atan, bp.d_group_bin0, pl.bins_ring, pl.NB, st);
     }
     for (size_t d = 1; d < fir_by_depth.size(); ++d)
         for (auto &j : fir_by_depth[d]) { Timed t(h, RCF_T_FIR_DERIVED); launch_fir_bank(j.dev, j.dims, st); }

@@ -292,7 +292,11 @@ struct PfbLaunch {
     const int32_t *tap_bins;
     float2 *tap_mat;
     int32_t tap_pitch;       // row pitch of tap_mat in samples (n_taps rounded up to 16)
-    int32_t pad_;
+    // slots [0, tap_first) -- a multiple of 16 -- are runs of 16 consecutive bins starting at a multiple of 16: row by
+    // row such a run is one aligned 128-byte piece of the frame-major ring itself, tap_finalize reads it there, and
+    // the bank copies only the slots from tap_first on.  With every bin tapped (the reference's intent,
+    // receiver.py:343-383) the bank costs what it costs untapped.
+    int32_t tap_first;
 };
 struct TapLaunch {           // one tapped bin, consumed by tap_finalize_kernel
     float2 *iq_ring;
@@ -306,8 +310,11 @@ struct TapLaunch {           // one tapped bin, consumed by tap_finalize_kernel
     static constexpr bool kHasRotRing = false;
 };
 // mat row r = the bank's frame k_first + r (tap output index); rows [0, n_rows)
+// group_bin0[g] >= 0: the 16 taps of slot group g are the bins group_bin0[g] .. + 15 -- read from the bank's frame-major
+// ring (bins_ring[((k_first + r) & ring_mask) n_bins + bin]) instead of the matrix
 void launch_tap_finalize(const TapLaunch *d_taps, int n_taps, const float2 *tap_mat, int tap_pitch, int n_rows,
-                         int64_t k_first, uint64_t ring_mask, const float *d_atan_table, hipStream_t s);
+                         int64_t k_first, uint64_t ring_mask, const float *d_atan_table, const int32_t *d_group_bin0,
+                         const float2 *bins_ring, int n_bins, hipStream_t s);
 bool pfb_supported(int NB, int D, int P);
 int pfb_padded_p(int NB, int D, int P);   // rows the kernel instantiation reads from ptaps (zero padded)
 void launch_pfb(const PfbLaunch &p, hipStream_t s);

@@ -448,3 +448,56 @@ def test_peak_picker_heavy_list_overflow_drops_nothing(gpu_required):
             np.testing.assert_array_equal(lines, want)
             results.append(lines)
         assert len(results[0]) == 5
+
+
+def test_pfb1600_tap_slots_full_runs_partial_runs_and_duplicates(gpu_required):
+    """The tap slot order: aligned runs of 16 bins that are tapped completely are read by tap_finalize from the bank's
+    own ring (no matrix copy), everything else goes through the matrix.  Full runs (one of them opened in reverse, one
+    at the last 16 bins), a run with one bin missing, an unaligned run of 16, scattered bins, the same bin opened
+    twice, and a full run opened between two pushes (its k_abs0 is not the bank's): every tap stream is its bin bit
+    for bit, and closing a tap of a full run (the run then goes through the matrix) changes nothing for the others."""
+    nat = gpu_required
+    fs, nb = 20e6, 1600
+    D, taps = G.channel_params(fs, 12500)                    # D = 800: the reference grid's bank (OS = 2)
+    rng = np.random.default_rng(321)
+    x = synth.awgn(rng, D * 700 + 123)
+    bins = list(range(32, 48)) + list(range(79, 63, -1)) + list(range(1584, 1600))      # three full runs
+    bins += list(range(96, 111))                                                        # 15 of 16
+    bins += list(range(200, 216))                                                       # 16 consecutive, unaligned
+    bins += [3, 1001, 517, 1234, 40, 40, 1599]                                          # scattered + duplicates of run bins
+    with nat.Frontend(fs, block_capacity=len(x), out_capacity=1 << 11) as fe:
+        fe.pfb_open(nb, D, taps)
+        ids = [fe.pfb_tap_open(k, gr_phase=False) for k in bins]
+        cuts = [D * 150 + 31, D * 290 + 7, D * 470]
+        fe.push(x[:cuts[0]])
+        n_late0 = fe.pfb_produced()
+        late = [fe.pfb_tap_open(k, gr_phase=False) for k in range(640, 656)]            # a full run that starts later
+        fe.push(x[cuts[0]:cuts[1]])
+        fe.chan_close(ids[5])                                                           # bin 37: run 32..47 is no longer full
+        fe.push(x[cuts[1]:cuts[2]])
+        fe.push(x[cuts[2]:])
+        n_out = fe.pfb_produced()
+        assert n_out > 600
+        ring = {}                                            # pfb_read_bin is a cursor: read each bin once
+
+        def bin_of(k):
+            if k not in ring:
+                ring[k] = fe.pfb_read_bin(k)
+            return ring[k]
+
+        for j, k in enumerate(bins):
+            if j == 5:
+                continue
+            y = fe.chan_read_iq(ids[j])
+            b = bin_of(k)
+            assert len(y) == len(b) == n_out, (j, k)
+            np.testing.assert_array_equal(y, b, err_msg="tap %d bin %d" % (j, k))
+            fm = fe.chan_read_fm(ids[j], 1.0)
+            np.testing.assert_array_equal(fm, G.quadrature_demod_cf(b.astype(np.complex64), 1.0))
+        for j, k in enumerate(range(640, 656)):
+            y = fe.chan_read_iq(late[j])
+            b = bin_of(k)[n_late0:]
+            assert len(y) == len(b) == n_out - n_late0
+            np.testing.assert_array_equal(y, b)
+            fm = fe.chan_read_fm(late[j], 1.0)
+            np.testing.assert_array_equal(fm, G.quadrature_demod_cf(b.astype(np.complex64), 1.0))

@@ -31,7 +31,9 @@ for _ in range(2):
         fe.ingest_write(tile[: min(len(tile), B - at)], at)
     fe.commit(B)
 ntap = int(os.environ.get("TAPS", 0))
-tids = [fe.pfb_tap_open((7 + 6 * i) % nb, gr_phase=bool(int(os.environ.get("GRPHASE", 1)))) for i in range(ntap)]
+# TAPSEQ=1: bins 0, 1, 2, ... (complete aligned runs of 16: read from the bank's ring); default: scattered bins (tap matrix)
+seq = bool(int(os.environ.get("TAPSEQ", 0)))
+tids = [fe.pfb_tap_open(i % nb if seq else (7 + 6 * i) % nb, gr_phase=bool(int(os.environ.get("GRPHASE", 1)))) for i in range(ntap)]
 for _ in range(3): fe.commit(B)
 fe.timing_enable(True, classes=None if os.environ.get('TIME_ALL') else [native.T_PFB]); fe.timing_read(native.T_PFB)
 for _ in range(steps): fe.commit(B)
@@ -46,4 +48,4 @@ if os.environ.get('TIME_ALL'):
 gbs = (8.0 * B + 8.0 * B * osf) / (ms * 1e-3) / 1e9
 print("NB=%d OS=%d taps=%d remap=%s : %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (
     nb, osf, len(taps),
-    "off" if os.environ.get("RCF_PFB_NOREMAP") else "on", ms, gbs, gbs / 80.0) + extra + ("  taps=%d" % ntap))
+    "off" if os.environ.get("RCF_PFB_NOREMAP") else "on", ms, gbs, gbs / 80.0) + extra + ("  taps=%d%s" % (ntap, " (consecutive)" if seq else "")))
