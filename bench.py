@@ -304,8 +304,10 @@ def reference_grid_leg(native, tile, device, B=1 << 25, n_taps=256):
     tap_points = []
     ids = []
     for n_t in (n_taps, 1600):
-        while len(ids) < n_t:
-            ids.append(fe.pfb_tap_open((7 + 6 * len(ids)) % 1600 if n_t < 1600 else len(ids), gr_phase=True))
+        for i in ids:
+            fe.chan_close(i)
+        # 256 scattered bins (all through the tap matrix), then every bin once (all read from the bank's ring)
+        ids = [fe.pfb_tap_open((7 + 6 * i) % 1600 if n_t < 1600 else i, gr_phase=True) for i in range(n_t)]
         fe.commit(B)
         tap_ms, fin_ms, tap_wall = timed()
         assert fe.chan_produced(ids[0]) > 0
@@ -347,10 +349,12 @@ def reference_grid_leg(native, tile, device, B=1 << 25, n_taps=256):
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (bank_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "sustained": sustained,
         "grid_6k25": fine,
-        "with_taps": {"note": "tapped bins leave the bank's kernel as a compact frame-major matrix (whole rows); "
-                              "tap_finalize_kernel transposes it into the channels' rings with GNU Radio's rotator per tap "
-                              "and the discriminator fused in (pfb_ms = the bank incl. the matrix, tap_finalize_ms = that "
-                              "kernel)", "points": tap_points},
+        "with_taps": {"note": "tapped bins leave the bank's kernel as a compact frame-major matrix (whole rows) -- except "
+                              "complete aligned runs of 16 bins, which are read from the bank's own ring; "
+                              "tap_finalize_kernel transposes either into the channels' rings with GNU Radio's rotator per "
+                              "tap and the discriminator fused in (pfb_ms = the bank incl. the matrix, tap_finalize_ms = "
+                              "that kernel).  Points: 256 scattered bins (matrix), all 1600 bins (ring)",
+                      "points": tap_points},
     }
 
 
