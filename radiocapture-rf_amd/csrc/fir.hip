@@ -607,13 +607,14 @@ __global__ __launch_bounds__(kThreads) void tap_finalize_kernel(const TapLaunch 
                         z[it] = L.iq_ring[(uint64_t)n & ring_mask];   // produced by an earlier launch: already rotated
                 }
             }
+            RotatorWalk<TapLaunch> walk(L, k_first + r_lds0 + rr - L.k_abs0, 16);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int lr = rr + 16 * it, r = r_lds0 + lr;
                 if (lr >= kTapLdsRows) break;
-                const int64_t n = k_first + r - L.k_abs0;
                 float2 v = z[it];
-                if (!idle && r >= 0) v = rotate_value(L, n, v.x, v.y);  // (a zero stays zero: rows outside the tap's range)
+                if (!idle && r >= 0) v = walk.rotate(L, v.x, v.y);     // (a zero stays zero: rows outside the tap's range)
+                walk.advance();
                 ys[lr * kTapLdsPitch + sl] = v;
             }
         }
