@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *_
     const StreamView sv = L.src;
     // all of a thread's tile loads are issued before the first LDS store: a load -> store loop exposes the full
     // memory latency once per iteration (measured: that, not arithmetic, was this kernel's time)
-    constexpr int LU = 12;
+    constexpr int LU = 8;     // the stage-2 shape of the timed configuration (D = 3, T = 11: 1544 samples) needs 7 per thread
     for (int p0 = tid; p0 < len; p0 += kThreads * LU) {
         float2 v[LU];
 #pragma unroll
