@@ -744,6 +744,8 @@ def main():
                 "stage2_fir_with_fused_discriminator": fir2_ms / max(n_extra, 1),
                 "separate_discriminator_launches": disc_ms / max(n_extra, 1),
                 "launch_records_and_history_copy": hist_ms / max(n_extra, 1),
+                "launch_records_and_history_copy_note": "0 = no launch of its own: the filterbank kernel's first workgroups "
+                                                        "do both copies on the way in (PfbLaunch::rider_*)",
             },
         }
         if sustained is not None:

@@ -178,6 +178,8 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
     cf *tw_lds = buf + F * RS;
 
     const int tid = threadIdx.x;
+    if (p.rider_n8[0] + p.rider_n8[1] && (int)blockIdx.x < kPfbRiderWgs)
+        pfb_copy_rider(p, blockIdx.x, min(kPfbRiderWgs, (int)gridDim.x), tid, NB);
     int wg;
     if (n_wg < 0) {
         wg = blockIdx.x;                                   // probe: no XCD remap
@@ -362,6 +364,12 @@ int env_int(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
+bool pfb_persistent(int NB)
+{
+    static const int pp_env = env_int("RCF_PFB_PP", -1);
+    return pp_env < 0 ? NB >= 512 : pp_env != 0;
+}
+
 template <int NB, int OS, int P, int MINW>
 void launch_os(const PfbLaunch &p, hipStream_t s)
 {
@@ -373,9 +381,7 @@ void launch_os(const PfbLaunch &p, hipStream_t s)
     // 512 / 1024 bins run the persistent form (2 / 1 workgroups per CU: +2 % / +10 %); at 256 bins and below four
     // independent workgroups per CU already overlap their phases and the persistent form's extra barrier per chunk
     // costs 8 % (measured, block 2^25).  RCF_PFB_PP=0 / 1 forces it off / on.
-    static const int pp_env = env_int("RCF_PFB_PP", -1);
-    const bool pp = pp_env < 0 ? NB >= 512 : pp_env != 0;
-    if (pp && !zh) {
+    if (pfb_persistent(NB) && !zh) {
         constexpr int PF = NB >= 1024 ? 8 : 16;
         const int wg_per_cu = NB <= 256 ? 4 : (NB == 512 ? 2 : 1);
         static const int cus = [] {
@@ -449,6 +455,14 @@ int pfb_padded_p(int NB, int D, int P)
 {
     if (NB % 25 == 0) return pfb5_padded_p(NB, D, P);
     return round_p(P, D > 0 ? NB / D : 1);
+}
+
+bool pfb_takes_rider(const PfbLaunch &p)
+{
+    if (pfb_frame_major(p.NB)) return false;            // pfb5_kernel: measured, +5.7 us on the 1600-bin launch for 4.7 saved
+    // (a launch that still sees zero history runs the plain form whatever the bin count: being wrong about that one
+    // launch costs a late start, nothing else)
+    return !pfb_persistent(p.NB);
 }
 
 void launch_pfb(const PfbLaunch &p, hipStream_t s)

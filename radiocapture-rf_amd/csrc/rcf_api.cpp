@@ -1035,7 +1035,7 @@ int launch_plan(rcf_t *h, BlockPlan &bp)
     auto &symf = bp.symf;
     auto &audf = bp.audf;
     auto &rot_fills = bp.rot_fills;
-    const PfbLaunch &pl = bp.pl;
+    PfbLaunch &pl = bp.pl;
     const bool run_pfb = bp.run_pfb;
     const TapLaunch *d_tap_list = bp.d_tap_list;
     const RotFill *d_rot_fills = bp.d_rot_fills;
@@ -1050,7 +1050,22 @@ int launch_plan(rcf_t *h, BlockPlan &bp)
         const size_t from = arena_base & ~size_t(63);
         const size_t bytes = ar.used > arena_base ? ((ar.used + 63) & ~size_t(63)) - from : 0;
         static const bool merge = [] { const char *e = getenv("RCF_COPY_MERGE"); return !e || atoi(e) != 0; }();   // A/B
-        if (h->copy_kernels && !merge) {
+        // ... or none at all: when the filterbank's launch is the first of the block that needs neither (no direct
+        // channels, no exact-rotator fill before it, no tap matrix whose slot list the bank itself reads from the
+        // arena), its first workgroups do both copies on the way in (PfbLaunch::rider_*)
+        static const bool ride_env = [] { const char *e = getenv("RCF_COPY_RIDE"); return !e || atoi(e) != 0; }();    // A/B
+        const bool ride = ride_env && merge && h->copy_kernels && run_pfb && !d_rot_fills &&
+                          (fir_by_depth.empty() || fir_by_depth[0].empty()) && pl.n_taps == pl.tap_first &&
+                          bytes / 8 < (1u << 31) && h->hist_cap < (1u << 28) && pfb_takes_rider(pl);
+        if (ride) {
+            pl.rider_dst[0] = reinterpret_cast<unsigned long long *>(ar.d + from);
+            pl.rider_src[0] = reinterpret_cast<const unsigned long long *>(h->h_arena_dev[a] + from);
+            pl.rider_n8[0] = (uint32_t)((bytes + 7) / 8);
+            pl.rider_dst[1] = reinterpret_cast<unsigned long long *>(h->d_buf[h->cur ^ 1]);
+            pl.rider_src[1] = reinterpret_cast<const unsigned long long *>(h->d_buf[h->cur] + bp.n);
+            pl.rider_n8[1] = (uint32_t)(sizeof(float2) * h->hist_cap / 8);
+            bp.history_done = true;
+        } else if (h->copy_kernels && !merge) {
             if (bytes) launch_copy8(ar.d + from, h->h_arena_dev[a] + from, bytes, st);
         } else if (h->copy_kernels) {
             Timed t(h, RCF_T_HISTORY);

@@ -297,7 +297,41 @@ struct PfbLaunch {
     // the bank copies only the slots from tap_first on.  With every bin tapped (the reference's intent,
     // receiver.py:343-383) the bank costs what it costs untapped.
     int32_t tap_first;
+    // Rider (launch_plan): when nothing before the bank's launch needs them, the block's launch records (pinned host ->
+    // device arena) and its history tail (behind the OTHER input buffer's block) are copied by the first kPfbRiderWgs
+    // workgroups of the bank's kernel before they start on their chunks -- one launch less per block (4.7 us of the
+    // timed configuration's 124).  8-byte words; rider_n8[0] + rider_n8[1] == 0: no rider.
+    unsigned long long *rider_dst[2];
+    const unsigned long long *rider_src[2];
+    uint32_t rider_n8[2];
 };
+constexpr int kPfbRiderWgs = 64;    // of thousands: the few microseconds the pinned-memory reads take are lost in the first round
+// whether this launch's kernel takes the rider (pfb_kernel_os does: step of the timed configuration 128.5 -> 124.5 us,
+// kernel unchanged): the persistent form of the 512 / 1024-bin banks does not -- its
+// workgroups are ONE resident round, and 64 of them starting late set the whole launch back by what the copy launch
+// cost (cfg5: kernel +2.8 us, step unchanged; spread over all 512 workgroups: every one waits for its pinned-memory
+// word, 1600 bins +7 us)
+bool pfb_takes_rider(const PfbLaunch &p);
+#ifdef __HIPCC__
+__device__ __forceinline__ void pfb_copy_rider(const PfbLaunch &p, int wg, int n_wgs, int tid, int n_threads)
+{
+    const size_t n0 = p.rider_n8[0], total = n0 + p.rider_n8[1], stride = (size_t)n_wgs * n_threads;
+    for (size_t i0 = (size_t)wg * n_threads + tid; i0 < total; i0 += 4 * stride) {
+        unsigned long long v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = i0 + u * stride;
+            v[u] = i < n0 ? p.rider_src[0][i] : i < total ? p.rider_src[1][i - n0] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = i0 + u * stride;
+            if (i < n0) p.rider_dst[0][i] = v[u];
+            else if (i < total) p.rider_dst[1][i - n0] = v[u];
+        }
+    }
+}
+#endif
 struct TapLaunch {           // one tapped bin, consumed by tap_finalize_kernel
     float2 *iq_ring;
     float *fm_ring;
