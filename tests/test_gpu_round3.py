@@ -501,3 +501,48 @@ def test_pfb1600_tap_slots_full_runs_partial_runs_and_duplicates(gpu_required):
             np.testing.assert_array_equal(y, b)
             fm = fe.chan_read_fm(late[j], 1.0)
             np.testing.assert_array_equal(fm, G.quadrature_demod_cf(b.astype(np.complex64), 1.0))
+
+
+def test_pfb256_stage2_ragged_pushes_equal_one_push(gpu_required):
+    """The launch records and the history tail travel inside the 256-bin bank's launch when nothing before it needs them
+    (PfbLaunch::rider_*): stage-2 channels behind the bank, fed (a) in one push, (b) in ragged pushes -- some shorter
+    than a frame (no bank launch: the copies take their own launch), some of a few frames (fewer workgroups than the
+    rider spreads over), one that sets in after a direct channel was opened on the same source (records needed BEFORE
+    the bank: no rider) -- must give the same bits, through rcf_push_iq (buffer events) and through in-place feeding."""
+    nat = gpu_required
+    fs, nb = 20e6, 256
+    x, meta = synth.cfg2(n=nb * 4096, n_active=4)
+    bw = fs / nb                                             # SURVEY 8(d) cfg2 prototype (3491 taps)
+    taps = G.low_pass_2(1.0, fs, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+
+    def run(cuts, in_place):
+        outs = {}
+        with nat.Frontend(fs, block_capacity=len(x), hist_capacity=1 << 16) as fe:
+            fe.pfb_open(nb, nb, taps)
+            ids = [fe.pfb_chan_open(c["bin"] % nb, 12500, c["delta"]) for c in meta["carriers"]]
+            direct = None
+            at = 0
+            for i, cut in enumerate(list(cuts) + [len(x)]):
+                if i == 3:
+                    direct = fe.chan_open(12500, 1.0e6)     # a depth-0 job from here on: the copies go first again
+                seg = x[at:cut]
+                if in_place and len(seg):
+                    fe.ingest_write(seg, 0)
+                    fe.commit(len(seg))
+                else:
+                    fe.push(seg)
+                at = cut
+            for j, cid in enumerate(ids):
+                outs[j] = (fe.chan_read_iq(cid), fe.chan_read_fm(cid, 1.0))
+            outs["pfb"] = fe.pfb_produced()
+        return outs
+
+    one = run([], False)
+    assert one["pfb"] == 4096 and len(one[0][0]) == 4096 // 3 + (1 if 4096 % 3 else 0)
+    cuts = [100, 100 + nb * 3 + 5, nb * 40 + 1, nb * 41, nb * 1500 + 77, nb * 1500 + 78, nb * 3000]
+    for in_place in (False, True):
+        got = run(cuts, in_place)
+        assert got["pfb"] == one["pfb"]
+        for j in range(len(meta["carriers"])):
+            np.testing.assert_array_equal(got[j][0], one[j][0], err_msg="iq, channel %d, in_place=%s" % (j, in_place))
+            np.testing.assert_array_equal(got[j][1], one[j][1], err_msg="fm, channel %d, in_place=%s" % (j, in_place))
