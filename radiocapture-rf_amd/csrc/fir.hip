@@ -571,7 +571,7 @@ __global__ __launch_bounds__(kThreads) void tap_finalize_kernel(const TapLaunch 
                                                                 const float2 *__restrict__ mat, int pitch, int n_rows,
                                                                 int64_t k_first, uint64_t ring_mask,
                                                                 const float *__restrict__ atan_tab,
-                                                                const int32_t *__restrict__ group_bin0,
+                                                                const int32_t *__restrict__ group_bin0, int tap_first,
                                                                 const float2 *__restrict__ bins_ring, int n_bins)
 {
     static_assert(kThreads == kTapCols * 16, "16 x 16 lanes");
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kThreads) void tap_finalize_kernel(const TapLaunch 
                 if (lr < kTapLdsRows) {
                     if (r >= 0 && r < n_rows && k >= L.k_lo && k < L.k_lo + L.n_k && n >= 0)
                         z[it] = b0 >= 0 ? bins_ring[((uint64_t)k & ring_mask) * (uint64_t)n_bins + (unsigned)(b0 + sl)]
-                                        : mat[(size_t)r * pitch + slot];
+                                        : mat[(size_t)r * pitch + (slot - tap_first)];
                     else if (r < 0 && n >= 0)
                         z[it] = L.iq_ring[(uint64_t)n & ring_mask];   // produced by an earlier launch: already rotated
                 }
@@ -714,13 +714,13 @@ void launch_rot_fill(const RotFill *d_items, int n_items, uint64_t ring_mask, hi
 
 void launch_tap_finalize(const TapLaunch *d_taps, int n_taps, const float2 *tap_mat, int tap_pitch, int n_rows,
                          int64_t k_first, uint64_t ring_mask, const float *d_atan_table, const int32_t *d_group_bin0,
-                         const float2 *bins_ring, int n_bins, hipStream_t s)
+                         int tap_first, const float2 *bins_ring, int n_bins, hipStream_t s)
 {
     if (n_taps <= 0 || n_rows <= 0) return;
     hipLaunchKernelGGL(tap_finalize_kernel,
                        dim3((n_taps + kTapCols - 1) / kTapCols, (n_rows + kTapAlign - 1 + kTapOut - 1) / kTapOut),
                        dim3(kThreads), 0, s, d_taps, n_taps, tap_mat, tap_pitch, n_rows, k_first, ring_mask,
-                       d_atan_table, d_group_bin0, bins_ring, n_bins);
+                       d_atan_table, d_group_bin0, tap_first, bins_ring, n_bins);
 }
 
 void launch_fm_level(const float *fm_ring, int64_t n_end, int window, float gain, uint64_t ring_mask, float *d_out,

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
     }
     TS(3);
     // ---- taps first, copy-out last: bins that are open as channels are copied into the launch's compact tap matrix,
-    // tap_mat[(frame - n_lo) tap_pitch + slot] -- lanes = consecutive slots, so every wavefront store is 512 contiguous
+    // tap_mat[(frame - n_lo) tap_pitch + slot - tap_first] -- lanes = consecutive slots, so every wavefront store is 512 contiguous
     // bytes of a row.  Rotators and the discriminator are tap_finalize_kernel's business (fir.hip).  The bin numbers
     // are requested before the barrier.
     constexpr int TAP_IT = 5;                                // 5 x 320 slots cover all 1600 bins; 3200 bins loop
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
     __syncthreads();
     TS(4);
     if (n_mat > 0) {
-        float2 *trow = p.tap_mat + (size_t)fb0 * p.tap_pitch + p.tap_first;
+        float2 *trow = p.tap_mat + (size_t)fb0 * p.tap_pitch;        // column = slot - tap_first
 #pragma unroll
         for (int it = 0; it < TAP_IT; ++it) {
             const int sl = tid + it * kThreads5;

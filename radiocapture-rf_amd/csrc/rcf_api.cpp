@@ -972,15 +972,7 @@ int plan_tail(rcf_t *h, BlockPlan &bp)
     const AudioLaunch *&d_audf = bp.d_audf;
 
     if (!tap_list.empty() && run_pfb) {
-        const size_t pitch = (tap_list.size() + 15) & ~size_t(15);
-        const size_t need = pitch * (size_t)pl.n_frames;
-        if (need > h->tapmat_cap) {
-            float2 *nm = nullptr;
-            RCF_HIP(hipMalloc(&nm, sizeof(float2) * need));
-            bury(h, h->d_tapmat);
-            h->d_tapmat = nm;
-            h->tapmat_cap = need;
-        }
+        const size_t pitch = (tap_list.size() + 15) & ~size_t(15);      // slots, whole groups of 16
         // Slot order: first every aligned run of 16 bins that is tapped completely (tap_finalize reads those from the
         // bank's ring: PfbLaunch::tap_first), then the remaining taps, which go through the matrix.
         const int NB = pl.NB;
@@ -1013,8 +1005,19 @@ int plan_tail(rcf_t *h, BlockPlan &bp)
             set_error("launch arena exhausted");
             return RCF_ENOMEM;
         }
+        // the matrix holds the slots from tap_first on and nothing else (every bin of a 1600-bin bank tapped, 2^25-sample
+        // blocks: no matrix at all instead of 537 MB of it)
+        const size_t mat_pitch = pitch - (size_t)pl.tap_first;
+        const size_t need = mat_pitch * (size_t)pl.n_frames;
+        if (need > h->tapmat_cap) {
+            float2 *nm = nullptr;
+            RCF_HIP(hipMalloc(&nm, sizeof(float2) * need));
+            bury(h, h->d_tapmat);
+            h->d_tapmat = nm;
+            h->tapmat_cap = need;
+        }
         pl.tap_mat = h->d_tapmat;
-        pl.tap_pitch = (int32_t)pitch;
+        pl.tap_pitch = (int32_t)mat_pitch;
         pl.n_taps = (int32_t)tap_list.size();
     }
     if (!rot_fills.empty() && !ar.put(rot_fills, &d_rot_fills)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
@@ -1091,7 +1094,7 @@ int launch_plan(rcf_t *h, BlockPlan &bp)
     if (run_pfb && pl.n_taps > 0) {
         Timed t(h, RCF_T_TAPS);
         launch_tap_finalize(d_tap_list, pl.n_taps, pl.tap_mat, pl.tap_pitch, pl.n_frames, pl.n_lo - pl.n_abs0,
-                            h->ring_mask, h->d_atan, bp.d_group_bin0, pl.bins_ring, pl.NB, st);
+                            h->ring_mask, h->d_atan, bp.d_group_bin0, pl.tap_first, pl.bins_ring, pl.NB, st);
     }
     for (size_t d = 1; d < fir_by_depth.size(); ++d)
         for (auto &j : fir_by_depth[d]) { Timed t(h, RCF_T_FIR_DERIVED); launch_fir_bank(j.dev, j.dims, st); }

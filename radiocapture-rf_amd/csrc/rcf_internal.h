@@ -283,7 +283,7 @@ struct PfbLaunch {
     int32_t n_taps;
     // frame-major banks: bins that are open as channels (rcf_pfb_tap_open).  The kernel has every bin of the chunk in
     // LDS when it writes the frames out, so it also copies the tapped bins -- and only those -- into a compact
-    // frame-major matrix of THIS launch's frames, tap_mat[(frame - n_lo) tap_pitch + slot] (slot = position in
+    // frame-major matrix of THIS launch's frames, tap_mat[(frame - n_lo) tap_pitch + slot - tap_first] (slot = position in
     // tap_bins): whole rows of n_taps x 8 contiguous bytes, like the bins ring itself.  tap_finalize_kernel (fir.hip)
     // then transposes that matrix tile by tile through LDS into the channels' own rings, 128-byte lines, applying each
     // tap's rotator and the discriminator on the way.  (Round 2 stored a tap's F frames straight into its ring from
@@ -291,7 +291,7 @@ struct PfbLaunch {
     // [16 frames][bin][16] gets the same 32-byte pieces and measures 0.79 ms.)
     const int32_t *tap_bins;
     float2 *tap_mat;
-    int32_t tap_pitch;       // row pitch of tap_mat in samples (n_taps rounded up to 16)
+    int32_t tap_pitch;       // row pitch of tap_mat in samples: the slots from tap_first on, rounded up to 16
     // slots [0, tap_first) -- a multiple of 16 -- are runs of 16 consecutive bins starting at a multiple of 16: row by
     // row such a run is one aligned 128-byte piece of the frame-major ring itself, tap_finalize reads it there, and
     // the bank copies only the slots from tap_first on.  With every bin tapped (the reference's intent,
@@ -348,7 +348,7 @@ struct TapLaunch {           // one tapped bin, consumed by tap_finalize_kernel
 // ring (bins_ring[((k_first + r) & ring_mask) n_bins + bin]) instead of the matrix
 void launch_tap_finalize(const TapLaunch *d_taps, int n_taps, const float2 *tap_mat, int tap_pitch, int n_rows,
                          int64_t k_first, uint64_t ring_mask, const float *d_atan_table, const int32_t *d_group_bin0,
-                         const float2 *bins_ring, int n_bins, hipStream_t s);
+                         int tap_first, const float2 *bins_ring, int n_bins, hipStream_t s);
 bool pfb_supported(int NB, int D, int P);
 int pfb_padded_p(int NB, int D, int P);   // rows the kernel instantiation reads from ptaps (zero padded)
 void launch_pfb(const PfbLaunch &p, hipStream_t s);
