@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *_
     // grid = (channels, output tiles): workgroups that run together work on the SAME stretch of time of different
     // channels -- when the channels are bins of one filterbank ring (tiled or frame-major) their lines sit in the
     // same tiles, i.e. the same pages
-    const ChanLaunch &L = chans[blockIdx.x];
+    const ChanLaunch L = chans[blockIdx.x];     // by value: ONE batch of scalar loads (a reference is re-read after every global store -- 25 serialized scalar-memory waits per wave)
     const int tid = threadIdx.x;
     const int j0 = blockIdx.y * KB;
     if (j0 >= L.n_k) return;
