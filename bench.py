@@ -330,7 +330,7 @@ def reference_grid_leg(native, tile, device, B=1 << 25, n_taps=256):
             for at in range(0, B, len(tile)):
                 fe.ingest_write(tile[: min(len(tile), B - at)], at)
             fe.commit(B)
-        for _ in range(30):
+        for _ in range(150):                           # ~40 ms of work before the timed hundred, as for the 1600-bin bank
             fe.commit(B)
         ms, _, wall = timed(100)
         fe.close()
@@ -374,7 +374,7 @@ def scan_leg(native, synth, device):
         fe.commit(B)
     fe.sync()
     res = {}
-    for rep in range(2):                            # second pass: buffers warm
+    for rep in range(4):                            # the last pass counts: buffers warm, launch times settled (~15 ms of work)
         fe.timing_enable(True, classes=[native.T_SCAN_FFT, native.T_SCAN_MOVSUM])
         fe.timing_read(native.T_SCAN_FFT)
         fe.timing_read(native.T_SCAN_MOVSUM)
