@@ -1,0 +1,57 @@
+"""The bench line's contract, checked on the tracked line of the round (profiles/r0N_bench.json is bench.py's own
+stdout on an MI355X): the keys the driver and the judge read, the arithmetic between them, and that the tracked
+rocprofv3 summary of the same command holds the kernel the roofline names."""
+import csv
+import glob
+import json
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _latest(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)),
+                   key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)))
+    if not files:
+        pytest.skip("no tracked bench line")
+    return files[-1]
+
+
+def test_bench_line_has_the_contract_keys_and_adds_up():
+    d = json.load(open(_latest("r[0-9][0-9]_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    # value = the units one step processes / the step time
+    block = d["config"]["block_samples"]
+    assert d["value"] == pytest.approx(block / (d["ms_per_step"] * 1e-3) / 1e6, rel=1e-6)
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
+    # achieved = algorithmic bytes per launch / the launch's average duration; 16 B per input sample of the block
+    assert r["algorithmic_bytes_per_launch"] == 16.0 * block
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-9)
+    assert r["avg_launch_ms"] < d["ms_per_step"]                     # the kernel is a part of the step
+    assert 0.98 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05   # PMC bytes: no wasted re-reads
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+
+
+def test_tracked_rocprof_summary_agrees_with_the_line_it_was_taken_with():
+    stats = _latest("r[0-9][0-9]_bench_kernel_stats.csv")
+    line = json.load(open(stats.replace("_bench_kernel_stats.csv", "_bench_head_under_rocprof.json")))
+    kernel = line["roofline"]["kernel"].split("<")[0]
+    rows = [r for r in csv.DictReader(open(stats)) if kernel + "<" in r["Name"] and "false>" in r["Name"]]
+    assert rows, "the roofline's kernel is not in the tracked kernel stats"
+    avg_us = float(rows[0]["AverageNs"]) * 1e-3
+    # HIP events around a launch see a few microseconds of queue overhead that rocprof's own timestamps do not
+    assert 0.90 < avg_us / (line["roofline"]["avg_launch_ms"] * 1e3) <= 1.0
