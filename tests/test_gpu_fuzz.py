@@ -1,0 +1,199 @@
+"""Randomised channel lifecycles against the oracle: random source rate, random ragged pushes, channels opened and
+closed at random block boundaries, retuned at random -- every channel that lived is compared over its whole life with
+the oracle's stream for a channel that starts with zero history at its opening sample (GNU Radio's own start-up) and
+keeps rotator phase and FIR history across a retune (freq_xlating_fir_filter_ccc::set_center_freq).  Three seeds in
+the suite; RCF_FUZZ_SEEDS=a:b runs a range (tools: gpurun -- 'RCF_FUZZ_SEEDS=0:200 pytest tests/test_gpu_fuzz.py')."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cbind as OC
+from oracle import grspec as G
+from rcf import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _seeds():
+    spec = os.environ.get("RCF_FUZZ_SEEDS")
+    if not spec:
+        return [11, 12, 13]
+    a, b = spec.split(":")
+    return list(range(int(a), int(b)))
+
+
+def rel_rms(a, b):
+    d = np.mean(np.abs(b) ** 2)
+    return float(np.sqrt(np.mean(np.abs(a - b) ** 2) / d)) if d > 0 else float(np.max(np.abs(a), initial=0.0))
+
+
+def _oracle_life(x, fs, cr, segments, start, stop):
+    """segments: [(first_sample, offset_hz)] -- the offset in force from that input sample on (retunes land on block
+    boundaries).  Zero history before `start`; outputs on the absolute decimation grid k D >= start, k D < stop.
+    The rotator keeps running across a retune with the NEW increment (rotator::set_phase_incr), the taps switch to
+    the new composite set at the boundary while the delay line keeps the samples."""
+    D, taps = G.channel_params(fs, cr)
+    xz = x[:stop].copy()
+    xz[:start] = 0
+    k0 = -(-start // D)
+    k1 = (stop - 1) // D + 1
+    out = np.zeros(max(k1 - k0, 0), dtype=np.complex64)
+    state = ()                                   # (phase, call counter) of GNU Radio's rotator, carried across retunes
+    for i, (s0, f0) in enumerate(segments):
+        s1 = segments[i + 1][0] if i + 1 < len(segments) else stop
+        ka, kb = max(-(-s0 // D), k0), min((s1 - 1) // D + 1, k1)
+        if kb <= ka:
+            continue
+        ct, incr = OC.xlating_composite(taps, D, f0, fs)
+        v = G.fir_decim_cc(xz, ct, D)[ka:kb]
+        ph, p_after, c_after = G.rotator_phases(incr, len(v), *state)       # continues with this segment's increment
+        state = (p_after, c_after)
+        out[ka - k0:kb - k0] = (v * ph).astype(np.complex64)
+    return out
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_channel_lifecycles_equal_the_oracle(gpu_required, seed):
+    nat = gpu_required
+    rng = np.random.default_rng(1000 + seed)
+    fs = float(rng.choice([2.4e6, 8e6, 10e6, 20e6]))
+    cr = 12500
+    D, taps = G.channel_params(fs, cr)
+    T = len(taps)
+    n_blocks = int(rng.integers(6, 14))
+    sizes = [int(rng.integers(1, 6 * D)) if rng.random() < 0.3 else int(rng.integers(T, T + 60 * D)) for _ in range(n_blocks)]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    x = synth.awgn(rng, int(cuts[-1]))
+    # a carrier per potential channel so that the comparison is not noise against noise
+    n_slots = int(rng.integers(3, 40))
+    grid = 6250.0
+    offs = [float(np.round(o / grid) * grid) for o in rng.uniform(-0.45, 0.45, n_slots) * fs]
+    t = np.arange(len(x)) / fs
+    for f in offs[:8]:
+        x = x + (0.5 * np.exp(2j * np.pi * (f + 500.0) * t)).astype(np.complex64)
+    x = x.astype(np.complex64)
+    lives = []                                   # dict(id, start, stop, segments, reads)
+    with nat.Frontend(fs, block_capacity=int(max(sizes)) + 16, out_capacity=1 << 12) as fe:
+        if getattr(fe, "set_rotator", None) and rng.random() < 0.5:
+            fe.set_rotator(True)
+        live = {}
+        for b in range(n_blocks):
+            s0 = int(cuts[b])
+            # events at this block boundary
+            for slot in range(n_slots):
+                r = rng.random()
+                if slot not in live and r < (0.6 if b == 0 else 0.12):
+                    cid = fe.chan_open(cr, offs[slot])
+                    live[slot] = dict(id=cid, start=s0, stop=None, segments=[(s0, offs[slot])], reads=[])
+                elif slot in live and r < 0.06:
+                    L = live.pop(slot)
+                    L["reads"].append(fe.chan_read_iq(L["id"]))
+                    fe.chan_close(L["id"])
+                    L["stop"] = s0
+                    lives.append(L)
+                elif slot in live and r < 0.14:
+                    f_new = offs[slot] + grid * float(rng.integers(-3, 4))
+                    fe.chan_set_offset(live[slot]["id"], f_new)
+                    live[slot]["segments"].append((s0, f_new))
+            fe.push(x[s0:int(cuts[b + 1])])
+            for L in live.values():
+                if rng.random() < 0.3:
+                    L["reads"].append(fe.chan_read_iq(L["id"]))
+        for L in live.values():
+            L["reads"].append(fe.chan_read_iq(L["id"]))
+            L["stop"] = int(cuts[-1])
+            lives.append(L)
+    assert lives
+    worst = 0.0
+    for L in lives:
+        y = np.concatenate(L["reads"]) if L["reads"] else np.zeros(0, np.complex64)
+        yo = _oracle_life(x, fs, cr, L["segments"], L["start"], L["stop"])
+        assert len(y) == len(yo), (seed, L["start"], L["stop"], len(y), len(yo))
+        if len(yo) == 0:
+            continue
+        e = rel_rms(y, yo)
+        worst = max(worst, e)
+        assert e < 2e-5, (seed, fs, L["segments"], L["start"], L["stop"], e)
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_filterbank_tap_lifecycles(gpu_required, seed):
+    """Bins of a frame-major bank opened and closed as channels at random block boundaries, in dense stretches (complete
+    aligned runs of 16: read from the bank's ring) and scattered (tap matrix), with duplicates, through ragged pushes:
+    every tap's stream is its bin over the tap's life, bit for bit, and its discriminator stream the discriminator of
+    that; two of the bins are also checked against the float64 exact-phase bank."""
+    nat = gpu_required
+    rng = np.random.default_rng(5000 + seed)
+    fs, nb = (5e6, 400) if rng.random() < 0.6 else (20e6, 1600)
+    D, taps = G.channel_params(fs, 12500)
+    assert nb == 2 * D
+    n_blocks = int(rng.integers(4, 9))
+    sizes = [int(rng.integers(1, 3 * D)) if rng.random() < 0.25 else int(rng.integers(2 * D, 90 * D)) for _ in range(n_blocks)]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    x = synth.awgn(rng, int(cuts[-1]))
+    # what gets opened when is drawn up front, so that the bins that are ever tapped can be followed from frame 0
+    plan = []
+    for b in range(n_blocks):
+        opens = []
+        for _ in range(int(rng.integers(0, 4))):
+            if rng.random() < 0.5:               # a dense stretch
+                lo = int(rng.integers(0, nb - 40))
+                bins = list(range(lo, lo + int(rng.integers(10, 40))))
+                if rng.random() < 0.3:
+                    rng.shuffle(bins)
+            else:
+                bins = [int(v) for v in rng.integers(0, nb, int(rng.integers(1, 12)))]
+            opens += bins
+        plan.append(opens)
+    ever = sorted({k for opens in plan for k in opens})
+    lives = []
+    with nat.Frontend(fs, block_capacity=int(max(sizes)) + 16, out_capacity=1 << 11) as fe:
+        fe.pfb_open(nb, D, taps)
+        live = []                                # dicts: id, bin, first (bank frame count at opening), iq, fm
+        ring = {k: [] for k in ever}
+        for b in range(n_blocks):
+            produced = fe.pfb_produced()
+            for k in plan[b]:
+                live.append(dict(id=fe.pfb_tap_open(k, gr_phase=False), bin=k, first=produced, iq=[], fm=[]))
+            for L in list(live):
+                if rng.random() < 0.08:
+                    L["iq"].append(fe.chan_read_iq(L["id"]))
+                    L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+                    fe.chan_close(L["id"])
+                    L["last"] = produced
+                    live.remove(L)
+                    lives.append(L)
+            fe.push(x[int(cuts[b]):int(cuts[b + 1])])
+            for k in ever:
+                ring[k].append(fe.pfb_read_bin(k))               # (a cursor: whatever is new since the last read)
+            for L in live:
+                if rng.random() < 0.4:
+                    L["iq"].append(fe.chan_read_iq(L["id"]))
+                    L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+        n_out = fe.pfb_produced()
+        for L in live:
+            L["iq"].append(fe.chan_read_iq(L["id"]))
+            L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+            L["last"] = n_out
+            lives.append(L)
+    if not lives:
+        return
+    assert n_out == (len(x) - 1) // D + 1
+    checked = 0
+    for L in lives:
+        y = np.concatenate(L["iq"]) if L["iq"] else np.zeros(0, np.complex64)
+        fm = np.concatenate(L["fm"]) if L["fm"] else np.zeros(0, np.float32)
+        full = np.concatenate(ring[L["bin"]])
+        assert len(full) == n_out
+        want = full[L["first"]:L["last"]]
+        assert len(y) == len(want), (seed, L["bin"], L["first"], L["last"], len(y), len(want))
+        np.testing.assert_array_equal(y, want, err_msg="seed %d bin %d" % (seed, L["bin"]))
+        if len(want):
+            np.testing.assert_array_equal(fm, G.quadrature_demod_cf(want, 1.0), err_msg="fm, seed %d bin %d" % (seed, L["bin"]))
+        checked += 1
+    assert checked == len(lives)
+    for k in ever[:2]:                            # and the bins themselves against the float64 exact-phase bank
+        f_k = (k if k <= nb // 2 else k - nb) * fs / nb
+        ref = G.xlating_fir_exact(x, D, taps, f_k, fs).astype(np.complex64)
+        assert rel_rms(np.concatenate(ring[k]), ref) < 3e-5
