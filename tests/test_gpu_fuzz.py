@@ -197,3 +197,48 @@ def test_random_filterbank_tap_lifecycles(gpu_required, seed):
         f_k = (k if k <= nb // 2 else k - nb) * fs / nb
         ref = G.xlating_fir_exact(x, D, taps, f_k, fs).astype(np.complex64)
         assert rel_rms(np.concatenate(ring[k]), ref) < 3e-5
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_scans_equal_the_oracle_chain(gpu_required, seed):
+    """fft_vector.py's chain at random lengths (single-pass and four-step FFTs), frame counts and averaging lengths,
+    fed in ragged pushes (frames straddle blocks, some pushes shorter than a frame, a scan restarted in mid-stream):
+    the emitted vector against the oracle's chain, and the device peak picker against scipy's on the same vector."""
+    from oracle import peaks as P
+    nat = gpu_required
+    rng = np.random.default_rng(9000 + seed)
+    N = 1 << int(rng.integers(8, 18))                        # 256 .. 131072
+    F = int(rng.integers(3, 30 if N <= 16384 else 8))
+    L = int(rng.integers(1, F + 1))
+    fs = 2.4e6 if N <= 16384 else 100e6
+    lead = int(rng.integers(0, 3 * N))                       # samples before the scan starts
+    x = synth.awgn(rng, lead + N * F + int(rng.integers(0, N)))
+    n = np.arange(len(x))
+    for _ in range(int(rng.integers(1, 5))):
+        x = x + (float(rng.uniform(1, 6)) * np.exp(2j * np.pi * float(rng.uniform(-0.45, 0.45)) * n)).astype(np.complex64)
+    x = x.astype(np.complex64)
+    cap = int(max(2 * N, 4096))
+    with nat.Frontend(fs, block_capacity=cap, hist_capacity=max(N, 1 << 12)) as fe:
+        if lead:
+            pos = 0
+            while pos < lead:
+                step = min(int(rng.integers(1, cap)), lead - pos)
+                fe.push(x[pos:pos + step])
+                pos += step
+        fe.scan_start(N, F, L)
+        pos = lead
+        while pos < len(x):
+            step = min(int(rng.integers(1, N // 2)) if rng.random() < 0.3 else int(rng.integers(N // 2, cap)), len(x) - pos)
+            fe.push(x[pos:pos + step])
+            pos += step
+        assert fe.scan_frames_done() == F
+        got = fe.scan_result()
+        idx, mean, _ = fe.scan_find_peaks(cap=4096)
+    want = OC.scan_chain(x[lead:], N, F, L)
+    assert got is not None and got.shape == (N,)
+    # a sum of L log-magnitudes: float32 FFT error shows where a frame's bin happens to be nearly empty (the log of a
+    # small difference) -- the bound on the worst bin is looser than the bound on the rest
+    err = np.abs(got - want)
+    assert err.max() < 0.5 and np.sort(err)[int(0.999 * N)] < 2e-3 and err.mean() < 1e-4, (seed, N, F, L, float(err.max()), float(err.mean()))
+    l_got, _ = P.peak_detect_scipy(got, fs, 0.0)
+    np.testing.assert_array_equal(idx, l_got, err_msg="seed %d N %d F %d L %d" % (seed, N, F, L))
