@@ -146,7 +146,7 @@ __device__ __forceinline__ void fir_item(const float2 *xs, const ChanLaunch *__r
 // output (the lanes-over-taps kernel above would idle 53 of 64 lanes at T = 11).  A workgroup stages the
 // KB D + T input samples of its KB outputs (plus the output just before them) in LDS with coalesced loads,
 // taps come from the scalar cache, and the FM discriminator is fused in: outputs meet their predecessor in LDS,
-// thread 0 recomputes the one that belongs to the previous workgroup.  One launch and one pass over the channel
+// thread 0 recomputes the one that belongs to the previous workgroup (the previous LAUNCH's is read back from the ring).  One launch and one pass over the channel
 // stream instead of two (the stage-2 FIR + discriminator pair was 22 % of the bench step).
 __global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *__restrict__ chans, int D, int T, int KB,
                                                              uint64_t ring_mask, const float *__restrict__ atan_tab)
@@ -200,7 +200,12 @@ __global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *_
         const int j = tid + o * kThreads;
         const int64_t n = k0 - 1 + j - L.k_abs0;               // relative output index
         y[o] = make_float2(0.f, 0.f);
-        if (j <= nj && n >= 0) {
+        if (j == 0 && j0 == 0) {
+            // the launch's first output meets the output the PREVIOUS launch stored, not a recomputation of it: after a
+            // retune the taps and the rotator increment in force now are not the ones that made it (quadrature_demod
+            // sees the stream as it was emitted -- found by tests/test_gpu_fuzz.py: one discriminator sample per retune)
+            if (n >= 0) y[o] = L.iq_ring[(uint64_t)n & ring_mask];
+        } else if (j <= nj && n >= 0) {
             const float2 *w = xs + (size_t)j * D + (T - 1);     // x[(k0 - 1 + j) D - i] = w[-i]
             float ar = 0.f, ai = 0.f;
             for (int i = 0; i < T; ++i) {

@@ -242,3 +242,94 @@ def test_random_scans_equal_the_oracle_chain(gpu_required, seed):
     assert err.max() < 0.5 and np.sort(err)[int(0.999 * N)] < 2e-3 and err.mean() < 1e-4, (seed, N, F, L, float(err.max()), float(err.mean()))
     l_got, _ = P.peak_detect_scipy(got, fs, 0.0)
     np.testing.assert_array_equal(idx, l_got, err_msg="seed %d N %d F %d L %d" % (seed, N, F, L))
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_stage2_channel_lifecycles_on_a_power_of_two_bank(gpu_required, seed):
+    """The BASELINE throughput shape under churn: a critically sampled power-of-two bank (64 .. 512 bins, prototype by
+    the low_pass_2 rule) with stage-2 channels (channel.py's rule at the bin rate + discriminator) opened, retuned and
+    closed at random block boundaries through ragged pushes -- each against the two-stage oracle: the float64
+    exact-phase bank's bin, zeroed before the channel's opening frame, through GNU Radio's xlating FIR and rotator."""
+    nat = gpu_required
+    rng = np.random.default_rng(7000 + seed)
+    nb = int(rng.choice([64, 128, 256, 512]))
+    fs = nb * 78125.0                                        # bin rate 78.125 kHz: channel.py gives D2 = 3, T2 = 11
+    bw = fs / nb
+    proto = G.low_pass_2(1.0, fs, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+    D2, taps2 = G.channel_params(bw, 12500)
+    n_blocks = int(rng.integers(5, 11))
+    sizes = [int(rng.integers(1, 4 * nb)) if rng.random() < 0.25 else int(rng.integers(20 * nb, 300 * nb)) for _ in range(n_blocks)]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    x = synth.awgn(rng, int(cuts[-1]))
+    slots = [(int(rng.integers(0, nb)), float(rng.integers(-4, 5)) * 1562.5) for _ in range(int(rng.integers(2, 9)))]
+    t = np.arange(len(x)) / fs
+    for k, d in slots:
+        f = (k if k <= nb // 2 else k - nb) * bw + d + 700.0
+        x = x + (0.7 * np.exp(2j * np.pi * f * t)).astype(np.complex64)
+    x = x.astype(np.complex64)
+    lives = []
+    with nat.Frontend(fs, block_capacity=int(max(sizes)) + 16, out_capacity=1 << 12) as fe:
+        fe.pfb_open(nb, nb, proto)
+        live = {}
+        for b in range(n_blocks):
+            frames = fe.pfb_produced()
+            for i, (k, d) in enumerate(slots):
+                r = rng.random()
+                if i not in live and r < (0.7 if b == 0 else 0.2):
+                    live[i] = dict(id=fe.pfb_chan_open(k, 12500, d), bin=k, first=frames, segments=[(frames, d)], iq=[], fm=[])
+                elif i in live and r < 0.07:
+                    L = live.pop(i)
+                    L["iq"].append(fe.chan_read_iq(L["id"]))
+                    L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+                    fe.chan_close(L["id"])
+                    L["last"] = frames
+                    lives.append(L)
+                elif i in live and r < 0.17:
+                    d_new = float(rng.integers(-4, 5)) * 1562.5
+                    fe.chan_set_offset(live[i]["id"], d_new)
+                    live[i]["segments"].append((frames, d_new))
+            fe.push(x[int(cuts[b]):int(cuts[b + 1])])
+        frames = fe.pfb_produced()
+        for L in live.values():
+            L["iq"].append(fe.chan_read_iq(L["id"]))
+            L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+            L["last"] = frames
+            lives.append(L)
+    assert frames == (len(x) - 1) // nb + 1
+    stage1 = {}
+    for L in lives:
+        k = L["bin"]
+        if k not in stage1:
+            stage1[k] = G.xlating_fir_exact(x, nb, proto, (k if k <= nb // 2 else k - nb) * bw, fs).astype(np.complex64)
+        s1 = stage1[k][:L["last"]].copy()
+        s1[:L["first"]] = 0
+        k0, k1 = -(-L["first"] // D2), ((L["last"] - 1) // D2 + 1 if L["last"] > 0 else 0)
+        want = np.zeros(max(k1 - k0, 0), dtype=np.complex64)
+        state = ()
+        for j, (f0, d) in enumerate(L["segments"]):
+            f1 = L["segments"][j + 1][0] if j + 1 < len(L["segments"]) else L["last"]
+            ka, kb = max(-(-f0 // D2), k0), min((f1 - 1) // D2 + 1 if f1 > 0 else 0, k1)
+            if kb <= ka:
+                continue
+            ct, incr = OC.xlating_composite(taps2, D2, d, bw)
+            v = G.fir_decim_cc(s1, ct, D2)[ka:kb]
+            ph, p_after, c_after = G.rotator_phases(incr, len(v), *state)
+            state = (p_after, c_after)
+            want[ka - k0:kb - k0] = (v * ph).astype(np.complex64)
+        y = np.concatenate(L["iq"])
+        fm = np.concatenate(L["fm"])
+        assert len(y) == len(want) == len(fm), (seed, nb, L["first"], L["last"], len(y), len(want))
+        if len(want) < 4:
+            continue
+        assert rel_rms(y, want) < 3e-5, (seed, nb, L["bin"], L["segments"], L["first"], L["last"], rel_rms(y, want))
+        fo = G.quadrature_demod_cf(want, 1.0)
+        bad = np.nonzero(np.abs(fm - fo) > 1e-3)[0]
+        if len(bad) and os.environ.get("RCF_FUZZ_DEBUG"):
+            print("DBG", seed, nb, L["bin"], L["segments"], L["first"], L["last"], "k0", k0, "bad", bad[:16].tolist(), len(bad),
+                  "|want|", [float(abs(want[i])) for i in bad[:4]], "fm", [float(fm[i]) for i in bad[:4]],
+                  "fo", [float(fo[i]) for i in bad[:4]], "rms", float(np.sqrt(np.mean(np.abs(want) ** 2))),
+                  "frames at cuts", [int((c - 1) // nb + 1) if c else 0 for c in cuts])
+        assert float(np.sqrt(np.mean((fm[2:] - fo[2:]) ** 2))) < 1e-4, (
+            seed, nb, L["bin"], L["segments"], L["first"], L["last"], k0, bad[:12].tolist(), len(bad),
+            [float(abs(want[i])) for i in bad[:4]], [float(fm[i]) for i in bad[:4]], [float(fo[i]) for i in bad[:4]],
+            float(np.sqrt(np.mean(np.abs(want) ** 2))), [int(c) for c in cuts[:12]])
