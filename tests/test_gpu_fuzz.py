@@ -348,3 +348,48 @@ def test_random_stage2_channel_lifecycles_on_a_power_of_two_bank(gpu_required, s
             seed, nb, L["bin"], L["segments"], L["first"], L["last"], k0, bad[:12].tolist(), len(bad),
             [float(abs(want[i])) for i in bad[:4]], [float(fm[i]) for i in bad[:4]], [float(fo[i]) for i in bad[:4]],
             float(np.sqrt(np.mean(np.abs(want) ** 2))), [int(c) for c in cuts[:12]])
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_voice_chain_cuts_and_silences(gpu_required, seed):
+    """The analog voice chain (pwr_squelch_cc with gating -> fm demod -> de-emphasis -> 300 Hz high-pass -> 25:8
+    resampler, logging_receiver.py:211-222) is stateful in every stage: an NBFM carrier with random stretches of exact
+    silence (the squelch closes and REMOVES samples), fed in random ragged pushes -- audio against oracle/audio.py on
+    the oracle's channel stream, sample counts included."""
+    from oracle import audio as A
+    from rcf import audio as host_audio
+    nat = gpu_required
+    rng = np.random.default_rng(3000 + seed)
+    fs, cr = 2.4e6, 12500
+    D = 96
+    f0 = float(np.round(rng.uniform(-0.4, 0.4) * fs / 6250) * 6250)
+    n_out = int(rng.integers(3000, 9000))
+    n = D * n_out + int(rng.integers(0, D))
+    x = synth.nbfm_carrier(n, fs, f0, float(rng.uniform(300, 2500)), float(rng.uniform(1000, 3000)), float(rng.uniform(0.1, 0.6)))
+    x = x.astype(np.complex64)
+    if rng.random() < 0.5:
+        x = (x + 1e-3 * synth.awgn(rng, n)).astype(np.complex64)       # a noise floor keeps the squelch open through the gaps
+    for _ in range(int(rng.integers(0, 4))):
+        a = int(rng.integers(0, n_out - 600)) * D
+        x[a:a + int(rng.integers(200, 2500)) * D] = 0
+    cuts = sorted({0, n} | {int(v) for v in rng.integers(1, n, int(rng.integers(1, 9)))})
+    with nat.Frontend(fs, block_capacity=n) as fe:
+        cid = fe.chan_open(cr, f0)
+        host_audio.open_analog_voice(fe, cid, 25000)
+        got = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            fe.push(x[a:b])
+            if rng.random() < 0.4:
+                got.append(fe.chan_read_audio(cid))
+        n_audio, n_ungated = fe.chan_audio_produced(cid)
+        got.append(fe.chan_read_audio(cid))
+    audio = np.concatenate(got)
+    Dd, taps = G.channel_params(fs, cr)
+    ct, incr = OC.xlating_composite(taps, Dd, f0, fs)
+    y, _ = OC.channel_bank(x, Dd, ct[None, :], np.array([incr]), acc_double=True)
+    st = A.analog_chain(y[0], 25000.0, stages=True)
+    assert n_ungated == len(st["gated"]), (seed, n_ungated, len(st["gated"]))
+    assert len(audio) == n_audio == len(st["audio"]), (seed, len(audio), n_audio, len(st["audio"]))
+    if len(audio):
+        e = float(np.sqrt(np.mean((audio.astype(np.float64) - st["audio"]) ** 2)))
+        assert e < 1e-4, (seed, e)
