@@ -393,3 +393,58 @@ def test_random_voice_chain_cuts_and_silences(gpu_required, seed):
     if len(audio):
         e = float(np.sqrt(np.mean((audio.astype(np.float64) - st["audio"]) ** 2)))
         assert e < 1e-4, (seed, e)
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_p25_front_half_chains(gpu_required, seed):
+    """p25_control_demod.py:105-137 under random cuts: wideband channel -> chained pre-filter channel (fir on the channel's
+    own output ring, opened at the start or in mid-stream) -> discriminator -> symbol filter, the parent retuned at random;
+    every stage against the oracle's chain (a chained channel opened later starts with zero history of ITS input)."""
+    nat = gpu_required
+    rng = np.random.default_rng(4000 + seed)
+    fs, cr = float(rng.choice([2.4e6, 8e6])), 12500
+    D, taps = G.channel_params(fs, cr)
+    f0 = float(np.round(rng.uniform(-0.4, 0.4) * fs / 6250) * 6250)
+    n_out = int(rng.integers(1500, 5000))
+    n = D * n_out + int(rng.integers(0, D))
+    x = (synth.nbfm_carrier(n, fs, f0 + float(rng.uniform(-300, 300)), 600.0, 1800.0, 0.5) + 0.02 * synth.awgn(rng, n)).astype(np.complex64)
+    pre = G.low_pass_2(1.0, 25000.0, 6250.0, float(rng.choice([500.0, 1500.0])), 30.0, G.WIN_BLACKMAN)
+    gain = G.p25_fm_gain(25000.0)
+    coeffs = np.full(5, 0.2, dtype=np.float32)
+    cuts = sorted({0, n} | {int(v) for v in rng.integers(1, n, int(rng.integers(2, 9)))})
+    open_at = int(rng.integers(0, len(cuts) - 1))            # block boundary at which the chained channel is opened
+    retune_at = int(rng.integers(1, len(cuts) - 1)) if rng.random() < 0.5 else None
+    f1 = f0 + 6250.0 * float(rng.integers(-1, 2))
+    got_sym, got_fm, got_iq = [], [], []
+    with nat.Frontend(fs, block_capacity=n) as fe:
+        c1 = fe.chan_open(cr, f0)
+        c2 = None
+        first2 = None
+        for b, (a, e) in enumerate(zip(cuts[:-1], cuts[1:])):
+            if b == open_at:
+                first2 = fe.chan_produced(c1)
+                c2 = fe.chan_open_taps(c1, 1, pre, 0.0)
+                fe.chan_fm_filter(c2, gain, coeffs)
+            if retune_at is not None and b == retune_at:
+                fe.chan_set_offset(c1, f1)
+            fe.push(x[a:e])
+            if c2 is not None and rng.random() < 0.4:
+                got_sym.append(fe.chan_read_sym(c2))
+                got_fm.append(fe.chan_read_fm(c2, gain))
+                got_iq.append(fe.chan_read_iq(c2))
+        got_sym.append(fe.chan_read_sym(c2))
+        got_fm.append(fe.chan_read_fm(c2, gain))
+        got_iq.append(fe.chan_read_iq(c2))
+    segs = [(0, f0)] + ([(cuts[retune_at], f1)] if retune_at is not None else [])
+    yo = _oracle_life(x, fs, cr, segs, 0, n)
+    y1 = yo.copy()
+    y1[:first2] = 0                                          # the chained channel's zero history
+    y2o = G.xlating_fir_ccc(y1, 1, pre, 0.0, 25000.0)[first2:]
+    fo = G.quadrature_demod_cf(y2o, gain)
+    so = np.convolve(fo.astype(np.float64), coeffs.astype(np.float64))[: len(fo)].astype(np.float32)
+    iq, fm, sym = np.concatenate(got_iq), np.concatenate(got_fm), np.concatenate(got_sym)
+    assert len(iq) == len(y2o) and len(fm) == len(fo) and len(sym) == len(so), (seed, len(iq), len(y2o), len(fm), len(sym))
+    if len(iq) > 16:
+        assert rel_rms(iq, y2o) < 2e-5, (seed, rel_rms(iq, y2o))
+        assert float(np.sqrt(np.mean((fm - fo) ** 2))) < 1e-4, seed
+        assert float(np.sqrt(np.mean((sym - so) ** 2))) < 1e-4, seed
