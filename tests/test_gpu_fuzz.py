@@ -78,14 +78,22 @@ def test_random_channel_lifecycles_equal_the_oracle(gpu_required, seed):
         if getattr(fe, "set_rotator", None) and rng.random() < 0.5:
             fe.set_rotator(True)
         live = {}
+        shift = 0.0                              # rcf_source_shift so far: every channel's NCO sits that much higher
         for b in range(n_blocks):
             s0 = int(cuts[b])
             # events at this block boundary
+            if b and rng.random() < 0.15:        # receiver.source_offset (receiver.py:436-475): all channels move together
+                d_hz = 25.0 * float(rng.integers(-8, 9))
+                fe.source_shift(d_hz)
+                shift += d_hz
+                for L in live.values():
+                    L["segments"].append((s0, L["nominal"] + shift))
             for slot in range(n_slots):
                 r = rng.random()
                 if slot not in live and r < (0.6 if b == 0 else 0.12):
                     cid = fe.chan_open(cr, offs[slot])
-                    live[slot] = dict(id=cid, start=s0, stop=None, segments=[(s0, offs[slot])], reads=[], fm=[])
+                    live[slot] = dict(id=cid, start=s0, stop=None, nominal=offs[slot], segments=[(s0, offs[slot] + shift)],
+                                      reads=[], fm=[])
                 elif slot in live and r < 0.06:
                     L = live.pop(slot)
                     L["reads"].append(fe.chan_read_iq(L["id"]))
@@ -96,7 +104,8 @@ def test_random_channel_lifecycles_equal_the_oracle(gpu_required, seed):
                 elif slot in live and r < 0.14:
                     f_new = offs[slot] + grid * float(rng.integers(-3, 4))
                     fe.chan_set_offset(live[slot]["id"], f_new)
-                    live[slot]["segments"].append((s0, f_new))
+                    live[slot]["nominal"] = f_new
+                    live[slot]["segments"].append((s0, f_new + shift))
             fe.push(x[s0:int(cuts[b + 1])])
             for L in live.values():
                 if rng.random() < 0.3:
