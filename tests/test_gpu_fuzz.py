@@ -295,12 +295,20 @@ def test_random_stage2_channel_lifecycles_on_a_power_of_two_bank(gpu_required, s
     with nat.Frontend(fs, block_capacity=int(max(sizes)) + 16, out_capacity=1 << 12) as fe:
         fe.pfb_open(nb, nb, proto)
         live = {}
+        shift = 0.0                              # rcf_source_shift: the stage-2 NCOs follow it (the bank's grid does not move)
         for b in range(n_blocks):
             frames = fe.pfb_produced()
+            if b and rng.random() < 0.15:
+                d_hz = 25.0 * float(rng.integers(-8, 9))
+                fe.source_shift(d_hz)
+                shift += d_hz
+                for L in live.values():
+                    L["segments"].append((frames, L["nominal"] + shift))
             for i, (k, d) in enumerate(slots):
                 r = rng.random()
                 if i not in live and r < (0.7 if b == 0 else 0.2):
-                    live[i] = dict(id=fe.pfb_chan_open(k, 12500, d), bin=k, first=frames, segments=[(frames, d)], iq=[], fm=[])
+                    live[i] = dict(id=fe.pfb_chan_open(k, 12500, d), bin=k, first=frames, nominal=d,
+                                   segments=[(frames, d + shift)], iq=[], fm=[])
                 elif i in live and r < 0.07:
                     L = live.pop(i)
                     L["iq"].append(fe.chan_read_iq(L["id"]))
@@ -311,7 +319,8 @@ def test_random_stage2_channel_lifecycles_on_a_power_of_two_bank(gpu_required, s
                 elif i in live and r < 0.17:
                     d_new = float(rng.integers(-4, 5)) * 1562.5
                     fe.chan_set_offset(live[i]["id"], d_new)
-                    live[i]["segments"].append((frames, d_new))
+                    live[i]["nominal"] = d_new
+                    live[i]["segments"].append((frames, d_new + shift))
             fe.push(x[int(cuts[b]):int(cuts[b + 1])])
         frames = fe.pfb_produced()
         for L in live.values():
