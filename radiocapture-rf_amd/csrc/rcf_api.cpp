@@ -1770,7 +1770,15 @@ int rcf_pfb_tap_open(rcf_t *h, int bin, int gr_phase, int *chan_id)
         // rotation of the whole output and goes into the rotator's start phase
         double cphase = 0.0;
         design_tap_leakage(h->fs, p.NB, p.proto.data(), (int)p.proto.size(), bin, nullptr, &cphase);
-        c->angle0 = (long double)cphase;
+        // ... and GNU Radio's rotator stands at 1 when the channel emits its FIRST output, whereas the bank's bin carries
+        // e^{-j 2 pi k D n / NB} counted from the stream's first sample: a channel that starts at the bank's frame n0
+        // is the bin times e^{+j 2 pi k D n0 / NB} (exact: integers mod NB; a sign for the 12.5 kHz grid's OS = 2 banks)
+        const int64_t n0 = p.n_abs0 + c->k_abs0;
+        const int64_t kd = (((int64_t)ks * p.D) % p.NB + p.NB) % p.NB;
+        const int64_t turn = (kd * (n0 % p.NB)) % p.NB;
+        c->angle0 = (long double)cphase +
+                    remainderl(2.0L * 3.14159265358979323846264338327950288L * (long double)turn / (long double)p.NB,
+                               2.0L * 3.14159265358979323846264338327950288L);
         rc = upload_composite(h, c);
     }
     return rc;

@@ -480,3 +480,71 @@ def test_random_p25_front_half_chains(gpu_required, seed):
             assert float(np.sqrt(np.mean((fm[ok] - fo[ok]) ** 2))) < 1e-4, seed
         if ok5.sum() > 16:
             assert float(np.sqrt(np.mean((sym[ok5] - so[ok5]) ** 2))) < 1e-4, seed
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_gr_phase_taps_equal_gnuradio_channels_started_at_their_opening(gpu_required, seed):
+    """What frontend_mode = 'pfb' hands out: a bin of the 400-bin bank (5 Msps, the reference's D = 200 / T = 727 channel
+    filter) opened WITH GNU Radio's phase convention at a random block boundary must be the stream of a
+    freq_xlating_fir_filter_ccc started at that sample -- zero history, rotator at 1 -- up to the tap-phase leakage the
+    parity budget allows (bins within +-100 of the centre: float32 tap phases below 1200 rad).  (No source shifts here: a
+    bin's filter cannot follow one, only the tap's rotator does -- test_source_shift_reaches_filterbank_taps.)"""
+    nat = gpu_required
+    rng = np.random.default_rng(8000 + seed)
+    fs, nb, cr = 5e6, 400, 12500
+    D, taps = G.channel_params(fs, cr)
+    assert D == 200 and nb == 2 * D
+    grid = fs / nb
+    n_blocks = int(rng.integers(3, 8))
+    sizes = [int(rng.integers(1, 3 * D)) if rng.random() < 0.2 else int(rng.integers(4 * D, 120 * D)) for _ in range(n_blocks)]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    x = synth.awgn(rng, int(cuts[-1]))
+    ks = [int(v) for v in rng.integers(-100, 101, int(rng.integers(2, 10)))]
+    t = np.arange(len(x)) / fs
+    for k in ks:
+        x = x + (0.8 * np.exp(2j * np.pi * (k * grid + float(rng.uniform(-2000, 2000))) * t)).astype(np.complex64)
+    x = x.astype(np.complex64)
+    lives = []
+    with nat.Frontend(fs, block_capacity=int(max(sizes)) + 16, out_capacity=1 << 11) as fe:
+        fe.pfb_open(nb, D, taps)
+        live = {}
+        shift = 0.0
+        for b in range(n_blocks):
+            s0 = int(cuts[b])
+            for i, k in enumerate(ks):
+                r = rng.random()
+                if i not in live and r < (0.6 if b == 0 else 0.25):
+                    cid = fe.pfb_tap_open(k % nb, gr_phase=True)
+                    live[i] = dict(id=cid, start=s0, nominal=k * grid, segments=[(s0, k * grid + shift)], iq=[], fm=[])
+                elif i in live and r < 0.08:
+                    L = live.pop(i)
+                    L["iq"].append(fe.chan_read_iq(L["id"]))
+                    L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+                    fe.chan_close(L["id"])
+                    L["stop"] = s0
+                    lives.append(L)
+            fe.push(x[s0:int(cuts[b + 1])])
+        for L in live.values():
+            L["iq"].append(fe.chan_read_iq(L["id"]))
+            L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+            L["stop"] = int(cuts[-1])
+            lives.append(L)
+    for L in lives:
+        y, fm = np.concatenate(L["iq"]), np.concatenate(L["fm"])
+        yo = _oracle_life(x, fs, cr, L["segments"], L["start"], L["stop"])
+        assert len(y) == len(yo) == len(fm), (seed, L["start"], L["stop"], len(y), len(yo))
+        # the one difference that is meant: the bank has been running, so a bin opened in mid-stream comes with the
+        # filter's history in it, where GNU Radio's new flowgraph starts from zeros -- the first (T - 1) / D outputs
+        warm = (len(taps) - 1) // D + 1 if L["start"] else 0
+        if len(yo) < warm + 16:
+            continue
+        e = rel_rms(y[warm:], yo[warm:])
+        assert e < 5e-4, (seed, L["segments"], L["start"], L["stop"], e)
+        fo = G.quadrature_demod_cf(yo, 1.0)
+        mag = np.abs(yo)
+        ok = np.zeros(len(yo), dtype=bool)
+        ok[1:] = (mag[1:] > 0.05 * mag.mean()) & (mag[:-1] > 0.05 * mag.mean())
+        ok[:warm + 1] = False
+        if ok.sum() > 8:
+            efm = float(np.sqrt(np.mean((fm[ok] - fo[ok]) ** 2)))
+            assert efm < 1e-4, (seed, L["segments"], L["start"], L["stop"], efm)
