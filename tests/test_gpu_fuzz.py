@@ -28,12 +28,12 @@ def rel_rms(a, b):
     return float(np.sqrt(np.mean(np.abs(a - b) ** 2) / d)) if d > 0 else float(np.max(np.abs(a), initial=0.0))
 
 
-def _oracle_life(x, fs, cr, segments, start, stop):
+def _oracle_life(x, fs, cr, segments, start, stop, filt=None):
     """segments: [(first_sample, offset_hz)] -- the offset in force from that input sample on (retunes land on block
     boundaries).  Zero history before `start`; outputs on the absolute decimation grid k D >= start, k D < stop.
     The rotator keeps running across a retune with the NEW increment (rotator::set_phase_incr), the taps switch to
     the new composite set at the boundary while the delay line keeps the samples."""
-    D, taps = G.channel_params(fs, cr)
+    D, taps = filt if filt is not None else G.channel_params(fs, cr)
     xz = x[:stop].copy()
     xz[:start] = 0
     k0 = -(-start // D)
@@ -491,15 +491,21 @@ def test_random_gr_phase_taps_equal_gnuradio_channels_started_at_their_opening(g
     bin's filter cannot follow one, only the tap's rotator does -- test_source_shift_reaches_filterbank_taps.)"""
     nat = gpu_required
     rng = np.random.default_rng(8000 + seed)
-    fs, nb, cr = 5e6, 400, 12500
-    D, taps = G.channel_params(fs, cr)
-    assert D == 200 and nb == 2 * D
+    cr = 12500
+    if rng.random() < 0.6:
+        fs, nb = 5e6, 400
+        D, taps = G.channel_params(fs, cr)
+        assert D == 200 and nb == 2 * D
+    else:                                        # an oversampled power-of-two bank: its taps are ordinary channels on a bin's ring
+        nb = int(rng.choice([128, 256]))
+        fs, D = nb * 25000.0, nb // 2
+        taps = G.low_pass_2(1.0, fs, fs / nb / 4, fs / nb / 4, 20.0)
     grid = fs / nb
     n_blocks = int(rng.integers(3, 8))
     sizes = [int(rng.integers(1, 3 * D)) if rng.random() < 0.2 else int(rng.integers(4 * D, 120 * D)) for _ in range(n_blocks)]
     cuts = np.concatenate([[0], np.cumsum(sizes)])
     x = synth.awgn(rng, int(cuts[-1]))
-    ks = [int(v) for v in rng.integers(-100, 101, int(rng.integers(2, 10)))]
+    ks = [int(v) for v in rng.integers(-(nb // 4), nb // 4 + 1, int(rng.integers(2, 10)))]
     t = np.arange(len(x)) / fs
     for k in ks:
         x = x + (0.8 * np.exp(2j * np.pi * (k * grid + float(rng.uniform(-2000, 2000))) * t)).astype(np.complex64)
@@ -531,7 +537,7 @@ def test_random_gr_phase_taps_equal_gnuradio_channels_started_at_their_opening(g
             lives.append(L)
     for L in lives:
         y, fm = np.concatenate(L["iq"]), np.concatenate(L["fm"])
-        yo = _oracle_life(x, fs, cr, L["segments"], L["start"], L["stop"])
+        yo = _oracle_life(x, fs, cr, L["segments"], L["start"], L["stop"], filt=(D, taps))
         assert len(y) == len(yo) == len(fm), (seed, L["start"], L["stop"], len(y), len(yo))
         # the one difference that is meant: the bank has been running, so a bin opened in mid-stream comes with the
         # filter's history in it, where GNU Radio's new flowgraph starts from zeros -- the first (T - 1) / D outputs
