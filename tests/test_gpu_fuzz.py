@@ -554,3 +554,55 @@ def test_random_gr_phase_taps_equal_gnuradio_channels_started_at_their_opening(g
         if ok.sum() > 8:
             efm = float(np.sqrt(np.mean((fm[ok] - fo[ok]) ** 2)))
             assert efm < 1e-4, (seed, L["segments"], L["start"], L["stop"], efm)
+
+
+def _hip_memcpy_h2d(dst_ptr, arr):
+    """test plumbing: overwrite device memory the library handed out (hipMemcpy through the runtime librcf loaded)"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    a = np.ascontiguousarray(arr)
+    assert hip.hipMemcpy(C.c_void_p(dst_ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0
+    assert hip.hipDeviceSynchronize() == 0
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_quantised_spectra_through_the_device_picker(gpu_required, seed):
+    """The device peak picker on spectra a scan never produces: values quantised so that plateaus, equal neighbours and
+    ties at the prominence walks' bases occur all over (scipy's plateau midpoints, left-to-right tie rules), carriers of
+    every width around the [3 kHz, 30 kHz] window, offsets that make the minimum negative -- injected into the finished
+    scan's device buffer, indices against scipy.signal.find_peaks through the reference's prologue."""
+    import ctypes as C
+    from oracle import peaks as P
+    nat = gpu_required
+    rng = np.random.default_rng(6000 + seed)
+    N = 1 << int(rng.integers(10, 18))
+    fs = float(rng.choice([2.4e6, 12.5e6, 100e6]))
+    hz = fs / N
+    x = rng.normal(100.0, float(rng.uniform(0.5, 6.0)), N)
+    for _ in range(int(rng.integers(0, 12))):
+        c = int(rng.integers(0, N))
+        w = float(rng.uniform(500.0, 60000.0)) / hz              # occupied width in bins, around the 3-30 kHz window
+        shape = rng.random()
+        d = (np.arange(N) - c) / max(w / 2.355, 0.5)
+        bump = np.exp(-0.5 * d ** 2) if shape < 0.6 else (np.abs(np.arange(N) - c) < w / 2).astype(np.float64)
+        x += float(rng.uniform(5, 60)) * bump
+    quant = float(rng.choice([0.0, 0.25, 1.0, 4.0, 16.0]))
+    if quant:
+        x = np.round(x / quant) * quant
+    x = (x - float(rng.choice([0.0, 480.0]))).astype(np.float32)
+    with nat.Frontend(fs, 855e6, block_capacity=max(2 * N, 4096), hist_capacity=max(N, 1 << 12)) as fe:
+        fe.scan_start(N, 1, 1)
+        fe.push(synth.awgn(rng, N))
+        assert fe.scan_result() is not None
+        dev = C.c_void_p()
+        assert nat.lib().rcf_scan_result_device(fe._h, C.byref(dev)) == 0 and dev.value
+        _hip_memcpy_h2d(dev.value, x)
+        np.testing.assert_array_equal(fe.scan_result(), x)       # the injected vector is what the picker will see
+        idx, mean, _ = fe.scan_find_peaks(cap=4096)
+    want, _ = P.peak_detect_scipy(x, fs, 855e6)
+    if len(want) <= 4096:
+        np.testing.assert_array_equal(idx, want, err_msg="seed %d N %d quant %s" % (seed, N, quant))
+    else:
+        np.testing.assert_array_equal(idx, want[:4096])
