@@ -606,3 +606,47 @@ def test_random_quantised_spectra_through_the_device_picker(gpu_required, seed):
         np.testing.assert_array_equal(idx, want, err_msg="seed %d N %d quant %s" % (seed, N, quant))
     else:
         np.testing.assert_array_equal(idx, want[:4096])
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_wire_format_pushes_equal_host_conversion(gpu_required, seed):
+    """rcf_push_raw (u8 / s8 / s16 straight off the SDR, converted on the device) mixed with cf32 pushes in random ragged
+    pieces -- including single samples and pieces that are not a multiple of anything -- must give a channel and a
+    filterbank bin the same bits as the host conversion (float(raw) - offset) * scale pushed as cf32 in one piece."""
+    nat = gpu_required
+    rng = np.random.default_rng(2000 + seed)
+    fmt_name, dtype = [("FMT_U8", np.uint8), ("FMT_S8", np.int8), ("FMT_S16", np.int16)][int(rng.integers(0, 3))]
+    info = np.iinfo(dtype)
+    scale = float(np.float32(1.0 / (info.max + 1)))
+    offset = 127.4 if dtype == np.uint8 else 0.0
+    fs, nb = 2.4e6, 64
+    n = int(rng.integers(3000, 60000))
+    raw = rng.integers(info.min, info.max + 1, size=2 * n).astype(dtype)
+    x = ((raw.astype(np.float32) - np.float32(offset)) * np.float32(scale)).view(np.complex64)
+    proto = G.low_pass_2(1.0, fs, fs / nb * 0.4, fs / nb * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+    f0 = float(np.round(rng.uniform(-0.4, 0.4) * fs / 6250) * 6250)
+    cuts = sorted({0, n} | {int(v) for v in rng.integers(1, n, int(rng.integers(1, 12)))} | {int(rng.integers(1, n - 1)) + d for d in (0, 1)})
+    cuts = [c for c in cuts if 0 <= c <= n]
+
+    def run(pieces_raw):
+        with nat.Frontend(fs, block_capacity=n + 16) as fe:
+            fe.set_rotator(True)         # GNU Radio's iterated phase: the same bits however the stream is cut (the closed form
+            fe.pfb_open(nb, nb, proto)   # is rebased every block and may round the last bit of a phase differently)
+            cid = fe.chan_open(12500, f0)
+            if pieces_raw is None:
+                fe.push(x)
+            else:
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    if pieces_raw[a]:
+                        fe.push_raw(raw[2 * a:2 * b], getattr(nat, fmt_name), scale, offset)
+                    else:
+                        fe.push(x[a:b])
+            return fe.chan_read_iq(cid), fe.chan_read_fm(cid, 1.0), fe.pfb_read_bin(5)
+
+    ref = run(None)
+    how = {a: bool(rng.random() < 0.7) for a in cuts}
+    got = run(how)
+    for g, r in zip(got, ref):
+        assert len(g) == len(r)
+        np.testing.assert_array_equal(g.view(np.float32) if g.dtype == np.complex64 else g,
+                                      r.view(np.float32) if r.dtype == np.complex64 else r)
