@@ -650,3 +650,82 @@ def test_random_wire_format_pushes_equal_host_conversion(gpu_required, seed):
         assert len(g) == len(r)
         np.testing.assert_array_equal(g.view(np.float32) if g.dtype == np.complex64 else g,
                                       r.view(np.float32) if r.dtype == np.complex64 else r)
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_split2_chains(gpu_required, seed):
+    """receiver_split2 (receiver.py:205-237) under churn: the two half-band sub-sources (decimation 2 at -/+ fs/4) stay open;
+    channels at the half rate (channel.py's rule: D = 48, T = 175 at 2.4 Msps -- the vector / matrix-core bank kernels on a
+    CHANNEL's ring as their source) are opened, retuned and closed on either half at random block boundaries through
+    ragged pushes.  Oracle: the two GNU Radio blocks in series, the child starting with zero history of the half-band
+    stream at its opening."""
+    nat = gpu_required
+    rng = np.random.default_rng(1500 + seed)
+    fs = float(rng.choice([2.4e6, 8e6]))
+    t1 = G.low_pass_2(1.0, fs, fs / 4, fs / 8, 53.0)
+    D2, t2 = G.channel_params(fs / 2, 12500)
+    n_blocks = int(rng.integers(4, 10))
+    T2 = len(t2)
+    sizes = [int(rng.integers(1, 8 * D2)) if rng.random() < 0.25 else int(rng.integers(2 * T2, 2 * T2 + 80 * 2 * D2)) for _ in range(n_blocks)]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    x = synth.awgn(rng, int(cuts[-1]))
+    n_slots = int(rng.integers(2, 14))             # >= 8 live children of one half ride the matrix cores
+    slots = [(int(rng.integers(0, 2)), float(np.round(rng.uniform(-0.4, 0.4) * fs / 2 / 6250) * 6250)) for _ in range(n_slots)]
+    t = np.arange(len(x)) / fs
+    for half, f in slots[:6]:
+        x = x + (0.5 * np.exp(2j * np.pi * ((-1.0 if half == 0 else 1.0) * fs / 4 + f + 400.0) * t)).astype(np.complex64)
+    x = x.astype(np.complex64)
+    lives = []
+    with nat.Frontend(fs, block_capacity=int(max(sizes)) + 16, out_capacity=1 << 14) as fe:
+        halves = [fe.chan_open_taps(-1, 2, t1, -fs / 4), fe.chan_open_taps(-1, 2, t1, fs / 4)]
+        live = {}
+        for b in range(n_blocks):
+            prod = [fe.chan_produced(h) for h in halves]
+            for i, (half, f) in enumerate(slots):
+                r = rng.random()
+                if i not in live and r < (0.6 if b == 0 else 0.2):
+                    cid = fe.chan_open_taps(halves[half], D2, t2, f)
+                    live[i] = dict(id=cid, half=half, start=prod[half], segments=[(prod[half], f)], iq=[], fm=[])
+                elif i in live and r < 0.07:
+                    L = live.pop(i)
+                    L["iq"].append(fe.chan_read_iq(L["id"]))
+                    L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+                    fe.chan_close(L["id"])
+                    L["stop"] = prod[L["half"]]
+                    lives.append(L)
+                elif i in live and r < 0.17:
+                    f_new = f + 6250.0 * float(rng.integers(-3, 4))
+                    fe.chan_set_offset(live[i]["id"], f_new)
+                    live[i]["segments"].append((prod[live[i]["half"]], f_new))
+            fe.push(x[int(cuts[b]):int(cuts[b + 1])])
+            for L in live.values():
+                if rng.random() < 0.3:
+                    L["iq"].append(fe.chan_read_iq(L["id"]))
+                    L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+        prod = [fe.chan_produced(h) for h in halves]
+        for L in live.values():
+            L["iq"].append(fe.chan_read_iq(L["id"]))
+            L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+            L["stop"] = prod[L["half"]]
+            lives.append(L)
+    hb = []
+    for sgn in (-1.0, 1.0):
+        ct1, incr1 = OC.xlating_composite(t1, 2, sgn * fs / 4, fs)
+        v1 = G.fir_decim_cc(x, ct1, 2)
+        ph1, _, _ = G.rotator_phases(incr1, len(v1))
+        hb.append((v1 * ph1).astype(np.complex64))
+    assert prod == [len(hb[0]), len(hb[1])]
+    for L in lives:
+        y, fm = np.concatenate(L["iq"]), np.concatenate(L["fm"])
+        yo = _oracle_life(hb[L["half"]], fs / 2, 12500, L["segments"], L["start"], L["stop"], filt=(D2, t2))
+        assert len(y) == len(yo) == len(fm), (seed, L["start"], L["stop"], len(y), len(yo))
+        if len(yo) < 8:
+            continue
+        e = rel_rms(y, yo)
+        assert e < 3e-5, (seed, fs, L["half"], L["segments"], L["start"], L["stop"], e)
+        fo = G.quadrature_demod_cf(yo, 1.0)
+        mag = np.abs(yo)
+        ok = np.zeros(len(yo), dtype=bool)
+        ok[1:] = (mag[1:] > 0.05 * mag.mean()) & (mag[:-1] > 0.05 * mag.mean())
+        if ok.sum() > 8:
+            assert float(np.sqrt(np.mean((fm[ok] - fo[ok]) ** 2))) < 1e-4, (seed, L["segments"])
