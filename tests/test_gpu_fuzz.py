@@ -58,8 +58,9 @@ def test_random_channel_lifecycles_equal_the_oracle(gpu_required, seed):
     nat = gpu_required
     rng = np.random.default_rng(1000 + seed)
     fs = float(rng.choice([2.4e6, 8e6, 10e6, 20e6]))
-    cr = 12500
-    D, taps = G.channel_params(fs, cr)
+    rates = [r for r in (6250, 12500, 25000, 50000) if (fs / r) == int(fs / r) and int(fs / r) % 2 == 0]
+    cr = 12500                                    # the reference's rate; a third of the slots take another one, so that
+    D, taps = G.channel_params(fs, cr)            # several (D, T) classes are scheduled side by side
     T = len(taps)
     n_blocks = int(rng.integers(6, 14))
     sizes = [int(rng.integers(1, 6 * D)) if rng.random() < 0.3 else int(rng.integers(T, T + 60 * D)) for _ in range(n_blocks)]
@@ -69,6 +70,7 @@ def test_random_channel_lifecycles_equal_the_oracle(gpu_required, seed):
     n_slots = int(rng.integers(3, 40))
     grid = 6250.0
     offs = [float(np.round(o / grid) * grid) for o in rng.uniform(-0.45, 0.45, n_slots) * fs]
+    crs = [int(rng.choice(rates)) if rng.random() < 0.33 else cr for _ in range(n_slots)]
     t = np.arange(len(x)) / fs
     for f in offs[:8]:
         x = x + (0.5 * np.exp(2j * np.pi * (f + 500.0) * t)).astype(np.complex64)
@@ -91,9 +93,9 @@ def test_random_channel_lifecycles_equal_the_oracle(gpu_required, seed):
             for slot in range(n_slots):
                 r = rng.random()
                 if slot not in live and r < (0.6 if b == 0 else 0.12):
-                    cid = fe.chan_open(cr, offs[slot])
-                    live[slot] = dict(id=cid, start=s0, stop=None, nominal=offs[slot], segments=[(s0, offs[slot] + shift)],
-                                      reads=[], fm=[])
+                    cid = fe.chan_open(crs[slot], offs[slot])
+                    live[slot] = dict(id=cid, cr=crs[slot], start=s0, stop=None, nominal=offs[slot],
+                                      segments=[(s0, offs[slot] + shift)], reads=[], fm=[])
                 elif slot in live and r < 0.06:
                     L = live.pop(slot)
                     L["reads"].append(fe.chan_read_iq(L["id"]))
@@ -121,8 +123,8 @@ def test_random_channel_lifecycles_equal_the_oracle(gpu_required, seed):
     worst = 0.0
     for L in lives:
         y = np.concatenate(L["reads"]) if L["reads"] else np.zeros(0, np.complex64)
-        yo = _oracle_life(x, fs, cr, L["segments"], L["start"], L["stop"])
-        assert len(y) == len(yo), (seed, L["start"], L["stop"], len(y), len(yo))
+        yo = _oracle_life(x, fs, L["cr"], L["segments"], L["start"], L["stop"])
+        assert len(y) == len(yo), (seed, L["cr"], L["start"], L["stop"], len(y), len(yo))
         if len(yo) == 0:
             continue
         e = rel_rms(y, yo)
