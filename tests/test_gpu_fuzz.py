@@ -731,3 +731,125 @@ def test_random_split2_chains(gpu_required, seed):
         ok[1:] = (mag[1:] > 0.05 * mag.mean()) & (mag[:-1] > 0.05 * mag.mean())
         if ok.sum() > 8:
             assert float(np.sqrt(np.mean((fm[ok] - fo[ok]) ** 2))) < 1e-4, (seed, L["segments"])
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_everything_on_one_front_end(gpu_required, seed):
+    """One source carrying it all at once, as a deployment does: direct channels (open / close / retune), a 64-bin bank
+    with stage-2 channels (open / close / retune) and a scan that is started somewhere in the stream -- ragged pushes, the
+    direct channels coming and going (which moves the launch records and the history copy into and out of the bank's
+    launch).  Every stream against its oracle."""
+    nat = gpu_required
+    rng = np.random.default_rng(12000 + seed)
+    nb = 64
+    fs = nb * 78125.0                                        # 5 Msps
+    bw = fs / nb
+    cr = 12500
+    D, taps = G.channel_params(fs, cr)                       # 200 / 727
+    proto = G.low_pass_2(1.0, fs, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+    D2, taps2 = G.channel_params(bw, cr)
+    N = 1 << int(rng.integers(9, 14))
+    F = int(rng.integers(2, 9))
+    Lavg = int(rng.integers(1, F + 1))
+    n_blocks = int(rng.integers(6, 12))
+    sizes = [int(rng.integers(1, 3 * D)) if rng.random() < 0.25 else int(rng.integers(800, 40 * D)) for _ in range(n_blocks)]
+    scan_at = int(rng.integers(0, n_blocks - 1))
+    need = N * F + 16
+    while sum(sizes[scan_at:]) < need:                       # enough stream behind the scan's start
+        sizes.append(int(rng.integers(2000, 40 * D)))
+    n_blocks = len(sizes)
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    x = synth.awgn(rng, int(cuts[-1]))
+    d_slots = [float(np.round(v / 6250) * 6250) for v in rng.uniform(-0.4, 0.4, int(rng.integers(1, 12))) * fs]
+    s_slots = [(int(rng.integers(0, nb)), float(rng.integers(-4, 5)) * 1562.5) for _ in range(int(rng.integers(1, 7)))]
+    t = np.arange(len(x)) / fs
+    for f in d_slots[:4]:
+        x = x + (0.4 * np.exp(2j * np.pi * (f + 300.0) * t)).astype(np.complex64)
+    for k, d in s_slots[:4]:
+        x = x + (0.4 * np.exp(2j * np.pi * ((k if k <= nb // 2 else k - nb) * bw + d + 500.0) * t)).astype(np.complex64)
+    x = x.astype(np.complex64)
+    d_lives, s_lives = [], []
+    spec = None
+    with nat.Frontend(fs, block_capacity=int(max(sizes)) + 16, hist_capacity=max(N, 1 << 12), out_capacity=1 << 12) as fe:
+        if rng.random() < 0.5:
+            fe.set_rotator(True)
+        fe.pfb_open(nb, nb, proto)
+        d_live, s_live = {}, {}
+        for b in range(n_blocks):
+            s0 = int(cuts[b])
+            frames = fe.pfb_produced()
+            if b == scan_at:
+                fe.scan_start(N, F, Lavg)
+            for i, f in enumerate(d_slots):
+                r = rng.random()
+                if i not in d_live and r < (0.4 if b == 0 else 0.15):
+                    d_live[i] = dict(id=fe.chan_open(cr, f), start=s0, segments=[(s0, f)], iq=[], fm=[])
+                elif i in d_live and r < 0.12:
+                    L = d_live.pop(i)
+                    L["iq"].append(fe.chan_read_iq(L["id"]))
+                    L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+                    fe.chan_close(L["id"])
+                    L["stop"] = s0
+                    d_lives.append(L)
+                elif i in d_live and r < 0.2:
+                    f_new = f + 6250.0 * float(rng.integers(-3, 4))
+                    fe.chan_set_offset(d_live[i]["id"], f_new)
+                    d_live[i]["segments"].append((s0, f_new))
+            for i, (k, d) in enumerate(s_slots):
+                r = rng.random()
+                if i not in s_live and r < (0.6 if b == 0 else 0.2):
+                    s_live[i] = dict(id=fe.pfb_chan_open(k, cr, d), bin=k, first=frames, segments=[(frames, d)], iq=[], fm=[])
+                elif i in s_live and r < 0.08:
+                    L = s_live.pop(i)
+                    L["iq"].append(fe.chan_read_iq(L["id"]))
+                    L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+                    fe.chan_close(L["id"])
+                    L["last"] = frames
+                    s_lives.append(L)
+                elif i in s_live and r < 0.18:
+                    d_new = float(rng.integers(-4, 5)) * 1562.5
+                    fe.chan_set_offset(s_live[i]["id"], d_new)
+                    s_live[i]["segments"].append((frames, d_new))
+            fe.push(x[s0:int(cuts[b + 1])])
+            if spec is None and b >= scan_at and fe.scan_frames_done() == F:
+                spec = fe.scan_result()
+        frames = fe.pfb_produced()
+        for L in d_live.values():
+            L["iq"].append(fe.chan_read_iq(L["id"]))
+            L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+            L["stop"] = int(cuts[-1])
+            d_lives.append(L)
+        for L in s_live.values():
+            L["iq"].append(fe.chan_read_iq(L["id"]))
+            L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+            L["last"] = frames
+            s_lives.append(L)
+    # the scan
+    assert spec is not None
+    want = OC.scan_chain(x[int(cuts[scan_at]):], N, F, Lavg)
+    err = np.abs(spec - want)
+    assert err.max() < 0.5 and np.sort(err)[int(0.999 * N)] < 2e-3 and err.mean() < 1e-4, (seed, N, F, Lavg)
+
+    def check(y, fm, yo, what):
+        assert len(y) == len(yo) == len(fm), (seed, what, len(y), len(yo), len(fm))
+        if len(yo) < 8:
+            return
+        e = rel_rms(y, yo)
+        assert e < 3e-5, (seed, what, e)
+        fo = G.quadrature_demod_cf(yo, 1.0)
+        mag = np.abs(yo)
+        ok = np.zeros(len(yo), dtype=bool)
+        ok[1:] = (mag[1:] > 0.05 * mag.mean()) & (mag[:-1] > 0.05 * mag.mean())
+        if ok.sum() > 8:
+            assert float(np.sqrt(np.mean((fm[ok] - fo[ok]) ** 2))) < 1e-4, (seed, what)
+
+    for L in d_lives:
+        check(np.concatenate(L["iq"]), np.concatenate(L["fm"]),
+              _oracle_life(x, fs, cr, L["segments"], L["start"], L["stop"]), ("direct", L["segments"], L["start"], L["stop"]))
+    stage1 = {}
+    for L in s_lives:
+        k = L["bin"]
+        if k not in stage1:
+            stage1[k] = G.xlating_fir_exact(x, nb, proto, (k if k <= nb // 2 else k - nb) * bw, fs).astype(np.complex64)
+        yo = _oracle_life(stage1[k], bw, cr, L["segments"], L["first"], L["last"], filt=(D2, taps2))
+        check(np.concatenate(L["iq"]), np.concatenate(L["fm"]), yo, ("stage2", k, L["segments"], L["first"], L["last"]))
