@@ -853,3 +853,111 @@ def test_random_everything_on_one_front_end(gpu_required, seed):
             stage1[k] = G.xlating_fir_exact(x, nb, proto, (k if k <= nb // 2 else k - nb) * bw, fs).astype(np.complex64)
         yo = _oracle_life(stage1[k], bw, cr, L["segments"], L["first"], L["last"], filt=(D2, taps2))
         check(np.concatenate(L["iq"]), np.concatenate(L["fm"]), yo, ("stage2", k, L["segments"], L["first"], L["last"]))
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_receiver_sessions_in_pfb_mode(gpu_required, seed):
+    """The reference's control plane over the device path, frontend_mode = 'pfb' (5 Msps, 400 bins): connect_channel /
+    release_channel / idle re-use (a released channel is RETUNED for the next request: channel.set_offset, which keeps the
+    native channel when the serving path stays and replaces it when a bin is involved) / the idle sweep, on-grid and
+    off-grid requests, ragged feeds.  Every native channel that lived -- idle ones keep producing, like the reference's
+    flowgraphs -- against GNU Radio's channel at the requested offset: direct-served to 3e-5 IQ, bank-served to the
+    parity budget (discriminator <= 1e-4, IQ <= 5e-4 behind the filter's warm-up)."""
+    import types
+    from rcf import receiver
+    nat = gpu_required
+    rng = np.random.default_rng(15000 + seed)
+    fs, fc, cr = 5e6, 850e6, 12500
+    D, taps = G.channel_params(fs, cr)
+    grid = 12500.0
+    n_blocks = int(rng.integers(4, 10))
+    sizes = [int(rng.integers(1, 3 * D)) if rng.random() < 0.2 else int(rng.integers(4 * D, 100 * D)) for _ in range(n_blocks)]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    x = synth.awgn(rng, int(cuts[-1]))
+    wanted = []
+    for _ in range(int(rng.integers(2, 9))):
+        k = int(rng.integers(-150, 151))
+        wanted.append(k * grid if rng.random() < 0.7 else k * grid + float(rng.choice([6250.0, 3125.0, -1250.0])))
+    t = np.arange(len(x)) / fs
+    for f in wanted:
+        x = x + (0.8 * np.exp(2j * np.pi * (f + float(rng.uniform(-1500, 1500))) * t)).astype(np.complex64)
+    x = x.astype(np.complex64)
+    cfg = types.SimpleNamespace(sources={0: dict(type="synthetic", center_freq=fc, samp_rate=int(fs))}, frontend_mode="pfb")
+    tb = receiver.receiver(cfg, frontend_factory=lambda sr, cf, dev: nat.Frontend(
+        sr, cf, device=dev, block_capacity=int(max(sizes)) + 16, out_capacity=1 << 11))
+    lives = []                                   # finished native lives
+    cur = {}                                     # block_id -> life of the native channel it holds now
+
+    def begin(bid, s0):
+        ch = tb.channels[bid]
+        cur[bid] = dict(chan_id=ch.chan_id, bin=ch.pfb_bin, start=s0, segments=[(s0, ch.offset)], iq=[], fm=[])
+
+    def drain(bid):
+        ch = tb.channels[bid]
+        cur[bid]["iq"].append(ch.read_iq())
+        cur[bid]["fm"].append(ch.read_fm(1.0))
+
+    try:
+        assert tb.sources[0].get("pfb") is not None
+        in_use = []
+        n_bank = 0
+        for b in range(n_blocks):
+            s0 = int(cuts[b])
+            for _ in range(int(rng.integers(0, 4))):
+                r = rng.random()
+                if r < 0.55 or not in_use:
+                    f = float(wanted[int(rng.integers(0, len(wanted)))])
+                    before = {bid: tb.channels[bid].chan_id for bid in tb.channels}
+                    bid, _ = tb.connect_channel(cr, fc + f)
+                    ch = tb.channels[bid]
+                    assert ch.offset == f
+                    if bid not in before:
+                        begin(bid, s0)                                   # a new channel object
+                    elif ch.chan_id != before[bid]:                      # re-used, and the native channel was replaced
+                        L = cur.pop(bid)                                 # (what it had produced went with the old id)
+                        L["stop"] = s0
+                        L["lost_tail"] = True
+                        lives.append(L)
+                        begin(bid, s0)
+                    else:                                                # re-used in place: a retune (or the same bin)
+                        if cur[bid]["bin"] is None:
+                            cur[bid]["segments"].append((s0, f))
+                    in_use.append(bid)
+                elif r < 0.85:
+                    bid = in_use.pop(int(rng.integers(0, len(in_use))))
+                    tb.release_channel(bid)
+                else:
+                    for bid in tb.sweep_idle_channels(now=1e12):         # everything idle goes
+                        L = cur.pop(bid)
+                        L["stop"] = s0
+                        L["lost_tail"] = True
+                        lives.append(L)
+            # what idle and busy channels produced so far belongs to the life they are in
+            tb.feed(0, x[s0:int(cuts[b + 1])])
+            for bid in list(cur):
+                drain(bid)
+        for bid, L in cur.items():
+            L["stop"] = int(cuts[-1])
+            lives.append(L)
+        n_bank = sum(1 for L in lives if L["bin"] is not None)
+    finally:
+        tb.close()
+    for L in lives:                              # (a seed may draw no request at all)
+        y = np.concatenate(L["iq"]) if L["iq"] else np.zeros(0, np.complex64)
+        fm = np.concatenate(L["fm"]) if L["fm"] else np.zeros(0, np.float32)
+        yo = _oracle_life(x, fs, cr, L["segments"], L["start"], L["stop"])
+        assert len(y) == len(yo) == len(fm), (seed, L["bin"], L["start"], L["stop"], len(y), len(yo))
+        bank = L["bin"] is not None
+        warm = ((len(taps) - 1) // D + 1) if (bank and L["start"]) else 0
+        if len(yo) < warm + 16:
+            continue
+        e = rel_rms(y[warm:], yo[warm:])
+        assert e < (5e-4 if bank else 3e-5), (seed, "bank" if bank else "direct", L["segments"], L["start"], L["stop"], e)
+        fo = G.quadrature_demod_cf(yo, 1.0)
+        mag = np.abs(yo)
+        ok = np.zeros(len(yo), dtype=bool)
+        ok[1:] = (mag[1:] > 0.05 * mag.mean()) & (mag[:-1] > 0.05 * mag.mean())
+        ok[:warm + 1] = False
+        if ok.sum() > 8:
+            efm = float(np.sqrt(np.mean((fm[ok] - fo[ok]) ** 2)))
+            assert efm < 1e-4, (seed, "bank" if bank else "direct", L["segments"], efm)
