@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -290,6 +291,10 @@ class Frontend:
         self._h = C.c_void_p()
         self.samp_rate = float(samp_rate)
         self.center_freq = float(center_freq)
+        # the scan's length sizes scan_result()'s buffer: a scan_start() on another thread must not change it between
+        # the allocation and the copy
+        self._scan_len = 0
+        self._scan_lock = threading.Lock()
         _check(lib().rcf_open_ex(device, samp_rate, center_freq, block_capacity, hist_capacity,
                                  out_capacity, C.byref(self._h)))
 
@@ -506,15 +511,19 @@ class Frontend:
 
     # -- scan
     def scan_start(self, fft_len, n_frames=1000, avg_len=100):
-        self._scan_len = int(fft_len)
-        _check(lib().rcf_scan_start(self._h, int(fft_len), int(n_frames), int(avg_len)))
+        with self._scan_lock:
+            _check(lib().rcf_scan_start(self._h, int(fft_len), int(n_frames), int(avg_len)))
+            self._scan_len = int(fft_len)            # (only once librcf has accepted the scan)
 
     def scan_frames_done(self):
         return _check(lib().rcf_scan_frames_done(self._h))
 
     def scan_result(self):
-        out = np.empty(self._scan_len, dtype=np.float32)
-        rc = lib().rcf_scan_result(self._h, _fp(out))
+        with self._scan_lock:
+            if not self._scan_len:
+                return None                          # no scan was ever started
+            out = np.empty(self._scan_len, dtype=np.float32)
+            rc = lib().rcf_scan_result(self._h, _fp(out))
         if rc == RCF_EAGAIN:
             return None
         _check(rc)

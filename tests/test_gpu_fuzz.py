@@ -961,3 +961,102 @@ def test_random_receiver_sessions_in_pfb_mode(gpu_required, seed):
         if ok.sum() > 8:
             efm = float(np.sqrt(np.mean((fm[ok] - fo[ok]) ** 2)))
             assert efm < 1e-4, (seed, "bank" if bank else "direct", L["segments"], efm)
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_threads_on_one_handle(gpu_required, seed):
+    """Feeder, two control threads and two readers on ONE handle (librcf serialises on the handle's mutex; a control call
+    lands between two blocks wherever the scheduler puts it): direct channels, stage-2 channels, bank taps and scans come
+    and go at random while three keepers -- a direct channel, a stage-2 channel, a bin tap -- live through it all and
+    must equal their oracles sample for sample; no call may fail."""
+    import threading
+    nat = gpu_required
+    rng = np.random.default_rng(17000 + seed)
+    nb = 64
+    fs = nb * 78125.0
+    bw = fs / nb
+    cr = 12500
+    D, taps = G.channel_params(fs, cr)
+    proto = G.low_pass_2(1.0, fs, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+    D2, taps2 = G.channel_params(bw, cr)
+    n_blocks = int(rng.integers(30, 80))
+    sizes = [int(rng.integers(1, 2 * D)) if rng.random() < 0.2 else int(rng.integers(2000, 30 * D)) for _ in range(n_blocks)]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    x = synth.awgn(rng, int(cuts[-1]))
+    f_keep, k_keep, d_keep, k_tap = 262500.0, 9, 3125.0, 21
+    t = np.arange(len(x)) / fs
+    x = (x + 0.5 * np.exp(2j * np.pi * (f_keep + 300.0) * t) + 0.5 * np.exp(2j * np.pi * (k_keep * bw + d_keep + 400.0) * t)).astype(np.complex64)
+    errors = []
+    kept = {"d": [], "s": [], "t": []}
+    with nat.Frontend(fs, block_capacity=int(max(sizes)) + 16, hist_capacity=1 << 13, out_capacity=1 << 14) as fe:
+        fe.pfb_open(nb, nb, proto)
+        keep_d = fe.chan_open(cr, f_keep)
+        keep_s = fe.pfb_chan_open(k_keep, cr, d_keep)
+        keep_t = fe.pfb_tap_open(k_tap, gr_phase=False)
+        stop = threading.Event()
+
+        def feeder():
+            try:
+                for b in range(n_blocks):
+                    fe.push(x[int(cuts[b]):int(cuts[b + 1])])
+            except Exception as e:               # pragma: no cover
+                errors.append(("feeder", e))
+            finally:
+                stop.set()
+
+        def control(s):
+            r = np.random.default_rng(s)
+            live = []
+            try:
+                while not stop.is_set():
+                    u = r.random()
+                    if u < 0.25 and len(live) < 20:
+                        live.append(fe.chan_open(cr, float(r.integers(-150, 150)) * 6250.0))
+                    elif u < 0.4 and len(live) < 20:
+                        live.append(fe.pfb_chan_open(int(r.integers(0, nb)), cr, float(r.integers(-4, 5)) * 1562.5))
+                    elif u < 0.5 and len(live) < 20:
+                        live.append(fe.pfb_tap_open(int(r.integers(0, nb)), gr_phase=bool(r.integers(0, 2))))
+                    elif u < 0.7 and live:
+                        fe.chan_set_offset(live[int(r.integers(len(live)))], float(r.integers(-100, 100)) * 1562.5)
+                    elif u < 0.9 and live:
+                        fe.chan_close(live.pop(int(r.integers(len(live)))))
+                    elif u < 0.93:
+                        fe.scan_start(1 << int(r.integers(8, 13)), int(r.integers(1, 6)), 1)
+                    else:
+                        fe.scan_result()
+                for c in live:
+                    fe.chan_close(c)
+            except Exception as e:               # pragma: no cover
+                errors.append(("control", e))
+
+        def reader(which, cid):
+            try:
+                while not stop.is_set():
+                    kept[which].append(fe.chan_read_iq(cid))
+            except Exception as e:               # pragma: no cover
+                errors.append(("reader", e))
+
+        th = [threading.Thread(target=feeder), threading.Thread(target=control, args=(seed * 2 + 1,)),
+              threading.Thread(target=control, args=(seed * 2 + 2,)), threading.Thread(target=reader, args=("d", keep_d)),
+              threading.Thread(target=reader, args=("s", keep_s))]
+        for q in th:
+            q.start()
+        for q in th:
+            q.join(timeout=300)
+        assert not any(q.is_alive() for q in th), "a thread is stuck"
+        kept["d"].append(fe.chan_read_iq(keep_d))
+        kept["s"].append(fe.chan_read_iq(keep_s))
+        kept["t"].append(fe.chan_read_iq(keep_t))
+        bin_t = fe.pfb_read_bin(k_tap)
+    assert not errors, errors
+    y = np.concatenate(kept["d"])
+    yo = _oracle_life(x, fs, cr, [(0, f_keep)], 0, len(x))
+    assert len(y) == len(yo) and rel_rms(y, yo) < 3e-5
+    s1 = G.xlating_fir_exact(x, nb, proto, k_keep * bw, fs).astype(np.complex64)
+    ys = np.concatenate(kept["s"])
+    yso = _oracle_life(s1, bw, cr, [(0, d_keep)], 0, len(s1), filt=(D2, taps2))
+    assert len(ys) == len(yso) and rel_rms(ys, yso) < 3e-5
+    yt = np.concatenate(kept["t"])
+    n_ring = min(len(bin_t), len(yt))             # the bin's own ring may have wrapped under the reader; its newest part
+    np.testing.assert_array_equal(yt[len(yt) - n_ring:], bin_t[len(bin_t) - n_ring:])
+    assert len(yt) == (len(x) - 1) // nb + 1
