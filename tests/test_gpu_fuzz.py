@@ -770,6 +770,8 @@ def test_random_everything_on_one_front_end(gpu_required, seed):
     x = x.astype(np.complex64)
     d_lives, s_lives = [], []
     spec = None
+    feed = str(rng.choice(["pageable", "pinned", "in_place"]))
+    pins = [nat.PinnedArray(int(max(sizes)) + 16, np.complex64) for _ in range(2)] if feed == "pinned" else None
     with nat.Frontend(fs, block_capacity=int(max(sizes)) + 16, hist_capacity=max(N, 1 << 12), out_capacity=1 << 12) as fe:
         if rng.random() < 0.5:
             fe.set_rotator(True)
@@ -810,7 +812,16 @@ def test_random_everything_on_one_front_end(gpu_required, seed):
                     d_new = float(rng.integers(-4, 5)) * 1562.5
                     fe.chan_set_offset(s_live[i]["id"], d_new)
                     s_live[i]["segments"].append((frames, d_new))
-            fe.push(x[s0:int(cuts[b + 1])])
+            seg = x[s0:int(cuts[b + 1])]
+            if feed == "pinned":                             # rcf_push_iq from rcf_host_alloc memory: the copy of this block
+                pin = pins[b & 1]                            # overlaps the kernels of the one before
+                pin.array[:len(seg)] = seg
+                fe.push(pin.array[:len(seg)])
+            elif feed == "in_place":                         # rcf_ingest_ptr / rcf_commit: no buffer events at all
+                fe.ingest_write(seg, 0)
+                fe.commit(len(seg))
+            else:
+                fe.push(seg)
             if spec is None and b >= scan_at and fe.scan_frames_done() == F:
                 spec = fe.scan_result()
         frames = fe.pfb_produced()
