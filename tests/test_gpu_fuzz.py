@@ -1071,3 +1071,71 @@ def test_random_threads_on_one_handle(gpu_required, seed):
     n_ring = min(len(bin_t), len(yt))             # the bin's own ring may have wrapped under the reader; its newest part
     np.testing.assert_array_equal(yt[len(yt) - n_ring:], bin_t[len(bin_t) - n_ring:])
     assert len(yt) == (len(x) - 1) // nb + 1
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_lagging_readers_get_the_newest_ring_full(gpu_required, seed):
+    """Small output rings and readers that come at random: a reader that fell behind by more than the ring holds gets the
+    newest ring-full, oldest first, and carries on from there (a PUB socket at its high-water mark drops the same way).
+    Channel IQ, its discriminator (own cursor), a stage-2 channel and a filterbank bin, each cursor modelled, every read
+    against the oracle's stream at the positions the model says."""
+    nat = gpu_required
+    rng = np.random.default_rng(19000 + seed)
+    nb = 64
+    fs = nb * 78125.0
+    bw = fs / nb
+    cr = 12500
+    D, taps = G.channel_params(fs, cr)
+    proto = G.low_pass_2(1.0, fs, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+    D2, taps2 = G.channel_params(bw, cr)
+    cap = 1 << int(rng.integers(6, 10))                      # 64 .. 512 outputs
+    n_blocks = int(rng.integers(8, 30))
+    max_block = (cap - 16) * nb                              # a block's frames + the history its stage-2 readers reach back must fit the ring (librcf refuses otherwise)
+    sizes = [int(rng.integers(1, max_block)) for _ in range(n_blocks)]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    x = synth.awgn(rng, int(cuts[-1]))
+    f0, k2, d2, kb = 187500.0, 7, -1562.5, 11
+    t = np.arange(len(x)) / fs
+    x = (x + 0.5 * np.exp(2j * np.pi * (f0 + 250.0) * t) + 0.5 * np.exp(2j * np.pi * (k2 * bw + d2 + 350.0) * t)).astype(np.complex64)
+    streams = ["iq", "fm", "s2", "bin"]
+    cursor = {k: 0 for k in streams}
+    produced = {k: 0 for k in streams}
+    reads = {k: [] for k in streams}                         # (first index, array)
+    with nat.Frontend(fs, block_capacity=int(max(sizes)) + 16, hist_capacity=1 << 13, out_capacity=cap) as fe:
+        fe.pfb_open(nb, nb, proto)
+        cid = fe.chan_open(cr, f0)
+        c2 = fe.pfb_chan_open(k2, cr, d2)
+        for b in range(n_blocks):
+            fe.push(x[int(cuts[b]):int(cuts[b + 1])])
+            produced["iq"] = produced["fm"] = fe.chan_produced(cid)
+            produced["s2"] = fe.chan_produced(c2)
+            produced["bin"] = fe.pfb_produced()
+            for k in streams:
+                if rng.random() < 0.25 or b == n_blocks - 1:
+                    got = {"iq": lambda: fe.chan_read_iq(cid), "fm": lambda: fe.chan_read_fm(cid, 1.0),
+                           "s2": lambda: fe.chan_read_iq(c2), "bin": lambda: fe.pfb_read_bin(kb)}[k]()
+                    first = max(cursor[k], produced[k] - cap)
+                    assert len(got) == produced[k] - first, (seed, k, b, len(got), produced[k], first, cap)
+                    reads[k].append((first, got))
+                    cursor[k] = produced[k]
+    yo = _oracle_life(x, fs, cr, [(0, f0)], 0, len(x))
+    fo = G.quadrature_demod_cf(yo, 1.0)
+    s1 = G.xlating_fir_exact(x, nb, proto, k2 * bw, fs).astype(np.complex64)
+    s2o = _oracle_life(s1, bw, cr, [(0, d2)], 0, len(s1), filt=(D2, taps2))
+    bo = G.xlating_fir_exact(x, nb, proto, kb * bw, fs).astype(np.complex64)
+    want = {"iq": yo, "fm": fo, "s2": s2o, "bin": bo}
+    for k in streams:
+        assert produced[k] == len(want[k]), (seed, k)
+        for first, got in reads[k]:
+            if len(got) < 4:
+                continue
+            w = want[k][first:first + len(got)]
+            if k == "fm":
+                mag = np.abs(yo)
+                good = np.zeros(len(yo), dtype=bool)
+                good[1:] = (mag[1:] > 0.05 * mag.mean()) & (mag[:-1] > 0.05 * mag.mean())
+                ok = good[first:first + len(got)]
+                if ok.sum() > 4:
+                    assert float(np.sqrt(np.mean((got[ok] - w[ok]) ** 2))) < 1e-4, (seed, k, first)
+            else:
+                assert rel_rms(got, w) < 3e-5, (seed, k, first, len(got), rel_rms(got, w))
