@@ -1139,3 +1139,60 @@ def test_random_lagging_readers_get_the_newest_ring_full(gpu_required, seed):
                     assert float(np.sqrt(np.mean((got[ok] - w[ok]) ** 2))) < 1e-4, (seed, k, first)
             else:
                 assert rel_rms(got, w) < 3e-5, (seed, k, first, len(got), rel_rms(got, w))
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_filterbank_shapes_and_cuts(gpu_required, seed):
+    """Every filterbank kernel family under random cuts: power-of-two banks (64 .. 1024 bins, critically sampled and
+    oversampled by 2, prototypes of 4 .. 16 taps per branch) and the frame-major 400 / 800 / 1600-bin banks built from the
+    reference's channel filter (12.5 and 6.25 kHz rasters: oversampling 1, 2, 4), opened at the start or in mid-stream
+    (zero history from there), fed in ragged pushes: bins against the float64 exact-phase bank, and bit for bit against
+    the same stream in one push."""
+    nat = gpu_required
+    rng = np.random.default_rng(21000 + seed)
+    if rng.random() < 0.5:
+        nb = int(rng.choice([64, 128, 256, 512, 1024]))
+        osf = int(rng.choice([1, 2]))
+        D = nb // osf
+        fs = nb * 25000.0
+        P = int(rng.choice([3, 4, 9, 14, 16])) if osf == 1 else int(rng.choice([3, 4, 12, 16]))
+        T = nb * P - int(rng.integers(0, nb // 2))
+        bw = fs / nb
+        proto = G.low_pass_2(1.0, fs, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+        # stretch / cut the design to the tap count drawn (any low-pass will do: the comparison is against the same taps)
+        proto = np.interp(np.linspace(0, len(proto) - 1, T), np.arange(len(proto)), proto).astype(np.float32)
+    else:
+        fs, nb, cr = [(5e6, 400, 12500), (10e6, 800, 12500), (5e6, 800, 12500), (20e6, 1600, 12500), (5e6, 800, 6250),
+                      (10e6, 800, 25000), (5e6, 400, 25000)][int(rng.integers(0, 7))]
+        D, proto = G.channel_params(fs, cr)
+        if nb % D:
+            pytest.skip("not a bank shape")
+    if not nat.pfb_shape_supported(nb, D, len(proto)):
+        pytest.skip("no kernel for bins=%d decim=%d taps=%d" % (nb, D, len(proto)))
+    n_frames = int(rng.integers(40, 400 if nb <= 512 else 120))
+    lead = int(rng.integers(0, 3 * D)) if rng.random() < 0.5 else 0       # samples before the bank is opened
+    n = lead + D * n_frames + int(rng.integers(0, D))
+    x = synth.awgn(rng, n)
+    cuts = sorted({lead, n} | {int(v) for v in rng.integers(lead + 1, n, int(rng.integers(0, 8)))})
+    ks = sorted({int(v) for v in rng.integers(0, nb, 3)})        # (pfb_read_bin is a cursor: each bin once)
+
+    def run(pieces):
+        with nat.Frontend(fs, block_capacity=n + 16, hist_capacity=max(1 << 14, len(proto) + 2 * nb), out_capacity=1 << 10) as fe:
+            if lead:
+                fe.push(x[:lead])
+            fe.pfb_open(nb, D, proto)
+            for a, b in pieces:
+                fe.push(x[a:b])
+            return fe.pfb_produced(), [fe.pfb_read_bin(k) for k in ks]
+
+    n_one, one = run([(lead, n)])
+    n_cut, cut = run(list(zip(cuts[:-1], cuts[1:])))
+    k0 = -(-lead // D)
+    assert n_one == n_cut == (n - 1) // D + 1 - k0
+    xz = x.copy()
+    xz[:lead] = 0
+    for k, a, b in zip(ks, one, cut):
+        np.testing.assert_array_equal(a, b, err_msg="cut invariance, seed %d bins %d decim %d bin %d" % (seed, nb, D, k))
+        ref = G.xlating_fir_exact(xz, D, proto, (k if k <= nb // 2 else k - nb) * fs / nb, fs).astype(np.complex64)[k0:]
+        assert len(a) == len(ref), (seed, nb, D, len(a), len(ref))
+        assert rel_rms(a, ref) < 3e-5, (seed, nb, D, len(proto), k, rel_rms(a, ref))
