@@ -285,31 +285,38 @@ def test_random_scans_equal_the_oracle_chain(gpu_required, seed):
 
 
 @pytest.mark.parametrize("seed", _seeds())
-def test_random_stage2_channel_lifecycles_on_a_power_of_two_bank(gpu_required, seed):
+def test_random_stage2_channel_lifecycles_on_a_bank(gpu_required, seed):
     """The BASELINE throughput shape under churn: a critically sampled power-of-two bank (64 .. 512 bins, prototype by
     the low_pass_2 rule) with stage-2 channels (channel.py's rule at the bin rate + discriminator) opened, retuned and
     closed at random block boundaries through ragged pushes -- each against the two-stage oracle: the float64
     exact-phase bank's bin, zeroed before the channel's opening frame, through GNU Radio's xlating FIR and rotator."""
     nat = gpu_required
     rng = np.random.default_rng(7000 + seed)
-    nb = int(rng.choice([64, 128, 256, 512]))
-    fs = nb * 78125.0                                        # bin rate 78.125 kHz: channel.py gives D2 = 3, T2 = 11
-    bw = fs / nb
-    proto = G.low_pass_2(1.0, fs, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+    if rng.random() < 0.75:
+        nb = int(rng.choice([64, 128, 256, 512]))
+        fs = nb * 78125.0                                    # bin rate 78.125 kHz: channel.py gives D2 = 3, T2 = 11
+        Db = nb
+        bw = fs / nb
+        proto = G.low_pass_2(1.0, fs, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+    else:                                                    # a frame-major bank (bins read with stride n_bins): 400 bins at
+        fs, nb = 5e6, 400                                    # 5 Msps from the reference's channel filter, 25 kS/s per bin
+        Db, proto = G.channel_params(fs, 12500)              # -> stage 2 at decimation 1
+        bw = fs / Db
     D2, taps2 = G.channel_params(bw, 12500)
+    grid_hz = fs / nb
     n_blocks = int(rng.integers(5, 11))
-    sizes = [int(rng.integers(1, 4 * nb)) if rng.random() < 0.25 else int(rng.integers(20 * nb, 300 * nb)) for _ in range(n_blocks)]
+    sizes = [int(rng.integers(1, 4 * Db)) if rng.random() < 0.25 else int(rng.integers(20 * Db, 300 * Db)) for _ in range(n_blocks)]
     cuts = np.concatenate([[0], np.cumsum(sizes)])
     x = synth.awgn(rng, int(cuts[-1]))
     slots = [(int(rng.integers(0, nb)), float(rng.integers(-4, 5)) * 1562.5) for _ in range(int(rng.integers(2, 9)))]
     t = np.arange(len(x)) / fs
     for k, d in slots:
-        f = (k if k <= nb // 2 else k - nb) * bw + d + 700.0
+        f = (k if k <= nb // 2 else k - nb) * grid_hz + d + 700.0
         x = x + (0.7 * np.exp(2j * np.pi * f * t)).astype(np.complex64)
     x = x.astype(np.complex64)
     lives = []
     with nat.Frontend(fs, block_capacity=int(max(sizes)) + 16, out_capacity=1 << 12) as fe:
-        fe.pfb_open(nb, nb, proto)
+        fe.pfb_open(nb, Db, proto)
         live = {}
         shift = 0.0                              # rcf_source_shift: the stage-2 NCOs follow it (the bank's grid does not move)
         for b in range(n_blocks):
@@ -344,12 +351,12 @@ def test_random_stage2_channel_lifecycles_on_a_power_of_two_bank(gpu_required, s
             L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
             L["last"] = frames
             lives.append(L)
-    assert frames == (len(x) - 1) // nb + 1
+    assert frames == (len(x) - 1) // Db + 1
     stage1 = {}
     for L in lives:
         k = L["bin"]
         if k not in stage1:
-            stage1[k] = G.xlating_fir_exact(x, nb, proto, (k if k <= nb // 2 else k - nb) * bw, fs).astype(np.complex64)
+            stage1[k] = G.xlating_fir_exact(x, Db, proto, (k if k <= nb // 2 else k - nb) * grid_hz, fs).astype(np.complex64)
         s1 = stage1[k][:L["last"]].copy()
         s1[:L["first"]] = 0
         k0, k1 = -(-L["first"] // D2), ((L["last"] - 1) // D2 + 1 if L["last"] > 0 else 0)
