@@ -65,7 +65,8 @@ def _oracle_life(x, fs, cr, segments, start, stop, filt=None):
 def test_random_channel_lifecycles_equal_the_oracle(gpu_required, seed):
     nat = gpu_required
     rng = np.random.default_rng(1000 + seed)
-    fs = float(rng.choice([2.4e6, 8e6, 10e6, 20e6]))
+    crowd = rng.random() < 0.12                  # now and then a crowd: several matrix-core groups of 32 with churn in them
+    fs = 2.4e6 if crowd else float(rng.choice([2.4e6, 8e6, 10e6, 20e6]))
     rates = [r for r in (6250, 12500, 25000, 50000) if (fs / r) == int(fs / r) and int(fs / r) % 2 == 0]
     cr = 12500                                    # the reference's rate; a third of the slots take another one, so that
     D, taps = G.channel_params(fs, cr)            # several (D, T) classes are scheduled side by side
@@ -75,7 +76,7 @@ def test_random_channel_lifecycles_equal_the_oracle(gpu_required, seed):
     cuts = np.concatenate([[0], np.cumsum(sizes)])
     x = synth.awgn(rng, int(cuts[-1]))
     # a carrier per potential channel so that the comparison is not noise against noise
-    n_slots = int(rng.integers(3, 40))
+    n_slots = int(rng.integers(70, 140)) if crowd else int(rng.integers(3, 40))
     grid = 6250.0
     offs = [float(np.round(o / grid) * grid) for o in rng.uniform(-0.45, 0.45, n_slots) * fs]
     crs = [int(rng.choice(rates)) if rng.random() < 0.33 else cr for _ in range(n_slots)]
