@@ -281,7 +281,11 @@ int rcf_pfb_chan_open(rcf_t *h, int bin, int channel_rate, double delta_hz, int 
  * audio / symbol filter all work), discriminator fused into the copy.  This is what the reference's dead
  * connect_channel_pfb (rc_frontend/receiver.py:343-383) was meant to do, without its second filter stage.
  * gr_phase != 0: the channel's rotator also carries the per-output phase and magnitude increment by which GNU
- * Radio's float32 rotator differs from the bank's exact phases, so the discriminator DC matches the reference's. */
+ * Radio's float32 rotator differs from the bank's exact phases, so the discriminator DC matches the reference's, and
+ * starts at the phase GNU Radio's rotator has at a channel's first output (1, where the bin carries
+ * e^{-j 2 pi k decim n0 / n_bins} at the frame n0 it is opened at): the IQ stream is that of a
+ * freq_xlating_fir_filter_ccc started at the opening sample -- except that the bin comes with the filter's history
+ * in it, where a new flowgraph starts from zeros. */
 int rcf_pfb_tap_open(rcf_t *h, int bin, int gr_phase, int *chan_id);
 /* How far bin `bin` of an exact-phase bank is from GNU Radio's own channel at that offset, before any sample is seen
  * (no device needed).  freq_xlating_fir_filter_ccc (rc_frontend/channel.py:35) builds its composite taps as
