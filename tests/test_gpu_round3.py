@@ -546,3 +546,60 @@ def test_pfb256_stage2_ragged_pushes_equal_one_push(gpu_required):
         for j in range(len(meta["carriers"])):
             np.testing.assert_array_equal(got[j][0], one[j][0], err_msg="iq, channel %d, in_place=%s" % (j, in_place))
             np.testing.assert_array_equal(got[j][1], one[j][1], err_msg="fm, channel %d, in_place=%s" % (j, in_place))
+
+
+def test_refused_blocks_leave_the_stream_where_it_was(gpu_required):
+    """Calls librcf refuses -- a push beyond the block capacity, a block whose filterbank frames (plus the history its
+    stage-2 channels reach back) would not fit the output ring, a channel that cannot be opened -- must leave the handle
+    exactly where it was: the pushes that follow give the oracle's stream of the ACCEPTED samples, nothing lost, nothing
+    doubled."""
+    nat = gpu_required
+    nb = 64
+    fs = nb * 78125.0
+    bw = fs / nb
+    cr = 12500
+    D, taps = G.channel_params(fs, cr)
+    proto = G.low_pass_2(1.0, fs, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+    D2, taps2 = G.channel_params(bw, cr)
+    rng = np.random.default_rng(77)
+    cap = 256
+    x = synth.awgn(rng, nb * 900)
+    x = (x + 0.5 * np.exp(2j * np.pi * (187500.0 + 300.0) * np.arange(len(x)) / fs)).astype(np.complex64)
+    junk = synth.awgn(rng, nb * 400)
+    good = [x[:nb * 100 + 7], x[nb * 100 + 7:nb * 330], x[nb * 330:nb * 331 + 5], x[nb * 331 + 5:nb * 560], x[nb * 560:nb * 790],
+            x[nb * 790:]]
+    with nat.Frontend(fs, block_capacity=nb * 300, hist_capacity=1 << 13, out_capacity=cap) as fe:
+        fe.pfb_open(nb, nb, proto)
+        cid = fe.chan_open(cr, 187500.0)
+        c2 = fe.pfb_chan_open(7, cr, -1562.5)
+        got_d, got_s, got_b = [], [], []
+        for i, seg in enumerate(good):
+            if i in (1, 3):
+                with pytest.raises(nat.RcfError):
+                    fe.push(junk[:nb * 300 + 1])                 # beyond the block capacity
+                with pytest.raises(nat.RcfError):
+                    fe.push(junk[:nb * 280])                     # 280 frames + stage-2 history > 256-frame ring
+                with pytest.raises(nat.RcfError):
+                    fe.pfb_chan_open(nb + 3, cr, 0.0)            # no such bin
+                with pytest.raises(nat.RcfError):
+                    fe.chan_open(12345, 0.0)                     # non-integral decimation
+            fe.push(seg)
+            got_d.append(fe.chan_read_iq(cid))
+            got_s.append(fe.chan_read_iq(c2))
+            got_b.append(fe.pfb_read_bin(11))
+        assert fe.pfb_produced() == (len(x) - 1) // nb + 1
+    ct, incr = OC.xlating_composite(taps, D, 187500.0, fs)
+    v = G.fir_decim_cc(x, ct, D)
+    ph, _, _ = G.rotator_phases(incr, len(v))
+    yo = (v * ph).astype(np.complex64)
+    y = np.concatenate(got_d)
+    assert len(y) == len(yo) and rel_rms(y, yo) < 2e-5
+    s1 = G.xlating_fir_exact(x, nb, proto, 7 * bw, fs).astype(np.complex64)
+    ct2, incr2 = OC.xlating_composite(taps2, D2, -1562.5, bw)
+    v2 = G.fir_decim_cc(s1, ct2, D2)
+    ph2, _, _ = G.rotator_phases(incr2, len(v2))
+    ys = np.concatenate(got_s)
+    assert len(ys) == len(v2) and rel_rms(ys, (v2 * ph2).astype(np.complex64)) < 3e-5
+    bo = G.xlating_fir_exact(x, nb, proto, 11 * bw, fs).astype(np.complex64)
+    b = np.concatenate(got_b)
+    assert len(b) == len(bo) and rel_rms(b, bo) < 3e-5
