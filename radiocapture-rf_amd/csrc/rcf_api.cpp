@@ -487,6 +487,8 @@ struct BlockPlan {
     // host's schedule time).
     std::unordered_map<int, size_t> reach_x;                // source id (channel id / RCF_SRC_PFB_BIN0) -> samples
     int max_depth = 0;
+    int min_d0 = 0;                    // smallest decimation among the channels on the wideband stream (0: none)
+    size_t max_reach = 1;              // largest consumer reach of any ring (see reach_x) / voice-chain filter
     size_t arena_need = 0;
     int a = 0;                         // arena in use, and where this commit's records start in it
     size_t arena_base = 0;
@@ -549,11 +551,15 @@ int plan_arena(rcf_t *h, BlockPlan &bp)
             if (c.d_sym) need += sizeof(FmFirLaunch);
             if (c.audio) need += sizeof(AudioLaunch);
             max_depth = std::max(max_depth, c.depth);
+            if (c.src < 0 && (bp.min_d0 == 0 || c.D < bp.min_d0)) bp.min_d0 = c.D;
+            if (c.audio) bp.max_reach = std::max<size_t>(bp.max_reach, (size_t)std::max(std::max(c.audio->n_lpf, c.audio->n_hpf), c.audio->nt_rs));
             if (c.d_sym) { size_t &own = reach_x[c.id]; own = std::max<size_t>(own, std::max<size_t>(1, (size_t)c.sym_ntaps)); }
             if (c.src >= 0) {
                 size_t &r = reach_x[c.src >= RCF_SRC_PFB_BIN0 ? RCF_SRC_PFB_BIN0 : c.src];
                 r = std::max<size_t>(r, (size_t)(c.T - 1 + c.D));
+                bp.max_reach = std::max(bp.max_reach, r);
             }
+            if (c.d_sym) bp.max_reach = std::max<size_t>(bp.max_reach, (size_t)c.sym_ntaps);
         }
         need += 64 * (h->chans.size() / 4 + 64);              // per-class alignment slack
         arena_need = need;
@@ -1177,6 +1183,54 @@ int finish_block(rcf_t *h, const BlockPlan &bp)
     return RCF_OK;
 }
 
+// plan_channel() advances a channel's state as it goes, so a block must not be refused half way through the schedule
+// (the channels planned before the refusal would have counted outputs nobody computed).  The one refusal that depends on
+// the block is a ring too small for what the block yields: this pass walks the channels in dependency order WITHOUT
+// touching them and reports it first.  It only runs when the cheap bound in process_block() says a ring could overflow.
+int check_block_capacity(rcf_t *h, const BlockPlan &bp)
+{
+    std::unordered_map<int, std::pair<int64_t, int64_t>> dry;      // channel id -> produced (before, after) this block
+    for (int depth = 0; depth <= bp.max_depth; ++depth)
+        for (auto &kv : h->chans) {
+            const Chan &c = *kv.second;
+            if (c.depth != depth) continue;
+            int64_t p0, p1;
+            if (c.src < 0) { p0 = bp.S0; p1 = bp.S1; }
+            else if (c.src >= RCF_SRC_PFB_BIN0) {
+                if (!h->pfb.open) continue;
+                p0 = h->pfb.produced_before; p1 = h->pfb.produced;
+            } else {
+                auto sit = h->chans.find(c.src);
+                if (sit == h->chans.end()) continue;
+                auto dit = dry.find(c.src);
+                p0 = dit == dry.end() ? sit->second->produced : dit->second.first;
+                p1 = dit == dry.end() ? sit->second->produced : dit->second.second;
+            }
+            const int64_t k_lo = std::max(ceil_div(p0, c.D), c.k_abs0);
+            const int64_t k_hi = floor_div(p1 - 1, c.D);
+            if (p1 <= p0 || k_hi < k_lo) { dry[c.id] = {c.produced, c.produced}; continue; }
+            const int64_t cnt = k_hi - k_lo + 1;
+            if ((size_t)cnt + bp.reach(c.id) > h->out_cap) {
+                set_error("block yields %lld outputs (+%zu of history its consumers need) > ring capacity %zu",
+                          (long long)cnt, bp.reach(c.id), h->out_cap);
+                return RCF_ECAP;
+            }
+            if (c.audio) {
+                const Chan::Audio &au = *c.audio;
+                const int64_t n_lo = k_lo - c.k_abs0;
+                const int64_t a_lo = std::max<int64_t>(n_lo, au.from);
+                const int64_t a_n = n_lo + cnt - a_lo;
+                const size_t reach = (size_t)std::max(std::max(au.n_lpf, au.n_hpf), au.nt_rs);
+                if (a_n > 0 && (size_t)a_n + reach > h->out_cap) {
+                    set_error("block yields %lld channel samples: audio rings of %zu too small", (long long)a_n, h->out_cap);
+                    return RCF_ECAP;
+                }
+            }
+            dry[c.id] = {c.produced, k_hi - c.k_abs0 + 1};
+        }
+    return RCF_OK;
+}
+
 int process_block(rcf_t *h, size_t n)
 {
     if (h->graveyard.size() > 512) drain_graveyard(h);     // bounded even if nobody ever syncs or reads
@@ -1187,6 +1241,15 @@ int process_block(rcf_t *h, size_t n)
     int rc = plan_arena(h, bp);
     if (rc == RCF_OK) rc = plan_pfb(h, bp);
     if (rc != RCF_OK) return rc;
+    {
+        // no ring can overflow when even the fastest channel's outputs of this block plus the longest reach fit
+        size_t worst = bp.min_d0 ? n / (size_t)bp.min_d0 + 2 : 0;
+        if (bp.run_pfb) worst = std::max(worst, (size_t)bp.pl.n_frames + 1);
+        if (worst + bp.max_reach > h->out_cap && (rc = check_block_capacity(h, bp)) != RCF_OK) {
+            if (h->pfb.open) h->pfb.produced = h->pfb.produced_before;      // plan_pfb had counted the block's frames
+            return rc;
+        }
+    }
     // channels, by depth then by (D, T) class
     bp.fir_by_depth.resize(bp.max_depth + 1);
     bp.serial = ++h->blk_serial;

@@ -603,3 +603,47 @@ def test_refused_blocks_leave_the_stream_where_it_was(gpu_required):
     bo = G.xlating_fir_exact(x, nb, proto, 11 * bw, fs).astype(np.complex64)
     b = np.concatenate(got_b)
     assert len(b) == len(bo) and rel_rms(b, bo) < 3e-5
+
+
+def test_block_refused_by_one_ring_is_refused_for_all(gpu_required):
+    """A block the filterbank's ring could take but a fast direct channel's cannot (107 outputs into a ring of 64) -- and the
+    other way round, a stage-2 channel's voice chain too long for the block -- is refused BEFORE any channel has counted
+    its outputs: the bank, the other channels and the refused one all carry on with the next accepted push as if the
+    refused one had never been made (check_block_capacity walks the channels without touching them before the
+    schedule, which advances channel state as it goes, is built)."""
+    nat = gpu_required
+    fs, nb = 2.4e6, 64
+    bw = fs / nb
+    proto = G.low_pass_2(1.0, fs, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+    D_fast, taps_fast = G.channel_params(fs, 50000)             # D = 24
+    D_slow, taps_slow = G.channel_params(fs, 12500)             # D = 96
+    assert D_fast == 24 and D_slow == 96
+    rng = np.random.default_rng(5)
+    x = synth.awgn(rng, nb * 200)
+    x = (x + 0.5 * np.exp(2j * np.pi * 100300.0 * np.arange(len(x)) / fs)).astype(np.complex64)
+    junk = synth.awgn(rng, nb * 40)
+    step = nb * 20                                               # 20 frames, 54 fast outputs, 14 slow ones: all fit 64
+    with nat.Frontend(fs, block_capacity=nb * 64, hist_capacity=1 << 13, out_capacity=64) as fe:
+        fe.pfb_open(nb, nb, proto)
+        slow = fe.chan_open(12500, 100000.0)                     # planned BEFORE the fast one (smaller id, other class)
+        fast = fe.chan_open(50000, 100000.0)
+        got = {"slow": [], "fast": [], "bin": []}
+        for i, at in enumerate(range(0, len(x), step)):
+            if i in (2, 5, 6):
+                with pytest.raises(nat.RcfError):
+                    fe.push(junk)                                # 40 frames fit; 107 fast outputs do not
+            fe.push(x[at:at + step])
+            got["slow"].append(fe.chan_read_iq(slow))
+            got["fast"].append(fe.chan_read_iq(fast))
+            got["bin"].append(fe.pfb_read_bin(3))
+        assert fe.pfb_produced() == len(x) // nb
+    for name, (D, taps) in (("slow", (D_slow, taps_slow)), ("fast", (D_fast, taps_fast))):
+        ct, incr = OC.xlating_composite(taps, D, 100000.0, fs)
+        v = G.fir_decim_cc(x, ct, D)
+        ph, _, _ = G.rotator_phases(incr, len(v))
+        y = np.concatenate(got[name])
+        assert len(y) == len(v), (name, len(y), len(v))
+        assert rel_rms(y, (v * ph).astype(np.complex64)) < 2e-5, name
+    b = np.concatenate(got["bin"])
+    bo = G.xlating_fir_exact(x, nb, proto, 3 * bw, fs).astype(np.complex64)
+    assert len(b) == len(bo) and rel_rms(b, bo) < 3e-5
