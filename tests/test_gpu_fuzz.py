@@ -1218,3 +1218,90 @@ def test_random_filterbank_shapes_and_cuts(gpu_required, seed):
         ref = G.xlating_fir_exact(xz, D, proto, (k if k <= nb // 2 else k - nb) * fs / nb, fs).astype(np.complex64)[k0:]
         assert len(a) == len(ref), (seed, nb, D, len(a), len(ref))
         assert rel_rms(a, ref) < 3e-5, (seed, nb, D, len(proto), k, rel_rms(a, ref))
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_structural_churn(gpu_required, seed):
+    """Things that go away under their users: the filterbank closed and opened again in another shape in mid-stream (its
+    taps and stage-2 channels go with it; channels chained to THOSE starve), a parent channel closed under its chained
+    child, ids used after their channel is gone (ENOCHAN, nothing else).  A keeper channel and the last bank's bins must
+    come through untouched: the keeper equals the oracle over the whole stream, the bank's bin the oracle's bin with
+    zero history from the sample the bank was opened at."""
+    nat = gpu_required
+    rng = np.random.default_rng(23000 + seed)
+    fs, cr = 5e6, 12500
+    D, taps = G.channel_params(fs, cr)                       # 200 / 727
+    pre = G.low_pass_2(1.0, 25000.0, 6250.0, 1500.0, 30.0, G.WIN_BLACKMAN)
+    shapes = [(64, 64), (128, 64), (256, 256), (400, 200), (800, 200)]
+
+    def proto_of(nb, Db):
+        if nb in (400, 800):                                 # the reference's 12.5 kHz channel filter on a 12.5 / 6.25 kHz raster
+            return G.channel_params(fs, 12500)[1]
+        return G.low_pass_2(1.0, fs, fs / nb * 0.4, fs / nb * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+
+    n_blocks = int(rng.integers(8, 18))
+    sizes = [int(rng.integers(1, 2 * D)) if rng.random() < 0.2 else int(rng.integers(1500, 40 * D)) for _ in range(n_blocks)]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    x = synth.awgn(rng, int(cuts[-1]))
+    f_keep = 312500.0
+    x = (x + 0.5 * np.exp(2j * np.pi * (f_keep + 200.0) * np.arange(len(x)) / fs)).astype(np.complex64)
+    kept = []
+    bank = None                                  # (nb, Db, proto, opened_at_sample, bin followed, reads)
+    with nat.Frontend(fs, block_capacity=int(max(sizes)) + 16, hist_capacity=1 << 14, out_capacity=1 << 12) as fe:
+        keeper = fe.chan_open(cr, f_keep)
+        on_bank, chained, parents = [], [], []
+        for b in range(n_blocks):
+            s0 = int(cuts[b])
+            for _ in range(int(rng.integers(0, 4))):
+                u = rng.random()
+                try:
+                    if u < 0.15:
+                        if bank is not None:
+                            fe.pfb_close()
+                            bank = None
+                            on_bank = []
+                        nb, Db = shapes[int(rng.integers(0, len(shapes)))]
+                        if nat.pfb_shape_supported(nb, Db, len(proto_of(nb, Db))):
+                            fe.pfb_open(nb, Db, proto_of(nb, Db))
+                            bank = dict(nb=nb, Db=Db, proto=proto_of(nb, Db), at=s0, bin=int(rng.integers(0, nb)), reads=[])
+                    elif u < 0.22 and bank is not None:
+                        fe.pfb_close()
+                        bank = None
+                        on_bank = []                         # their ids are gone with the bank
+                    elif u < 0.4 and bank is not None:
+                        k = int(rng.integers(0, bank["nb"]))
+                        on_bank.append(fe.pfb_tap_open(k, gr_phase=bool(rng.integers(0, 2))) if rng.random() < 0.5
+                                       else fe.pfb_chan_open(k, cr, 0.0))
+                    elif u < 0.5 and on_bank:
+                        chained.append(fe.chan_open_taps(on_bank[int(rng.integers(len(on_bank)))], 1, pre, 0.0))
+                    elif u < 0.6:
+                        parents.append(fe.chan_open(cr, float(rng.integers(-150, 150)) * 6250.0))
+                    elif u < 0.7 and parents:
+                        chained.append(fe.chan_open_taps(parents[int(rng.integers(len(parents)))], 1, pre, 0.0))
+                    elif u < 0.8 and parents:
+                        fe.chan_close(parents.pop(int(rng.integers(len(parents)))))      # children keep their ids and starve
+                    elif u < 0.9 and chained:
+                        cid = chained[int(rng.integers(len(chained)))]
+                        fe.chan_read_iq(cid)
+                        fe.chan_read_fm(cid, 1.0)
+                    elif chained:
+                        fe.chan_close(chained.pop(int(rng.integers(len(chained)))))
+                except nat.RcfError as e:
+                    assert e.code in (nat.RCF_ENOCHAN, nat.RCF_ECAP, nat.RCF_EINVAL, nat.RCF_ERANGE), (seed, str(e))
+            fe.push(x[s0:int(cuts[b + 1])])
+            kept.append(fe.chan_read_iq(keeper))
+            if bank is not None:
+                bank["reads"].append(fe.pfb_read_bin(bank["bin"]))
+    y = np.concatenate(kept)
+    yo = _oracle_life(x, fs, cr, [(0, f_keep)], 0, len(x))
+    assert len(y) == len(yo) and rel_rms(y, yo) < 2e-5, seed
+    if bank is not None and bank["reads"]:
+        got = np.concatenate(bank["reads"])
+        xz = x.copy()
+        xz[:bank["at"]] = 0
+        k, nb, Db = bank["bin"], bank["nb"], bank["Db"]
+        ref = G.xlating_fir_exact(xz, Db, bank["proto"], (k if k <= nb // 2 else k - nb) * fs / nb, fs).astype(np.complex64)
+        ref = ref[-(-bank["at"] // Db):]
+        assert len(got) == len(ref), (seed, nb, Db, len(got), len(ref))
+        if len(ref) > 4:
+            assert rel_rms(got, ref) < 3e-5, (seed, nb, Db, k)
