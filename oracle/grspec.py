@@ -126,6 +126,26 @@ def channel_params(samp_rate: float, channel_rate: float):
 # --------------------------------------------------------------------------------------------
 # filter.freq_xlating_fir_filter_ccc
 # --------------------------------------------------------------------------------------------
+def _libm_sincosf(theta):
+    """(cosf, sinf) of float32 angles by the C library's float routines -- what GNU Radio's exp(gr_complex(0, x)) /
+    gr_expj(x) end in (cexpf -> sincosf).  numpy's own float32 cos / sin and a correctly rounded double result both
+    differ from libm's in the last bit on a quarter of the arguments: harmless per tap (6e-8), but one ulp in the ROTATOR
+    INCREMENT is a phase drift of 6e-8 rad per output -- 1e-5 of IQ error after a few hundred outputs, the size of the
+    parity bar.  The C restatement (rcf_oracle.c) and the product (rcf_design.cpp) call the same routines."""
+    import ctypes
+    import ctypes.util
+    th = np.ascontiguousarray(theta, dtype=f32).ravel()
+    try:
+        libm = _libm_sincosf.lib
+    except AttributeError:
+        libm = _libm_sincosf.lib = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        libm.cosf.restype = libm.sinf.restype = ctypes.c_float
+        libm.cosf.argtypes = libm.sinf.argtypes = [ctypes.c_float]
+    c = np.fromiter((libm.cosf(float(v)) for v in th), dtype=f32, count=len(th))
+    s = np.fromiter((libm.sinf(float(v)) for v in th), dtype=f32, count=len(th))
+    return c, s
+
+
 def xlating_composite(taps: np.ndarray, D: int, f0: float, fs: float):
     """GR `build_composite_fir`: float32 phase arithmetic is part of the answer.
 
@@ -136,13 +156,13 @@ def xlating_composite(taps: np.ndarray, D: int, f0: float, fs: float):
     fwT0 = f32(2.0 * math.pi * f0 / fs)
     i = np.arange(len(taps), dtype=np.uint32).astype(f32)
     theta = (i * fwT0).astype(f32)
-    c = np.cos(theta).astype(f32)
-    s = np.sin(theta).astype(f32)
+    c, s = _libm_sincosf(theta)
     ctaps = np.empty(len(taps), dtype=np.complex64)
     ctaps.real = taps.astype(f32) * c
     ctaps.imag = taps.astype(f32) * s
     a = f32(f32(-fwT0) * f32(D))
-    incr = np.complex64(complex(f32(math.cos(float(a))), f32(math.sin(float(a)))))
+    ci, si = _libm_sincosf(np.array([a], dtype=f32))
+    incr = np.complex64(complex(ci[0], si[0]))
     return ctaps, incr
 
 
