@@ -1305,3 +1305,88 @@ def test_random_structural_churn(gpu_required, seed):
         assert len(got) == len(ref), (seed, nb, Db, len(got), len(ref))
         if len(ref) > 4:
             assert rel_rms(got, ref) < 3e-5, (seed, nb, Db, k)
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_voice_chains_on_every_kind_of_channel(gpu_required, seed):
+    """The voice chain on a direct channel, on a stage-2 channel behind a 64-bin bank and on a tapped bin of the 400-bin
+    bank, attached at the start or at a random block boundary (a flowgraph started at that channel sample: zero state in
+    every stage), small rings that wrap, ragged pushes, random reads -- audio against oracle/audio.py run on the ORACLE's
+    channel stream from the attachment on."""
+    from oracle import audio as A
+    from rcf import audio as host_audio
+    nat = gpu_required
+    rng = np.random.default_rng(25000 + seed)
+    kind = str(rng.choice(["direct", "stage2", "tap"]))
+    cr = 12500
+    if kind == "stage2":
+        nb = 64
+        fs = nb * 75000.0                                    # bin rate 75 kHz: stage 2 at /3 gives the chain's 25 kS/s
+        Db = nb
+        proto = G.low_pass_2(1.0, fs, fs / nb * 0.4, fs / nb * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+        k, delta = int(rng.integers(1, nb // 2)), float(rng.integers(-3, 4)) * 1562.5
+        f_sig = k * fs / nb + delta
+        out_rate = 25000.0
+    elif kind == "tap":
+        fs, nb = 5e6, 400
+        Db, proto = G.channel_params(fs, cr)
+        k = int(rng.integers(1, nb // 2))
+        f_sig = k * fs / nb
+        out_rate = 25000.0
+    else:
+        fs = float(rng.choice([2.4e6, 5e6]))
+        f_sig = float(np.round(rng.uniform(-0.4, 0.4) * fs / 6250) * 6250)
+        out_rate = 25000.0
+    D, taps = G.channel_params(fs, cr)
+    n_ch = int(rng.integers(2500, 7000))                    # channel samples
+    dec = (Db * 3 if kind == "stage2" else Db) if kind != "direct" else D
+    n = dec * n_ch + int(rng.integers(0, dec))
+    x = synth.nbfm_carrier(n, fs, f_sig, float(rng.uniform(300, 2500)), float(rng.uniform(1000, 3000)), float(rng.uniform(0.1, 0.6)))
+    x = (x + 1e-3 * synth.awgn(rng, n)).astype(np.complex64)
+    for _ in range(int(rng.integers(0, 3))):
+        a = int(rng.integers(0, n_ch - 600)) * dec
+        x[a:a + int(rng.integers(200, 1500)) * dec] = 0
+    out_cap = 1 << int(rng.integers(12, 15))
+    max_step = (out_cap // 4) * dec                          # a block's channel samples + the chain's reach must fit its rings
+    cuts = [0]
+    while cuts[-1] < n:
+        cuts.append(min(n, cuts[-1] + int(rng.integers(1, max_step))))
+    attach_at = int(rng.integers(0, len(cuts) - 1)) if rng.random() < 0.5 else 0
+    got = []
+    with nat.Frontend(fs, block_capacity=max_step + 16, out_capacity=out_cap) as fe:
+        if kind == "direct":
+            cid = fe.chan_open(cr, f_sig)
+        else:
+            fe.pfb_open(nb, Db, proto)
+            cid = fe.pfb_chan_open(k, cr, delta) if kind == "stage2" else fe.pfb_tap_open(k, gr_phase=False)
+        k_attach = None
+        for b, (a, e) in enumerate(zip(cuts[:-1], cuts[1:])):
+            if b == attach_at:
+                k_attach = fe.chan_produced(cid)
+                host_audio.open_analog_voice(fe, cid, out_rate)
+            fe.push(x[a:e])
+            if k_attach is not None and rng.random() < 0.5:
+                got.append(fe.chan_read_audio(cid))
+        n_audio, n_ungated = fe.chan_audio_produced(cid)
+        got.append(fe.chan_read_audio(cid))
+    audio = np.concatenate(got)
+    if kind == "direct":
+        y = _oracle_life(x, fs, cr, [(0, f_sig)], 0, n)
+    elif kind == "tap":
+        y = G.xlating_fir_exact(x, Db, proto, f_sig, fs).astype(np.complex64)
+    else:
+        s1 = G.xlating_fir_exact(x, Db, proto, k * fs / nb, fs).astype(np.complex64)
+        y = _oracle_life(s1, fs / nb, cr, [(0, delta)], 0, len(s1))
+    if len(y) - k_attach < 64:                               # attached too late for the oracle's filters to have anything to do
+        assert len(audio) == n_audio <= 32
+        return
+    try:
+        st = A.analog_chain(y[k_attach:], out_rate, stages=True)
+    except ValueError:                                       # the squelch let nothing through: the oracle's filters have no input
+        assert n_ungated == 0 and len(audio) == n_audio == 0, (seed, kind, n_ungated, n_audio)
+        return
+    assert n_ungated == len(st["gated"]), (seed, kind, n_ungated, len(st["gated"]))
+    assert len(audio) == n_audio == len(st["audio"]), (seed, kind, len(audio), n_audio, len(st["audio"]))
+    if len(audio):
+        e = float(np.sqrt(np.mean((audio.astype(np.float64) - st["audio"]) ** 2)))
+        assert e < 1e-4, (seed, kind, e)
