@@ -117,6 +117,39 @@ run_case("scan_mode", [
     ("scan_mode_set_freq", (770000000,), ["success"]),
 ])
 
+# seeded random scripts: every call in every order, replies that succeed, refuse (na / fail), or are malformed, so that
+# the mirror's state machine (connect on first use, host kept or dropped, what is returned on a refusal) is pinned on
+# paths nobody wrote a case for
+rs = random.Random(20260929)
+for case in range(80):
+    script = []
+    for _ in range(rs.randint(1, 7)):
+        u = rs.random()
+        if u < 0.35:
+            rate, freq = rs.choice([12500, 25000, 6250]), rs.choice([855000000, 851012500, 100, 5000, 770000000])
+            kind = rs.random()
+            if kind < 0.6:
+                reps = ["connect,%d" % rs.randint(0, 99), "create,u-%d,%d" % (rs.randint(0, 999), rs.randint(10000, 60000))]
+            elif kind < 0.8:
+                reps = ["connect,%d" % rs.randint(0, 99), "na,%d" % freq]
+            else:
+                reps = ["connect,%d" % rs.randint(0, 99), rs.choice(["fail,1", "create,only-two", "garbage"])]
+            script.append(("create_channel", (rate, freq), reps))
+        elif u < 0.55:
+            script.append(("release_channel", (), [rs.choice(["release,u-1", "na,u-1", "fail,0"])]))
+        elif u < 0.75:
+            # (any other reply leaves the reference's report_offset holding its thread_lock for good: frontend_connector.py
+            #  falls off the end of the if / elif chain without releasing it -- the next call would never return)
+            script.append(("report_offset", (rs.choice([0.1, 0.25, 0.75, 1.5, -2.0, 0.0]),), [rs.choice(["offset,7", "na,7"])]))
+        elif u < 0.9:
+            script.append(("send", (rs.choice(["hb,7", "quit,7"]),), [rs.choice(["hb,7", "fail,7", "quit,7"])]))
+        else:
+            script.append(("scan_mode_set_freq", (rs.choice([770000000, 855000000]),), [rs.choice(["success", "fail"])]))
+    try:
+        run_case("random_%02d" % case, script)
+    except Exception as e:          # a script the reference itself cannot get through (e.g. a reply it cannot parse): not a golden
+        print("skipped random_%02d: %s: %s" % (case, type(e).__name__, e))
+
 # ---------------------------------------------------------------- rcm selection rule
 mgr = RCM.redis_channelizer_manager.__new__(RCM.redis_channelizer_manager)
 import logging
@@ -148,6 +181,24 @@ for name, table in tables.items():
         got = mgr.get_channelizer_for_frequency(q)
         golden["rcm"].append({"table": name, "channelizers": table, "frequency": q,
                               "result": list(got)})
+
+# seeded random tables and queries (overlapping sources, channelizers with several sources, queries on the band edges)
+for t in range(40):
+    table = {}
+    for c in range(rs.randint(1, 5)):
+        table["C%d" % c] = {"address": "10.0.%d.%d" % (t, c), "port": 5000 + c,
+                            "sources": [[rs.choice([851000000, 853000000, 855000000, 855900000, 860000000]) + rs.randint(-3, 3) * 100000,
+                                         rs.choice([2400000, 8000000, 10000000, 20000000])] for _ in range(rs.randint(1, 3))]}
+    mgr.channelizers = table
+    for _ in range(6):
+        cf, bw = rs.choice([s2 for c in table.values() for s2 in c["sources"]])
+        q = rs.choice([cf, cf + bw // 2, cf - bw // 2, cf + bw // 2 - 1, cf - bw // 2 + 1, cf + rs.randint(-bw, bw)])
+        random.seed(0)
+        try:
+            got = mgr.get_channelizer_for_frequency(q)
+        except Exception as e:
+            got = ("EXC", type(e).__name__)
+        golden["rcm"].append({"table": "random_%02d" % t, "channelizers": table, "frequency": q, "result": list(got)})
 
 with open(OUT, "w") as f:
     json.dump(golden, f, indent=1, sort_keys=True)

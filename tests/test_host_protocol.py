@@ -575,3 +575,20 @@ def test_rep_loop_survives_handler_errors_and_egress_isolates_channels():
     assert socks[23456].closed and not pump.prebound          # no live channel on 23456: swept
     pump.pump_once()
     assert pump.errors == 2 and socks[22222].sent == 64 and pump.bytes_out == 64
+
+
+def test_report_offset_survives_the_reply_that_wedges_the_reference():
+    """frontend_connector.py:170-185: a reply that is neither 'offset' nor 'na' falls off the reference's if / elif chain
+    with thread_lock still held -- its next call never returns (which is why the random golden scripts leave that reply
+    out).  The mirror returns the same value (None) and stays usable."""
+    sent, replies = [], []
+    fc = FC.frontend_connector("parent-uuid", FakeRCM(), transport_factory=lambda h, p: ScriptedSocket(replies, sent),
+                               heartbeat=False)
+    replies[:] = ["connect,7", "create,u-1,12345"]
+    assert fc.create_channel(12500, 855000000) == ("u-1", "12345")
+    replies[:] = ["fail,7"]
+    assert fc.report_offset(0.25) is None
+    replies[:] = ["offset,7"]
+    assert fc.report_offset(0.25) is True
+    replies[:] = ["release,u-1"]
+    assert fc.release_channel() == "u-1"
