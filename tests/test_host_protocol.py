@@ -592,3 +592,53 @@ def test_report_offset_survives_the_reply_that_wedges_the_reference():
     assert fc.report_offset(0.25) is True
     replies[:] = ["release,u-1"]
     assert fc.release_channel() == "u-1"
+
+
+HANDLER_GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "handler.json")))
+
+
+@pytest.mark.parametrize("sess", HANDLER_GOLD["sessions"], ids=lambda s: "seed%d" % s["seed"])
+def test_server_handler_replays_the_references_own_sessions(sess):
+    """tests/golden/handler.json was made by RUNNING the reference's nested handler(msg, tb) (rc_frontend/receiver.py:503-
+    614, extracted with ast: tests/golden/make_handler_goldens.py) on seeded random sessions against a recording top
+    block.  FrontendServer.handle must give the same reply -- or raise where the reference raises --, make the same
+    calls on the top block in the same order, and leave the same client tables, message by message."""
+    class FakeTB:
+        def __init__(self):
+            self.calls, self.n, self.channels, self.script = [], 0, {}, []
+
+        def connect_channel(self, channel_rate, freq):
+            self.calls.append(["connect_channel", channel_rate, freq])
+            if not self.script.pop(0):                           # what the generator's top block did on this very call
+                raise Exception("Unable to find source for frequency %s" % freq)
+            self.n += 1
+            self.channels["blk-%d" % self.n] = object()
+            return "blk-%d" % self.n, 10000 + self.n
+
+        def release_channel(self, block_id):
+            self.calls.append(["release_channel", block_id])
+            return True
+
+        def source_offset(self, block_id, offset):
+            self.calls.append(["source_offset", block_id, offset])
+            return True
+
+        def scan_mode_set_freq(self, freq):
+            self.calls.append(["scan_mode_set_freq", freq])
+            return True
+
+    tb = FakeTB()
+    srv = protocol.FrontendServer(tb, clock=lambda: 0.0)
+    for st in sess["steps"]:
+        tb.script[:] = list(st["connect_ok"])
+        del tb.calls[:]
+        try:
+            reply, exc = srv.handle(st["msg"]), None
+        except Exception as e:
+            reply, exc = None, type(e).__name__
+        assert exc == st["raises"], (st["msg"], exc, st["raises"])
+        assert reply == st["reply"], (st["msg"], reply, st["reply"])
+        assert tb.calls == st["calls"], (st["msg"], tb.calls, st["calls"])
+        assert {str(k): list(v) for k, v in srv.clients.items()} == st["clients"], st["msg"]
+        assert sorted(str(k) for k in srv.client_hb) == st["client_hb"], st["msg"]
+        assert srv.client_num == st["client_num"]
