@@ -200,6 +200,49 @@ for t in range(40):
             got = ("EXC", type(e).__name__)
         golden["rcm"].append({"table": "random_%02d" % t, "channelizers": table, "frequency": q, "result": list(got)})
 
+# ---------------------------------------------------------------- the registry record, as the reference publishes it
+# rc_frontend/redis_channel_publisher.py run with a recording redis pipeline and a ZMQ socket stub: one pass of its
+# publish loop, with and without a device index.  Volatile values (uuid, times, host, pid, address) are replaced by their
+# type names; everything a reader keys on is kept.
+sys.path.insert(0, os.path.join(REF, "rc_frontend"))
+zmq.LAST_ENDPOINT = 32
+ops = []
+
+
+class _Pipe:
+    def sadd(self, k, v): ops.append(["sadd", k, v])
+    def set(self, k, v): ops.append(["set", k, v])
+    def execute(self): ops.append(["execute"])
+
+
+_R.pipeline = lambda self: _Pipe()
+
+
+class _ZSock:
+    def getsockopt(self, opt): return b"tcp://0.0.0.0:47123"
+
+
+import redis_channel_publisher as RCP    # noqa: E402
+golden["publisher"] = []
+for index in (None, 3):
+    del ops[:]
+    srcs = {0: {"center_freq": 855050000, "samp_rate": 2400000}, 1: {"center_freq": 857000000.0, "samp_rate": 8000000}}
+    pub = RCP.redis_channel_publisher(sources=srcs, channels={"a": 1, "b": 2}, zmq_socket=_ZSock(), index=index)
+    t0 = time.time()
+    while not any(o[0] == "execute" for o in ops) and time.time() - t0 < 5:
+        time.sleep(0.05)
+    pub.continue_running = False
+    first = ops[:[o[0] for o in ops].index("execute") + 1]
+    rec = json.loads([o for o in first if o[0] == "set"][0][2])
+    volatile = ("instance_uuid", "start_time", "current_time", "hostname", "pid", "address")
+    golden["publisher"].append({
+        "index": index,
+        "sources": {str(k): v for k, v in srcs.items()}, "n_channels": 2, "port": 47123,
+        "ops": [[o[0]] + ([o[1]] if o[0] == "sadd" else []) for o in first],
+        "key_is_uuid_in_both_ops": first[0][2] == first[1][1] == rec["instance_uuid"],
+        "record": {k: (type(v).__name__ if k in volatile else v) for k, v in rec.items()},
+    })
+
 with open(OUT, "w") as f:
     json.dump(golden, f, indent=1, sort_keys=True)
 print("wrote", OUT, len(golden["connector"]), "connector cases,", len(golden["rcm"]), "rcm queries")

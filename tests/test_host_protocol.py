@@ -642,3 +642,26 @@ def test_server_handler_replays_the_references_own_sessions(sess):
         assert {str(k): list(v) for k, v in srv.clients.items()} == st["clients"], st["msg"]
         assert sorted(str(k) for k in srv.client_hb) == st["client_hb"], st["msg"]
         assert srv.client_num == st["client_num"]
+
+
+@pytest.mark.parametrize("case", GOLD["publisher"], ids=lambda c: "index_%s" % c["index"])
+def test_registry_record_is_the_references_record(case):
+    """tests/golden/protocol.json 'publisher': the record rc_frontend/redis_channel_publisher.py itself wrote (run here with
+    a recording redis and a ZMQ stub).  The mirror must SADD the same set, SET the same key, and the JSON must carry the
+    same keys with the same value types -- and the same values wherever they are not host- or time-dependent."""
+    ops = []
+
+    class Rec:
+        def sadd(self, k, v): ops.append(["sadd", k, v])
+        def set(self, k, v): ops.append(["set", k, v])
+
+    sources = {int(k): v for k, v in case["sources"].items()}
+    pub = registry.redis_channel_publisher(sources=sources, channels={i: i for i in range(case["n_channels"])},
+                                           port=case["port"], index=case["index"], client=Rec(), start_thread=False)
+    pub.publish_once()
+    assert [[o[0]] + ([o[1]] if o[0] == "sadd" else []) for o in ops] == [o for o in case["ops"] if o[0] != "execute"]
+    rec = json.loads(ops[1][2])
+    assert ops[0][2] == ops[1][1] == rec["instance_uuid"]
+    volatile = ("instance_uuid", "start_time", "current_time", "hostname", "pid", "address")
+    got = {k: (type(v).__name__ if k in volatile else v) for k, v in rec.items()}
+    assert got == case["record"]
