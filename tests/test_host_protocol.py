@@ -665,3 +665,69 @@ def test_registry_record_is_the_references_record(case):
     volatile = ("instance_uuid", "start_time", "current_time", "hostname", "pid", "address")
     got = {k: (type(v).__name__ if k in volatile else v) for k, v in rec.items()}
     assert got == case["record"]
+
+
+RECV_GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "receiver.json")))
+
+
+@pytest.mark.parametrize("sess", RECV_GOLD["sessions"], ids=lambda s: "%s-%d" % (s["config"], s["seed"]))
+def test_receiver_replays_the_references_own_sessions(sess):
+    """tests/golden/receiver.json was made by RUNNING rc_frontend/receiver.py's receiver class (GNU Radio, UHD and ZeroMQ
+    replaced by stand-ins: tests/golden/make_receiver_goldens.py) on seeded random sessions of connect_channel /
+    release_channel / source_offset.  rcf.receiver must choose the same source, compute the same offset, re-use the same
+    idle channel, draw the same port, accumulate the same drift correction and refuse the same requests, call by call.
+    One deliberate difference: with receiver_split2 the reference cannot create a channel at all (its half-band sources
+    are copied before 'source_id' is set: KeyError) -- there only the source table and the out-of-range refusals are held
+    against it; the working split2 path is tested against the two-stage oracle on the GPU."""
+    cfgd = RECV_GOLD["configs"][sess["config"]]
+    cfg = types.SimpleNamespace(sources={int(i): dict(s, type="synthetic") for i, s in cfgd["sources"].items()},
+                                frontend_mode="xlat", receiver_split2=cfgd["split2"])
+    StubFrontend.instances = []
+    random.seed(sess["seed"])
+    tb = receiver.receiver(cfg, frontend_factory=StubFrontend)
+    order = []
+
+    def snapshot():
+        chans = []
+        for bid in order:
+            if bid in tb.channels:
+                c = tb.channels[bid]
+                chans.append({"n": order.index(bid), "source_id": c.source_id, "channel_rate": c.channel_rate, "offset": c.offset,
+                              "in_use": c.in_use, "port": c.port, "idle": c.channel_close_time != 0})
+        return {"channels": chans,
+                "accumulated": {str(i): tb.sources[i].get("accumulated_offset") for i in tb.sources},
+                "sources": {str(i): [tb.sources[i]["center_freq"], tb.sources[i]["samp_rate"]] for i in tb.sources}}
+
+    try:
+        for st in sess["steps"]:
+            call = st["call"]
+            ref_broken = st["raises"] is not None and st["raises"].startswith("KeyError")      # split2 in the reference
+            try:
+                if call[0] == "connect_channel":
+                    bid, port = tb.connect_channel(call[1], call[2])
+                    if bid not in order and bid is not False:
+                        order.append(bid)
+                    ret = [order.index(bid) if bid in order else bid, port]
+                elif call[0] == "release_channel":
+                    ret = tb.release_channel(order[call[1]] if 0 <= call[1] < len(order) else "no-such-id")
+                else:
+                    ret = tb.source_offset(order[call[1]] if 0 <= call[1] < len(order) else "no-such-id", call[2])
+                exc = None
+            except Exception as e:
+                ret, exc = None, "%s: %s" % (type(e).__name__, e)
+            if cfgd["split2"]:
+                assert snapshot()["sources"] == st["after"]["sources"]
+                if not ref_broken and call[0] == "connect_channel":
+                    assert exc == st["raises"], (call, exc, st["raises"])                      # out of every source's band
+                continue
+            assert exc == st["raises"], (call, exc, st["raises"])
+            assert ret == st["returns"], (call, ret, st["returns"])
+            assert snapshot() == st["after"], (call, snapshot(), st["after"])
+            # what the reference told its SDR to tune to is centre + accumulated (+ the source's static offset): the
+            # mirror applies the same Hz to the channels' NCOs instead -- the accumulated value is the comparison
+            for i, freqs in st["tuned"].items():
+                src = tb.sources[int(i)]
+                assert freqs[-1] == src["center_freq"] + src["accumulated_offset"] + src.get("offset", 0)
+                assert src["block"].shift == pytest.approx(src["accumulated_offset"])
+    finally:
+        tb.close()
