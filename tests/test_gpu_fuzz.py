@@ -1390,3 +1390,24 @@ def test_random_voice_chains_on_every_kind_of_channel(gpu_required, seed):
     if len(audio):
         e = float(np.sqrt(np.mean((audio.astype(np.float64) - st["audio"]) ** 2)))
         assert e < 1e-4, (seed, kind, e)
+
+
+def test_device_picker_names_the_frequencies_the_reference_found(gpu_required):
+    """tests/golden/peaks.npz: what /root/reference/fft_peak_detection.py:44-73 itself found on 16 quantised spectra (the
+    statements run as they stand, tests/golden/make_peak_goldens.py).  The device picker on the same vectors, injected
+    into a finished scan's buffer, through rcf_peak_frequency."""
+    import ctypes as C
+    nat = gpu_required
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "peaks.npz"))
+    for i in range(len(g["meta"])):
+        x, want = g["spectrum_%02d" % i], [int(v) for v in g["freqs_%02d" % i]]
+        fs, fc = int(g["meta"][i][0]), int(g["meta"][i][1])
+        N = len(x)
+        with nat.Frontend(float(fs), float(fc), block_capacity=2 * N, hist_capacity=N) as fe:
+            fe.scan_start(N, 1, 1)
+            fe.push(synth.awgn(np.random.default_rng(i), N))
+            dev = C.c_void_p()
+            assert nat.lib().rcf_scan_result_device(fe._h, C.byref(dev)) == 0 and dev.value
+            _hip_memcpy_h2d(dev.value, x)
+            idx, _, _ = fe.scan_find_peaks(cap=4096)
+        assert [nat.peak_frequency(int(l), fs, N, fc) for l in idx] == want, i

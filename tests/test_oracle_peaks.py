@@ -71,3 +71,28 @@ def test_full_detect_three_ways(seed):
     if len(l0):
         hz = fs / n
         assert f0[0] == int(l0[0] * hz - fs / 2 + fc)
+
+
+def _peak_goldens():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "peaks.npz"))
+    return [(i, g["spectrum_%02d" % i], [int(v) for v in g["freqs_%02d" % i]], int(g["meta"][i][0]), int(g["meta"][i][1]))
+            for i in range(len(g["meta"]))]
+
+
+@pytest.mark.parametrize("case", _peak_goldens(), ids=lambda c: "spectrum%02d" % c[0])
+def test_detection_equals_the_references_own_run(case):
+    """tests/golden/peaks.npz holds what /root/reference/fft_peak_detection.py:44-73 ITSELF found (those statements lifted
+    out with ast and executed as they stand: tests/golden/make_peak_goldens.py) on quantised synthetic spectra.  The
+    scipy-backed restatement, the numpy one, the C one and the product's host picker must name the same frequencies."""
+    from rcf import native
+    _, x, want, fs, fc = case
+    l0, f0 = P.peak_detect_scipy(x, fs, fc)
+    assert [int(v) for v in f0] == want
+    l1, f1 = P.peak_detect_restated(x, fs, fc)
+    assert [int(v) for v in f1] == want
+    l2, _ = OC.peak_detect(x, fs)
+    assert [native.peak_frequency(int(l), fs, len(x), fc) for l in l2] == want
+    _, _, a, b = P.prologue(x, fs, len(x))
+    l3, _, _ = native.find_peaks(x, a, b)
+    assert [native.peak_frequency(int(l), fs, len(x), fc) for l in l3] == want
