@@ -119,11 +119,20 @@ def session(cfg_name, seed):
             call = ["release_channel", rs.choice(list(range(len(order))) + [-1])]
         else:
             call = ["source_offset", rs.choice(list(range(len(order))) + [-1]), rs.choice(OFFSETS)]
+        design = None
         try:
             if call[0] == "connect_channel":
+                gnuradio.filter.freq_xlating_fir_filter_ccc.reset_mock()
+                gnuradio.filter.firdes.low_pass_2.reset_mock()
                 bid, port = tb.connect_channel(call[1], call[2])
                 if bid not in order and bid is not False:
                     order.append(bid)
+                    # a NEW channel: what rc_frontend/channel.py:31-35 asked GNU Radio for (decimation, filter design
+                    # arguments, xlating offset and rate), read off the stand-ins
+                    xl = gnuradio.filter.freq_xlating_fir_filter_ccc.call_args[0]
+                    lp = gnuradio.filter.firdes.low_pass_2.call_args[0]
+                    design = {"decim": xl[0], "offset": xl[2], "samp_rate": xl[3], "low_pass_2": [float(v) for v in lp[:5]],
+                              "window_is_hamming": lp[5] is gnuradio.filter.firdes.WIN_HAMMING}
                 ret = [order.index(bid) if bid in order else bid, port]
             elif call[0] == "release_channel":
                 ret = tb.release_channel(order[call[1]] if call[1] >= 0 else "no-such-id")
@@ -132,7 +141,7 @@ def session(cfg_name, seed):
             exc = None
         except Exception as e:
             ret, exc = None, "%s: %s" % (type(e).__name__, e)
-        steps.append({"call": call, "returns": ret, "raises": exc, "tuned": {str(k): list(v) for k, v in tuned.items()},
+        steps.append({"call": call, "returns": ret, "raises": exc, "design": design, "tuned": {str(k): list(v) for k, v in tuned.items()},
                       "after": snapshot(tb, order)})
     return {"config": cfg_name, "seed": seed, "steps": steps}
 

@@ -723,6 +723,16 @@ def test_receiver_replays_the_references_own_sessions(sess):
             assert exc == st["raises"], (call, exc, st["raises"])
             assert ret == st["returns"], (call, ret, st["returns"])
             assert snapshot() == st["after"], (call, snapshot(), st["after"])
+            if st.get("design"):
+                # a new channel: the decimation and the filter design arguments rc_frontend/channel.py handed to GNU
+                # Radio (read off the stand-ins) against the C ABI's own rule and design call for that (rate, rate)
+                from rcf import native
+                d = st["design"]
+                ch = tb.channels[order[ret[0]]]
+                D, T = native.channel_params(d["samp_rate"], call[1])
+                assert D == d["decim"] and d["window_is_hamming"] and d["offset"] == ch.offset
+                assert d["low_pass_2"] == [1.0, float(d["samp_rate"]), call[1] / 2, call[1] / 2, 20.0]
+                assert T == len(native.design_low_pass_2(*d["low_pass_2"]))
             # what the reference told its SDR to tune to is centre + accumulated (+ the source's static offset): the
             # mirror applies the same Hz to the channels' NCOs instead -- the accumulated value is the comparison
             for i, freqs in st["tuned"].items():
