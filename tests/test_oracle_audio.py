@@ -123,3 +123,40 @@ def test_analog_chain_recovers_the_tone():
     hd = abs((b[0] + b[1] * np.exp(-1j * w)) / (1 + a[1] * np.exp(-1j * w)))
     assert abs(abs(c) - 8 * dev / 15000 * hd) < 0.02 * 8 * dev / 15000
     assert np.sqrt(np.mean((seg - np.real(c * np.exp(2j * math.pi * fm * m / 8000.0))) ** 2)) < 0.02
+
+
+def test_chain_parameters_are_the_ones_the_reference_hands_to_gnuradio():
+    """tests/golden/demod_params.json: the constructor arguments /root/reference/logging_receiver.py ('analog', 'p25') and
+    p25_control_demod.py (C4FM) pass to GNU Radio's blocks, read off MagicMock stand-ins while the reference's own
+    constructors ran (tests/golden/make_demod_param_goldens.py).  rcf.audio's defaults, the oracle's chain defaults and
+    the constants the P25 front-half tests use are those numbers."""
+    import inspect
+    import json
+    import math
+    import os
+    from oracle import grspec as G
+    from rcf import audio as host_audio, native
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "demod_params.json")))
+    an = gold["logging_receiver_analog"]
+    rate = an["fm_demod_cf"]["kwargs"]["channel_rate"]
+    assert rate == 25000 and an["rational_resampler_fff"]["kwargs"] == dict(interpolation=8000, decimation=rate, taps=None, fractional_bw=None)
+    d = inspect.signature(host_audio.analog_chain_params).parameters
+    sq = an["pwr_squelch_cc"]["args"]
+    assert [d["squelch_db"].default, d["squelch_alpha"].default] == sq[:2] and sq[2:] == [0, True]     # ramp 0, gate on
+    fm = an["fm_demod_cf"]["kwargs"]
+    assert (d["deviation"].default, d["gain"].default, d["tau"].default) == (fm["deviation"], fm["gain"], fm["tau"])
+    assert fm["audio_decim"] == 1 and fm["audio_pass"] == rate * 0.25 and fm["audio_stop"] == rate * 0.25 + 2000
+    assert d["audio_rate"].default == an["rational_resampler_fff"]["kwargs"]["interpolation"]
+    hp = an["high_pass"]["args"]
+    assert hp[:4] == [1, rate, 300, 30] and hp[5] == 6.76 and an["high_pass_window_is_hamming"]
+    p = host_audio.analog_chain_params(rate)
+    assert p["quad_gain"] == rate / (2 * math.pi * fm["deviation"])
+    np.testing.assert_array_equal(p["hpf_taps"], native.design_firdes(native.FIR_HIGH_PASS, 1.0, float(rate), 300.0, 30.0,
+                                                                        native.WIN_HAMMING, 6.76))
+    # the P25 front half (p25_control_demod.py:105-137; logging_receiver's 'p25' branch uses the same gain)
+    c4 = gold["p25_control_demod_c4fm"]
+    assert c4["low_pass_2"]["args"][:5] == [1.0, 25000, 6250.0, 500.0, 30.0] and c4["low_pass_2_window_is_blackman"]
+    assert c4["freq_xlating_fir_filter_ccc"]["args"][0] == 1 and c4["freq_xlating_fir_filter_ccc"]["args"][2:] == [0, 25000]
+    assert c4["quadrature_demod_cf"]["args"] == [G.p25_fm_gain(25000.0)] == gold["logging_receiver_p25"]["quadrature_demod_cf"]["args"]
+    assert c4["fir_filter_fff"]["args"] == [1, [1.0 / 5] * 5]
+    assert c4["moving_average_ff"]["args"][:2] == [10000, 1] and c4["multiply_const_vff"]["args"] == [[0.0001]]
