@@ -46,7 +46,7 @@ class _Finder:                                       # every other import that i
         top = name.split(".")[0]
         if top in sys.builtin_module_names or top in sys.stdlib_module_names or top in ("numpy", "scipy"):
             return None
-        if os.path.exists(os.path.join(REF, top + ".py")) and top in ("p25_control_demod", "logging_receiver"):
+        if os.path.exists(os.path.join(REF, top + ".py")) and top in ("p25_control_demod", "logging_receiver", "fft_vector"):
             return None
         return importlib.machinery.ModuleSpec(name, self)
 
@@ -129,6 +129,23 @@ for proto in ("analog", "p25"):
             "freq_xlating_fir_filter_ccc": args_of(gnuradio.filter.freq_xlating_fir_filter_ccc),
             "quadrature_demod_cf": args_of(gnuradio.analog.quadrature_demod_cf),
         }
+
+# ---------------------------------------------------------------- the scan flowgraph (fft_vector.py:31-60)
+sys.modules["gnuradio.fft.window"] = gnuradio.fft.window
+import fft_vector as FV                # noqa: E402
+edges = []
+_TopBlock.connect = lambda self, *ends: edges.append(ends)
+tbv = FV.fft_vector(0)
+names = {id(getattr(tbv, n)): n for n in dir(tbv) if n.startswith(("blocks_", "fft_", "zeromq_"))}
+golden["fft_vector"] = {
+    "samp_rate": tbv.samp_rate, "length": tbv.length,
+    "fft_vcc": args_of(gnuradio.fft.fft_vcc), "window_blackmanharris": args_of(gnuradio.fft.window.blackmanharris),
+    "window_passed_is_that_one": gnuradio.fft.fft_vcc.call_args[0][2] is gnuradio.fft.window.blackmanharris.return_value,
+    "stream_to_vector": args_of(gnuradio.blocks.stream_to_vector), "complex_to_mag_squared": args_of(gnuradio.blocks.complex_to_mag_squared),
+    "nlog10_ff": args_of(gnuradio.blocks.nlog10_ff), "moving_average_ff": args_of(gnuradio.blocks.moving_average_ff),
+    "head": args_of(gnuradio.blocks.head), "skiphead": args_of(gnuradio.blocks.skiphead),
+    "edges": sorted([names[id(a[0])], names[id(b[0])]] for a, b in edges),
+}
 
 with open(OUT, "w") as f:
     json.dump(golden, f, indent=1, sort_keys=True)

@@ -219,3 +219,33 @@ def test_the_two_restatements_build_the_same_composite_bits(seed):
     ct_n, incr_n = G.xlating_composite(taps, D, f0, fs)
     np.testing.assert_array_equal(ct_c.view(np.float32), ct_n.view(np.float32))
     assert np.complex64(incr_c) == np.complex64(incr_n)
+
+
+def test_scan_chain_is_the_flowgraph_the_reference_builds():
+    """tests/golden/demod_params.json 'fft_vector': /root/reference/fft_vector.py's own constructor run over stand-ins --
+    the blocks' arguments and who is connected to whom.  The oracle's scan_chain is that chain with those numbers:
+    stream -> vectors of 16384 -> forward FFT, Blackman-Harris window, shifted -> |.|^2 -> 1 log10(.) + 1 -> moving SUM of
+    100 vectors (scale 1) -> the 1000th vector only (head 1000, skiphead 999)."""
+    import inspect
+    import json
+    import os
+    fv = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "demod_params.json")))["fft_vector"]
+    d = inspect.signature(G.scan_chain).parameters
+    ours = (d["N"].default, d["n_frames"].default, d["avg_len"].default)
+    assert ours == (fv["length"], fv["head"]["args"][1], fv["moving_average_ff"]["args"][0]) == (16384, 1000, 100)
+    assert fv["fft_vcc"]["args"][0] == fv["length"] and fv["fft_vcc"]["args"][1] is True and fv["fft_vcc"]["args"][3] is True
+    assert fv["window_passed_is_that_one"] and fv["window_blackmanharris"]["args"] == [fv["length"]]
+    assert fv["nlog10_ff"]["args"] == [1, fv["length"], 1]
+    dl = inspect.signature(G.nlog10_ff).parameters
+    assert (dl["n"].default, dl["k"].default) == (1.0, 1.0)
+    assert fv["moving_average_ff"]["args"][:2] == [100, 1] and fv["moving_average_ff"]["args"][3] == fv["length"]
+    assert inspect.signature(G.moving_sum_ff).parameters["scale"].default == 1.0
+    assert fv["skiphead"]["args"][1] == fv["head"]["args"][1] - 1            # exactly one vector leaves: the last
+    nxt = dict(fv["edges"])
+    chain, b = [], "zeromq_sub_source_0"
+    while b in nxt:
+        chain.append(b)
+        b = nxt[b]
+    assert chain + [b] == ["zeromq_sub_source_0", "blocks_stream_to_vector_0", "fft_vxx_0", "blocks_complex_to_mag_squared_0",
+                           "blocks_nlog10_ff_0", "blocks_moving_average_xx_1", "blocks_head_0", "blocks_skiphead_0",
+                           "blocks_file_sink_0"]
