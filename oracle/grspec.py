@@ -14,6 +14,9 @@ against third-party implementations of the same mathematics (scipy.signal.firwin
 lfilter, numpy FFT: tests/test_oracle_thirdparty.py).  GNU Radio's float32 operation ORDER (tap-phase
 rounding, rotator iteration, VOLK summation) has no such twin and stays unpinned.  The live third-party
 oracles are ``scipy.signal.find_peaks`` (oracle/peaks.py) and ``scipy.signal.remez`` (oracle/audio.py).
+What the reference does in its own Python IS pinned, by running it in the build container (tests/golden/*.json|npz and
+the make_*_goldens.py beside them): the channel parameter rule and the arguments handed to GNU Radio's blocks
+(channel.py, p25_control_demod.py, logging_receiver.py, fft_vector.py), the peak detection, the control plane.
 
 Reference call sites each function follows (paths relative to /root/reference):
   * low_pass_2 / windows      rc_frontend/channel.py:33, p25_control_demod.py:106-108

@@ -2,6 +2,10 @@
 
 TEST INFRASTRUCTURE ONLY (see oracle/grspec.py header for the import rule).
 
+PINNED: tests/golden/peaks.npz holds what fft_peak_detection.py:44-73 ITSELF found on 16 synthetic spectra (those
+statements lifted out with ast and executed as they stand in the build container: tests/golden/make_peak_goldens.py);
+tests/test_oracle_peaks.py holds every restatement here, and the product's pickers, to those frequencies.
+
 Two restatements live here:
   * ``peak_detect_scipy``  -- lines 38-73 of the reference with the one third-party call it makes
     (``scipy.signal.find_peaks``, available in this image) left in place.  This is the LIVE oracle:
