@@ -200,6 +200,48 @@ for t in range(40):
             got = ("EXC", type(e).__name__)
         golden["rcm"].append({"table": "random_%02d" % t, "channelizers": table, "frequency": q, "result": list(got)})
 
+# ---------------------------------------------------------------- one pass of the manager's poll loop
+# redis_channelizer_manager.manager_loop (:79-124) run ONCE (its sleep ends the loop) over seeded random registry
+# contents: records of different ages around the 5 s expiry, with and without a device index, one key without a record.
+# Written: the registry before, the index the manager filters on, the channelizers it ends up with and what it removed.
+golden["rcm_poll"] = []
+for case in range(40):
+    now = 1000000.0
+    table, kv = set(), {}
+    for c in range(rs.randint(0, 6)):
+        uid = "uuid-%d-%d" % (case, c)
+        table.add(uid.encode())
+        if rs.random() < 0.1:
+            continue                                              # announced, record missing
+        rec = {"address": "10.0.0.%d" % c, "port": 5000 + c, "sources": [[855000000 + c * 1000000, 2400000]],
+               "current_time": now - rs.choice([0.0, 1.0, 4.9, 4.999, 5.0, 5.001, 6.0, 60.0])}
+        if rs.random() < 0.7:
+            rec["index"] = rs.choice([0, 1, 3])
+        kv[uid] = json.dumps(rec)
+    removed = []
+
+    class _Poll:
+        def smembers(self, k): return set(table)
+        def get(self, k): return kv.get(k.decode() if isinstance(k, bytes) else k)
+        def srem(self, k, v): removed.append(["srem", k, v])
+        def delete(self, k): removed.append(["delete", k])
+
+    m = RCM.redis_channelizer_manager.__new__(RCM.redis_channelizer_manager)
+    m.log = logging.getLogger("x")
+    m.clients = [_Poll()]
+    m.index = rs.choice([None, None, 0, 1, 3])
+    m.channelizers = {}
+    m.continue_running = True
+    real_time, real_sleep = RCM.time.time, RCM.time.sleep
+    RCM.time.time = lambda: now
+    RCM.time.sleep = lambda s: setattr(m, "continue_running", False)
+    try:
+        m.manager_loop()
+    finally:
+        RCM.time.time, RCM.time.sleep = real_time, real_sleep
+    golden["rcm_poll"].append({"now": now, "index": m.index, "members": sorted(t.decode() for t in table), "records": kv,
+                               "channelizers": m.channelizers, "removed": removed})
+
 # ---------------------------------------------------------------- the registry record, as the reference publishes it
 # rc_frontend/redis_channel_publisher.py run with a recording redis pipeline and a ZMQ socket stub: one pass of its
 # publish loop, with and without a device index.  Volatile values (uuid, times, host, pid, address) are replaced by their

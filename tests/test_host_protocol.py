@@ -741,3 +741,28 @@ def test_receiver_replays_the_references_own_sessions(sess):
                 assert src["block"].shift == pytest.approx(src["accumulated_offset"])
     finally:
         tb.close()
+
+
+@pytest.mark.parametrize("case", GOLD["rcm_poll"], ids=lambda c: "idx_%s_n%d" % (c["index"], len(c["members"])))
+def test_manager_poll_is_the_references_pass(case):
+    """One pass of /root/reference/redis_channelizer_manager.py's manager_loop, run here over seeded random registry contents
+    (tests/golden/protocol.json 'rcm_poll').  The mirror removes the same records from Redis (5 s, strictly older) and keeps
+    the same live ones under the same index filter.  Two things the reference does are NOT mirrored, both slips in its
+    loop: an expired record stays in ITS table until the next pass (`del channelizer[deletion]` deletes from the wrong
+    object), and a key whose record is missing takes on the record parsed just before it (`channelizer` is not reset)."""
+    table = [m.encode() for m in case["members"]]
+    removed = []
+
+    class R:
+        def smembers(self, k): return set(table)
+        def get(self, k): return case["records"].get(k.decode() if isinstance(k, bytes) else k)
+        def srem(self, k, v): removed.append(["srem", k, v])
+        def delete(self, k): removed.append(["delete", k])
+
+    mgr = registry.redis_channelizer_manager(index=case["index"], clients=[R()], start_thread=False)
+    mgr.poll_once(now=case["now"])
+    expired = {r[2] for r in case["removed"] if r[0] == "srem"}
+    ghosts = {k for k in case["channelizers"] if k not in case["records"]}      # the reference's carried-over record
+    assert sorted(map(tuple, removed)) == sorted(tuple(r) for r in case["removed"] if r[-1] not in ghosts)
+    want = {k: v for k, v in case["channelizers"].items() if k not in expired and k not in ghosts}
+    assert mgr.channelizers == want
