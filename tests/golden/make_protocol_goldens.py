@@ -63,6 +63,7 @@ sys.path.insert(0, REF)
 import frontend_connector as FC          # noqa: E402
 # the 0.25 s heartbeat thread (frontend_connector.py:197-229) would race the scripted replies; its
 # one request ('hb,<cid>', :210) is captured explicitly through the same send() path instead.
+_real_connection_handler = FC.frontend_connector.connection_handler
 FC.frontend_connector.connection_handler = lambda self: None
 import redis_channelizer_manager as RCM  # noqa: E402
 
@@ -149,6 +150,62 @@ for case in range(80):
         run_case("random_%02d" % case, script)
     except Exception as e:          # a script the reference itself cannot get through (e.g. a reply it cannot parse): not a golden
         print("skipped random_%02d: %s: %s" % (case, type(e).__name__, e))
+
+# ---------------------------------------------------------------- the heartbeat loop (frontend_connector.py:197-229)
+# run synchronously: its sleeps are counted instead of slept, the loop is stopped after a scripted number of beats.  Each
+# beat is answered 'hb', 'fail' (the channelizer forgot the client: teardown, init, connect again) or not at all.
+golden["heartbeat"] = []
+for case in range(30):
+    fc = FC.frontend_connector("parent-uuid", FakeRCM())
+    sent.clear()
+    replies[:] = ["connect,7", "create,u-1,12345"]
+    fc.create_channel(12500, 855000000)
+    beats = [rs.choice(["ok", "ok", "fail", "silent"]) for _ in range(rs.randint(1, 8))]
+    script = []
+    cid = 7
+    for b in beats:
+        if b == "ok":
+            script.append("hb,%d" % cid)
+        elif b == "fail":
+            cid += 1
+            script += ["fail,0", "connect,%d" % cid]
+        else:
+            cid += 1
+            script.append(None)                                   # no reply: recv raises, five tries, then reconnect
+            script.append("connect,%d" % cid)
+    script.append("quit,%d" % cid)
+    sent.clear()
+
+    # a silent beat makes send() try to receive five times: give it five timeouts
+    expanded = []
+    for v in script:
+        expanded += [None] * 5 if v is None else [v]
+    queue = list(expanded)
+
+    def recv2():
+        v = queue.pop(0)
+        if v is None:
+            raise Exception("timeout")
+        return v
+    _Sock.recv_string = lambda self: recv2()
+    n = {"beats": 0}
+    real_sleep = FC.time.sleep
+
+    def fake_sleep(t):
+        if t == 0.25:
+            n["beats"] += 1
+            if n["beats"] >= len(beats):
+                fc.continue_running = False
+    FC.time.sleep = fake_sleep
+    try:
+        _real_connection_handler(fc)
+    finally:
+        FC.time.sleep = real_sleep
+        _Sock.recv_string = lambda self: replies.pop(0)
+    golden["heartbeat"].append({"beats": beats, "replies": script,
+                                "requests": [s2 for k, s2 in sent if k == "REQ"],
+                                "connects": [s2 for k, s2 in sent if k == "CONNECT"],
+                                "client_id_after": fc.my_client_id})
 
 # ---------------------------------------------------------------- rcm selection rule
 mgr = RCM.redis_channelizer_manager.__new__(RCM.redis_channelizer_manager)

@@ -766,3 +766,39 @@ def test_manager_poll_is_the_references_pass(case):
     assert sorted(map(tuple, removed)) == sorted(tuple(r) for r in case["removed"] if r[-1] not in ghosts)
     want = {k: v for k, v in case["channelizers"].items() if k not in expired and k not in ghosts}
     assert mgr.channelizers == want
+
+
+@pytest.mark.parametrize("case", GOLD["heartbeat"], ids=lambda c: "-".join(c["beats"]))
+def test_heartbeat_loop_is_the_references(case):
+    """frontend_connector.py:197-229 run synchronously here (sleeps counted, not slept) over scripted beats -- answered,
+    refused ('fail': the channelizer forgot the client) or unanswered (five receive timeouts) -- then its quit.  The
+    mirror's beats send the same requests, reconnect at the same points to the same address and end with the same
+    client id."""
+    sent, connects = [], []
+    queue = []
+
+    class Sock:
+        def send_string(self, s): sent.append(s)
+        def recv_string(self):
+            v = queue.pop(0)
+            if v is None:
+                raise Exception("timeout")
+            return v
+        def close(self): pass
+
+    def factory(host, port):
+        connects.append("tcp://%s:%s" % (host, port))
+        return Sock()
+
+    fc = FC.frontend_connector("parent-uuid", FakeRCM(), transport_factory=factory, heartbeat=False)
+    queue[:] = ["connect,7", "create,u-1,12345"]
+    assert fc.create_channel(12500, 855000000) == ("u-1", "12345")
+    del sent[:], connects[:]
+    for v in case["replies"]:
+        queue += [None] * 5 if v is None else [v]
+    for _ in case["beats"]:
+        fc.heartbeat_once()
+    fc._call("quit", fc.my_client_id)
+    assert sent == case["requests"]
+    assert connects == case["connects"]
+    assert fc.my_client_id == case["client_id_after"]
