@@ -129,7 +129,85 @@ def session(seed):
     return {"seed": seed, "steps": steps}
 
 
-golden = {"sessions": [session(s) for s in range(120)]}
+# ---------------------------------------------------------------- the main loop's housekeeping (receiver.py:620-680)
+# The `while 1:` statement under __main__ -- 10 s status, idle-channel sweep, 5 s client-heartbeat expiry, then a
+# non-blocking receive -- lifted out the same way and run for ONE turn at a scripted time (the receive raises zmq.Again,
+# the sleep that follows ends the loop) over seeded random client tables and channel tables.
+loop = None
+for node in ast.walk(tree):
+    if isinstance(node, ast.While) and isinstance(node.test, ast.Constant) and node.test.value == 1:
+        loop = node
+assert loop is not None, "no main loop in the reference"
+loop_code = compile(ast.Module(body=[loop], type_ignores=[]), REF, "exec")
+
+
+class _Stop(Exception):
+    pass
+
+
+def tick_case(seed):
+    rs = random.Random(10000 + seed)
+    now = 5000.0 + rs.random() * 100
+
+    class Again(Exception):
+        pass
+
+    released, destroyed = [], []
+
+    class Chan:
+        def __init__(self, bid, close_time):
+            self.block_id, self.channel_close_time = bid, close_time
+
+        def destroy(self):
+            destroyed.append(self.block_id)
+
+    class TB:
+        pass
+    tb = TB()
+    tb.channel_idle_timeout = 10
+    tb.last_channel_cleanup = now - rs.choice([0.0, 5.0, 19.9, 20.1, 45.0])
+    tb.channels = {}
+    for i in range(rs.randint(0, 6)):
+        bid = "blk-%d" % i
+        tb.channels[bid] = Chan(bid, rs.choice([0, 0, now - 1.0, now - 9.9, now - 10.1, now - 60.0]))
+    tb.release_channel = lambda bid: released.append(bid) or True
+    clients, client_hb = {}, {}
+    for c in range(rs.randint(0, 5)):
+        if rs.random() < 0.9:
+            clients[c] = ["blk-%d" % rs.randint(0, 6) for _ in range(rs.randint(0, 3))]
+        if rs.random() < 0.9:
+            client_hb[c] = now - rs.choice([0.0, 1.0, 4.9, 5.1, 30.0])
+    before = {"clients": {str(k): list(v) for k, v in clients.items()}, "client_hb": {str(k): v for k, v in client_hb.items()},
+              "channels": {k: v.channel_close_time for k, v in tb.channels.items()},
+              "last_channel_cleanup": tb.last_channel_cleanup, "last_status": None}
+    last_status = now - rs.choice([0.0, 9.9, 10.1, 100.0])
+    before["last_status"] = last_status
+
+    def sleep(t):
+        raise _Stop()
+
+    class Sock:
+        def recv_string(self, flags=0):
+            raise Again()
+
+    g = {"clients": clients, "client_hb": client_hb, "tb": tb, "log": logging.getLogger("golden"),
+         "time": types.SimpleNamespace(time=lambda: now, sleep=sleep), "zmq": types.SimpleNamespace(Again=Again, NOBLOCK=1),
+         "socket": Sock(), "last_status": last_status, "start_time": now - 1000.0, "handler": None,
+         "__builtins__": __builtins__}
+    raised = None
+    try:
+        exec(loop_code, g)
+    except _Stop:
+        pass
+    except Exception as e:                               # the reference's loop lets a KeyError out (client_hb without clients)
+        raised = type(e).__name__
+    return {"seed": seed, "now": now, "before": before, "raises": raised, "released": released, "destroyed": destroyed,
+            "after": {"clients": {str(k): list(v) for k, v in clients.items()}, "client_hb": sorted(str(k) for k in client_hb),
+                      "channels": sorted(tb.channels), "last_channel_cleanup": tb.last_channel_cleanup,
+                      "last_status": g["last_status"]}}
+
+
+golden = {"sessions": [session(s) for s in range(120)], "ticks": [tick_case(s) for s in range(150)]}
 with open(OUT, "w") as f:
     json.dump(golden, f, indent=0, sort_keys=True)
 print("wrote", OUT, len(golden["sessions"]), "sessions,", sum(len(s["steps"]) for s in golden["sessions"]), "messages")

@@ -802,3 +802,42 @@ def test_heartbeat_loop_is_the_references(case):
     assert sent == case["requests"]
     assert connects == case["connects"]
     assert fc.my_client_id == case["client_id_after"]
+
+
+@pytest.mark.parametrize("case", HANDLER_GOLD["ticks"], ids=lambda c: "seed%d" % c["seed"])
+def test_server_tick_is_one_turn_of_the_references_main_loop(case):
+    """tests/golden/handler.json 'ticks': the `while 1:` statement under rc_frontend/receiver.py's __main__ (:620-699) lifted
+    out with ast and run for one turn at a scripted time over seeded random client / heartbeat / channel tables.
+    FrontendServer.tick + receiver.sweep_idle_channels must release the same channels of the same expired clients, destroy
+    the same idle channels, and leave the same tables and timers.  Where the reference's loop dies (a heartbeat entry
+    without a client entry: KeyError out of the main loop) the mirror must simply not."""
+    import threading
+    b = case["before"]
+    released, destroyed = [], []
+
+    class Chan:
+        def __init__(self, bid, close_time):
+            self.block_id, self.channel_close_time = bid, close_time
+
+        def destroy(self):
+            destroyed.append(self.block_id)
+
+    tb = types.SimpleNamespace(access_lock=threading.RLock(), channel_idle_timeout=10,
+                               last_channel_cleanup=b["last_channel_cleanup"],
+                               channels={k: Chan(k, v) for k, v in b["channels"].items()},
+                               release_channel=lambda bid: released.append(bid) or True)
+    tb.sweep_idle_channels = lambda now=None: receiver.receiver.sweep_idle_channels(tb, now)
+    srv = protocol.FrontendServer(tb, clock=lambda: case["now"])
+    srv.clients = {int(k): list(v) for k, v in b["clients"].items()}
+    srv.client_hb = {int(k): v for k, v in b["client_hb"].items()}
+    srv.last_status = b["last_status"]
+    srv.tick(case["now"])
+    if case["raises"] is not None:
+        return                                                   # the reference crashed here; the mirror came through
+    a = case["after"]
+    assert released == case["released"]
+    assert sorted(destroyed) == sorted(case["destroyed"])
+    assert sorted(tb.channels) == a["channels"]
+    assert {str(k): list(v) for k, v in srv.clients.items()} == a["clients"]
+    assert sorted(str(k) for k in srv.client_hb) == a["client_hb"]
+    assert srv.last_status == a["last_status"] and tb.last_channel_cleanup == a["last_channel_cleanup"]
