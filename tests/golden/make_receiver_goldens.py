@@ -63,6 +63,8 @@ CONFIGS = {
         0: dict(type="usrp", device_addr="a", otw_format="sc16", args="", samp_rate=8000000, center_freq=854000000, rf_gain=10, offset=1200),
         1: dict(type="usrp", device_addr="b", otw_format="sc16", args="", samp_rate=2400000, center_freq=857000000, rf_gain=10),
         2: dict(type="usrp", device_addr="c", otw_format="sc16", args="", samp_rate=10000000, center_freq=862000000, rf_gain=10)}),
+    "scan_mode": dict(split2=False, scan_mode=True, sources={
+        0: dict(type="usrp", device_addr="a", otw_format="sc16", args="", samp_rate=2400000, center_freq=855050000, rf_gain=10)}),
     "split2": dict(split2=True, sources={
         0: dict(type="usrp", device_addr="a", otw_format="sc16", args="", samp_rate=8000000, center_freq=855000000, rf_gain=10)}),
 }
@@ -71,7 +73,7 @@ FREQS = [855050000, 854987500, 855500000, 856100000, 857000000, 857900000, 85830
 OFFSETS = [0.1, 0.25, 0.6, 0.9, 1.0, 1.2, 1.5, 2.0, -0.3, -0.75, -1.01, -2.5, 3.0, -4.0, 0.0, 130.0]
 
 sys.path.insert(0, REF)
-golden = {"configs": {k: {"split2": v["split2"], "sources": {str(i): s for i, s in v["sources"].items()}} for k, v in CONFIGS.items()},
+golden = {"configs": {k: {"split2": v["split2"], "scan_mode": bool(v.get("scan_mode")), "sources": {str(i): s for i, s in v["sources"].items()}} for k, v in CONFIGS.items()},
           "sessions": []}
 
 
@@ -97,6 +99,8 @@ def session(cfg_name, seed):
             self.sources = copy.deepcopy(cfg["sources"])
             self.frontend_mode = "xlat"
             self.receiver_split2 = cfg["split2"]
+            if cfg.get("scan_mode"):
+                self.scan_mode = True
     config.rc_config = rc_config
     sys.modules["config"] = config
     for m in ("receiver", "channel"):
@@ -114,7 +118,8 @@ def session(cfg_name, seed):
         u = rs.random()
         tuned.clear()
         if u < 0.5 or not order:
-            call = ["connect_channel", rs.choice([12500, 12500, 25000]), rs.choice(FREQS)]
+            call = ["connect_channel", rs.choice([12500, 12500, 25000]),
+                    rs.choice(FREQS if not cfg.get("scan_mode") else [5000, -250000, 100, 600000, 855050000, 1100000, 0])]
         elif u < 0.8:
             call = ["release_channel", rs.choice(list(range(len(order))) + [-1])]
         else:

@@ -681,7 +681,7 @@ def test_receiver_replays_the_references_own_sessions(sess):
     against it; the working split2 path is tested against the two-stage oracle on the GPU."""
     cfgd = RECV_GOLD["configs"][sess["config"]]
     cfg = types.SimpleNamespace(sources={int(i): dict(s, type="synthetic") for i, s in cfgd["sources"].items()},
-                                frontend_mode="xlat", receiver_split2=cfgd["split2"])
+                                frontend_mode="xlat", receiver_split2=cfgd["split2"], scan_mode=cfgd.get("scan_mode", False))
     StubFrontend.instances = []
     random.seed(sess["seed"])
     tb = receiver.receiver(cfg, frontend_factory=StubFrontend)
