@@ -31,8 +31,13 @@ the slice, <= 1024 peaks per rank into the all-gather); the default (cfg4) is co
 `sustained`: the metric says "sustained" -- after the timed region the same commit loop runs for >= 2 s and reports the
 filterbank launch time per window of 100 launches (first, last, slowest) with the shader clock read from sysfs.
 
-Launch: python bench.py [--gpus 1 --steps K --warmup W]   or, for N > 1,
-        python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Launch: python bench.py [--gpus N --steps K --warmup W].  For N > 1 either a launcher starts the ranks
+        (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...: RANK / LOCAL_RANK /
+        WORLD_SIZE / MASTER_* come from the environment), or -- when WORLD_SIZE is not set -- bench.py starts its own
+        N rank processes (one per GPU, the way the reference starts one channelizer process per source:
+        rc_frontend/receiver.py:67-70, systemd/radiocapture-channelizer@.service:11), waits for them and relays rank
+        0's line.  Fewer than N visible devices is an error (rc 2), not a silent downgrade; RCF_BENCH_DEVICE=<d> puts
+        every rank on device d (the N > 1 code on a 1-GPU box: host transport, RCCL cannot span one device twice).
 """
 import argparse
 import json
@@ -481,6 +486,82 @@ def control_plane_leg(device):
                     "+ protocol; channel buffers come from the handle's slab pool"}
 
 
+# ------------------------------------------------------------------------------------------------ rank launcher
+def load_native():
+    """librcf's ctypes layer.  RCF_BENCH_NATIVE=<module> swaps in another module with the same surface: the CPU test of
+    the launcher (tests/test_bench_launcher.py) runs the whole N-rank protocol over a stub Frontend that way."""
+    name = os.environ.get("RCF_BENCH_NATIVE")
+    if name:
+        import importlib
+        return importlib.import_module(name)
+    from rcf import native
+    return native
+
+
+def spawn_ranks(n, argv, timeout_s=3600.0):
+    """--gpus n > 1 and no launcher around us: start n rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, HIP_VISIBLE_DEVICES untouched, device = local rank), relay rank 0's stdout, return
+    the first non-zero exit code (the other ranks are then terminated by pid)."""
+    import socket
+    import subprocess
+    native = load_native()
+    have = native.device_count()
+    if have < n and "RCF_BENCH_DEVICE" not in os.environ:
+        print("bench.py: --gpus %d but %d HIP device(s) visible: refusing to measure fewer GPUs than asked for "
+              "(RCF_BENCH_DEVICE=<d> runs every rank on device d)" % (n, have), file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RCF_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    deadline = time.time() + timeout_s
+    rc, out0 = 0, b""
+    pending = set(range(n))
+    try:
+        while pending and rc == 0:
+            for r in sorted(pending):
+                if r == 0:
+                    try:                               # drain rank 0's pipe while waiting (its line can be > 64 KB)
+                        o, _ = procs[0].communicate(timeout=0.2)
+                        out0 += o or b""
+                    except subprocess.TimeoutExpired:
+                        continue
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    rc = code
+                    print("bench.py: rank %d exited with %d" % (r, code), file=sys.stderr)
+                    break
+            if time.time() > deadline:
+                rc = 124
+                print("bench.py: ranks still running after %.0f s" % timeout_s, file=sys.stderr)
+            time.sleep(0.05)
+    finally:
+        for r in pending:
+            if procs[r].poll() is None:
+                procs[r].terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if rc == 0 and not out0.strip():
+        print("bench.py: rank 0 printed no line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 # ------------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -502,6 +583,8 @@ def main():
     ap.add_argument("--sweep-max", type=int, default=196608, help="largest direct-bank channel count to open")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -511,9 +594,12 @@ def main():
     if args.gpus != n_gpus and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
 
-    from rcf import multigpu, native, synth
+    from rcf import multigpu, synth
+    native = load_native()
     if native.device_count() < 1:
         raise RuntimeError("bench.py needs an MI355X (no HIP device visible)")
+    if native.device_count() <= local_rank:
+        raise RuntimeError("rank %d: device %d asked for, %d visible" % (rank, local_rank, native.device_count()))
 
     cfg5 = args.config == "cfg5"
     # cfg5 (BASELINE configs[4]): 8 spectrum slices of 25 Msps, a 512-bin bank each = 4096 channels at 200 Msps
@@ -531,6 +617,7 @@ def main():
                          out_capacity=out_cap)
     group = None
     use_rccl = os.environ.get("RCF_BENCH_TRANSPORT", "rccl") == "rccl"
+    rccl_ranks, rccl_proof = 0, None
     if world > 1:
         group = multigpu.HostGroup(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
                                    int(os.environ.get("MASTER_PORT", "29500")) + 101)
@@ -555,6 +642,18 @@ def main():
             use_rccl = all(p == b"1" for p in group.all_gather(b"1" if ok else b"0"))
             if not use_rccl:
                 fe.comm_destroy()
+        if use_rccl:
+            # prove the communicator BEFORE anything is timed: one ncclAllGather of the rank numbers and one
+            # ncclAllReduce(max) over all `world` GPUs; a run whose RCCL ring does not work fails here, loudly
+            rccl_ranks = fe.comm_size()
+            parts = fe.allgather_peaks(np.array([rank], dtype=np.int64), 8)
+            seen = [int(p[0]) if len(p) else -1 for p in parts]
+            top = fe.allreduce_max(float(rank))
+            if rccl_ranks != world or seen != list(range(world)) or top != float(world - 1):
+                raise RuntimeError("RCCL proof failed on rank %d: comm size %d of %d, all-gather %s, all-reduce max %s"
+                                   % (rank, rccl_ranks, world, seen, top))
+            rccl_proof = {"allgather_of_rank_numbers": seen, "allreduce_max_of_rank_numbers": top,
+                          "when": "before the warm-up steps"}
     taps = proto_taps(native, fs, nb)
     fe.pfb_open(nb, nb, taps)
     if cfg5:
@@ -608,6 +707,9 @@ def main():
     fe.sync()
     t1 = time.perf_counter()
     elapsed = barrier_max(t1 - t0)
+    import struct
+    per_rank_ms = [(t1 - t0) / args.steps * 1e3] if group is None else \
+        [struct.unpack("<d", p)[0] / args.steps * 1e3 for p in group.all_gather(struct.pack("<d", t1 - t0))]
 
     pfb_ms, pfb_n = fe.timing_read(native.T_PFB)
     fe.timing_stride(1)
@@ -703,7 +805,7 @@ def main():
             workload = ("BASELINE configs[4], per-GPU shape: 512-bin critically-sampled PFB (6981-tap prototype) over "
                         "one 25 Msps cf32 spectrum slice per GPU (x8 = 4096 channels at 200 Msps), N=2^20 scan of the "
                         "slice + <=1024 peaks per rank into the all-gather outside the timed region")
-            kname = "pfb_kernel_pp<512,1,14,...> (persistent form)"
+            kname = "pfb_kernel_2b<256, 14, 3, false> (512 bins: 256-thread workgroups, two branches per thread)"
         else:
             workload = ("BASELINE configs[1]: 256-bin critically-sampled PFB (3491-tap prototype) over one "
                         "20 Msps cf32 stream per GPU, stage-2 xlating FIR /3 + FM discriminator on 32 active bins")
@@ -718,6 +820,12 @@ def main():
             "prewarm": {"seconds": args.prewarm_seconds, "untimed_steps": n_prewarm,
                         "why": "steady state before the W warm-up steps (metric: sustained); see `sustained`"},
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_by_rank": per_rank_ms,
+            "ranks_started_by": ("bench.py itself (one process per GPU)" if os.environ.get("RCF_BENCH_SPAWNED")
+                                 else "the launcher's environment (RANK / WORLD_SIZE)") if world > 1 else "single process",
+            "rccl_ranks": rccl_ranks if world > 1 else 1,
+            "transport": ("rccl" if use_rccl else "host-tcp") if world > 1 else "none (one rank)",
+            "rccl_proof": rccl_proof,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -41,6 +41,8 @@ constexpr int F = 16;   // frames per LDS chunk
 int env_int(const char *name, int dflt);
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 template <int NB> struct Plan;
 template <> struct Plan<64>   { static constexpr int n = 2; static constexpr int r[3] = {16, 4, 1}; };
@@ -63,7 +65,7 @@ __device__ __forceinline__ void wave_sync()
 // When NB/R divides 64 every frame's butterflies sit in a single wavefront (frame = b / (NB/R)), so
 // the read->write hazard of the in-place pass is wave-local; END_WG says whether the NEXT consumer of
 // the buffer uses a different frame->wave map (then the trailing barrier must be workgroup-wide).
-template <int NB, int R, int NS, bool END_WG>
+template <int NB, int R, int NS, bool END_WG, int TWS = 1>
 __device__ __forceinline__ void pfb_pass(cf *buf, const cf *tw_lds, int tid)
 {
     constexpr bool WAVE_LOCAL = (64 % (NB / R)) == 0;
@@ -83,7 +85,7 @@ __device__ __forceinline__ void pfb_pass(cf *buf, const cf *tw_lds, int tid)
         const int k = j & (NS - 1);
 #pragma unroll
         for (int t = 1; t < R; ++t) {
-            const cf w = tw_lds[(k * t) * (NB / (NS * R))];   // exact table entry e^{+2 pi i k t / (NS R)}
+            const cf w = tw_lds[(k * t) * (NB / (NS * R)) * TWS];   // exact table entry e^{+2 pi i k t / (NS R)}
 #pragma unroll
             for (int i = 0; i < CNT; ++i) v[i][t] = cmul(v[i][t], w);
         }
@@ -100,13 +102,14 @@ __device__ __forceinline__ void pfb_pass(cf *buf, const cf *tw_lds, int tid)
 }
 
 // the FFT passes over the chunk in LDS (after the barrier that follows the branch sums' LDS writes)
-template <int NB>
+// TWS: the table holds e^{+2 pi i n / (TWS NB)} (the two-branch kernel keeps ONE table, of the whole bank's size)
+template <int NB, int TWS = 1>
 __device__ __forceinline__ void pfb_fft(cf *buf, const cf *tw_lds, int tid)
 {
     using PL = Plan<NB>;
-    pfb_pass<NB, PL::r[0], 1, (PL::n < 2 || PL::r[1] != PL::r[0])>(buf, tw_lds, tid);
+    pfb_pass<NB, PL::r[0], 1, (PL::n < 2 || PL::r[1] != PL::r[0]), TWS>(buf, tw_lds, tid);
     if constexpr (PL::n >= 2)
-        pfb_pass<NB, PL::r[1], PL::r[0], (PL::n < 3 || PL::r[2] != PL::r[1])>(buf, tw_lds, tid);
+        pfb_pass<NB, PL::r[1], PL::r[0], (PL::n < 3 || PL::r[2] != PL::r[1]), TWS>(buf, tw_lds, tid);
     // a third pass (radix 2 for 512 bins, 4 for 1024) is NOT run over LDS: its butterfly j reads and writes
     // the same R3 positions j + t NB/R3, and those are exactly the bins one epilogue lane handles (bins
     // k0 + i NB/F), so it is done in registers on the way out -- one LDS round trip and two barriers less
@@ -358,6 +361,199 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_pp(PfbLaunch p, int n_chu
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Two-branch form for critically sampled banks of NB = 2 NH >= 512 bins: the workgroup is NH threads -- the size, the LDS
+// footprint and therefore the residency (four independent workgroups per CU at 512 bins, two at 1024) of the kernel for
+// HALF as many bins -- and thread r owns the two ADJACENT branches 2r and 2r + 1:
+//   * x[mD - 2r - 1], x[mD - 2r] are one 16-byte load: half the load instructions, a wavefront reads 1 KB contiguous;
+//   * decimation in time over the branch index: out[k'] = E[k'] + W_NB^{k'} O[k'], out[k' + NH] = E[k'] - W_NB^{k'} O[k']
+//     with E / O the NH-point transforms of the even / odd branch sums.  The two transforms go through the SAME
+//     16-frame LDS buffer one after the other (the odd sums wait in their 32 registers while E is transformed, E's
+//     transposed read-back waits in 32 while O is), and the combine is done in registers on the way out -- the
+//     radix-2 pass the persistent form ran as its epilogue, now between two half-size transforms;
+//   * the ring's tile is unchanged: bins k' and k' + NH of the lane's 16 frames leave as whole 128-byte lines, four
+//     consecutive bins of a wavefront store = 512 contiguous bytes, in both halves of the tile.
+// What the 512-thread persistent form could not get: its two barrier-coupled workgroups per CU leave the memory pipe
+// idle whenever both are inside their transforms; four independent half-size workgroups overlap their phases the way
+// the 256-bin kernel's do.
+template <int NH>
+__device__ __forceinline__ void pfb2_read_bins(const cf *buf, const cf *tw_lds, int k0, int f_lane, cf (&vv)[F])
+{
+    using PL = Plan<NH>;
+    constexpr int RS = row_stride<NH>();
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+        const int k = k0 + i * (NH / F);
+        vv[i] = ((NH / F) % 16 == 0) ? buf[f_lane * RS + lds_pad(k0) + i * ((NH / F) + (NH / F) / 16)]
+                                     : buf[f_lane * RS + lds_pad(k)];
+    }
+    if constexpr (PL::n >= 3) {                      // the NH-point transform's own last pass, in registers (as pfb_epilogue)
+        constexpr int R3 = PL::r[2];
+#pragma unroll
+        for (int i = 0; i < F / R3; ++i) {
+            const int j = k0 + i * (NH / F);
+            cf w[R3];
+#pragma unroll
+            for (int t = 0; t < R3; ++t) w[t] = vv[i + t * (F / R3)];
+#pragma unroll
+            for (int t = 1; t < R3; ++t) w[t] = cmul(w[t], tw_lds[2 * ((j * t) & (NH - 1))]);
+            Dft<R3, +1>::run(w);
+#pragma unroll
+            for (int f = 0; f < R3; ++f) vv[i + f * (F / R3)] = w[Dft<R3, +1>::reg_of(f)];
+        }
+    }
+}
+
+template <int NH, int P, int MINW, bool ZH>
+__global__ __launch_bounds__(NH, MINW) void pfb_kernel_2b(PfbLaunch p, int n_wg)
+{
+    constexpr int NB = 2 * NH, D = NB;
+    constexpr int HALO = P - 1;
+    constexpr int W = F + HALO;
+    // rows in flight per thread: measured on the chip (block 2^25, P = 14), 512 bins: G = 4 single-buffered 0.575 of the
+    // HBM peak (= the persistent form it replaces), 6: 0.61, 8: 0.635, 4 + 4 double-buffered 0.625, and at THREE
+    // workgroups per CU (168 VGPRs) 8 + 8 double-buffered 0.65 (6 + 6, 10 + 10, 16 single: the same within 1 %);
+    // 1024 bins (512-thread workgroups, 128 VGPRs): 4 + 4 double-buffered 0.59, 8 single 0.585, 4 single 0.525
+    constexpr int G = ZH ? 4 : (NH == 256 ? 8 : 4);
+    constexpr bool DB = !ZH;
+    constexpr int RS = row_stride<NH>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+    cf *tw_lds = buf + F * RS;                       // e^{+2 pi i n / NB}, n < NB
+
+    const int tid = threadIdx.x;
+    if (p.rider_n8[0] + p.rider_n8[1] && (int)blockIdx.x < kPfbRiderWgs)
+        pfb_copy_rider(p, blockIdx.x, min(kPfbRiderWgs, (int)gridDim.x), tid, NH);
+    int wg;
+    if (n_wg < 0) {
+        wg = blockIdx.x;
+    } else {
+        const int b = blockIdx.x, q = n_wg / 8, r = n_wg % 8, xcd = b % 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    }
+    const int fb0 = wg * F;
+    if (fb0 >= p.n_frames) return;
+    const int nf = min(F, p.n_frames - fb0);
+    const int64_t n0 = p.n_lo + fb0;
+
+    tw_lds[tid] = p.tw[tid];
+    tw_lds[tid + NH] = p.tw[tid + NH];
+    float he[P], ho[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const float2 hh = *reinterpret_cast<const float2 *>(p.ptaps + q * NB + 2 * tid);
+        he[q] = hh.x;
+        ho[q] = hh.y;
+    }
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cf *>(p.src.base), 0, (int)(p.src_len * (int64_t)sizeof(cf)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.bins_ring, 0, (int)((int64_t)((p.ring_mask + 1) >> kPfbTileLog2) * p.tile_pitch * (int64_t)sizeof(cf)), 0x00020000);
+    const int64_t m_min_e = (p.start_sample + 2 * tid + D - 1) / D;
+    const int64_t m_min_o = (p.start_sample + 2 * tid + 1 + D - 1) / D;
+    const int64_t m0 = n0 - HALO;
+    // rows of this chunk's window that still lie before the stream's start, per branch (zero-history launches only)
+    const int jz_e = (int)max((int64_t)0, min((int64_t)W, m_min_e - m0));
+    const int jz_o = (int)max((int64_t)0, min((int64_t)W, m_min_o - m0));
+    // the 16 bytes at sample m D - 2 tid - 1: .xy = the odd branch's sample, .zw = the even branch's
+    const int vo_in = (int)((m0 * D - 2 * tid - 1 - p.src.origin) * (int64_t)sizeof(cf));
+
+    float er[F], ei[F], orr[F], oi[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) er[f] = ei[f] = orr[f] = oi[f] = 0.f;
+    // Rows in groups of G; with DB the NEXT group's loads are issued before the current group's FMAs (two groups of
+    // registers), without it a group is loaded, waited for and consumed.  The schedule is fully unrolled, and left
+    // alone the scheduler hoists seventeen 16-byte loads above the first FMA (68 VGPRs of rows) and spills the
+    // accumulators: sched_barrier pins the group structure.
+    constexpr int NG = (W + G - 1) / G;
+    v4f xb[DB ? 2 : 1][G];
+    auto load_group = [&](v4f (&x)[G], int j0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            x[g] = (v4f)(0.f);
+            if (j0 + g < W) {
+                const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, vo_in, (j0 + g) * D * (int)sizeof(cf), 0);
+                x[g].x = __uint_as_float(r.x);
+                x[g].y = __uint_as_float(r.y);
+                x[g].z = __uint_as_float(r.z);
+                x[g].w = __uint_as_float(r.w);
+                if (ZH && j0 + g < jz_o) x[g].x = x[g].y = 0.f;
+                if (ZH && j0 + g < jz_e) x[g].z = x[g].w = 0.f;
+            }
+        }
+    };
+    auto use_group = [&](const v4f (&x)[G], int j0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int j = j0 + g;
+            if (j < W) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const int t = HALO + f - j;
+                    if (t >= 0 && t < P) {
+                        er[f] = fmaf(he[t], x[g].z, er[f]);
+                        ei[f] = fmaf(he[t], x[g].w, ei[f]);
+                        orr[f] = fmaf(ho[t], x[g].x, orr[f]);
+                        oi[f] = fmaf(ho[t], x[g].y, oi[f]);
+                    }
+                }
+            }
+        }
+    };
+    if constexpr (DB) {
+        load_group(xb[0], 0);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            if (gi + 1 < NG) load_group(xb[(gi + 1) & 1], (gi + 1) * G);
+            __builtin_amdgcn_sched_barrier(0);
+            use_group(xb[gi & 1], gi * G);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            load_group(xb[0], gi * G);
+            __builtin_amdgcn_sched_barrier(0);
+            use_group(xb[0], gi * G);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const int k0 = tid / F, f_lane = tid % F;
+    cf vE[F], vO[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) buf[f * RS + lds_pad(tid)] = make_float2(er[f], ei[f]);
+    __syncthreads();
+    pfb_fft<NH, 2>(buf, tw_lds, tid);
+    pfb2_read_bins<NH>(buf, tw_lds, k0, f_lane, vE);
+    __syncthreads();                               // every lane has read E before the odd sums overwrite the buffer
+#pragma unroll
+    for (int f = 0; f < F; ++f) buf[f * RS + lds_pad(tid)] = make_float2(orr[f], oi[f]);
+    __syncthreads();
+    pfb_fft<NH, 2>(buf, tw_lds, tid);
+    pfb2_read_bins<NH>(buf, tw_lds, k0, f_lane, vO);
+
+    constexpr int out_so_step = (NH / F) * F * (int)sizeof(cf);
+    constexpr int out_so_half = NH * F * (int)sizeof(cf);
+    const int64_t n = n0 + f_lane;
+    const int64_t ridx = (int64_t)((uint64_t)(n - p.n_abs0) & p.ring_mask);
+    const int vo = (int)(((ridx >> 4) * p.tile_pitch + k0 * F + (ridx & 15)) * (int64_t)sizeof(cf));
+    if (f_lane >= nf) return;
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+        const int k = k0 + i * (NH / F);
+        const cf t = cmul(vO[i], tw_lds[k]);
+        const cf lo = cadd(vE[i], t), hi = csub(vE[i], t);
+        u32x2 o;
+        o.x = __float_as_uint(lo.x);
+        o.y = __float_as_uint(lo.y);
+        __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, vo, i * out_so_step, 2);
+        o.x = __float_as_uint(hi.x);
+        o.y = __float_as_uint(hi.y);
+        __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, vo, out_so_half + i * out_so_step, 2);
+    }
+}
+
 int env_int(const char *name, int dflt)
 {
     const char *e = getenv(name);
@@ -370,6 +566,14 @@ bool pfb_persistent(int NB)
     return pp_env < 0 ? NB >= 512 : pp_env != 0;
 }
 
+// critically sampled banks of >= 512 bins run the two-branch form (RCF_PFB_2B=0: the persistent form instead)
+bool pfb_two_branch(int NB, int OS)
+{
+    // (256 bins as 128-thread two-branch workgroups, eight per CU: 0.56-0.60 against the plain kernel's 0.63 -- not kept)
+    static const int env = env_int("RCF_PFB_2B", 1);
+    return env != 0 && OS == 1 && NB >= 512;
+}
+
 template <int NB, int OS, int P, int MINW>
 void launch_os(const PfbLaunch &p, hipStream_t s)
 {
@@ -378,6 +582,24 @@ void launch_os(const PfbLaunch &p, hipStream_t s)
     const int arg = no_remap ? -n_wg : n_wg;
     const size_t lds = ((size_t)F * row_stride<NB>() + NB) * sizeof(cf);
     const bool zh = (p.n_lo - (int64_t)OS * (P - 1)) * (NB / OS) - (NB - 1) < p.start_sample;
+    if constexpr (OS == 1 && NB >= 512) {
+        if (pfb_two_branch(NB, OS)) {
+            constexpr int NH = NB / 2;
+            // waves per SIMD the register budget is for: 3 / 2 workgroups per CU.  The zero-history instantiation (the
+            // first launch after rcf_pfb_open only) masks rows and gets 256 VGPRs instead of spilling
+            constexpr int MW2 = NH == 256 ? 3 : 4;
+            const size_t lds2 = ((size_t)F * row_stride<NH>() + NB) * sizeof(cf);
+            static DynLdsAttr attr_zh, attr;
+            if (zh) {
+                attr_zh.ensure((const void *)pfb_kernel_2b<NH, P, 2, true>, lds2);
+                hipLaunchKernelGGL((pfb_kernel_2b<NH, P, 2, true>), dim3(n_wg), dim3(NH), lds2, s, p, arg);
+            } else {
+                attr.ensure((const void *)pfb_kernel_2b<NH, P, MW2, false>, lds2);
+                hipLaunchKernelGGL((pfb_kernel_2b<NH, P, MW2, false>), dim3(n_wg), dim3(NH), lds2, s, p, arg);
+            }
+            return;
+        }
+    }
     // 512 / 1024 bins run the persistent form (2 / 1 workgroups per CU: +2 % / +10 %); at 256 bins and below four
     // independent workgroups per CU already overlap their phases and the persistent form's extra barrier per chunk
     // costs 8 % (measured, block 2^25).  RCF_PFB_PP=0 / 1 forces it off / on.
@@ -462,7 +684,7 @@ bool pfb_takes_rider(const PfbLaunch &p)
     if (pfb_frame_major(p.NB)) return false;            // pfb5_kernel: measured, +5.7 us on the 1600-bin launch for 4.7 saved
     // (a launch that still sees zero history runs the plain form whatever the bin count: being wrong about that one
     // launch costs a late start, nothing else)
-    return !pfb_persistent(p.NB);
+    return pfb_two_branch(p.NB, p.D > 0 ? p.NB / p.D : 1) || !pfb_persistent(p.NB);
 }
 
 void launch_pfb(const PfbLaunch &p, hipStream_t s)

@@ -339,6 +339,10 @@ class Frontend:
     def comm_destroy(self):
         _check(lib().rcf_comm_destroy(self._h))
 
+    def comm_size(self) -> int:
+        """ranks of the handle's RCCL communicator (1 without one)"""
+        return int(lib().rcf_comm_size(self._h))
+
     def allgather_peaks(self, mine, cap=1024):
         """-> list (one int64 array per rank) of every rank's values, via ncclAllGather on the handle's device"""
         mine = np.ascontiguousarray(mine, dtype=np.int64)

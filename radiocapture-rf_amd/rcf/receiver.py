@@ -175,6 +175,23 @@ class receiver:
             raise
         self._fed[source_id] = self._fed.get(source_id, 0) + len(iq)
 
+    def feed_raw(self, source_id, raw, fmt, scale, offset=0.0):
+        """feed() for samples still in the SDR's wire format (interleaved I, Q as uint8 / int8 / int16: what the rtlsdr
+        and USRP sc8 / sc16 links of receiver.py:91-98,170-191 carry before the driver converts them): (v - offset) *
+        scale happens on the GPU (rcf_push_raw), the link carries 2 or 4 bytes per sample instead of 8."""
+        src = self.sources[source_id]
+        n = len(raw) // 2
+        try:
+            step = src.get("feed_chunk", 1 << 16) if "parent_chan" in src else max(n, 1)
+            for at in range(0, n, step):
+                src["block"].push_raw(raw[2 * at:2 * (at + step)], fmt, scale, offset)
+        except Exception as e:
+            if self.fault is None:
+                self.fault = "%s: %s" % (type(e).__name__, e)
+                self.log.error("data plane failed on source %s: %s" % (source_id, self.fault))
+            raise
+        self._fed[source_id] = self._fed.get(source_id, 0) + n
+
     def healthy(self):
         """False once a push has failed (GPU / driver error).  The reference has no such signal: a dead flowgraph
         keeps publishing; here the heartbeat stops (registry.redis_channel_publisher(health=...))."""

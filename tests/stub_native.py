@@ -1,0 +1,88 @@
+"""A stand-in for rcf.native with the surface bench.py's multi-rank protocol touches (RCF_BENCH_NATIVE=stub_native):
+lets the CPU suite run the rank launcher, the host rendezvous, max-over-ranks timing and the peak gather of
+`python bench.py --gpus 2` end to end without a GPU.  It computes nothing: a commit is a short sleep."""
+import os
+import time
+
+import numpy as np
+
+WIN_HAMMING, WIN_BLACKMAN, WIN_KAISER, WIN_BLACKMAN_HARRIS = 0, 2, 4, 5
+T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY, T_FIR_MFMA, T_AUDIO, T_TAPS = range(10)
+
+
+def device_count():
+    return int(os.environ.get("STUB_DEVICES", "2"))
+
+
+def design_low_pass_2(gain, fs, fc, tw, att, window=WIN_HAMMING):
+    return np.ones(33, dtype=np.float32) / 33
+
+
+def comm_unique_id():
+    raise RuntimeError("stub: no RCCL")
+
+
+def peak_frequency(index, fs, n, center):
+    return int(index * fs / n - fs / 2 + center)
+
+
+class Frontend:
+    def __init__(self, samp_rate, center_freq=0.0, device=0, block_capacity=0, hist_capacity=0, out_capacity=0):
+        self.device, self.samples_in, self._launches, self._chans = device, 0, 0, 0
+        if os.environ.get("STUB_FAIL_RANK") == os.environ.get("RANK", "0"):
+            raise RuntimeError("stub: this rank was told to fail")
+
+    def pfb_open(self, nb, D, taps):
+        self.nb = nb
+
+    def pfb_chan_open(self, bin_, cr, delta):
+        self._chans += 1
+        return self._chans
+
+    def ingest_write(self, x, at):
+        pass
+
+    def commit(self, n):
+        self.samples_in += n
+        self._launches += 1
+        time.sleep(0.0005 * (1 + int(os.environ.get("RANK", "0"))))      # rank 1 is the slower one
+
+    def sync(self):
+        pass
+
+    def timing_enable(self, on=True, classes=None):
+        pass
+
+    def timing_stride(self, n):
+        pass
+
+    def timing_read(self, cls, reset=False):
+        n, self._launches = self._launches, 0
+        return 0.1 * max(n, 1), max(n, 1)
+
+    def chan_produced(self, c):
+        return 1
+
+    def chan_read_fm(self, c, gain, max_samples=0):
+        return np.zeros(8, dtype=np.float32)
+
+    def scan_start(self, n, f, l):
+        pass
+
+    def scan_frames_done(self):
+        return 1 << 30
+
+    def scan_find_peaks(self, cap=1024):
+        return np.array([100 + self.device], dtype=np.int64), 0.0, None
+
+    def comm_init(self, rank, n, uid=None):
+        raise RuntimeError("stub: no RCCL")
+
+    def comm_destroy(self):
+        pass
+
+    def comm_size(self):
+        return 1
+
+    def close(self):
+        pass

@@ -1,0 +1,59 @@
+"""`python bench.py --gpus N` with no launcher around it starts its own N ranks (the reference
+starts one channelizer process per source: rc_frontend/receiver.py:67-70).  Run here end to end on a stub of
+librcf's Python layer (tests/stub_native.py): spawn, host rendezvous, max-over-ranks timing, peak gather, ONE line."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FLAGS = ["--steps", "6", "--warmup", "1", "--block", str(1 << 16), "--prewarm-seconds", "0", "--no-extras",
+         "--no-cpu-baseline", "--no-sustained"]
+
+
+def _run(gpus, extra_env=None, timeout=180):
+    env = dict(os.environ, RCF_BENCH_NATIVE="stub_native", RCF_BENCH_TRANSPORT="host",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), os.environ.get("PYTHONPATH", "")]))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus)] + FLAGS,
+                          env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_plain_invocation_with_gpus_2_starts_two_ranks_and_prints_one_line():
+    r = _run(2)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 6
+    assert d["transport"] == "host-tcp" and d["ranks_started_by"].startswith("bench.py itself")
+    assert len(d["ms_per_step_by_rank"]) == 2
+    # the stub's rank 1 sleeps twice as long per commit: the line's time is the MAX over ranks, and value the whole job
+    assert d["ms_per_step"] >= max(d["ms_per_step_by_rank"]) * 0.999
+    assert d["ms_per_step_by_rank"][1] > d["ms_per_step_by_rank"][0]
+    total = 2 * 6 * (1 << 16)
+    assert abs(d["value"] - total / (d["ms_per_step"] * 6e-3) / 1e6) / d["value"] < 1e-6
+    assert d["peaks_allgather"]["ranks"] == 2 and d["peaks_allgather"]["values_gathered"] >= 2
+
+
+def test_fewer_devices_than_ranks_is_refused_not_downgraded():
+    r = _run(2, {"STUB_DEVICES": "1"})
+    assert r.returncode == 2 and not r.stdout.strip()
+    assert "refusing" in r.stderr
+    r = _run(2, {"STUB_DEVICES": "1", "RCF_BENCH_DEVICE": "0"})       # every rank on device 0, on request
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout)["n_gpus"] == 2
+
+
+def test_a_failing_rank_fails_the_whole_run():
+    r = _run(2, {"STUB_FAIL_RANK": "1"}, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip()
+
+
+def test_one_gpu_line_is_unchanged_by_the_launcher():
+    r = _run(1)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["n_gpus"] == 1 and d["transport"].startswith("none") and d["rccl_ranks"] == 1

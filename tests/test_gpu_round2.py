@@ -637,9 +637,10 @@ def test_source_shift_reaches_filterbank_taps(gpu_required):
 @pytest.mark.gpu
 @pytest.mark.parametrize("nb", [512, 1024])
 def test_pfb_persistent_form_walks_many_chunks(gpu_required, nb):
-    """512 / 1024-bin banks run the persistent kernel (one resident round of workgroups, each walking several chunks
-    with the next chunk's rows prefetched): a block long enough for 2.5 chunks per workgroup must give bit-identical
-    bins to the same stream pushed in small blocks (one chunk per workgroup), and the oracle's bins at the tail."""
+    """512 / 1024-bin banks: a block of many rounds of workgroups (the critically sampled ones run the two-branch
+    kernel since round 4, the oversampled ones the persistent kernel: one resident round, each workgroup walking several
+    chunks with the next chunk's rows prefetched) must give bit-identical bins to the same stream pushed in small
+    blocks (a single round per launch), and the oracle's bins at the tail."""
     nat = gpu_required
     fs = 20e6
     bw = fs / nb

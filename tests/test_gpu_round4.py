@@ -1,0 +1,62 @@
+"""Round-4 parity cases: the two-branch filterbank kernel (pfb_kernel_2b, 512 / 1024 critically sampled bins) against a
+float64 filterbank over EVERY bin -- its decimation-in-time combine writes bins k and k + NB/2 from one lane, so every
+bin is checked, not a sample of them."""
+import numpy as np
+import pytest
+
+from oracle import grspec as G
+from rcf import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bank_f64(x, nb, taps, n_frames, start=0):
+    """out[n, k] = sum_i h[i] e^{+2 pi j k i / nb} x[n nb - i] (== freq_xlating_fir_filter_ccc(nb, h, k fs / nb, fs) for
+    every on-grid k: rc_frontend/channel.py:35), samples before `start` zero; float64."""
+    P = -(-len(taps) // nb)
+    h = np.zeros(P * nb)
+    h[: len(taps)] = taps
+    xz = x.astype(np.complex128).copy()
+    xz[:start] = 0
+    n_first = -(-start // nb)
+    pad = np.concatenate([np.zeros(P * nb, dtype=np.complex128), xz])
+    out = np.empty((n_frames, nb), dtype=np.complex128)
+    rho = np.arange(nb)
+    for f in range(n_frames):
+        n = n_first + f
+        u = np.zeros(nb, dtype=np.complex128)
+        for p in range(P):
+            u += h[p * nb + rho] * pad[P * nb + n * nb - rho - p * nb]
+        out[f] = np.fft.ifft(u) * nb
+    return out
+
+
+@pytest.mark.parametrize("nb,P,lead", [(512, 14, 0), (512, 4, 700), (512, 16, 0), (1024, 14, 1500), (1024, 4, 0)])
+def test_two_branch_bank_every_bin(gpu_required, nb, P, lead):
+    nat = gpu_required
+    fs = nb * 25000.0
+    bw = fs / nb
+    proto = G.low_pass_2(1.0, fs, bw * 0.4, bw * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+    T = nb * P - nb // 3
+    proto = np.interp(np.linspace(0, len(proto) - 1, T), np.arange(len(proto)), proto).astype(np.float32)
+    assert nat.pfb_shape_supported(nb, nb, T)
+    n_frames = 16 * 9 + 5                                  # nine whole chunks and a ragged one
+    n = lead + nb * n_frames
+    rng = np.random.default_rng(nb + P)
+    x = synth.awgn(rng, n)
+    cut = lead + nb * 37 + 11                              # the second launch has history, the first does not
+    with nat.Frontend(fs, block_capacity=n + 16, hist_capacity=max(1 << 15, 2 * T + 2 * nb), out_capacity=1 << 9) as fe:
+        if lead:
+            fe.push(x[:lead])
+        fe.pfb_open(nb, nb, proto)
+        fe.push(x[lead:cut])
+        fe.push(x[cut:])
+        produced = fe.pfb_produced()
+        got = np.stack([fe.pfb_read_bin(k) for k in range(nb)], axis=1)
+    n_first = -(-lead // nb)
+    want_frames = (n - 1) // nb + 1 - n_first
+    assert produced == want_frames == got.shape[0]
+    want = _bank_f64(x, nb, proto, want_frames, start=lead)
+    scale = np.sqrt(np.mean(np.abs(want) ** 2))
+    err_bin = np.sqrt(np.mean(np.abs(got - want) ** 2, axis=0)) / scale
+    assert err_bin.max() < 2e-5, (int(err_bin.argmax()), float(err_bin.max()))

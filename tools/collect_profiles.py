@@ -76,6 +76,13 @@ def pmc_record(tag, kernel, out, extra):
         rec["kernel"] = short(name)
     if rec:
         rec.update(extra)
+        alg = extra.get("algorithmic_read_bytes")
+        f, w = rec.get("pass3", {}).get("FETCH_SIZE"), rec.get("pass4", {}).get("WRITE_SIZE")
+        if alg and f is not None and w is not None:
+            rec["fetch_x2_bytes"] = f * 1024 * 2
+            rec["write_bytes"] = w * 1024
+            rec["fetch_x2_over_algorithmic_read"] = f * 1024 * 2 / alg
+            rec["hbm_bytes_over_algorithmic"] = (f * 1024 * 2 + w * 1024) / extra["algorithmic_bytes"]
         json.dump(rec, open(out, "w"), indent=1)
         print("wrote", out)
 
@@ -87,13 +94,16 @@ pmc_record("%s_fir4096" % R, "fir_mfma_kernel<", "profiles/%s_fir_mfma_pmc.json"
                    "GRBM_GUI_ACTIVE / 8 / kernel_us; SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles; "
                    "FETCH_SIZE in KiB and x2 on gfx950 (MI355X_MICROARCH.md)"})
 pmc_record("%s_pfb512" % R, "pfb_kernel", "profiles/%s_pfb512_traffic.json" % R, {
-    "workload": "tools/pfb_probe.py NB=512: 512-bin critically sampled bank (persistent form pfb_kernel_pp), block 2^25; algorithmic 16 B/sample = 536.9 MB",
+    "workload": "tools/pfb_probe.py NB=512: 512-bin critically sampled bank (two-branch form pfb_kernel_2b<256, 14, 3>), block 2^25; algorithmic 16 B/sample = 536.9 MB",
+    "algorithmic_read_bytes": 8.0 * (1 << 25), "algorithmic_bytes": 16.0 * (1 << 25),
     "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
 pmc_record("%s_pfb1024" % R, "pfb_kernel", "profiles/%s_pfb1024_traffic.json" % R, {
-    "workload": "tools/pfb_probe.py NB=1024: 1024-bin critically sampled bank (persistent form pfb_kernel_pp), block 2^25; algorithmic 16 B/sample = 536.9 MB",
+    "workload": "tools/pfb_probe.py NB=1024: 1024-bin critically sampled bank (two-branch form pfb_kernel_2b<512, 14, 4>), block 2^25; algorithmic 16 B/sample = 536.9 MB",
+    "algorithmic_read_bytes": 8.0 * (1 << 25), "algorithmic_bytes": 16.0 * (1 << 25),
     "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
 pmc_record("%s_pfb1600" % R, "pfb5_kernel", "profiles/%s_pfb1600_pmc.json" % R, {
     "workload": "tools/pfb_probe.py NB=1600 BLOCK=2^25: 1600-bin bank, D = 800, 2909 taps; algorithmic 24 B/sample = 805.3 MB",
+    "algorithmic_read_bytes": 8.0 * (1 << 25), "algorithmic_bytes": 24.0 * (1 << 25),
     "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
 
 # ---- shader clock of the filterbank launches over the sustained leg (first / last 100 dispatches)

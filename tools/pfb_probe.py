@@ -37,7 +37,7 @@ tids = [fe.pfb_tap_open(i % nb if seq else (7 + 6 * i) % nb, gr_phase=bool(int(o
 # STAGE2=n: n stage-2 channels (xlating FIR /D2 + discriminator) on bins spread over the bank, as the timed configuration has 32
 n2 = int(os.environ.get("STAGE2", 0))
 s2 = [fe.pfb_chan_open((3 + (nb // max(n2, 1)) * i) % nb, 12500, 1000.0 + 10 * i) for i in range(n2)]
-for _ in range(3): fe.commit(B)
+for _ in range(int(os.environ.get("WARM", 3))): fe.commit(B)
 fe.timing_enable(True, classes=None if os.environ.get('TIME_ALL') else [native.T_PFB]); fe.timing_read(native.T_PFB)
 for _ in range(steps): fe.commit(B)
 ms, n = fe.timing_read(native.T_PFB)
