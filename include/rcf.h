@@ -187,6 +187,11 @@ int rcf_chan_close(rcf_t *h, int chan_id);
 int rcf_chan_info(rcf_t *h, int chan_id, int *decim, int *ntaps, double *out_rate, double *offset_hz);
 /* samples produced so far / not yet read */
 int64_t rcf_chan_produced(rcf_t *h, int chan_id);
+/* index, in the channel's SOURCE stream (wideband samples for rcf_chan_open; frames of the bank / outputs of the parent
+ * for chained channels and taps), of the first sample the channel sees -- everything before it counts as zero (GNU
+ * Radio's zero history, the state a freshly started channel.py flowgraph is in).  The reference's data wire carries no
+ * timestamps; with this a consumer can place output n at source sample start + n * decim. */
+int64_t rcf_chan_start(rcf_t *h, int chan_id);
 /* Non-blocking reads (return the sample count, 0 if nothing is ready, <0 on error).  read_iq is the
  * payload of the channel's zeromq.pub_sink (rc_frontend/channel.py:36); read_fm is
  * analog.quadrature_demod_cf(gain) applied to that stream (p25_control_demod.py:120-121,

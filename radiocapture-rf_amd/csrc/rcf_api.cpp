@@ -1893,6 +1893,14 @@ int64_t rcf_chan_produced(rcf_t *h, int chan_id)
     return c->produced;
 }
 
+int64_t rcf_chan_start(rcf_t *h, int chan_id)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    FIND_CHAN(h, chan_id, c);
+    return c->start_sample;
+}
+
 int64_t rcf_chan_read_iq(rcf_t *h, int chan_id, float *out, size_t max_samples)
 {
     if (!h || !out) return RCF_EINVAL;

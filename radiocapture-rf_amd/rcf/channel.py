@@ -29,6 +29,7 @@ class channel:
         self.pfb = pfb
         self.pfb_bin = None
         self.chan_id = None
+        self.start_sample = None
         self._build(offset)
         self.init_time = time.time()
         self.channel_close_time = 0
@@ -60,9 +61,11 @@ class channel:
         # the C ABI derives both (rcf_chan_open) and rejects non-integral decimations
         if bin_ is not None:
             chan_id = frontend.pfb_tap_open(bin_, gr_phase=True)
+            start = self._start_of(chan_id)
             self.chan_id, self.pfb_bin = chan_id, bin_
             self.decim, self.ntaps = pfb["decim"], pfb["ntaps"]
             self.out_rate = samp_rate / pfb["decim"]
+            self.start_sample = start
             return
         if self.parent_chan is None:
             chan_id = frontend.chan_open(channel_rate, offset)
@@ -72,11 +75,27 @@ class channel:
             taps = native.design_low_pass_2(1.0, samp_rate, channel_rate / 2, channel_rate / 2, 20.0)
             assert len(taps) == ntaps
             chan_id = frontend.chan_open_taps(self.parent_chan, decim, taps, offset)
-        info = frontend.chan_info(chan_id)
+        try:
+            info = frontend.chan_info(chan_id)
+            start = self._start_of(chan_id)
+        except Exception:
+            # nothing holds chan_id yet: close it, or the native channel leaks with no owner
+            try:
+                frontend.chan_close(chan_id)
+            except Exception:
+                pass
+            raise
         self.chan_id, self.pfb_bin = chan_id, None
         self.decim = info["decim"]
         self.ntaps = info["ntaps"]
         self.out_rate = info["out_rate"]
+        self.start_sample = start
+
+    def _start_of(self, chan_id):
+        """index in the channel's source stream of the first sample it sees (rcf_chan_start); None for front-ends
+        that cannot tell (stubs)"""
+        f = getattr(self.frontend, "chan_start", None)
+        return f(chan_id) if f is not None else None
 
     def __str__(self):
         return "Channel: port:%s channel_rate:%s samp_rate:%s offset:%s init_time:%s" % (
@@ -119,7 +138,12 @@ class channel:
         old = self.chan_id
         self._build(offset)                                            # raises before any state changed
         self.offset = offset
-        self.frontend.chan_close(old)
+        try:
+            self.frontend.chan_close(old)
+        except Exception as e:
+            # the object already points at the new native channel; the old one is unreferenced from here on
+            import logging
+            logging.getLogger("frontend").error("closing replaced native channel %s failed: %s" % (old, e))
 
     def destroy(self):
         """channel.py:64-67"""

@@ -108,9 +108,12 @@ class Daemon:
         m = self.tb.metrics()
         m["rcf_egress_bytes"] = self.pump.bytes_out
         m["rcf_egress_errors"] = self.pump.errors
-        late = sum(s.late for s in self.sources)
         if self.sources:
-            m["rcf_source_late_blocks"] = late
+            m["rcf_source_late_blocks"] = sum(s.late for s in self.sources)
+        # the data wire has no timestamps: where each channel's stream starts, for consumers that care
+        with self.tb.access_lock:
+            m["rcf_channel_starts"] = {b: [c.start_sample, c.decim] for b, c in self.tb.channels.items()
+                                       if getattr(c, "start_sample", None) is not None}
         return m
 
     def serve_forever(self):

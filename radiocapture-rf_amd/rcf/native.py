@@ -27,7 +27,7 @@ SYMBOLS = [
     "rcf_version", "rcf_last_error", "rcf_device_count", "rcf_design_low_pass_2", "rcf_design_window",
     "rcf_channel_params", "rcf_open", "rcf_open_ex", "rcf_close", "rcf_sync", "rcf_stream", "rcf_device",
     "rcf_push_iq", "rcf_ingest_ptr", "rcf_commit", "rcf_samples_in", "rcf_chan_open", "rcf_chan_open_taps",
-    "rcf_chan_set_offset", "rcf_chan_close", "rcf_chan_info", "rcf_chan_produced", "rcf_chan_read_iq",
+    "rcf_chan_set_offset", "rcf_chan_close", "rcf_chan_info", "rcf_chan_produced", "rcf_chan_start", "rcf_chan_read_iq",
     "rcf_chan_read_fm", "rcf_chan_rings", "rcf_source_shift", "rcf_pfb_open", "rcf_pfb_close",
     "rcf_pfb_produced", "rcf_pfb_read_bin", "rcf_pfb_rings", "rcf_pfb_chan_open", "rcf_scan_start",
     "rcf_scan_result", "rcf_scan_frames_done", "rcf_scan_result_device", "rcf_find_peaks",
@@ -105,6 +105,7 @@ def lib():
         "rcf_chan_close": (C.c_int, [vp, C.c_int]),
         "rcf_chan_info": (C.c_int, [vp, C.c_int, ip, ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "rcf_chan_produced": (i64, [vp, C.c_int]),
+        "rcf_chan_start": (i64, [vp, C.c_int]),
         "rcf_chan_read_iq": (i64, [vp, C.c_int, fp, sz]),
         "rcf_chan_read_fm": (i64, [vp, C.c_int, C.c_float, fp, sz]),
         "rcf_chan_rings": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]),
@@ -436,6 +437,10 @@ class Frontend:
         d, t, r, o = C.c_int(), C.c_int(), C.c_double(), C.c_double()
         _check(lib().rcf_chan_info(self._h, cid, C.byref(d), C.byref(t), C.byref(r), C.byref(o)))
         return dict(decim=d.value, ntaps=t.value, out_rate=r.value, offset_hz=o.value)
+
+    def chan_start(self, cid):
+        """first source-stream sample the channel sees (zero history before it)"""
+        return _check(lib().rcf_chan_start(self._h, cid))
 
     def chan_produced(self, cid):
         return _check(lib().rcf_chan_produced(self._h, cid))
