@@ -486,6 +486,179 @@ def control_plane_leg(device):
                     "+ protocol; channel buffers come from the handle's slab pool"}
 
 
+# ------------------------------------------------------------------------------------------- paced real-time leg
+def read_gpu_busy_percent():
+    """amdgpu's own utilisation figure from sysfs (the busiest card: nothing maps a HIP device to its card index
+    without the PCI bus id); None where the node does not expose it"""
+    import glob
+    best = None
+    for f in glob.glob("/sys/class/drm/card*/device/gpu_busy_percent"):
+        try:
+            v = float(open(f).read().strip())
+            best = v if best is None else max(best, v)
+        except Exception:
+            continue
+    return best
+
+
+def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_ms, n_threads):
+    """K independent 20 Msps front-ends on ONE GPU (the reference's deployment shape: ten sources per host,
+    configs/config_denver_dev_den817.py:25-118, one channelizer process each), every one fed its own u8 stream --
+    what an SDR link delivers, 2 bytes per sample -- at exactly 20 Msps of WALL-CLOCK time in blocks of `block_ms`
+    through rcf_push_raw from pinned memory, and drained: after each block every front-end's channel outputs are read
+    back to the host (rcf_chan_read_many, the egress pump's read).  Latency of a block = from the instant its last
+    sample exists (the tick) to its channels' outputs being in host memory.  A deadline is missed when that exceeds
+    the block period; an overrun is a tick that STARTS more than one period late (the source's double buffer would
+    have been overwritten)."""
+    import threading
+    blk = int(round(FS * block_ms * 1e-3))
+    period = blk / FS
+    warm = max(2, int(round(0.3 / period)))               # first ticks (lazy allocations, module loads): run, not judged
+    n_ticks = max(4, int(round(seconds / period))) + warm
+    fes, chans = [], []
+    t_setup = time.perf_counter()
+    for i in range(K):
+        if shape == "pfb256":
+            fe = native.Frontend(FS, 0.0, device=device, block_capacity=blk, hist_capacity=1 << 14, out_capacity=1 << 12)
+            fe.pfb_open(NB, NB, proto_taps(native))
+            ids = [fe.pfb_chan_open(c["bin"] % NB, 12500, c["delta"]) for c in carriers]
+        else:                                            # the bank whose bins ARE the reference's channels + 256 of them tapped
+            D, T = native.channel_params(FS, 12500)
+            fe = native.Frontend(FS, 0.0, device=device, block_capacity=blk, hist_capacity=1 << 14, out_capacity=1 << 11)
+            fe.pfb_open(1600, D, native.design_low_pass_2(1.0, FS, 6250.0, 6250.0, 20.0))
+            ids = [fe.pfb_tap_open((7 + 6 * j) % 1600, gr_phase=True) for j in range(256)]
+        fes.append(fe)
+        chans.append(ids)
+    setup_s = time.perf_counter() - t_setup
+    n_tile = len(raw_tile) // 2
+    lat = [[] for _ in range(n_threads)]
+    stats = [dict(miss=0, overrun=0, read=0, push_ms=0.0, drain_ms=0.0) for _ in range(n_threads)]
+    errors = []
+    t0 = time.perf_counter() + 0.25
+
+    def worker(w):
+        mine = list(range(w, K, n_threads))
+        outs = {i: np.empty((len(chans[i]), 1024), dtype=np.float32) for i in mine}
+        st, ls = stats[w], lat[w]
+        try:
+            for k in range(n_ticks):
+                due = t0 + (k + 1) * period                       # block k's last sample exists now
+                now = time.perf_counter()
+                if now < due:
+                    time.sleep(due - now)
+                elif now - due > period and k >= warm:
+                    st["overrun"] += 1
+                ta = time.perf_counter()
+                for i in mine:
+                    at = ((i * 7919 + k) * blk) % (n_tile - blk)
+                    fes[i].push_raw(raw_tile[2 * at: 2 * (at + blk)], native.FMT_U8, 1.0 / 32, 127.4)
+                tb_ = time.perf_counter()
+                for i in mine:
+                    got = fes[i].chan_read_many(chans[i], "fm", gain=1.0, cap_each=1024, out=outs[i])
+                    st["read"] += sum(len(g) for g in got)
+                    done = time.perf_counter()
+                    if k >= warm:
+                        ls.append(done - due)
+                        if done - due > period:
+                            st["miss"] += 1
+                st["push_ms"] += (tb_ - ta) * 1e3
+                st["drain_ms"] += (time.perf_counter() - tb_) * 1e3
+        except Exception as e:
+            errors.append("%s: %s" % (type(e).__name__, e))
+
+    busy = []
+    stop = threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            v = read_gpu_busy_percent()
+            if v is not None:
+                busy.append(v)
+            stop.wait(0.25)
+
+    ths = [threading.Thread(target=worker, args=(w,)) for w in range(n_threads)]
+    smp = threading.Thread(target=sampler)
+    smp.start()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    wall = time.perf_counter() - t0
+    stop.set()
+    smp.join()
+    produced = sum(fes[i].chan_produced(c) for i in range(K) for c in chans[i])
+    read = sum(s["read"] for s in stats)
+    for fe in fes:
+        fe.close()
+    alll = sorted(x for l in lat for x in l)
+    pct = lambda p: alll[min(len(alll) - 1, int(p * len(alll)))] * 1e3 if alll else None
+    n_ch = len(chans[0]) if chans else 0
+    return {
+        "front_ends": K, "seconds": wall, "blocks_per_front_end": n_ticks - warm, "warmup_blocks_not_judged": warm,
+        "block_ms": period * 1e3,
+        "deadline_misses": sum(s["miss"] for s in stats), "ring_overruns": sum(s["overrun"] for s in stats),
+        "output_samples_lost": int(produced - read), "errors": errors,
+        "latency_ms_p50": pct(0.50), "latency_ms_p99": pct(0.99), "latency_ms_max": alll[-1] * 1e3 if alll else None,
+        "host_push_ms_per_tick_slowest_thread": max(s["push_ms"] for s in stats) / n_ticks,
+        "host_drain_ms_per_tick_slowest_thread": max(s["drain_ms"] for s in stats) / n_ticks,
+        "gpu_busy_percent_mean": sum(busy) / len(busy) if busy else None,
+        "gpu_busy_percent_max": max(busy) if busy else None,
+        "pcie_GBps_in": K * FS * 2 / 1e9, "pcie_GBps_out": K * n_ch * (FS / NB / 3 if shape == "pfb256" else 25000.0) * 4 / 1e9,
+        "input_Msps_sustained": K * FS / 1e6, "setup_s": setup_s,
+        "ok": not errors and sum(s["miss"] for s in stats) == 0 and sum(s["overrun"] for s in stats) == 0
+              and produced == read,
+    }
+
+
+def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_first=16, k_cap=512, shapes=("pfb256", "grid1600")):
+    """`sustained`, as the metric means it: how many 20 Msps front-ends one MI355X keeps up with in real time.  K is
+    doubled from k_first until a point misses a deadline (or k_cap), then the midpoint between the last good and the first
+    bad K is tried once.  Per shape: pfb256 = BASELINE configs[1] per front-end (256-bin bank + 32 FM channels);
+    grid1600 = the 1600-bin reference-grid bank (every bin one of channel.py's 25 kS/s channels) with 256 bins tapped
+    and demodulated."""
+    raw = native.PinnedArray(2 * len(tile), np.uint8)
+    raw.array[:] = np.clip(np.round(tile.view(np.float32) * 32 + 127.4), 0, 255).astype(np.uint8)
+    try:
+        n_threads = max(1, min(16, (os.cpu_count() or 8) // 4))
+    except Exception:
+        n_threads = 4
+    out = {"what": "K independent 20 Msps u8 front-ends on one GPU, paced at wall-clock rate in %.0f ms blocks through "
+                   "rcf_push_raw (pinned), every channel's discriminator output drained to the host after each block "
+                   "(rcf_chan_read_many); %d host threads share the front-ends" % (block_ms, n_threads),
+           "host_threads": n_threads, "seconds_per_point": seconds}
+    for shape in shapes:
+        pts, good, bad = [], None, None
+        K = k_first
+        while K <= k_cap:
+            p = realtime_point(native, K, shape, raw.array, carriers, device, seconds, block_ms, min(n_threads, K))
+            pts.append(p)
+            if p["ok"]:
+                good = K
+                K *= 2
+            else:
+                bad = K
+                break
+        if good is not None and bad is not None and bad - good > max(8, good // 4):
+            mid = (good + bad) // 2
+            p = realtime_point(native, mid, shape, raw.array, carriers, device, seconds, block_ms, min(n_threads, mid))
+            pts.append(p)
+            if p["ok"]:
+                good = mid
+        bins, demod = (NB, len(carriers)) if shape == "pfb256" else (1600, 256)
+        best = next((p for p in pts if p["front_ends"] == good), None)
+        out[shape] = {
+            "K_max": good or 0, "first_K_that_missed": bad, "bins_per_front_end": bins, "demodulated_per_front_end": demod,
+            "channels_sustained": (good or 0) * bins, "fm_channels_sustained": (good or 0) * demod,
+            "input_Msps_sustained": (good or 0) * FS / 1e6,
+            "at_K_max": best, "points": [{k: p[k] for k in ("front_ends", "ok", "deadline_misses", "ring_overruns",
+                                                            "latency_ms_p50", "latency_ms_p99", "gpu_busy_percent_mean",
+                                                            "host_push_ms_per_tick_slowest_thread",
+                                                            "host_drain_ms_per_tick_slowest_thread", "errors")} for p in pts],
+        }
+    raw.free()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ rank launcher
 def load_native():
     """librcf's ctypes layer.  RCF_BENCH_NATIVE=<module> swaps in another module with the same surface: the CPU test of
@@ -581,6 +754,9 @@ def main():
                          "needs ~100 launches (15 ms) after idling before the filterbank launch settles (the first "
                          "window of the sustained leg shows it); 0 = none")
     ap.add_argument("--sweep-max", type=int, default=196608, help="largest direct-bank channel count to open")
+    ap.add_argument("--rt-seconds", type=float, default=10.0, help="seconds per point of the paced real-time leg (0 = skip it)")
+    ap.add_argument("--rt-block-ms", type=float, default=20.0, help="block length of the paced real-time leg")
+    ap.add_argument("--rt-k-first", type=int, default=32, help="front-end count the real-time search starts at")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -880,6 +1056,9 @@ def main():
         out["channels"]["reference_grid_filterbank"] = reference_grid_leg(native, tile, local_rank)
         out["scan"] = scan_leg(native, synth, local_rank)
         out["end_to_end"] = end_to_end_leg(native, tile, local_rank)
+        if args.rt_seconds > 0:
+            out["realtime"] = realtime_leg(native, tile, meta["carriers"], local_rank, seconds=args.rt_seconds,
+                                           block_ms=args.rt_block_ms, k_first=args.rt_k_first)
         out["control_plane"] = control_plane_leg(local_rank)
         counts = [c for c in (256, 1024, 4096, 16384, 65536, 131072, 196608) if c <= args.sweep_max]
         out["channels"]["direct_bank"] = direct_bank_sweep(native, tile, local_rank, counts)

@@ -200,6 +200,15 @@ int64_t rcf_chan_start(rcf_t *h, int chan_id);
  * samples (as a PUB socket at its HWM does). */
 int64_t rcf_chan_read_iq(rcf_t *h, int chan_id, float *out_interleaved, size_t max_samples);
 int64_t rcf_chan_read_fm(rcf_t *h, int chan_id, float gain, float *out, size_t max_samples);
+/* The same reads for MANY channels behind one stream synchronisation -- what an egress pump that serves hundreds of
+ * channel.py:36 PUB sockets needs per pass (a single-channel read costs a device round trip each).  what: RCF_READ_IQ
+ * (out = float2[n_chans][cap_each]) or RCF_READ_FM (out = float[n_chans][cap_each], scaled by gain); counts[i] = samples
+ * copied for chan_ids[i] (0: nothing new; RCF_ENOCHAN: no such channel, the others are still served).  `out` may be
+ * pinned memory (rcf_host_alloc): the copies then overlap each other. */
+#define RCF_READ_IQ 0
+#define RCF_READ_FM 1
+int rcf_chan_read_many(rcf_t *h, int what, const int *chan_ids, int n_chans, float gain, void *out, size_t cap_each,
+                       int64_t *counts);
 /* P25 C4FM front half after the discriminator (p25_control_demod.py:129-133, logging_receiver.py:240-244):
  * filter.fir_filter_fff(1, taps) over quadrature_demod_cf(gain) -- e.g. the 5-tap boxcar symbol filter
  * (1/sps,)*sps.  Enabled per channel; applies from the next block on; output read with rcf_chan_read_sym

@@ -103,6 +103,24 @@ void launch_copy8(void *dst, const void *src, size_t bytes, hipStream_t s)
                        static_cast<const unsigned long long *>(src), n8);
 }
 
+// rcf_chan_read_many: the new samples of many channel rings packed back to back into ONE staging buffer (pinned host
+// memory the device writes across PCIe) -- one launch and one synchronisation per egress pass instead of a device
+// round trip per channel.  Records live in pinned host memory too.  Units: 4-byte words.
+static __global__ __launch_bounds__(256) void gather_rings_kernel(const GatherRec *__restrict__ recs, uint32_t *__restrict__ dst)
+{
+    const GatherRec r = recs[blockIdx.y];
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < r.n_w; w += stride)
+        dst[r.dst_w + w] = r.ring[(r.pos_w + w) & r.mask_w];
+}
+
+void launch_gather_rings(const GatherRec *d_recs, int n_recs, uint32_t *d_dst, uint32_t max_words, hipStream_t s)
+{
+    if (n_recs <= 0 || max_words == 0) return;
+    const unsigned gx = std::min<unsigned>((max_words + 255) / 256, 16);
+    hipLaunchKernelGGL(gather_rings_kernel, dim3(gx, (unsigned)n_recs), dim3(256), 0, s, d_recs, d_dst);
+}
+
 void launch_gather_view(const StreamView &v, int64_t first, float2 *dst, size_t n, hipStream_t s)
 {
     if (n == 0) return;

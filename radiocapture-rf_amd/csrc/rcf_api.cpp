@@ -192,6 +192,9 @@ struct rcf {
     int comm_rank = 0, comm_size = 1;
     int64_t *d_gather = nullptr;
     size_t gather_cap = 0;
+    // rcf_chan_read_many: pinned staging the gather kernel writes (and reads its records from) across PCIe
+    unsigned char *h_many = nullptr, *h_many_dev = nullptr;
+    size_t many_cap = 0;
     // optional per-kernel-class HIP-event timing (rcf_timing_*)
     bool timing = false;
     unsigned timing_mask = ~0u;
@@ -1273,8 +1276,10 @@ int process_block(rcf_t *h, size_t n)
     return finish_block(h, bp);
 }
 
-int64_t ring_read(rcf_t *h, const void *ring, size_t elem, int64_t produced, int64_t *cursor, void *out,
-                  size_t max_items)
+// queue the copies of one ring read on the handle's stream; the caller synchronises and then advances *cursor by the
+// count returned (ring_read does both for a single ring; rcf_chan_read_many batches many rings behind ONE sync)
+int64_t ring_read_enqueue(rcf_t *h, const void *ring, size_t elem, int64_t produced, int64_t *cursor, void *out,
+                          size_t max_items)
 {
     int64_t avail = produced - *cursor;
     if (avail <= 0 || max_items == 0) return 0;
@@ -1296,6 +1301,14 @@ int64_t ring_read(rcf_t *h, const void *ring, size_t elem, int64_t produced, int
         set_error("ring read failed");
         return RCF_EHIP;
     }
+    return n;
+}
+
+int64_t ring_read(rcf_t *h, const void *ring, size_t elem, int64_t produced, int64_t *cursor, void *out,
+                  size_t max_items)
+{
+    const int64_t n = ring_read_enqueue(h, ring, elem, produced, cursor, out, max_items);
+    if (n <= 0) return n;
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("stream sync failed"); return RCF_EHIP; }
     free_graveyard_idle(h);       // retuned / closed channels' old buffers: every read is a chance to release them
     *cursor += n;
@@ -1592,6 +1605,7 @@ int rcf_close(rcf_t *h)
         if (h->arena_ev[i]) (void)hipEventDestroy(h->arena_ev[i]);
     }
     bury(h, h->d_gather);
+    if (h->h_many) (void)hipHostFree(h->h_many);
     bury(h, h->d_partial);
     bury(h, h->d_tapmat);
     drain_graveyard(h);
@@ -1920,6 +1934,107 @@ int64_t rcf_chan_read_fm(rcf_t *h, int chan_id, float gain, float *out, size_t m
     // quadrature_demod_cf: out = gain * fast_atan2f(...), one float32 multiply per sample
     for (int64_t i = 0; i < n; ++i) out[i] = gain * out[i];
     return n;
+}
+
+int rcf_chan_read_many(rcf_t *h, int what, const int *chan_ids, int n_chans, float gain, void *out, size_t cap_each,
+                       int64_t *counts)
+{
+    if (!h || !chan_ids || !out || !counts || n_chans < 0 || (what != RCF_READ_IQ && what != RCF_READ_FM)) {
+        set_error("bad batched read arguments");
+        return RCF_EINVAL;
+    }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    const size_t elem = what == RCF_READ_IQ ? sizeof(float2) : sizeof(float);
+    const uint32_t ew = (uint32_t)(elem / 4);
+    // what every channel has to give, and where its reader stands
+    struct Item { Chan *c; int64_t *cur; const void *ring; int64_t n; size_t pos; };
+    std::vector<Item> items((size_t)n_chans);
+    size_t total = 0;
+    uint32_t max_w = 0;
+    for (int i = 0; i < n_chans; ++i) {
+        Item &it = items[(size_t)i];
+        it = Item{nullptr, nullptr, nullptr, 0, 0};
+        auto f = h->chans.find(chan_ids[i]);
+        if (f == h->chans.end()) { counts[i] = RCF_ENOCHAN; continue; }
+        Chan *c = f->second.get();
+        it.c = c;
+        it.cur = what == RCF_READ_IQ ? &c->rd_iq : &c->rd_fm;
+        it.ring = what == RCF_READ_IQ ? (const void *)c->d_iq : (const void *)c->d_fm;
+        int64_t avail = c->produced - *it.cur;
+        if (avail > 0 && (size_t)avail > h->out_cap) {          // reader lagged: oldest samples are gone
+            *it.cur = c->produced - (int64_t)h->out_cap;
+            avail = (int64_t)h->out_cap;
+        }
+        it.n = avail <= 0 ? 0 : std::min<int64_t>(avail, (int64_t)cap_each);
+        it.pos = (size_t)((uint64_t)*it.cur & h->ring_mask);
+        counts[i] = it.n;
+        total += (size_t)it.n;
+        max_w = std::max<uint32_t>(max_w, (uint32_t)it.n * ew);
+    }
+    if (total == 0) return RCF_OK;
+    // One gather launch packs every ring segment back to back into pinned host memory, one synchronisation, then the
+    // rows are handed out.  (A device round trip per channel -- rcf_chan_read_iq in a loop -- costs ~10 us each: 256
+    // tapped bins of ten front-ends are 25 ms per pass.)
+    const size_t rec_bytes = ((size_t)n_chans * sizeof(GatherRec) + 255) & ~(size_t)255;
+    const size_t need = rec_bytes + total * elem;
+    if (need > h->many_cap) {
+        if (h->h_many) { (void)hipStreamSynchronize(h->stream); (void)hipHostFree(h->h_many); h->h_many = nullptr; h->many_cap = 0; }
+        size_t cap = 1 << 16;
+        while (cap < need) cap <<= 1;
+        void *p = nullptr, *dv = nullptr;
+        if (hipHostMalloc(&p, cap, hipHostMallocDefault) == hipSuccess && hipHostGetDevicePointer(&dv, p, 0) == hipSuccess) {
+            h->h_many = static_cast<unsigned char *>(p);
+            h->h_many_dev = static_cast<unsigned char *>(dv);
+            h->many_cap = cap;
+        } else if (p) {
+            (void)hipHostFree(p);
+        }
+    }
+    if (h->h_many && need <= h->many_cap) {
+        GatherRec *recs = reinterpret_cast<GatherRec *>(h->h_many);
+        uint32_t at_w = 0;
+        int n_recs = 0;
+        for (int i = 0; i < n_chans; ++i) {
+            const Item &it = items[(size_t)i];
+            if (it.n <= 0) continue;
+            recs[n_recs++] = GatherRec{static_cast<const uint32_t *>(it.ring), (uint32_t)(it.pos * ew), (uint32_t)it.n * ew,
+                                       (uint32_t)(h->out_cap * ew - 1), at_w};
+            at_w += (uint32_t)it.n * ew;
+        }
+        launch_gather_rings(reinterpret_cast<const GatherRec *>(h->h_many_dev), n_recs,
+                            reinterpret_cast<uint32_t *>(h->h_many_dev + rec_bytes), max_w, h->stream);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("stream sync failed"); return RCF_EHIP; }
+        const unsigned char *src = h->h_many + rec_bytes;
+        for (int i = 0; i < n_chans; ++i) {
+            const Item &it = items[(size_t)i];
+            if (it.n <= 0) continue;
+            std::memcpy(static_cast<unsigned char *>(out) + (size_t)i * cap_each * elem, src, (size_t)it.n * elem);
+            src += (size_t)it.n * elem;
+        }
+    } else {
+        // no mapped pinned memory: ring by ring, still behind one synchronisation
+        for (int i = 0; i < n_chans; ++i) {
+            const Item &it = items[(size_t)i];
+            if (it.n <= 0) continue;
+            int64_t cur = *it.cur;
+            const int64_t n = ring_read_enqueue(h, it.ring, elem, it.c->produced, &cur,
+                                                static_cast<unsigned char *>(out) + (size_t)i * cap_each * elem, (size_t)it.n);
+            if (n < 0) { (void)hipStreamSynchronize(h->stream); return (int)n; }
+        }
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("stream sync failed"); return RCF_EHIP; }
+    }
+    free_graveyard_idle(h);
+    for (int i = 0; i < n_chans; ++i) {
+        const Item &it = items[(size_t)i];
+        if (it.n <= 0) continue;
+        *it.cur += it.n;
+        if (what == RCF_READ_FM) {
+            float *o = static_cast<float *>(out) + (size_t)i * cap_each;
+            for (int64_t k = 0; k < it.n; ++k) o[k] = gain * o[k];
+        }
+    }
+    return RCF_OK;
 }
 
 int rcf_chan_fm_filter(rcf_t *h, int chan_id, float gain, const float *taps, int ntaps)

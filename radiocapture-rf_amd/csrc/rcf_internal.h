@@ -357,6 +357,12 @@ bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s);
 inline bool pfb_frame_major(int NB) { return NB % 25 == 0; }
 // dst[i] = view sample (first + i), i < n (one bin's samples out of a bank ring; ingest.hip)
 void launch_gather_view(const StreamView &v, int64_t first, float2 *dst, size_t n, hipStream_t s);
+// one ring segment of a batched read (rcf_chan_read_many), in 4-byte words: dst[dst_w + w] = ring[(pos_w + w) & mask_w], w < n_w
+struct GatherRec {
+    const uint32_t *ring;
+    uint32_t pos_w, n_w, mask_w, dst_w;
+};
+void launch_gather_rings(const GatherRec *d_recs, int n_recs, uint32_t *d_dst, uint32_t max_words, hipStream_t s);
 // dst[0, bytes) = src[0, bytes), both 8-byte aligned, bytes rounded up to 8; src may be pinned (device-mapped) host memory
 void launch_copy8(void *dst, const void *src, size_t bytes, hipStream_t s);
 void launch_copy8x2(void *d0, const void *s0, size_t bytes0, void *d1, const void *s1, size_t bytes1, hipStream_t s);

@@ -37,6 +37,7 @@ class EgressPump:
         self.period = period
         self.fm_gain = fm_gain
         self.fm_port_offset = fm_port_offset
+        self.batch_cap = 1 << 13                         # samples per channel and pass in the batched read (0.3 s at 25 kS/s)
         self.socks = {}
         self.fm_socks = {}
         self.continue_running = True
@@ -83,11 +84,13 @@ class EgressPump:
             live_ports = {ch.port for ch in chans.values() if ch.chan_id is not None}
             for port in [p for p in self.prebound if p not in live_ports]:   # bound, but the channel is gone
                 self.release_port(port)
-        for block_id, ch in chans.items():
-            # one channel's failure (destroyed between the snapshot and the read, port already bound, reader error)
-            # must not end the pump for everybody else: log, drop that channel's sockets, go on
-            try:
-                with self.tb.access_lock:                # destroy() / the idle sweep run under the same lock
+        ready = []                                       # (block_id, iq, fm)
+        with self.tb.access_lock:                        # destroy() / the idle sweep run under the same lock
+            groups = {}
+            for block_id, ch in chans.items():
+                # one channel's failure (destroyed between the snapshot and the read, port already bound, reader
+                # error) must not end the pump for everybody else: log, drop that channel's sockets, go on
+                try:
                     if ch.chan_id is None:
                         continue
                     if block_id not in self.socks:
@@ -95,20 +98,49 @@ class EgressPump:
                         self.socks[block_id] = iq_s if iq_s is not None else self.make(ch.port)
                         if self.fm_gain is not None:
                             self.fm_socks[block_id] = fm_s if fm_s is not None else self.make(ch.port + self.fm_port_offset)
-                    iq = ch.read_iq()
-                    fm = ch.read_fm(self.fm_gain) if block_id in self.fm_socks else None
+                    fe = getattr(ch, "frontend", None)       # channel-like objects without one are read singly
+                    groups.setdefault(id(fe) if fe is not None else ("solo", block_id), (fe, []))[1].append((block_id, ch))
+                except Exception as e:
+                    self._fail(block_id, e)
+            for fe, items in groups.values():
+                got = None
+                if len(items) > 1 and hasattr(fe, "chan_read_many"):
+                    # all channels of one front-end behind ONE device synchronisation (rcf_chan_read_many)
+                    try:
+                        ids = [ch.chan_id for _, ch in items]
+                        iqs = fe.chan_read_many(ids, "iq", cap_each=self.batch_cap)
+                        fms = fe.chan_read_many(ids, "fm", gain=self.fm_gain, cap_each=self.batch_cap) \
+                            if self.fm_gain is not None else [None] * len(ids)
+                        got = list(zip(iqs, fms))
+                    except Exception as e:
+                        log.error("batched egress read failed (%s): reading channel by channel" % e)
+                for i, (block_id, ch) in enumerate(items):
+                    try:
+                        if got is not None and got[i][0] is not None:
+                            iq, fm = got[i]
+                        else:
+                            iq = ch.read_iq()
+                            fm = ch.read_fm(self.fm_gain) if block_id in self.fm_socks else None
+                        ready.append((block_id, iq, fm))
+                    except Exception as e:
+                        self._fail(block_id, e)
+        for block_id, iq, fm in ready:
+            try:
                 if len(iq):
                     payload = iq.tobytes()               # raw gr_complex items, arbitrary chunking
                     self.socks[block_id].send(payload)
                     self.bytes_out += len(payload)
-                if fm is not None and len(fm):
+                if fm is not None and len(fm) and block_id in self.fm_socks:
                     self.fm_socks[block_id].send(fm.tobytes())
             except Exception as e:
-                self.errors += 1
-                log.error("egress of channel %s failed: %s" % (block_id, e))
-                self._drop(block_id)
+                self._fail(block_id, e)
         for block_id in [b for b in self.socks if b not in chans]:   # destroyed channels
             self._drop(block_id)
+
+    def _fail(self, block_id, e):
+        self.errors += 1
+        log.error("egress of channel %s failed: %s" % (block_id, e))
+        self._drop(block_id)
 
     def _drop(self, block_id):
         for table in (self.socks, self.fm_socks):

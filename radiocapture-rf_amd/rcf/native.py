@@ -27,7 +27,7 @@ SYMBOLS = [
     "rcf_version", "rcf_last_error", "rcf_device_count", "rcf_design_low_pass_2", "rcf_design_window",
     "rcf_channel_params", "rcf_open", "rcf_open_ex", "rcf_close", "rcf_sync", "rcf_stream", "rcf_device",
     "rcf_push_iq", "rcf_ingest_ptr", "rcf_commit", "rcf_samples_in", "rcf_chan_open", "rcf_chan_open_taps",
-    "rcf_chan_set_offset", "rcf_chan_close", "rcf_chan_info", "rcf_chan_produced", "rcf_chan_start", "rcf_chan_read_iq",
+    "rcf_chan_set_offset", "rcf_chan_close", "rcf_chan_info", "rcf_chan_produced", "rcf_chan_start", "rcf_chan_read_many", "rcf_chan_read_iq",
     "rcf_chan_read_fm", "rcf_chan_rings", "rcf_source_shift", "rcf_pfb_open", "rcf_pfb_close",
     "rcf_pfb_produced", "rcf_pfb_read_bin", "rcf_pfb_rings", "rcf_pfb_chan_open", "rcf_scan_start",
     "rcf_scan_result", "rcf_scan_frames_done", "rcf_scan_result_device", "rcf_find_peaks",
@@ -106,6 +106,8 @@ def lib():
         "rcf_chan_info": (C.c_int, [vp, C.c_int, ip, ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "rcf_chan_produced": (i64, [vp, C.c_int]),
         "rcf_chan_start": (i64, [vp, C.c_int]),
+        "rcf_chan_read_many": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_float, vp, C.c_size_t,
+                                         C.POINTER(C.c_int64)]),
         "rcf_chan_read_iq": (i64, [vp, C.c_int, fp, sz]),
         "rcf_chan_read_fm": (i64, [vp, C.c_int, C.c_float, fp, sz]),
         "rcf_chan_rings": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]),
@@ -454,6 +456,21 @@ class Frontend:
         out = np.empty(max_samples, dtype=np.float32)
         n = _check(lib().rcf_chan_read_fm(self._h, cid, float(gain), _fp(out), max_samples))
         return out[:n].copy()
+
+    def chan_read_many(self, cids, what="iq", gain=1.0, cap_each=1 << 14, out=None):
+        """new samples of many channels behind ONE device synchronisation (rcf_chan_read_many) -> list of arrays
+        (views into `out`, a [len(cids), cap_each] complex64 / float32 array -- pass a PinnedArray's for overlapping
+        copies), None where the channel no longer exists"""
+        n = len(cids)
+        dt = np.complex64 if what == "iq" else np.float32
+        if out is None:
+            out = np.empty((max(n, 1), cap_each), dtype=dt)
+        out = out.reshape(-1, cap_each)
+        ids = (C.c_int * max(n, 1))(*[int(c) for c in cids])
+        counts = (C.c_int64 * max(n, 1))()
+        _check(lib().rcf_chan_read_many(self._h, 0 if what == "iq" else 1, ids, n, float(gain),
+                                        out.ctypes.data_as(C.c_void_p), int(cap_each), counts))
+        return [None if counts[i] < 0 else out[i, :counts[i]] for i in range(n)]
 
     def chan_fm_filter(self, cid, gain, taps):
         taps = np.ascontiguousarray(taps, dtype=np.float32)

@@ -60,3 +60,55 @@ def test_two_branch_bank_every_bin(gpu_required, nb, P, lead):
     scale = np.sqrt(np.mean(np.abs(want) ** 2))
     err_bin = np.sqrt(np.mean(np.abs(got - want) ** 2, axis=0)) / scale
     assert err_bin.max() < 2e-5, (int(err_bin.argmax()), float(err_bin.max()))
+
+
+def test_batched_read_equals_channel_by_channel_reads(gpu_required):
+    """rcf_chan_read_many (one gather launch + one synchronisation for all channels: the egress pump's read) hands
+    out exactly what rcf_chan_read_iq / rcf_chan_read_fm do channel by channel -- across ring wrap, ragged pushes, a
+    closed channel in the list and a reader that lagged more than a ring."""
+    nat = gpu_required
+    fs = 2.4e6
+    rng = np.random.default_rng(44)
+    x = synth.awgn(rng, 96 * 9000)
+    offs = [-300e3, -62500.0, 0.0, 125e3, 412.5e3]
+
+    def open_all(fe):
+        return [fe.chan_open(12500, f) for f in offs]
+
+    with nat.Frontend(fs, out_capacity=1 << 11) as a, nat.Frontend(fs, out_capacity=1 << 11) as b:
+        ia, ib = open_all(a), open_all(b)
+        one = {i: ([], []) for i in range(len(offs))}
+        many = {i: ([], []) for i in range(len(offs))}
+        cuts = [0, 96 * 700 + 5, 96 * 1900, 96 * 2000 + 17, 96 * 3900, 96 * 5500, 96 * 7000, len(x)]
+        unread = {3, 4}                                    # 1900 + 1600 outputs pile up unread: more than the 2048 ring
+        for k, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+            a.push(x[lo:hi])
+            b.push(x[lo:hi])
+            if k == 2:
+                a.chan_close(ia[1])
+                b.chan_close(ib[1])
+            if k in unread:
+                continue
+            for i, c in enumerate(ia):
+                if k >= 2 and i == 1:
+                    continue
+                one[i][0].append(a.chan_read_iq(c))
+                one[i][1].append(a.chan_read_fm(c, 5.0))
+            iq = b.chan_read_many(ib, "iq", cap_each=4096)
+            fm = b.chan_read_many(ib, "fm", gain=5.0, cap_each=4096)
+            for i in range(len(offs)):
+                if k >= 2 and i == 1:
+                    assert iq[i] is None and fm[i] is None
+                    continue
+                many[i][0].append(iq[i].copy())
+                many[i][1].append(fm[i].copy())
+        for i in range(len(offs)):
+            for w in (0, 1):
+                p, q = np.concatenate(one[i][w]), np.concatenate(many[i][w])
+                assert len(p) == len(q) > 0 and np.array_equal(p, q), (i, w, len(p), len(q))
+        # cap_each smaller than what is waiting: the rest stays for the next call
+        a.push(x[: 96 * 500])
+        b.push(x[: 96 * 500])
+        first = b.chan_read_many([ib[0]], "iq", cap_each=100)[0].copy()
+        rest = b.chan_read_many([ib[0]], "iq", cap_each=4096)[0].copy()
+        assert len(first) == 100 and np.array_equal(np.concatenate([first, rest]), a.chan_read_iq(ia[0]))
