@@ -21,9 +21,16 @@ Outside the timed region, rank 0 at N = 1 also reports:
   channels.reference_grid_filterbank   the 1600-bin bank whose bins are the reference's channels (20 Msps, D = 800)
   scan                   BASELINE configs[2]: 1M-point FFT x 1000 frames / 100-frame average + peak pick
   end_to_end             PCIe-inclusive ingest (pinned cf32 rcf_push_iq, u8 rcf_push_raw), copy overlapped
+  realtime               the paced leg: K independent 20 Msps u8 front-ends on this GPU fed at WALL-CLOCK rate in
+                         20 ms blocks (rcf_push_raw from pinned memory) and drained after every block
+                         (rcf_chan_read_many); K doubled until a block misses its deadline -> K_max, channels sustained,
+                         per-block latency p50 / p99, overruns; for the 256-bin + 32 FM shape and for the 1600-bin
+                         reference-grid bank with 256 bins demodulated
   control_plane          100 x create / release through the frontend_connector protocol
-  cpu_baseline           the oracle's C port of the reference path on the host cores (+ the parity check of the
-                         timed configuration's FM outputs against the oracle)
+  cpu_baseline           the oracle's C port of the reference path on the host cores: one channel on one core, every
+                         physical core busy (pinned, private first-touched streams, 2 s of signal per channel), SURVEY's
+                         cores x single-core formula, and a time-tiled "best CPU" form (+ the parity check of the timed
+                         configuration's FM outputs against the oracle)
 
 --config cfg5 = BASELINE configs[4]'s per-GPU shape instead (25 Msps slice, 512-bin bank, N = 2^20 / 1000 / 100 scan on
 the slice, <= 1024 peaks per rank into the all-gather); the default (cfg4) is configs[1] / configs[3].
@@ -121,57 +128,96 @@ def sustained_leg(fe, native, B, alg_bytes, seconds=2.0, window=100):
 
 
 # ------------------------------------------------------------------------------------------- CPU baseline leg
-def cpu_baseline(tile, carriers, fm_check=None, seconds=0.5, reps=3, FS=FS):
-    """The reference's structure on the host cores: one 2909-tap xlating FIR (D=800) + discriminator per
-    channel over the whole 20 Msps stream (rc_frontend/channel.py:31-38), oracle C port.  This leg is the only
-    place bench.py touches oracle/: as the timed CPU baseline and as the checker of the GPU's FM outputs."""
+def cpu_baseline(tile, carriers, fm_check=None, signal_seconds=2.0, reps=3, FS=FS, chans_per_thread=2):
+    """The reference's structure on the host cores: one 2909-tap xlating FIR (D=800) + discriminator per channel over
+    the whole 20 Msps stream (rc_frontend/channel.py:31-38), oracle C port (oracle/rcf_oracle.c: ro_bank_bench, the same
+    arithmetic as the oracle's channel bank -- tests/test_oracle_kat.py holds the two together bit for bit).  This leg
+    is the only place bench.py touches oracle/: as the timed CPU baseline and as the checker of the GPU's FM outputs.
+
+    SURVEY 8(d) asks for (i) one channel on one core and (ii) all cores busy; `signal_seconds` of signal per channel
+    (a 0.25 s periodic tile walked 8 times), one thread pinned per PHYSICAL core, every thread on its own first-touched
+    copy of the stream (the reference hands every channel flowgraph its own copy too: zeromq.pub_sink -> sub_source,
+    channel.py:29), only the filtering timed.  Three all-core figures are reported and the GPU is compared with the
+    LARGEST: the measured reference structure, SURVEY's formula cores x single-core rate, and a time-tiled form
+    ("best CPU": blocks outer, the thread's channels inner, stream read once) that GNU Radio does not run."""
     from oracle import cbind as OC
     from oracle import grspec as G
-    n = int(FS * seconds)
-    x = np.tile(tile, (n + len(tile) - 1) // len(tile))[:n]
     D, taps = G.channel_params(FS, 12500)
-    threads = OC.max_threads()
-    try:
-        phys = len({(l.split(":")[1].strip()) for l in open("/proc/cpuinfo") if l.startswith("core id")}) * \
-            max(1, len({(l.split(":")[1].strip()) for l in open("/proc/cpuinfo") if l.startswith("physical id")}))
-    except Exception:
-        phys = None
-    # (ii) one channel per host thread, so that every thread the baseline claims is actually busy (the bank is
-    # parallel over channels): the 32 bench carriers, repeated on a 12.5 kHz raster
-    offs = [carriers[i % len(carriers)]["f_off"] + 12500.0 * (i // len(carriers)) for i in range(max(threads, 1))]
-    ct = np.stack([OC.xlating_composite(taps, D, f, FS)[0] for f in offs])
-    inc = np.array([OC.xlating_composite(taps, D, f, FS)[1] for f in offs], dtype=np.complex64)
-    gains = np.full(len(offs), G.p25_fm_gain(25000.0), dtype=np.float32)
-    OC.channel_bank(x[: n // 8], D, ct, inc, gains, acc_double=False)            # warm
-    times = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        OC.channel_bank(x, D, ct, inc, gains, acc_double=False)
-        times.append(time.perf_counter() - t0)
-    t = sorted(times)[len(times) // 2]
+    n_tile = int(FS * 0.25) // D * D
+    x = np.tile(tile, (n_tile + len(tile) - 1) // len(tile))[:n_tile]
+    passes = max(1, int(round(signal_seconds * FS / n_tile)))
+    signal_s = passes * n_tile / FS
+    cores = OC.physical_cores()
+    n_thr = max(1, len(cores)) if cores else max(1, OC.max_threads())
+    cpu_ids = cores if cores else None
+    cpt = chans_per_thread
+    n_ch = n_thr * cpt
+    # the 32 bench carriers, repeated on a 12.5 kHz raster
+    offs = [carriers[i % len(carriers)]["f_off"] + 12500.0 * (i // len(carriers)) for i in range(n_ch)]
+    comp = [OC.xlating_composite(taps, D, f, FS) for f in offs]
+    ct = np.stack([c[0] for c in comp])
+    inc = np.array([c[1] for c in comp], dtype=np.complex64)
+    gains = np.full(n_ch, G.p25_fm_gain(25000.0), dtype=np.float32)
+    med = lambda v: sorted(v)[len(v) // 2]
+    OC.bank_bench(x, 1, D, ct, inc, gains, n_thr, cpt, cpu_ids)                      # warm: threads, pages, clocks
     # (i) a single channel on one core == one of the reference's per-channel GNU Radio flowgraphs
-    t1s = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        OC.channel_bank(x, D, ct[:1], inc[:1], gains[:1], acc_double=False, nthreads=1)
-        t1s.append(time.perf_counter() - t0)
-    t1 = sorted(t1s)[len(t1s) // 2]
+    t1 = med([OC.bank_bench(x, passes, D, ct[:1], inc[:1], gains[:1], 1, 1, cpu_ids)[0] for _ in range(reps)])
+    # (ii) every physical core busy with `cpt` channels, the reference's structure (each channel walks the whole stream)
+    t_ref = med([OC.bank_bench(x, passes, D, ct, inc, gains, n_thr, cpt, cpu_ids)[0] for _ in range(reps)])
+    # (iii) "best CPU": time-tiled -- 64-output blocks (51 200 samples = 410 KB: L2) outer, EIGHT channels per thread
+    # inner, so the stream comes from DRAM once per eight channels
+    cpt_t = 8
+    offs_t = [carriers[i % len(carriers)]["f_off"] + 12500.0 * (i // len(carriers)) for i in range(n_thr * cpt_t)]
+    comp_t = [OC.xlating_composite(taps, D, f, FS) for f in offs_t]
+    ct_t = np.stack([c[0] for c in comp_t])
+    inc_t = np.array([c[1] for c in comp_t], dtype=np.complex64)
+    g_t = np.full(len(offs_t), G.p25_fm_gain(25000.0), dtype=np.float32)
+    p_t = max(1, passes // 2)                             # half the signal, four times the channels: same work bound
+    t_tiled = med([OC.bank_bench(x, p_t, D, ct_t, inc_t, g_t, n_thr, cpt_t, cpu_ids, tiled=True, tile_block=64 * D)[0]
+                   for _ in range(reps)])
+    bw = OC.read_bandwidth(64 << 20, 4, n_thr, cpu_ids)
+    rt_single = signal_s / t1
+    rt_ref = n_ch * signal_s / t_ref
+    rt_tiled = n_thr * cpt_t * (p_t * n_tile / FS) / t_tiled
+    rt_formula = n_thr * rt_single
+    traffic_ref = n_ch * passes * n_tile * 8.0 / t_ref
+    largest = max(rt_ref, rt_tiled, rt_formula)
     out = {
-        "value": n / t / 1e6,
+        "value": signal_s * FS / t_ref / 1e6,
         "unit": "Msamples/s",
-        "cores": min(threads, len(offs)),
-        "cores_are": "hardware threads (OpenMP max threads of the box%s)" % (
-            "; %d physical cores" % phys if phys else ""),
+        "cores": n_thr,
+        "cores_are": "physical cores, one pinned thread each (%d hardware threads on the box)" % OC.max_threads(),
         "kind": "port",
-        "sample": "%.2f s of the same %g Msps synthetic stream, %d concurrent 12.5 kHz channels "
-                  "(%d-tap xlating FIR /%d + discriminator each, one per host thread), median of %d, OpenMP over channels; "
+        "sample": "%.2f s of the same %g Msps synthetic stream per channel (a %.2f s periodic tile x %d), %d concurrent "
+                  "12.5 kHz channels = %d per physical core (%d-tap xlating FIR /%d + discriminator each), median of %d; "
                   "CPU restatement of the reference's GNU Radio path (GNU Radio itself unavailable)"
-                  % (seconds, FS / 1e6, len(offs), len(taps), D, reps),
-        "channels": len(offs),
-        "realtime_channels_at_20Msps": len(offs) * seconds / t,
-        "single_channel_one_core": {"seconds_per_second_of_signal": t1 / seconds,
-                                    "Msamples_per_s": n / t1 / 1e6,
-                                    "realtime_channels_per_core_at_20Msps": seconds / t1},
+                  % (signal_s, FS / 1e6, n_tile / FS, passes, n_ch, cpt, len(taps), D, reps),
+        "channels": n_ch,
+        "realtime_channels_at_20Msps": rt_ref,
+        "single_channel_one_core": {"seconds_per_second_of_signal": t1 / signal_s, "Msamples_per_s": signal_s * FS / t1 / 1e6,
+                                    "realtime_channels_per_core_at_20Msps": rt_single},
+        "all_cores": {
+            "reference_structure_measured": {"realtime_channels": rt_ref, "seconds": t_ref,
+                                             "stream_read_GBps": traffic_ref / 1e9,
+                                             "what": "channel outer, whole stream per channel: how GNU Radio runs it"},
+            "survey_formula_cores_x_single_core": {"realtime_channels": rt_formula,
+                                                   "what": "SURVEY 8(d): cores x 1 / per-channel real-time fraction"},
+            "best_cpu_time_tiled_measured": {"realtime_channels": rt_tiled, "seconds": t_tiled,
+                                             "channels": n_thr * cpt_t, "signal_seconds_per_channel": p_t * n_tile / FS,
+                                             "what": "NOT the reference's structure: 64-output time blocks outer, the "
+                                                     "thread's %d channels inner, stream read from DRAM once per thread" % cpt_t},
+            "measured_over_formula": rt_ref / rt_formula,
+            "host_read_bandwidth_GBps": bw / 1e9,
+            "measured_vs_formula": (
+                "measured all-core figure within %.0f %% of cores x single-core" % (100 * abs(1 - rt_ref / rt_formula))
+                if rt_ref / rt_formula > 0.8 else
+                "below the formula because every channel streams the whole wideband buffer (160 MB/s x its speed-up): %d "
+                "channels at once read %.0f GB/s, %.0f %% of the %.0f GB/s the same pinned threads reach summing private "
+                "buffers, while the single-core run has the memory system to itself; the time-tiled form (stream read "
+                "once per thread) shows what is left when that is taken away"
+                % (n_ch, traffic_ref / 1e9, 100 * traffic_ref / bw, bw / 1e9)),
+        },
+        "largest_cpu_realtime_channels": largest,
     }
     if fm_check is not None:
         out["gpu_fm_parity_vs_oracle"] = fm_parity(G, tile, fm_check)
@@ -576,13 +622,19 @@ def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_
                 busy.append(v)
             stop.wait(0.25)
 
+    import gc
     ths = [threading.Thread(target=worker, args=(w,)) for w in range(n_threads)]
     smp = threading.Thread(target=sampler)
-    smp.start()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
+    gc.collect()
+    gc.disable()                                         # a generation-2 collection of this process is a 20 ms block
+    try:
+        smp.start()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    finally:
+        gc.enable()
     wall = time.perf_counter() - t0
     stop.set()
     smp.join()
@@ -629,9 +681,22 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
     for shape in shapes:
         pts, good, bad = [], None, None
         K = k_first
-        while K <= k_cap:
+        def point(K):
             p = realtime_point(native, K, shape, raw.array, carriers, device, seconds, block_ms, min(n_threads, K))
             pts.append(p)
+            n_blocks = K * p["blocks_per_front_end"]
+            if not p["ok"] and not p["errors"] and p["ring_overruns"] == 0 and p["output_samples_lost"] == 0 \
+                    and p["deadline_misses"] <= max(K, n_blocks // 100):
+                # at most one tick's worth of late blocks (or 1 %): one hiccup of a shared host, or the limit?  Once more,
+                # both attempts stay in `points`
+                p["retried"] = True
+                p = realtime_point(native, K, shape, raw.array, carriers, device, seconds, block_ms, min(n_threads, K))
+                p["second_attempt"] = True
+                pts.append(p)
+            return p
+
+        while K <= k_cap:
+            p = point(K)
             if p["ok"]:
                 good = K
                 K *= 2
@@ -640,12 +705,10 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
                 break
         if good is not None and bad is not None and bad - good > max(8, good // 4):
             mid = (good + bad) // 2
-            p = realtime_point(native, mid, shape, raw.array, carriers, device, seconds, block_ms, min(n_threads, mid))
-            pts.append(p)
-            if p["ok"]:
+            if point(mid)["ok"]:
                 good = mid
         bins, demod = (NB, len(carriers)) if shape == "pfb256" else (1600, 256)
-        best = next((p for p in pts if p["front_ends"] == good), None)
+        best = next((p for p in pts if p["front_ends"] == good and p["ok"]), None)
         out[shape] = {
             "K_max": good or 0, "first_K_that_missed": bad, "bins_per_front_end": bins, "demodulated_per_front_end": demod,
             "channels_sustained": (good or 0) * bins, "fm_channels_sustained": (good or 0) * demod,
@@ -653,7 +716,8 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
             "at_K_max": best, "points": [{k: p[k] for k in ("front_ends", "ok", "deadline_misses", "ring_overruns",
                                                             "latency_ms_p50", "latency_ms_p99", "gpu_busy_percent_mean",
                                                             "host_push_ms_per_tick_slowest_thread",
-                                                            "host_drain_ms_per_tick_slowest_thread", "errors")} for p in pts],
+                                                            "host_drain_ms_per_tick_slowest_thread", "errors")} | {k: p[k] for k in ("retried", "second_attempt") if k in p}
+                                         for p in pts],
         }
     raw.free()
     return out
@@ -1070,8 +1134,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(tile, meta["carriers"], fm_check)
         db = out["channels"].get("direct_bank")
         if db:
-            out["cpu_baseline"]["gpu_channels_run_in_real_time_over_cpu_realtime_channels"] = (
-                db["channels_run_in_real_time"] / out["cpu_baseline"]["realtime_channels_at_20Msps"])
+            # against the LARGEST of the CPU figures (measured reference structure, SURVEY's formula, time-tiled best CPU)
+            cb = out["cpu_baseline"]
+            cb["gpu_channels_run_in_real_time_over_cpu_realtime_channels"] = (
+                db["channels_run_in_real_time"] / cb["largest_cpu_realtime_channels"])
+            cb["gpu_over_cpu_note"] = ("%d reference-shaped channels opened and run in real time on one MI355X (direct "
+                                       "bank) / %.0f, the largest CPU figure above" % (db["channels_run_in_real_time"],
+                                                                                      cb["largest_cpu_realtime_channels"]))
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

@@ -46,6 +46,16 @@ def lib():
                                       C.c_int, C.c_int]
         L.ro_channel_bank.restype = C.c_int
         L.ro_max_threads.restype = C.c_int
+        ip = C.POINTER(C.c_int)
+        L.ro_bank_bench.argtypes = [fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, fp, ip, C.c_int,
+                                    C.c_int64, fp, fp]
+        L.ro_bank_bench.restype = C.c_double
+        L.ro_read_bandwidth.argtypes = [C.c_int64, C.c_int, C.c_int, ip, fp]
+        L.ro_read_bandwidth.restype = C.c_double
+        L.ro_fir_summation.argtypes = [fp, C.c_int64, C.c_int, fp, C.c_int, C.c_int, fp]
+        L.ro_fir_summation.restype = C.c_int
+        L.ro_rotator_phases.argtypes = [fp, C.c_int64, C.c_int, fp]
+        L.ro_rotator_phases.restype = None
         L.ro_scan_chain.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp]
         L.ro_scan_chain.restype = C.c_int
         L.ro_peak_detect.argtypes = [fp, C.c_int64, C.c_double, C.c_double, C.c_double,
@@ -135,3 +145,71 @@ def peak_detect(spectrum, samp_rate, fft_width=None, cap=4096):
 
 def max_threads():
     return lib().ro_max_threads()
+
+
+def physical_cores():
+    """one logical CPU id per physical core this process may run on (sysfs thread_siblings_list); [] if unknown"""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except Exception:
+        return []
+    seen, out = set(), []
+    for cpu in allowed:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % cpu) as f:
+                sib = f.read().strip()
+        except OSError:
+            sib = str(cpu)
+        if sib not in seen:
+            seen.add(sib)
+            out.append(cpu)
+    return out
+
+
+def bank_bench(tile, passes, D, ctaps, incr, gains, n_threads, cpt, cpu_ids=None, tiled=False, tile_block=0,
+               want_y0=False):
+    """seconds of the timed region of ro_bank_bench (see rcf_oracle.c): n_threads x cpt channels, each over
+    passes x len(tile) samples.  ctaps: (n_threads * cpt, T)"""
+    tile = np.ascontiguousarray(tile, dtype=np.complex64)
+    ctaps = np.ascontiguousarray(ctaps, dtype=np.complex64)
+    incr = np.ascontiguousarray(incr, dtype=np.complex64)
+    gains = np.ascontiguousarray(gains, dtype=np.float32)
+    assert ctaps.shape[0] == n_threads * cpt == len(incr) == len(gains)
+    ids = (C.c_int * n_threads)(*cpu_ids[:n_threads]) if cpu_ids else None
+    chk = np.zeros(n_threads, dtype=np.float32)
+    y0 = np.zeros(len(tile) // D, dtype=np.complex64) if want_y0 else None
+    t = lib().ro_bank_bench(_fp(tile.view(np.float32)), len(tile), int(passes), int(D), ctaps.shape[1], int(n_threads),
+                            int(cpt), _fp(ctaps.view(np.float32)), _fp(incr.view(np.float32)), _fp(gains), ids,
+                            1 if tiled else 0, int(tile_block), _fp(chk),
+                            _fp(y0.view(np.float32)) if y0 is not None else None)
+    if t < 0:
+        raise RuntimeError("ro_bank_bench failed (arguments / memory)")
+    return (t, chk, y0) if want_y0 else (t, chk)
+
+
+def read_bandwidth(bytes_per_thread, reps, n_threads, cpu_ids=None):
+    ids = (C.c_int * n_threads)(*cpu_ids[:n_threads]) if cpu_ids else None
+    sink = np.zeros(n_threads, dtype=np.float32)
+    return lib().ro_read_bandwidth(int(bytes_per_thread), int(reps), int(n_threads), ids, _fp(sink))
+
+
+SUM_8_LANES, SUM_SEQUENTIAL, SUM_PAIRWISE, SUM_16_LANES, SUM_FLOAT64 = 0, 1, 2, 3, 4
+
+
+def fir_summation(x, D, ctaps, mode):
+    """v[k] = sum_i ctaps[i] x[kD - i] with the dot product summed in `mode` (SUM_*): the orders a VOLK build may use"""
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    ctaps = np.ascontiguousarray(ctaps, dtype=np.complex64)
+    n_out = (len(x) - 1) // D + 1 if len(x) else 0
+    v = np.empty(n_out, dtype=np.complex64)
+    assert lib().ro_fir_summation(_fp(x.view(np.float32)), len(x), D, _fp(ctaps.view(np.float32)), len(ctaps), mode,
+                                  _fp(v.view(np.float32))) == 0
+    return v
+
+
+def rotator_phases(incr, n, fma=False):
+    """gr::blocks::rotator's phase for outputs 0 .. n-1, with or without FMA contraction of the complex multiply"""
+    inc = np.array([incr], dtype=np.complex64)
+    out = np.empty(n, dtype=np.complex64)
+    lib().ro_rotator_phases(_fp(inc.view(np.float32)), n, 1 if fma else 0, _fp(out.view(np.float32)))
+    return out

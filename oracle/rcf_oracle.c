@@ -1,3 +1,4 @@
+#define _GNU_SOURCE
 /*
  * rcf_oracle.c -- plain-C CPU restatement of the radiocapture-rf channelizer / discriminator /
  * scan hot path.  TEST INFRASTRUCTURE ONLY: loaded (ctypes) by tests/, __graft_entry__.smoke()
@@ -283,6 +284,265 @@ int ro_channel_bank(const float *x, int64_t n_in, int D, int T, int C,
     }
     free(xp);
     return 0;
+}
+
+/*
+ * cpu_baseline leg of bench.py: the same per-channel arithmetic, laid out so that the all-core figure is defensible.
+ *   - n_threads workers, worker w pinned to cpu_ids[w] (one per PHYSICAL core; NULL = unpinned)
+ *   - every worker owns a PRIVATE copy of the wideband tile, first-touched by itself -- the reference gives every
+ *     channel flowgraph its own copy of the stream too (zeromq.pub_sink -> one sub_source per channel.py:29)
+ *   - the tile (n_tile samples, periodic: its own tail is its history) is walked `passes` times per channel:
+ *     passes * n_tile samples of signal per channel without passes * n_tile * 8 bytes of memory per thread
+ *   - tiled == 0: the reference's structure -- channel outer, the whole stream per channel (cpt channels in turn)
+ *     tiled != 0: "best CPU" -- time blocks of tile_block samples outer, the thread's cpt channels inner: the
+ *     stream comes from DRAM once per thread instead of once per channel (NOT how GNU Radio runs; labelled so)
+ *   - only the region between the two barriers is timed (allocation, first touch and thread start are outside)
+ * Returns the wall seconds of the timed region; checksum[w] keeps the work observable; y0_last (optional, n_tile / D
+ * complex) receives worker 0's first channel over the LAST pass, so that a test can hold what is timed against
+ * ro_channel_bank on the same stream.
+ */
+#include <sched.h>
+#include <time.h>
+static double ro_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+double ro_bank_bench(const float *tile, int64_t n_tile, int passes, int D, int T, int n_threads, int cpt,
+                     const float *ctaps, const float *incr, const float *gains, const int *cpu_ids,
+                     int tiled, int64_t tile_block, float *checksum, float *y0_last)
+{
+    if (n_tile % D || n_tile < T || n_threads < 1 || cpt < 1 || passes < 1) return -1.0;
+    if (tile_block <= 0 || tile_block % D) tile_block = n_tile;
+    const int64_t n_out = n_tile / D;
+    double t_begin = 0.0, t_end = 0.0;
+    int failed = 0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads) reduction(+ : failed)
+#endif
+    {
+#ifdef _OPENMP
+        const int w = omp_get_thread_num();
+#else
+        const int w = 0;
+#endif
+        if (cpu_ids) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            CPU_SET(cpu_ids[w], &set);
+            (void)sched_setaffinity(0, sizeof set, &set);
+        }
+        float *xp = (float *)malloc(sizeof(float) * 2 * (size_t)(n_tile + T - 1));
+        float *y = (float *)malloc(sizeof(float) * 2 * (size_t)n_out);
+        float *fm = (float *)malloc(sizeof(float) * (size_t)n_out);
+        if (!xp || !y || !fm) failed = 1;
+        if (!failed) {
+            /* history = the tile's own tail (periodic stream); first touch by this thread */
+            memcpy(xp, tile + 2 * (size_t)(n_tile - (T - 1)), sizeof(float) * 2 * (size_t)(T - 1));
+            memcpy(xp + 2 * (size_t)(T - 1), tile, sizeof(float) * 2 * (size_t)n_tile);
+            memset(y, 0, sizeof(float) * 2 * (size_t)n_out);
+            memset(fm, 0, sizeof(float) * (size_t)n_out);
+        }
+        const float *xh = xp + 2 * (size_t)(T - 1);
+        float acc = 0.f;
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp master
+#endif
+        t_begin = ro_now();
+#ifdef _OPENMP
+#pragma omp barrier
+#endif
+        if (!failed) {
+            ro_rot_state st[64];
+            float prev[64][2];
+            const int nc = cpt > 64 ? 64 : cpt;
+            for (int c = 0; c < nc; c++) { st[c].phase_re = 1.f; st[c].phase_im = 0.f; st[c].counter = 0; prev[c][0] = prev[c][1] = 0.f; }
+            for (int p = 0; p < passes; p++) {
+                if (!tiled) {
+                    for (int c = 0; c < nc; c++) {
+                        const size_t ch = (size_t)w * cpt + c;
+                        ro_xlating_fir_ccc(xh, 0, n_out, D, ctaps + 2 * ch * T, T, incr + 2 * ch, &st[c], y, 0);
+                        ro_quad_demod_cf(y, n_out, gains[ch], prev[c], fm);
+                        acc += fm[n_out - 1] + y[0];
+                        if (y0_last && w == 0 && c == 0 && p == passes - 1) memcpy(y0_last, y, sizeof(float) * 2 * (size_t)n_out);
+                    }
+                } else {
+                    for (int64_t s0 = 0; s0 < n_tile; s0 += tile_block) {
+                        const int64_t k0 = s0 / D, k1 = (s0 + tile_block < n_tile ? s0 + tile_block : n_tile) / D;
+                        for (int c = 0; c < nc; c++) {
+                            const size_t ch = (size_t)w * cpt + c;
+                            ro_xlating_fir_ccc(xh, k0, k1 - k0, D, ctaps + 2 * ch * T, T, incr + 2 * ch, &st[c], y + 2 * k0, 0);
+                            ro_quad_demod_cf(y + 2 * k0, k1 - k0, gains[ch], prev[c], fm + k0);
+                            acc += fm[k1 - 1] + y[2 * k0];
+                            if (y0_last && w == 0 && c == 0 && p == passes - 1)
+                                memcpy(y0_last + 2 * k0, y + 2 * k0, sizeof(float) * 2 * (size_t)(k1 - k0));
+                        }
+                    }
+                }
+            }
+        }
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp master
+#endif
+        t_end = ro_now();
+        if (checksum) checksum[w] = acc;
+        free(xp); free(y); free(fm);
+    }
+    return failed ? -1.0 : t_end - t_begin;
+}
+
+/* streaming read bandwidth of the host with the same pinning: every worker sums its own first-touched buffer `reps`
+ * times; returns bytes per second over all workers (what bounds the all-core run of the reference's structure) */
+double ro_read_bandwidth(int64_t bytes_per_thread, int reps, int n_threads, const int *cpu_ids, float *sink)
+{
+    const int64_t n = bytes_per_thread / (int64_t)sizeof(float);
+    double t_begin = 0.0, t_end = 0.0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads)
+#endif
+    {
+#ifdef _OPENMP
+        const int w = omp_get_thread_num();
+#else
+        const int w = 0;
+#endif
+        if (cpu_ids) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            CPU_SET(cpu_ids[w], &set);
+            (void)sched_setaffinity(0, sizeof set, &set);
+        }
+        float *b = (float *)malloc(sizeof(float) * (size_t)n);
+        for (int64_t i = 0; b && i < n; i++) b[i] = (float)(i & 7);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp master
+#endif
+        t_begin = ro_now();
+#ifdef _OPENMP
+#pragma omp barrier
+#endif
+        for (int r = 0; b && r < reps; r++)
+            for (int64_t i = 0; i + 16 <= n; i += 16) {
+                s0 += b[i] + b[i + 4] + b[i + 8] + b[i + 12];
+                s1 += b[i + 1] + b[i + 5] + b[i + 9] + b[i + 13];
+                s2 += b[i + 2] + b[i + 6] + b[i + 10] + b[i + 14];
+                s3 += b[i + 3] + b[i + 7] + b[i + 11] + b[i + 15];
+            }
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp master
+#endif
+        t_end = ro_now();
+        if (sink) sink[w] = s0 + s1 + s2 + s3;
+        free(b);
+    }
+    return (double)bytes_per_thread * reps * n_threads / (t_end - t_begin);
+}
+
+/* ---------------------------------------------------------------- bounds on what cannot be pinned (tests only)
+ * GNU Radio / VOLK leave three things to the build and the machine: the order in which a dot product is summed
+ * (SIMD width of the VOLK kernel picked at run time), whether the compiler contracted the rotator's complex
+ * multiply into fused multiply-adds, and the polynomial inside volk_32f_log2.  These restate the alternatives so that
+ * tests/test_oracle_unpinned_bounds.py can bound how far each moves the outputs. */
+static void ro_dot_mode(const float *cr, const float *xs, int T, int mode, float *vr, float *vi)
+{
+    if (mode == 0) { ro_dot_f32(cr, xs, T, vr, vi); return; }
+    if (mode == 4) { ro_dot_f64(cr, xs, T, vr, vi); return; }
+    if (mode == 1) {                                   /* strictly sequential float32 (VOLK generic) */
+        float tr = 0.f, ti = 0.f;
+        for (int j = 0; j < T; j++) {
+            float a = cr[2 * j], b = cr[2 * j + 1], c = xs[2 * j], d = xs[2 * j + 1];
+            float p0 = a * c, p1 = b * d, p2 = a * d, p3 = b * c;
+            tr += p0 - p1;
+            ti += p2 + p3;
+        }
+        *vr = tr; *vi = ti;
+        return;
+    }
+    if (mode == 3) {                                   /* 16 lanes (AVX-512 width), lanes added in order at the end */
+        float sr[16] = {0}, si[16] = {0};
+        int j = 0;
+        for (; j + 16 <= T; j += 16)
+            for (int l = 0; l < 16; l++) {
+                float a = cr[2 * (j + l)], b = cr[2 * (j + l) + 1], c = xs[2 * (j + l)], d = xs[2 * (j + l) + 1];
+                float p0 = a * c, p1 = b * d, p2 = a * d, p3 = b * c;
+                sr[l] += p0 - p1;
+                si[l] += p2 + p3;
+            }
+        float tr = 0.f, ti = 0.f;
+        for (; j < T; j++) {
+            float a = cr[2 * j], b = cr[2 * j + 1], c = xs[2 * j], d = xs[2 * j + 1];
+            float p0 = a * c, p1 = b * d, p2 = a * d, p3 = b * c;
+            tr += p0 - p1;
+            ti += p2 + p3;
+        }
+        for (int l = 0; l < 16; l++) { tr += sr[l]; ti += si[l]; }
+        *vr = tr; *vi = ti;
+        return;
+    }
+    /* mode 2: pairwise (tree) summation of the float32 products */
+    float *pr = (float *)malloc(sizeof(float) * 2 * (size_t)T);
+    for (int j = 0; j < T; j++) {
+        float a = cr[2 * j], b = cr[2 * j + 1], c = xs[2 * j], d = xs[2 * j + 1];
+        float p0 = a * c, p1 = b * d, p2 = a * d, p3 = b * c;
+        pr[2 * j] = p0 - p1;
+        pr[2 * j + 1] = p2 + p3;
+    }
+    for (int n = T; n > 1; n = (n + 1) / 2)
+        for (int j = 0; j < n / 2; j++) {
+            pr[2 * j] = pr[2 * (2 * j)] + pr[2 * (2 * j + 1)];
+            pr[2 * j + 1] = pr[2 * (2 * j) + 1] + pr[2 * (2 * j + 1) + 1];
+            if (j == n / 2 - 1 && (n & 1)) { pr[2 * (j + 1)] = pr[2 * (n - 1)]; pr[2 * (j + 1) + 1] = pr[2 * (n - 1) + 1]; }
+        }
+    *vr = pr[0]; *vi = pr[1];
+    free(pr);
+}
+
+/* v[k] = sum_i ctaps[i] x[kD - i] (no rotator), dot product summed in `mode` (0: 8 lanes, 1: sequential, 2: pairwise,
+ * 3: 16 lanes, 4: float64); x has T-1 zeros of history */
+int ro_fir_summation(const float *x, int64_t n_in, int D, const float *ctaps, int T, int mode, float *v)
+{
+    const int64_t n_out = n_in > 0 ? (n_in - 1) / D + 1 : 0;
+    float *xp = (float *)calloc((size_t)(n_in + T - 1) * 2, sizeof(float));
+    float *cr = (float *)malloc(sizeof(float) * 2 * (size_t)T);
+    if (!xp || !cr) { free(xp); free(cr); return -1; }
+    memcpy(xp + 2 * (size_t)(T - 1), x, sizeof(float) * 2 * (size_t)n_in);
+    for (int j = 0; j < T; j++) { cr[2 * j] = ctaps[2 * (T - 1 - j)]; cr[2 * j + 1] = ctaps[2 * (T - 1 - j) + 1]; }
+    for (int64_t k = 0; k < n_out; k++) ro_dot_mode(cr, xp + 2 * (size_t)(k * D), T, mode, v + 2 * k, v + 2 * k + 1);
+    free(xp); free(cr);
+    return 0;
+}
+
+/* gr::blocks::rotator phases of outputs 0 .. n-1.  fma_mode 0: every product rounded (x86-64 baseline build: what the
+ * oracle and the HIP kernels iterate); 1: the complex multiply contracted the way GCC / clang -ffp-contract=fast do
+ * it on an FMA machine, re = fma(a, c, -(b d)), im = fma(a, d, b c) */
+void ro_rotator_phases(const float *incr, int64_t n, int fma_mode, float *out)
+{
+    float pr = 1.f, pi = 0.f;
+    const float ir = incr[0], ii = incr[1];
+    for (int64_t k = 0; k < n; k++) {
+        out[2 * k] = pr; out[2 * k + 1] = pi;
+        float nr, ni;
+        if (fma_mode) {
+            float m1 = pi * ii, m3 = pi * ir;
+            nr = fmaf(pr, ir, -m1);
+            ni = fmaf(pr, ii, m3);
+        } else {
+            float m0 = pr * ir, m1 = pi * ii, m2 = pr * ii, m3 = pi * ir;
+            nr = m0 - m1; ni = m2 + m3;
+        }
+        pr = nr; pi = ni;
+        if (((uint32_t)(k + 1) % 512u) == 0) {
+            float mag = hypotf(pr, pi);
+            pr /= mag; pi /= mag;
+        }
+    }
 }
 
 int ro_max_threads(void)

@@ -249,3 +249,27 @@ def test_scan_chain_is_the_flowgraph_the_reference_builds():
     assert chain + [b] == ["zeromq_sub_source_0", "blocks_stream_to_vector_0", "fft_vxx_0", "blocks_complex_to_mag_squared_0",
                            "blocks_nlog10_ff_0", "blocks_moving_average_xx_1", "blocks_head_0", "blocks_skiphead_0",
                            "blocks_file_sink_0"]
+
+
+def test_the_timed_cpu_baseline_computes_the_channel_bank():
+    """bench.py's cpu_baseline times ro_bank_bench (pinned threads, private first-touched copies of a periodic tile,
+    reference structure or time-tiled): both forms must BE the channel the oracle's ro_channel_bank computes -- the last
+    pass over the tile equals the tail of the bank run over the tile repeated, bit for bit (same float32 order)."""
+    from oracle import cbind as OC
+    fs = 2.4e6
+    D, taps = G.channel_params(fs, 12500)
+    rng = np.random.default_rng(5)
+    n = D * 400
+    tile = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    offs = [-62500.0, 100e3, 412.5e3, -1e6]
+    ct = np.stack([OC.xlating_composite(taps, D, f, fs)[0] for f in offs])
+    inc = np.array([OC.xlating_composite(taps, D, f, fs)[1] for f in offs], dtype=np.complex64)
+    g = np.full(4, 5.0, dtype=np.float32)
+    passes = 3
+    want, _ = OC.channel_bank(np.tile(tile, passes + 1), D, ct[:1], inc[:1], g[:1], acc_double=False)
+    for tiled, block in ((False, 0), (True, D * 16), (True, D * 7)):
+        t, chk, y0 = OC.bank_bench(tile, passes + 1, D, ct, inc, g, n_threads=2, cpt=2, cpu_ids=None, tiled=tiled,
+                                   tile_block=block, want_y0=True)
+        assert t > 0 and np.all(np.isfinite(chk))
+        # the bench's first pass sees the tile's tail as history, the bank zeros: compare the LAST pass, far from either
+        assert np.array_equal(y0, want[0][-len(y0):]), (tiled, block)
