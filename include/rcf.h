@@ -79,6 +79,16 @@ int rcf_design_resampler(int interpolation, int decimation, int *interp_out, int
 /* rc_frontend/channel.py:31-33: decim = int(fs/cr)/2 (must be integral -> else RCF_ERANGE) and the
  * tap count of low_pass_2(1.0, fs, cr/2, cr/2, 20.0, WIN_HAMMING). */
 int rcf_channel_params(double samp_rate, int channel_rate, int *decim, int *ntaps);
+/* The same with the rule for a non-integral int(fs/cr)/2 spelled out.  rc_frontend/channel.py:31 was written for
+ * Python 2, where int / int floors: the author's deployment (configs/config_denver_massive_p25.py:20,31: 10 666 666 sps,
+ * receiver_split2 = False) ran 12.5 kHz channels at decim = 853 // 2 = 426, output rate 10 666 666 / 426 = 25 039 S/s.
+ * Under Python 3 the same line hands GNU Radio 426.5 and the channel cannot be built.
+ *   RCF_DECIM_EXACT (default)  reject (RCF_ERANGE) unless int(fs/cr) is even       -- Python 3 behaviour made explicit
+ *   RCF_DECIM_FLOOR            decim = int(fs/cr) // 2                              -- what the Python 2 deployment ran
+ * out_rate (may be NULL) = fs / decim: NOT 2 cr in the floored case; consumers read it from rcf_chan_info. */
+#define RCF_DECIM_EXACT 0
+#define RCF_DECIM_FLOOR 1
+int rcf_channel_params_ex(double samp_rate, int channel_rate, int decim_rule, int *decim, int *ntaps, double *out_rate);
 
 /* ------------------------------------------------------------------ front-end lifecycle */
 /*
@@ -100,11 +110,15 @@ int rcf_close(rcf_t *h);
  *   discriminator and magnitudes are not affected.
  * exact != 0: GNU Radio's own recurrence, phase *= incr in float32 with the renormalisation every 512 calls, iterated
  *   per channel on the device before each block's FIR launches: the IQ stream then carries GNU Radio's phase output for
- *   output at any stream length.  Sequential by nature (~4 ns per output and channel per block): meant for real-time
+ *   output at any stream length.  Sequential by nature (measured ~30 ns per output per block -- 0.15 ms for a 5243-output block, whatever the
+ *   channel count: channels run side by side): meant for real-time
  *   block sizes.  Plain channels only -- filterbank bin taps keep the closed form (their rotator also carries the
  *   bank's own phases).  Must be called before the first channel is opened (RCF_ESTATE otherwise); the environment
  *   variable RCF_ROTATOR=exact sets it at rcf_open. */
 int rcf_set_rotator(rcf_t *h, int exact);
+/* The decimation rule rcf_chan_open / rcf_pfb_chan_open apply on this handle (rcf_channel_params_ex); default
+ * RCF_DECIM_EXACT, or RCF_DECIM_FLOOR when the environment variable RCF_DECIM_FLOOR=1 is set at rcf_open. */
+int rcf_set_decim_rule(rcf_t *h, int decim_rule);
 /* wait until everything queued on the handle's stream has finished */
 int rcf_sync(rcf_t *h);
 /* the handle's hipStream_t, for callers that time the kernels with HIP events */

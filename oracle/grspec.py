@@ -111,14 +111,16 @@ def low_pass_2(gain: float, fs: float, fc: float, tw: float, att_db: float,
 # --------------------------------------------------------------------------------------------
 # rc_frontend/channel.py:31-35 parameter derivation
 # --------------------------------------------------------------------------------------------
-def channel_params(samp_rate: float, channel_rate: float):
+def channel_params(samp_rate: float, channel_rate: float, py2_floor: bool = False):
     """(D, taps) exactly as rc_frontend/channel.py:31-35 derives them.
 
     The reference computes ``int(samp_rate/channel_rate)/2`` (a python float).  Only integral
-    values are meaningful; non-integral cases are rejected (documented divergence).
+    values are meaningful; non-integral cases are rejected (documented divergence) --
+    unless ``py2_floor``: under Python 2, which the line was written for, int / int floors
+    (configs/config_denver_massive_p25.py:20: 10 666 666 sps -> 853 / 2 = 426).
     """
     q = int(samp_rate / channel_rate)
-    if q % 2 != 0 or q < 2:
+    if (q % 2 != 0 and not py2_floor) or q < 2:
         raise ValueError("decimation int(fs/cr)/2 is not a positive integer for fs=%r cr=%r"
                          % (samp_rate, channel_rate))
     D = q // 2

@@ -201,6 +201,7 @@ struct rcf {
     int mfma_min = 8;             // fewest channels of a class worth a matrix-core launch (RCF_FIR_MFMA_MIN)
     int mfma_nt = 0, mfma_parts = 0;   // RCF_FIR_MFMA_NT / RCF_FIR_MFMA_PARTS: override the launch plan (measurements)
     bool exact_rot = false;       // rcf_set_rotator / RCF_ROTATOR=exact: channels iterate GNU Radio's float32 rotator
+    int decim_rule = RCF_DECIM_EXACT;   // rcf_set_decim_rule / RCF_DECIM_FLOOR=1
     float2 *d_tapmat = nullptr;   // filterbank taps: the current launch's compact tap matrix (PfbLaunch::tap_mat)
     size_t tapmat_cap = 0;        // in float2
     float2 *d_partial = nullptr;  // split-K slabs of the matrix-core bank
@@ -1253,6 +1254,27 @@ int process_block(rcf_t *h, size_t n)
             return rc;
         }
     }
+    // Planning advances every channel's counters and rotator model (plan_channel) and can still fail after that -- a
+    // bank matrix, split-K slab or tap matrix that cannot be allocated, an exhausted launch arena.  Nothing has been
+    // queued at that point: put the counters back, so that they never claim outputs nobody computed (and the exact
+    // rotator's device state stays in step with them).
+    struct Saved { Chan *c; int64_t produced, n_seg0, blk_before, blk_after; uint64_t blk_serial; long double angle0; double logmag0; };
+    std::vector<Saved> saved;
+    saved.reserve(h->chans.size());
+    for (auto &kv : h->chans) {
+        Chan *c = kv.second.get();
+        saved.push_back(Saved{c, c->produced, c->n_seg0, c->blk_before, c->blk_after, c->blk_serial, c->angle0, c->logmag0});
+    }
+    const uint64_t serial_before = h->blk_serial;
+    auto roll_back = [&](int code) {
+        for (const Saved &s : saved) {
+            s.c->produced = s.produced; s.c->n_seg0 = s.n_seg0; s.c->blk_before = s.blk_before; s.c->blk_after = s.blk_after;
+            s.c->blk_serial = s.blk_serial; s.c->angle0 = s.angle0; s.c->logmag0 = s.logmag0;
+        }
+        if (h->pfb.open) h->pfb.produced = h->pfb.produced_before;
+        h->blk_serial = serial_before;
+        return code;
+    };
     // channels, by depth then by (D, T) class
     bp.fir_by_depth.resize(bp.max_depth + 1);
     bp.serial = ++h->blk_serial;
@@ -1266,12 +1288,12 @@ int process_block(rcf_t *h, size_t n)
             cp.launched.reserve(cls.second.size());
             cp.discs.reserve(cls.second.size());
             for (Chan *c : cls.second)
-                if ((rc = plan_channel(h, bp, cp, c, cls.first.first)) != RCF_OK) return rc;
-            if ((rc = plan_class_jobs(h, bp, cp, depth, cls.first)) != RCF_OK) return rc;
+                if ((rc = plan_channel(h, bp, cp, c, cls.first.first)) != RCF_OK) return roll_back(rc);
+            if ((rc = plan_class_jobs(h, bp, cp, depth, cls.first)) != RCF_OK) return roll_back(rc);
         }
     }
-    if ((rc = plan_tail(h, bp)) != RCF_OK) return rc;
-    if ((rc = launch_plan(h, bp)) != RCF_OK) return rc;
+    if ((rc = plan_tail(h, bp)) != RCF_OK) return roll_back(rc);
+    if ((rc = launch_plan(h, bp)) != RCF_OK) return rc;      // kernels may be queued: the handle's stream state is undefined now
     if ((rc = run_scan(h, bp)) != RCF_OK) return rc;
     return finish_block(h, bp);
 }
@@ -1511,17 +1533,26 @@ int rcf_design_window(int window, int n, float *w)
     return RCF_OK;
 }
 
-int rcf_channel_params(double samp_rate, int channel_rate, int *decim, int *ntaps)
+int rcf_channel_params_ex(double samp_rate, int channel_rate, int decim_rule, int *decim, int *ntaps, double *out_rate)
 {
-    if (samp_rate <= 0 || channel_rate <= 0) { set_error("bad rates"); return RCF_EINVAL; }
+    if (samp_rate <= 0 || channel_rate <= 0 || (decim_rule != RCF_DECIM_EXACT && decim_rule != RCF_DECIM_FLOOR)) {
+        set_error("bad rates / decimation rule");
+        return RCF_EINVAL;
+    }
     const int q = (int)(samp_rate / channel_rate);
-    if (q < 2 || (q & 1)) {
+    if (q < 2 || ((q & 1) && decim_rule == RCF_DECIM_EXACT)) {
         set_error("int(fs/cr)/2 is not a positive integer for fs=%g cr=%d", samp_rate, channel_rate);
         return RCF_ERANGE;
     }
     if (decim) *decim = q / 2;
     if (ntaps) *ntaps = design_ntaps(samp_rate, channel_rate / 2.0, 20.0);
+    if (out_rate) *out_rate = samp_rate / (q / 2);
     return RCF_OK;
+}
+
+int rcf_channel_params(double samp_rate, int channel_rate, int *decim, int *ntaps)
+{
+    return rcf_channel_params_ex(samp_rate, channel_rate, RCF_DECIM_EXACT, decim, ntaps, nullptr);
 }
 
 int rcf_open(int device, double samp_rate, double center_freq, rcf_t **out)
@@ -1550,6 +1581,7 @@ int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_c
     {
         if (const char *nm = getenv("RCF_FIR_NOMFMA")) h->no_mfma = atoi(nm) != 0;
         if (const char *rm = getenv("RCF_ROTATOR")) h->exact_rot = std::strcmp(rm, "exact") == 0;
+        if (const char *df = getenv("RCF_DECIM_FLOOR")) h->decim_rule = std::atoi(df) ? RCF_DECIM_FLOOR : RCF_DECIM_EXACT;
         if (const char *ck = getenv("RCF_COPY_KERNELS")) h->copy_kernels = h->copy_kernels && atoi(ck) != 0;
     if (const char *nm = getenv("RCF_FIR_MFMA_MIN")) h->mfma_min = std::max(1, atoi(nm));
         if (const char *nm = getenv("RCF_FIR_MFMA_NT")) h->mfma_nt = atoi(nm);
@@ -1677,6 +1709,14 @@ int rcf_set_rotator(rcf_t *h, int exact)
     return RCF_OK;
 }
 
+int rcf_set_decim_rule(rcf_t *h, int decim_rule)
+{
+    if (!h || (decim_rule != RCF_DECIM_EXACT && decim_rule != RCF_DECIM_FLOOR)) { set_error("bad decimation rule"); return RCF_EINVAL; }
+    std::lock_guard<std::mutex> g(h->mu);
+    h->decim_rule = decim_rule;
+    return RCF_OK;
+}
+
 void *rcf_stream(rcf_t *h) { return h ? (void *)h->stream : nullptr; }
 int rcf_device(rcf_t *h) { return h ? h->device : RCF_EINVAL; }
 int64_t rcf_samples_in(rcf_t *h) { return h ? h->total_in : RCF_EINVAL; }
@@ -1780,7 +1820,7 @@ int rcf_chan_open(rcf_t *h, int channel_rate, double offset_hz, int *chan_id)
 {
     if (!h || !chan_id) { set_error("bad channel arguments"); return RCF_EINVAL; }
     int D = 0, T = 0;
-    int rc = rcf_channel_params(h->fs, channel_rate, &D, &T);
+    int rc = rcf_channel_params_ex(h->fs, channel_rate, h->decim_rule, &D, &T, nullptr);
     if (rc != RCF_OK) return rc;
     if (!(std::fabs(offset_hz) < h->fs / 2)) { set_error("offset %g Hz outside +-fs/2", offset_hz); return RCF_ERANGE; }
     std::lock_guard<std::mutex> g(h->mu);
@@ -1808,7 +1848,7 @@ int rcf_pfb_chan_open(rcf_t *h, int bin, int channel_rate, double delta_hz, int 
     if (!h->pfb.open || bin < 0 || bin >= h->pfb.NB) { set_error("no such PFB bin %d", bin); return RCF_EINVAL; }
     const double rate = h->fs / h->pfb.D;
     int D = 0, T = 0;
-    int rc = rcf_channel_params(rate, channel_rate, &D, &T);
+    int rc = rcf_channel_params_ex(rate, channel_rate, h->decim_rule, &D, &T, nullptr);
     if (rc != RCF_OK) return rc;
     std::vector<float> taps = design_low_pass_2(1.0, rate, channel_rate / 2.0, channel_rate / 2.0, 20.0,
                                                 RCF_WIN_HAMMING);
@@ -1857,6 +1897,16 @@ int rcf_pfb_tap_open(rcf_t *h, int bin, int gr_phase, int *chan_id)
                     remainderl(2.0L * 3.14159265358979323846264338327950288L * (long double)turn / (long double)p.NB,
                                2.0L * 3.14159265358979323846264338327950288L);
         rc = upload_composite(h, c);
+    }
+    {
+        // plan_channel never iterates the exact rotator for a frame-major bank's tap or a channel that carries GNU
+        // Radio's phase corrections: give the phase ring (8 out_cap bytes, half a megabyte at 2^16) back -- a
+        // receiver in 'pfb' mode opens hundreds of these.  Nothing has been queued on it yet.
+        Chan *c = h->chans[*chan_id].get();
+        if (c->d_rot && (c->is_tap || c->extra_dangle != 0.0 || c->extra_dlogmag != 0.0)) {
+            h->pools[slice_round(sizeof(float2) * h->out_cap + 256)].free_.push_back(c->d_rot);
+            c->d_rot = nullptr;
+        }
     }
     return rc;
 }

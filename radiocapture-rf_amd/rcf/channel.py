@@ -29,6 +29,7 @@ class channel:
         self.pfb = pfb
         self.pfb_bin = None
         self.chan_id = None
+        self.route = "direct"
         self.start_sample = None
         self._build(offset)
         self.init_time = time.time()
@@ -41,14 +42,23 @@ class channel:
         does a bin whose exact phases are too far from GNU Radio's float32 ones for the discriminator budget --
         receiver._open_pfb)"""
         pfb = self.pfb
+        self.route = "direct"
         if pfb is None or self.parent_chan is not None or self.channel_rate != pfb["channel_rate"]:
             return None
         k = int(round(offset / pfb["grid"]))
         if offset != k * pfb["grid"] or abs(k) > pfb["n_bins"] // 2 or not abs(offset) < self.samp_rate / 2:
+            self.route = "direct (off the bank's grid)"
             return None
         from .receiver import receiver
         if not receiver.pfb_serves_bin(pfb, k):
+            # on the grid, but the bank's exact phases are further from GNU Radio's float32 ones than the budget allows
+            # at this offset: a 2909-tap direct channel instead.  Counted (receiver.metrics) -- it costs what `xlat`
+            # mode costs, and a deployment whose carriers are weaker or stronger than the default environment
+            # (pfb_parity_env_db) wants to know how its requests were routed
+            self.route = "direct (parity budget: predicted fm error %.1e > %.1e)" % (
+                receiver.pfb_predicted_fm_error(pfb, k), pfb["parity"]["budget"])
             return None
+        self.route = "bank bin %d" % (k % pfb["n_bins"])
         return k % pfb["n_bins"]                               # receiver.py:373-375: wrap negative bins
 
     def _build(self, offset):

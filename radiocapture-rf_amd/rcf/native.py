@@ -25,7 +25,7 @@ SRC_PFB_BIN0 = 0x40000000
 # every symbol include/rcf.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "rcf_version", "rcf_last_error", "rcf_device_count", "rcf_design_low_pass_2", "rcf_design_window",
-    "rcf_channel_params", "rcf_open", "rcf_open_ex", "rcf_close", "rcf_sync", "rcf_stream", "rcf_device",
+    "rcf_channel_params", "rcf_channel_params_ex", "rcf_set_decim_rule", "rcf_open", "rcf_open_ex", "rcf_close", "rcf_sync", "rcf_stream", "rcf_device",
     "rcf_push_iq", "rcf_ingest_ptr", "rcf_commit", "rcf_samples_in", "rcf_chan_open", "rcf_chan_open_taps",
     "rcf_chan_set_offset", "rcf_chan_close", "rcf_chan_info", "rcf_chan_produced", "rcf_chan_start", "rcf_chan_read_many", "rcf_chan_read_iq",
     "rcf_chan_read_fm", "rcf_chan_rings", "rcf_source_shift", "rcf_pfb_open", "rcf_pfb_close",
@@ -75,6 +75,8 @@ def lib():
         "rcf_design_low_pass_2": (C.c_int, [C.c_double] * 5 + [C.c_int, fp, C.c_int]),
         "rcf_design_window": (C.c_int, [C.c_int, C.c_int, fp]),
         "rcf_channel_params": (C.c_int, [C.c_double, C.c_int, ip, ip]),
+        "rcf_channel_params_ex": (C.c_int, [C.c_double, C.c_int, C.c_int, ip, ip, C.POINTER(C.c_double)]),
+        "rcf_set_decim_rule": (C.c_int, [vp, C.c_int]),
         "rcf_open": (C.c_int, [C.c_int, C.c_double, C.c_double, C.POINTER(vp)]),
         "rcf_open_ex": (C.c_int, [C.c_int, C.c_double, C.c_double, sz, sz, sz, C.POINTER(vp)]),
         "rcf_close": (C.c_int, [vp]),
@@ -221,9 +223,13 @@ def design_window(window, n) -> np.ndarray:
     return w
 
 
-def channel_params(samp_rate, channel_rate):
+DECIM_EXACT, DECIM_FLOOR = 0, 1
+
+
+def channel_params(samp_rate, channel_rate, decim_rule=DECIM_EXACT):
+    """(decim, ntaps) of rc_frontend/channel.py:31-33; decim_rule=DECIM_FLOOR: the Python-2 reading int(fs/cr) // 2"""
     d, t = C.c_int(), C.c_int()
-    _check(lib().rcf_channel_params(samp_rate, int(channel_rate), C.byref(d), C.byref(t)))
+    _check(lib().rcf_channel_params_ex(samp_rate, int(channel_rate), int(decim_rule), C.byref(d), C.byref(t), None))
     return d.value, t.value
 
 
@@ -322,6 +328,10 @@ class Frontend:
     def set_rotator(self, exact=True):
         """exact: iterate GNU Radio's float32 rotator per channel (rcf_set_rotator); before the first channel"""
         _check(lib().rcf_set_rotator(self._h, 1 if exact else 0))
+
+    def set_decim_rule(self, rule):
+        """DECIM_EXACT (default) | DECIM_FLOOR (rcf_set_decim_rule): what rcf_chan_open does with an odd int(fs/cr)"""
+        _check(lib().rcf_set_decim_rule(self._h, int(rule)))
 
     def sync(self):
         _check(lib().rcf_sync(self._h))

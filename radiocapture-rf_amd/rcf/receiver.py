@@ -62,6 +62,11 @@ class receiver:
             # discriminator cannot tell the two apart, the IQ stream differs by a slowly turning common phase).
             if getattr(config, "rotator", "exact") == "exact" and hasattr(fe, "set_rotator"):
                 fe.set_rotator(True)
+            # config.py2_decim = True: decim = int(fs/cr) // 2, the Python-2 reading of channel.py:31 that the author's
+            # 10 666 666 sps deployment ran (configs/config_denver_massive_p25.py:20,31 with receiver_split2 = False);
+            # default: such a request is refused, as GNU Radio refuses the 426.5 Python 3 hands it
+            if getattr(config, "py2_decim", False) and hasattr(fe, "set_decim_rule"):
+                fe.set_decim_rule(1)
             if getattr(config, "receiver_split2", False):
                 # receiver.py:205-237: each source becomes two half-rate sources, centre -/+ fs/4, through
                 # freq_xlating_fir_filter_ccc(2, firdes.low_pass(1, fs, fs/4, fs/8), -/+fs/4, fs).
@@ -97,7 +102,18 @@ class receiver:
         filter itself -- decim = int(fs/cr)/2, low_pass_2(1, fs, cr/2, cr/2, 20, HAMMING) (channel.py:31-33) on a
         `pfb_grid` Hz raster (default: cr = 12.5 kHz) -- so every bin IS the channel the xlat path would have built
         at that frequency and no second stage is needed.  Returns the plan, or None when librcf has no kernel for
-        the shape (then every request takes the direct path, as in 'xlat' mode)."""
+        the shape (then every request takes the direct path, as in 'xlat' mode).
+
+        Deployment knobs (config attributes; defaults reproduce the SURVEY 8(d) cfg2 environment):
+          pfb_parity_budget   discriminator rms error allowed between a served bin and GNU Radio's channel (1e-4);
+                              None = no routing, every on-grid request is a bin (exact phases instead of GNU Radio's)
+          pfb_parity_env_db   wideband input power over the served carrier's power in dB (default 15.3 = unit noise + 32
+                              carriers of +30 dB at 20 Msps).  Weaker carriers in a busier band -> larger value -> fewer
+                              bins served by the bank; measure it as 10 log10(mean |x|^2 / carrier power)
+          pfb_parity_gain     discriminator gain of the consumers (default P25's out_rate / (2 pi 600))
+          pfb_parity_margin   measured / predicted safety factor (2.5)
+        How requests were routed is logged per channel and counted in metrics() (rcf_pfb_served_by_bank,
+        rcf_pfb_direct_parity_budget, rcf_pfb_direct_off_grid)."""
         from . import native
         cr = int(getattr(self.config, "pfb_channel_rate", 12500))
         grid = float(getattr(self.config, "pfb_grid", cr))
@@ -208,8 +224,14 @@ class receiver:
         with self.access_lock:
             in_use = sum(1 for c in self.channels.values() if getattr(c, "in_use", False))
             n_chan = len(self.channels)
+            routes = [getattr(c, "route", "direct") for c in self.channels.values()]
         out = {"rcf_samples_in": int(total), "rcf_msps_in": rate, "rcf_channels_in_use": in_use,
                "rcf_channels_open": n_chan, "rcf_healthy": self.fault is None}
+        if any(s.get("pfb") is not None for s in self.sources.values()):
+            # frontend_mode == 'pfb': how the open channels are served (the parity routing was silent)
+            out["rcf_pfb_served_by_bank"] = sum(1 for r in routes if r.startswith("bank"))
+            out["rcf_pfb_direct_parity_budget"] = sum(1 for r in routes if "parity budget" in r)
+            out["rcf_pfb_direct_off_grid"] = sum(1 for r in routes if "off the bank" in r)
         if self.fault is not None:
             out["rcf_fault"] = self.fault
         return out
@@ -275,6 +297,8 @@ class receiver:
                         self.release_port(port)
                     raise
                 block.source_id = source_id
+                if self.sources[source_id].get("pfb") is not None:
+                    self.log.info("channel at offset %s Hz served by: %s" % (offset, block.route))
                 block.block_id = "%s" % uuid.uuid4()
                 self.channels[block.block_id] = block
                 block.start()

@@ -58,6 +58,10 @@ class _Finder:                                       # every other import that i
 
 
 sys.meta_path.insert(0, _Finder())
+# logging_receiver's constructor makes its audio/<y>/<m>/<d>/... directory tree relative to the working directory
+# (logging_receiver.py: os.makedirs): run in a scratch directory so that nothing is left in the repository
+import tempfile
+os.chdir(tempfile.mkdtemp(prefix="rcf_goldens_"))
 sys.path.insert(0, REF)
 
 

@@ -41,6 +41,11 @@ def test_host_entry_points_work_without_gpu():
     with pytest.raises(native.RcfError) as e:
         native.channel_params(10666666, 12500)      # 426.5: rejected (documented divergence)
     assert e.value.code == native.RCF_ERANGE
+    # ... unless the Python-2 reading of channel.py:31 is asked for (config_denver_massive_p25.py:20: 853 // 2)
+    assert native.channel_params(10666666, 12500, native.DECIM_FLOOR) == (426, 1551)
+    assert native.channel_params(20e6, 12500, native.DECIM_FLOOR) == (800, 2909)      # integral cases do not change
+    D, taps = G.channel_params(10666666, 12500, py2_floor=True)
+    assert (D, len(taps)) == (426, 1551)
     # product design code == oracle restatement (both restate firdes.low_pass_2 / windows)
     for fs, cr in ((2.4e6, 12500), (20e6, 12500), (2.4e6, 25000)):
         a = native.design_low_pass_2(1.0, fs, cr / 2, cr / 2, 20.0)

@@ -112,3 +112,32 @@ def test_batched_read_equals_channel_by_channel_reads(gpu_required):
         first = b.chan_read_many([ib[0]], "iq", cap_each=100)[0].copy()
         rest = b.chan_read_many([ib[0]], "iq", cap_each=4096)[0].copy()
         assert len(first) == 100 and np.array_equal(np.concatenate([first, rest]), a.chan_read_iq(ia[0]))
+
+
+def test_python2_decimation_rule_opens_the_10p67_msps_channels(gpu_required):
+    """configs/config_denver_massive_p25.py:20,31 (10 666 666 sps, receiver_split2 = False): int(fs/cr)/2 = 426.5 under
+    Python 3 -- refused by default -- and 853 // 2 = 426 under the Python 2 the line was written for.  With
+    rcf_set_decim_rule(RCF_DECIM_FLOOR) the channel opens at D = 426, 25 039 S/s, and equals the oracle's channel."""
+    from oracle import cbind as OC
+    nat = gpu_required
+    fs, cr, f0 = 10666666.0, 12500, 771106250 - 771500000      # a control channel of that config's system 0
+    rng = np.random.default_rng(426)
+    D, taps = G.channel_params(fs, cr, py2_floor=True)
+    x = synth.awgn(rng, D * 900 + 77)
+    x = (x + synth.nbfm_carrier(len(x), fs, f0, 1000.0, 2500.0, synth.snr_amp(30.0, 12500.0, fs))).astype(np.complex64)
+    with nat.Frontend(fs) as fe:
+        with pytest.raises(nat.RcfError) as e:
+            fe.chan_open(cr, f0)
+        assert e.value.code == nat.RCF_ERANGE
+        fe.set_decim_rule(nat.DECIM_FLOOR)
+        cid = fe.chan_open(cr, f0)
+        info = fe.chan_info(cid)
+        assert info["decim"] == 426 and info["ntaps"] == len(taps) == 1551 and abs(info["out_rate"] - fs / 426) < 1e-6
+        fe.push(x[: D * 333 + 5])
+        fe.push(x[D * 333 + 5:])
+        y, fm = fe.chan_read_iq(cid), fe.chan_read_fm(cid, 5.0)
+    ct, inc = OC.xlating_composite(taps, D, float(f0), fs)
+    yo, fo = OC.channel_bank(x, D, ct[None, :], np.array([inc]), gains=[5.0])
+    assert len(y) == len(yo[0])
+    assert np.sqrt(np.mean(np.abs(y - yo[0]) ** 2) / np.mean(np.abs(yo[0]) ** 2)) < 1e-5
+    assert np.sqrt(np.mean((fm - fo[0]) ** 2)) < 1e-4

@@ -393,6 +393,11 @@ def test_pfb_mode_parity_budget_routes_high_offset_bins_to_the_direct_kernel():
             routed.append(k)
     # low offsets stay on the bank, the band edge goes direct
     assert 8 in served and 80 in served and 799 in routed and -799 in routed
+    # ... and none of it is silent: the receiver's metrics count how the open channels are served
+    tb.connect_channel(12500, 855000000 + 8 * 12500 + 300)            # off the bank's grid
+    m = tb.metrics()
+    assert m["rcf_pfb_served_by_bank"] == len(served) and m["rcf_pfb_direct_parity_budget"] == len(routed)
+    assert m["rcf_pfb_direct_off_grid"] == 1 and "parity budget" in tb.channels[bid].route
     # the prediction is monotone in the float32 exponent ranges: no bin above fs/4 is cheaper than one below fs/32
     assert receiver.receiver.pfb_predicted_fm_error(plan, 799) > 4 * receiver.receiver.pfb_predicted_fm_error(plan, 40)
     # retune of a served channel to a routed bin moves it to the direct kernel, same object
