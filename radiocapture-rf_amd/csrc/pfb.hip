@@ -174,7 +174,6 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
     constexpr int D = NB / OS;
     constexpr int HALO = OS * (P - 1);
     constexpr int W = F + HALO;
-    constexpr int G = 8;
     constexpr int RS = row_stride<NB>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf *buf = reinterpret_cast<cf *>(smem_raw);
@@ -211,31 +210,61 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
     float ur[F], ui[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) ur[f] = ui[f] = 0.f;
+    {
+        // Rows in two pinned groups of <= 16, the second requested before the first is consumed (sched_barrier keeps
+        // the scheduler from re-interleaving the fully unrolled schedule).  Left to itself the compiler kept ~5 loads in
+        // flight at the tail of the row loop; measured at 256 bins, block 2^25 (same session): compiler's schedule
+        // 0.1054-0.1061 ms, 8 rows single-buffered 0.1054, 4 + 4 double-buffered 0.1054, 8 + 8 0.1024, 16 single 0.1014-
+        // 0.1029, 15 + 14 0.1019-0.1020, all 29 up front 0.1019-0.1023: 0.635 -> 0.66 of the HBM peak (73-78 VGPRs,
+        // still four workgroups per CU: the LDS limit).  The zero-history instantiation keeps groups of 8.
+        constexpr int GX = ZH ? 8 : ((W + 1) / 2 < 16 ? (W + 1) / 2 : 16);
+        constexpr bool DBX = !ZH;
+        constexpr int NG = (W + GX - 1) / GX;
+        v2f xb[DBX ? 2 : 1][GX];
+        auto load_group = [&](v2f (&x)[GX], int j0) {
 #pragma unroll
-    for (int j0 = 0; j0 < W; j0 += G) {
-        v2f x[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            x[g] = (v2f)(0.f);
-            if (j0 + g < W) {
-                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, vo_in, (j0 + g) * D * (int)sizeof(cf), 0);
-                x[g].x = __uint_as_float(r.x);
-                x[g].y = __uint_as_float(r.y);
-                if (ZH && m0 + j0 + g < m_min) x[g] = (v2f)(0.f);
+            for (int g = 0; g < GX; ++g) {
+                x[g] = (v2f)(0.f);
+                if (j0 + g < W) {
+                    const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, vo_in, (j0 + g) * D * (int)sizeof(cf), 0);
+                    x[g].x = __uint_as_float(r.x);
+                    x[g].y = __uint_as_float(r.y);
+                    if (ZH && m0 + j0 + g < m_min) x[g] = (v2f)(0.f);
+                }
             }
-        }
+        };
+        auto use_group = [&](const v2f (&x)[GX], int j0) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int j = j0 + g;
-            if (j < W) {
+            for (int g = 0; g < GX; ++g) {
+                const int j = j0 + g;
+                if (j < W) {
 #pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    const int t = HALO + f - j;          // = OS * q
-                    if (t >= 0 && t % OS == 0 && t / OS < P) {
-                        ur[f] = fmaf(h[t / OS], x[g].x, ur[f]);
-                        ui[f] = fmaf(h[t / OS], x[g].y, ui[f]);
+                    for (int f = 0; f < F; ++f) {
+                        const int t = HALO + f - j;
+                        if (t >= 0 && t % OS == 0 && t / OS < P) {
+                            ur[f] = fmaf(h[t / OS], x[g].x, ur[f]);
+                            ui[f] = fmaf(h[t / OS], x[g].y, ui[f]);
+                        }
                     }
                 }
+            }
+        };
+        if constexpr (DBX) {
+            load_group(xb[0], 0);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                if (gi + 1 < NG) load_group(xb[(gi + 1) & 1], (gi + 1) * GX);
+                __builtin_amdgcn_sched_barrier(0);
+                use_group(xb[gi & 1], gi * GX);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                load_group(xb[0], gi * GX);
+                __builtin_amdgcn_sched_barrier(0);
+                use_group(xb[0], gi * GX);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
