@@ -137,11 +137,14 @@ if len(ser) > 400:
     print("clock: first 100 %.3f GHz, last 100 %.3f GHz over %d dispatches" % (
         w([c for c, _ in ser[:100]]), w([c for c, _ in ser[-100:]]), len(ser)))
 
-for tag in ("bench", "bench_cfg5", "bench_head_under_rocprof"):
+for tag in ("bench", "bench_cfg5", "bench_head_under_rocprof", "bench_2ranks_1gpu", "unpinned_bounds"):
     src = "gpurun_out/%s_%s.json" % (R, tag)
     if os.path.exists(src):
-        lines = [l for l in open(src).read().splitlines() if l.startswith("{")]
-        if lines:
+        text = open(src).read()
+        lines = [l for l in text.splitlines() if l.startswith("{") and l.rstrip().endswith("}")]
+        if tag == "unpinned_bounds" and text.strip():
+            open("profiles/%s_%s.json" % (R, tag), "w").write(text)
+        elif lines:
             open("profiles/%s_%s.json" % (R, tag), "w").write(lines[-1] + "\n")
 f = newest("gpurun_out/%s_trace/**/*kernel_stats.csv" % R)
 if f:

@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Every measured number DESIGN.md 5, README.md and profiles/README.md quote for the current round, generated from the
+tracked files under profiles/ -- so that prose cannot drift from the evidence.
+
+    python tools/gen_docs_numbers.py r04            rewrite the blocks between the markers in the three documents
+    python tools/gen_docs_numbers.py r04 --check    exit 1 if a document's block differs from what the files give
+
+Markers:  <!-- numbers:<name> <round> -->  ...  <!-- /numbers:<name> -->      names: measured, files
+tests/test_docs_numbers.py runs the check on the newest round that has a bench line.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+
+
+def _j(name):
+    f = os.path.join(P, name)
+    if not os.path.exists(f):
+        return None
+    with open(f) as fh:
+        text = fh.read().strip()
+    try:
+        return json.loads(text)
+    except Exception:
+        lines = [l for l in text.splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if lines else None
+
+
+def _stats(name, pat):
+    f = os.path.join(P, name)
+    if not os.path.exists(f):
+        return None
+    for r in csv.DictReader(open(f)):
+        if re.search(pat, r["Name"]):
+            return {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) * 1e-3, "name": r["Name"]}
+    return None
+
+
+def f3(x):
+    return "%.3f" % x
+
+
+def latest_round():
+    rs = sorted(int(re.search(r"r(\d+)_bench\.json", f).group(1)) for f in glob.glob(os.path.join(P, "r[0-9][0-9]_bench.json")))
+    return "r%02d" % rs[-1] if rs else None
+
+
+def measured_block(R):
+    """the table of this round's numbers; every cell names the file (and key) it comes from"""
+    L = []
+    add = L.append
+    b = _j("%s_bench.json" % R)
+    if b is None:
+        return "(no %s_bench.json under profiles/)" % R
+    ro = b["roofline"]
+    add("| what | value | where it comes from |")
+    add("|---|---|---|")
+    add("| headline `value` (BASELINE configs[1], N = 1) | %.0f Msamples/s, step %.4f ms | `%s_bench.json`: `value`, `ms_per_step` |"
+        % (b["value"], b["ms_per_step"], R))
+    add("| filterbank launch, HIP events in the timed region | %.1f µs over %d bracketed launches ⇒ %.0f GB/s = **%s** of 8 TB/s | `%s_bench.json`: `roofline.avg_launch_ms`, `.launches`, `.achieved`, `.frac` |"
+        % (ro["avg_launch_ms"] * 1e3, ro["launches"], ro["achieved"], f3(ro["frac"]), R))
+    st = _stats("%s_bench_kernel_stats.csv" % R, r"pfb_kernel_os<256, 1, 14, 4, false>")
+    hu = _j("%s_bench_head_under_rocprof.json" % R)
+    if st:
+        frac = 16.0 * b["config"]["block_samples"] / (st["avg_us"] * 1e-6) / 1e9 / 8000.0
+        add("| the same kernel by `rocprofv3 --kernel-trace --stats` | %.1f µs over %d launches ⇒ **%s** | `%s_bench_kernel_stats.csv`, row `pfb_kernel_os<256, 1, 14, 4, false>` |"
+            % (st["avg_us"], st["calls"], f3(frac), R))
+    if hu:
+        add("| … and the bench line printed in that profiled run | %.1f µs (`frac` %s) | `%s_bench_head_under_rocprof.json`: `roofline.avg_launch_ms` |"
+            % (hu["roofline"]["avg_launch_ms"] * 1e3, f3(hu["roofline"]["frac"]), R))
+    su = b.get("sustained")
+    if su:
+        add("| sustained leg, %.1f s / %d launches | first window %s, last %s, slowest %s of the peak | `%s_bench.json`: `sustained.frac_*_window` |"
+            % (su["seconds"], su["launches"], f3(su["frac_first_window"]), f3(su["frac_last_window"]), f3(su["frac_slowest_window"]), R))
+    tr = _j("pfb_traffic.json")
+    if tr:
+        add("| HBM traffic per 256-bin launch (PMC, separate passes) | FETCH×2 %.1f MB + WRITE %.1f MB = %.1f MB = %.3f × algorithmic | `pfb_traffic.json` (%s) |"
+            % (tr["fetch_bytes_corrected_x2"] / 1e6, tr["write_bytes"] / 1e6, tr["hbm_bytes_per_launch"] / 1e6,
+               tr["hbm_bytes_per_launch"] / tr["algorithmic_bytes_per_launch"], tr.get("measured", "?")))
+    k = b.get("kernel_ms_per_step", {})
+    if k:
+        add("| step = filterbank + stage-2 FIR with fused discriminator | %.4f + %.4f ms | `%s_bench.json`: `kernel_ms_per_step` |"
+            % (k["pfb"], k["stage2_fir_with_fused_discriminator"], R))
+    c5 = _j("%s_bench_cfg5.json" % R)
+    if c5:
+        add("| cfg5 (BASELINE configs[4] per GPU: 512 bins, 25 Msps) | %.0f Msamples/s, launch %.1f µs = **%s**, sustained %s | `%s_bench_cfg5.json`: `value`, `roofline`, `sustained.frac_last_window` |"
+            % (c5["value"], c5["roofline"]["avg_launch_ms"] * 1e3, f3(c5["roofline"]["frac"]),
+               f3(c5["sustained"]["frac_last_window"]) if c5.get("sustained") else "–", R))
+        s5 = _stats("%s_bench_cfg5_kernel_stats.csv" % R, r"pfb_kernel_2b<256, 14")
+        if s5:
+            add("| the 512-bin kernel by rocprofv3 | %.1f µs over %d launches ⇒ **%s** | `%s_bench_cfg5_kernel_stats.csv`, row `pfb_kernel_2b<256, 14, 3, false>` |"
+                % (s5["avg_us"], s5["calls"], f3(16.0 * c5["config"]["block_samples"] / (s5["avg_us"] * 1e-6) / 1e9 / 8000.0), R))
+    for nb in (512, 1024):
+        t = _j("%s_pfb%d_traffic.json" % (R, nb))
+        if t and "fetch_x2_over_algorithmic_read" in t:
+            add("| %d-bin bank, PMC passes of `tools/pfb_probe.py` | FETCH×2 = %.3f × algorithmic read, FETCH×2 + WRITE = %.3f × algorithmic; %.1f µs per launch under the counters | `%s_pfb%d_traffic.json` |"
+                % (nb, t["fetch_x2_over_algorithmic_read"], t["hbm_bytes_over_algorithmic"],
+                   t["pass3"]["kernel_us_in_this_pass"], R, nb))
+    g = b.get("channels", {}).get("reference_grid_filterbank")
+    if g:
+        add("| 1600-bin reference-grid bank (every bin one `channel.py` channel) | %.4f ms per 2^25 block = **%s**; sustained %s | `%s_bench.json`: `channels.reference_grid_filterbank.roofline.frac`, `.sustained.frac_last_window` |"
+            % (g["pfb_ms_per_block"], f3(g["roofline"]["frac"]), f3(g["sustained"]["frac_last_window"]), R))
+        for x in g.get("grid_6k25", []):
+            add("| 3200 bins, decim %d, %d taps | %.4f ms = %s | `%s_bench.json`: `…grid_6k25[]` |"
+                % (x["decim"], x["taps"], x["pfb_ms_per_block"], f3(x["frac_of_hbm_peak"]), R))
+        for pt in g.get("with_taps", {}).get("points", []):
+            add("| … with %d bins tapped and demodulated | bank %.4f ms (%.2f × untapped), finalize %.4f ms | `…with_taps.points[]` |"
+                % (pt["bins_tapped"], pt["pfb_ms_per_block"], pt["pfb_over_untapped"], pt["tap_finalize_ms_per_block"]))
+    db = b.get("channels", {}).get("direct_bank")
+    if db:
+        top = db["points"][-1]
+        add("| reference-shaped direct bank (2909-tap xlating FIR per channel, FP32 matrix cores) | %d channels run in real time; at %d: kernel %.1f ms / wall %.1f ms per %.1f ms block, %.1f TFLOP/s = %s of 157.3 | `%s_bench.json`: `channels.direct_bank` |"
+            % (db["channels_run_in_real_time"], top["channels"], top["kernel_ms_per_block"], top["wall_ms_per_block"],
+               top["block_ms_of_signal"], top["tflops_fp32"], f3(top["frac_of_fp32_matrix_peak"]), R))
+    sc = b.get("scan")
+    if sc:
+        add("| scan (BASELINE configs[2]: N = 2^20 × 1000 frames, 100-frame sum) | FFT+log %.2f ms, running sum %.2f ms, pick %.2f ms; %.0f Msamples/s; **%s** of the HBM peak; %d peaks | `%s_bench.json`: `scan` |"
+            % (sc["fft_logmag_ms"], sc["moving_sum_ms"], sc["peak_pick_ms_incl_readback"], sc["input_Msamples_per_s"],
+               f3(sc["roofline"]["frac"]), sc["peaks_found"], R))
+    e = b.get("end_to_end")
+    if e:
+        add("| PCIe-inclusive ingest (never `value`) | cf32 %.0f Msamples/s, u8 %.0f Msamples/s | `%s_bench.json`: `end_to_end` |"
+            % (e["pinned_cf32_push_iq_Msps"], e["pinned_u8_push_raw_Msps"], R))
+    rt = b.get("realtime")
+    if rt:
+        for shape, label in (("pfb256", "256-bin bank + 32 FM"), ("grid1600", "1600-bin reference-grid bank, 256 bins demodulated")):
+            s = rt.get(shape)
+            if not s:
+                continue
+            a = s.get("at_K_max") or {}
+            add("| **paced real time**, %s, 20 Msps u8 per front-end, %.0f ms blocks | K_max = **%d** front-ends (%d bins, %d demodulated channels, %.0f Msamples/s), first K that missed: %s; at K_max latency p50 %.2f / p99 %.2f ms, %d misses, %d overruns, PCIe in %.2f GB/s | `%s_bench.json`: `realtime.%s` |"
+                % (label, a.get("block_ms", 0), s["K_max"], s["channels_sustained"], s["fm_channels_sustained"],
+                   s["input_Msps_sustained"], s["first_K_that_missed"], a.get("latency_ms_p50") or 0, a.get("latency_ms_p99") or 0,
+                   a.get("deadline_misses", 0), a.get("ring_overruns", 0), a.get("pcie_GBps_in", 0), R, shape))
+    cb = b.get("cpu_baseline")
+    if cb and "all_cores" in cb:
+        ac = cb["all_cores"]
+        add("| CPU baseline (oracle C port, %d physical cores) | one channel on one core %.1f × real time; all cores, reference structure %.0f real-time channels (%.0f GB/s of stream reads, host read bandwidth %.0f GB/s); SURVEY formula cores × single-core %.0f; time-tiled best CPU %.0f | `%s_bench.json`: `cpu_baseline` |"
+            % (cb["cores"], cb["single_channel_one_core"]["realtime_channels_per_core_at_20Msps"],
+               ac["reference_structure_measured"]["realtime_channels"], ac["reference_structure_measured"]["stream_read_GBps"],
+               ac["host_read_bandwidth_GBps"], ac["survey_formula_cores_x_single_core"]["realtime_channels"],
+               ac["best_cpu_time_tiled_measured"]["realtime_channels"], R))
+        if "gpu_channels_run_in_real_time_over_cpu_realtime_channels" in cb:
+            add("| GPU / CPU concurrent channels at 20 Msps | %.1f × (against the largest CPU figure, %.0f) | `cpu_baseline.gpu_channels_run_in_real_time_over_cpu_realtime_channels` |"
+                % (cb["gpu_channels_run_in_real_time_over_cpu_realtime_channels"], cb["largest_cpu_realtime_channels"]))
+        if "gpu_fm_parity_vs_oracle" in cb:
+            pv = cb["gpu_fm_parity_vs_oracle"]
+            add("| the timed configuration's own FM outputs vs the oracle | worst rms %.1e over %d channels (bar %.0e) | `cpu_baseline.gpu_fm_parity_vs_oracle` |"
+                % (pv["worst_fm_rms_error"], pv["channels_checked"], pv["tolerance"]))
+    cp = b.get("control_plane")
+    if cp:
+        add("| control plane, 100 × create / release through `frontend_connector` | create %.3f ms median, release %.3f ms, new channel %.3f ms | `%s_bench.json`: `control_plane` |"
+            % (cp["create_ms_median"], cp["release_ms_median"], cp["connect_channel_new_ms_mean"], R))
+    t2 = _j("%s_bench_2ranks_1gpu.json" % R)
+    if t2:
+        add("| `RCF_BENCH_DEVICE=0 python bench.py --gpus 2` (no launcher; both ranks on the one GPU of the box) | `n_gpus` %d, %s, transport %s, step by rank %s ms, peak gather %.0f µs | `%s_bench_2ranks_1gpu.json` |"
+            % (t2["n_gpus"], t2["ranks_started_by"], t2["transport"], ", ".join("%.4f" % v for v in t2["ms_per_step_by_rank"]),
+               t2.get("peaks_allgather_us") or 0, R))
+    ub = _j("%s_unpinned_bounds.json" % R)
+    if ub:
+        l = ub["log2"]
+        add("| unpinned GNU Radio details, worst case (CPU, `tools/unpinned_bounds.py`) | log2 ±%.0e per value: %d of %d index lists changed (N = 16384), %d of %d (N = 2^20); first index moves at ±%s; atan literals ±1 digit: fm ≤ %.1e; summation orders: ≤ %.1e between two float32 orders; rotator FMA: phase step ≤ %.1e rad, common phase ≤ %.1e rad after 10^6 outputs | `%s_unpinned_bounds.json` |"
+            % (l["N=16384"]["per_value_error_log2_units"], l["N=16384"]["index_lists_changed"], l["N=16384"]["patterns"],
+               l["N=1048576"]["index_lists_changed"], l["N=1048576"]["patterns"], l.get("smallest_error_that_moves_an_index_N=16384"),
+               ub["atan_table"]["max_fm_change_p25_gain"],
+               max(v["largest_between_two_float32_orders"] for v in ub["summation"].values()),
+               ub["rotator_fma"]["max_step_difference_rad"], ub["rotator_fma"]["max_phase_difference"], R))
+    return "\n".join(L)
+
+
+def files_block(R):
+    """what is tracked for the round (profiles/README.md)"""
+    L = ["| file | present |", "|---|---|"]
+    for f in sorted(os.listdir(P)):
+        if f.startswith(R + "_") or f in ("pfb_traffic.json", "pfb512_traffic.json"):
+            L.append("| `%s` | %d bytes |" % (f, os.path.getsize(os.path.join(P, f))))
+    return "\n".join(L)
+
+
+BLOCKS = {"measured": measured_block, "files": files_block}
+DOCS = ["DESIGN.md", "README.md", os.path.join("profiles", "README.md")]
+
+
+def apply(R, check=False):
+    bad = []
+    for doc in DOCS:
+        path = os.path.join(ROOT, doc)
+        text = open(path).read()
+        new = text
+        for name, fn in BLOCKS.items():
+            pat = re.compile(r"(<!-- numbers:%s )(r\d+)( -->\n)(.*?)(\n<!-- /numbers:%s -->)" % (name, name), re.S)
+            if not pat.search(new):
+                continue
+            body = fn(R)
+            new = pat.sub(lambda m: m.group(1) + R + m.group(3) + body + m.group(5), new)
+        if new != text:
+            if check:
+                bad.append(doc)
+            else:
+                open(path, "w").write(new)
+                print("rewrote", doc)
+    return bad
+
+
+if __name__ == "__main__":
+    R = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else latest_round()
+    bad = apply(R, check="--check" in sys.argv)
+    if bad:
+        print("out of date with profiles/:", ", ".join(bad))
+        sys.exit(1)

@@ -12,7 +12,7 @@
 # gpurun merges only gpurun_out/ back: run `python tools/collect_profiles.py <R>` locally afterwards.
 # Counter passes never share a run with trace domains other than --kernel-trace.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 cd "$(dirname "$0")/.."
 ROOT=$PWD
 mkdir -p profiles gpurun_out
@@ -26,7 +26,7 @@ HEAD="python $ROOT/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 
 rm -rf gpurun_out/${R}_trace gpurun_out/${R}_trace_legs gpurun_out/${R}_trace_cfg5
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace -- $HEAD > gpurun_out_head.json 2>/dev/null; cp gpurun_out_head.json $ROOT/gpurun_out/${R}_bench_head_under_rocprof.json)
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace_cfg5 -- $HEAD --config cfg5 > /dev/null 2>&1)
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace_legs -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sustained --sweep-max 16384 > /dev/null 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace_legs -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sustained --sweep-max 16384 --rt-seconds 0 > /dev/null 2>&1)
 
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/${R}_pmc_$c gpurun_out/${R}_pmc5_$c
@@ -37,6 +37,10 @@ done
 # shader clock over the sustained leg: GRBM_GUI_ACTIVE per filterbank dispatch (8 XCDs) / its duration
 rm -rf gpurun_out/${R}_pmc_clock
 (cd /tmp && timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $ROOT/gpurun_out/${R}_pmc_clock -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > /dev/null 2>&1)
+
+# the N > 1 code on this 1-GPU box: bench.py starts its own two ranks, both on device 0 (host transport: RCCL cannot span one device twice)
+RCF_BENCH_DEVICE=0 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_2ranks_1gpu.json 2> gpurun_out/${R}_bench_2ranks_1gpu.err
+python tools/unpinned_bounds.py > gpurun_out/${R}_unpinned_bounds.json 2> /dev/null
 
 tools/fir_pmc.sh ${R}_fir4096 C=4096 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb_kernel tools/fir_pmc.sh ${R}_pfb512 NB=512 > /dev/null 2>&1

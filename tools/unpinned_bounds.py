@@ -29,6 +29,11 @@ for fs, f0 in ((2.4e6, -62500.0), (20e6, 5.0125e6)):
     xx = synth.awgn(np.random.default_rng(11), D * 600)
     vs64, between, _ = U.iq_under_summation_orders(xx, D, ct)
     out["summation"]["fs=%g T=%d" % (fs, len(taps))] = {"rel_rms_vs_float64": vs64, "largest_between_two_float32_orders": between}
-_, inc = OC.xlating_composite(G.channel_params(20e6, 12500)[1], 800, 5.0125e6, 20e6)
-out["rotator_fma"] = U.rotator_fma_drift(inc, 1_000_000)
+rot = {}
+for f0 in T.ROTATOR_OFFSETS:
+    _, inc = OC.xlating_composite(G.channel_params(20e6, 12500)[1], 800, f0, 20e6)
+    rot["f0=%g" % f0] = U.rotator_fma_drift(inc, 1_000_000)
+out["rotator_fma"] = {"by_offset": rot,
+                      "max_step_difference_rad": max(r["max_step_difference_rad"] for r in rot.values()),
+                      "max_phase_difference": max(r["max_phase_difference"] for r in rot.values())}
 print(json.dumps(out, indent=1))
