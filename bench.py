@@ -532,6 +532,53 @@ def control_plane_leg(device):
                     "+ protocol; channel buffers come from the handle's slab pool"}
 
 
+# ------------------------------------------------------------------------------------------- live PMC traffic
+def measure_traffic_live(cfg5, block, kernel_substr, timeout_s=150):
+    """HBM bytes per filterbank launch from the PMC counters, measured in THIS run on THIS box: two separate rocprofv3
+    passes (FETCH_SIZE, then WRITE_SIZE -- they do not fit one pass: MI355X_MICROARCH.md) over a short headline-only child
+    run of this script, counters averaged per dispatch of the kernel; KiB -> bytes, FETCH x 2 on gfx950 (same guide).
+    Counter passes carry --kernel-trace only.  None when rocprofv3 is not there or a pass fails (the line then falls back
+    to the dated file under profiles/ and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None
+    out = {}
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "1", "--block", str(block), "--no-extras",
+             "--no-cpu-baseline", "--no-sustained", "--no-live-traffic", "--prewarm-seconds", "0.2"]
+    if cfg5:
+        child += ["--config", "cfg5"]
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="rcf_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            r = subprocess.run([rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child,
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel_substr in row["Kernel_Name"] and "true>" not in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or len(vals) < 3:
+                return None
+            vals = vals[1:]                                   # the first dispatch still sees zero history / cold caches
+            out[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch = out["FETCH_SIZE"][0] * 1024.0 * 2.0
+    write = out["WRITE_SIZE"][0] * 1024.0
+    return {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
+            "dispatches_averaged": min(out["FETCH_SIZE"][1], out["WRITE_SIZE"][1])}
+
+
 # ------------------------------------------------------------------------------------------- paced real-time leg
 def read_gpu_busy_percent():
     """amdgpu's own utilisation figure from sysfs (the busiest card: nothing maps a HIP device to its card index
@@ -811,6 +858,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs (sweep, scan, end-to-end, ...)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained leg")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run")
     ap.add_argument("--time-every", type=int, default=4,
                     help="HIP events around every n-th filterbank launch of the timed region (1 = all of them)")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5,
@@ -1029,6 +1078,10 @@ def main():
         avg_pfb_s = (pfb_ms / max(pfb_n, 1)) * 1e-3
         achieved = alg_bytes / avg_pfb_s / 1e9 if avg_pfb_s > 0 else 0.0
         traffic, traffic_src = None, None
+        live = None
+        if n_gpus == 1 and not args.no_live_traffic and B == 1 << 25:
+            fe.sync()
+            live = measure_traffic_live(cfg5, B, "pfb_kernel_2b<256" if cfg5 else "pfb_kernel_os<256")
         tname = "pfb512_traffic.json" if cfg5 else "pfb_traffic.json"
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
@@ -1041,6 +1094,13 @@ def main():
                                   "in this run)" % (tname, tj.get("measured", "an earlier run of this configuration"))
             except Exception:
                 traffic = None
+        traffic_file, traffic_file_src = traffic, traffic_src
+        if live is not None:
+            traffic = live["hbm_bytes_per_launch"]
+            traffic_src = ("measured in this run on this box: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE; "
+                           "--kernel-trace only) over `bench.py --steps 5 --no-extras --no-cpu-baseline --no-sustained`, "
+                           "%d dispatches of the kernel averaged; KiB x 1024, FETCH x 2 (gfx950, MI355X_MICROARCH.md)"
+                           % live["dispatches_averaged"])
         if cfg5:
             workload = ("BASELINE configs[4], per-GPU shape: 512-bin critically-sampled PFB (6981-tap prototype) over "
                         "one 25 Msps cf32 spectrum slice per GPU (x8 = 4096 channels at 200 Msps), N=2^20 scan of the "
@@ -1083,6 +1143,9 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_fetch_x2_bytes": live["fetch_bytes_corrected_x2"] if live else None,
+                "traffic_write_bytes": live["write_bytes"] if live else None,
+                "traffic_from_tracked_file": traffic_file if live is not None else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_pfb_s * 1e3, "launches": pfb_n, "timed_every": time_every,
                 "avg_launch_ms_slowest_rank": pfb_avg_ms_max,
