@@ -78,7 +78,7 @@ def measured_block(R):
     if su:
         add("| sustained leg, %.1f s / %d launches | first window %s, last %s, slowest %s of the peak | `%s_bench.json`: `sustained.frac_*_window` |"
             % (su["seconds"], su["launches"], f3(su["frac_first_window"]), f3(su["frac_last_window"]), f3(su["frac_slowest_window"]), R))
-    if ro.get("traffic") and "measured in this run" in (ro.get("traffic_source") or ""):
+    if ro.get("traffic") and ro.get("traffic_fetch_x2_bytes"):
         add("| HBM traffic per launch, PMC child passes of the SAME run | FETCH×2 %.1f MB + WRITE %.1f MB = %.1f MB = %.3f × algorithmic | `%s_bench.json`: `roofline.traffic`, `.traffic_fetch_x2_bytes`, `.traffic_write_bytes` |"
             % (ro["traffic_fetch_x2_bytes"] / 1e6, ro["traffic_write_bytes"] / 1e6, ro["traffic"] / 1e6,
                ro["traffic"] / ro["algorithmic_bytes_per_launch"], R))
