@@ -202,6 +202,7 @@ struct rcf {
     int mfma_nt = 0, mfma_parts = 0;   // RCF_FIR_MFMA_NT / RCF_FIR_MFMA_PARTS: override the launch plan (measurements)
     bool exact_rot = false;       // rcf_set_rotator / RCF_ROTATOR=exact: channels iterate GNU Radio's float32 rotator
     int decim_rule = RCF_DECIM_EXACT;   // rcf_set_decim_rule / RCF_DECIM_FLOOR=1
+    uint64_t plan_calls = 0;            // blocks planned so far (RCF_FAIL_PLAN_AT)
     float2 *d_tapmat = nullptr;   // filterbank taps: the current launch's compact tap matrix (PfbLaunch::tap_mat)
     size_t tapmat_cap = 0;        // in float2
     float2 *d_partial = nullptr;  // split-K slabs of the matrix-core bank
@@ -1293,6 +1294,15 @@ int process_block(rcf_t *h, size_t n)
         }
     }
     if ((rc = plan_tail(h, bp)) != RCF_OK) return roll_back(rc);
+    {
+        // RCF_FAIL_PLAN_AT=<k>: the k-th block of a handle fails here as an exhausted launch arena would (tests of the
+        // roll-back above: tests/test_gpu_round4.py)
+        static const long fail_at = [] { const char *e = getenv("RCF_FAIL_PLAN_AT"); return e ? atol(e) : 0L; }();
+        if (fail_at > 0 && (long)++h->plan_calls == fail_at) {
+            set_error("injected planning failure (RCF_FAIL_PLAN_AT)");
+            return roll_back(RCF_ENOMEM);
+        }
+    }
     if ((rc = launch_plan(h, bp)) != RCF_OK) return rc;      // kernels may be queued: the handle's stream state is undefined now
     if ((rc = run_scan(h, bp)) != RCF_OK) return rc;
     return finish_block(h, bp);

@@ -116,3 +116,102 @@ def test_channelizer_process_serves_a_backend(gpu_required, tmp_path, wire):
         if proc.poll() is None:
             proc.kill()
         log.close()
+
+
+CONFIG_PFB = '''
+class rc_config:
+    def __init__(self):
+        self.receiver_split2 = False
+        self.frontend_mode = 'pfb'
+        self.sources = {
+            0: {'type': 'file', 'path': %r, 'format': 's16', 'loop': True, 'center_freq': %d, 'samp_rate': %d, 'block_ms': 10.0},
+        }
+'''
+
+
+def test_channelizer_process_in_pfb_mode_replaying_a_capture_file(gpu_required, tmp_path):
+    """the same process with `frontend_mode = 'pfb'` (the reference's unfinished branch, receiver.py:242-261,343-383)
+    and a `'file'` source in the s16 wire format: an on-grid request is served by a bin of the 400-bin bank (the registry
+    metrics say so), an off-grid one by the direct kernel, and both streams off the data wire equal the GR-faithful
+    oracle's channels over the looped capture."""
+    fs, fc = 5000000, 460000000
+    D, taps = G.channel_params(fs, CR)                                   # 200, 727: the bank is 400 bins
+    rng = np.random.default_rng(77)
+    n = 1 << 20
+    from rcf import synth
+    x = synth.awgn(rng, n).astype(np.complex128)
+    for f_off in (25 * 12500.0, -31 * 12500.0 + 300.0):
+        x += synth.nbfm_carrier(n, fs, round(f_off * n / fs) * fs / n, round(900.0 * n / fs) * fs / n, 2500.0,
+                                synth.snr_amp(30.0, 12500.0, fs))
+    raw = sources.to_wire(x.astype(np.complex64), "s16")
+    cap = tmp_path / "capture.s16"
+    raw.tofile(cap)
+    scale, off = sources.WIRE_SCALE["s16"]
+    tile = ((raw.astype(np.float32) - np.float32(off)) * np.float32(scale)).view(np.complex64)
+    cfg = tmp_path / "config.py"
+    cfg.write_text(CONFIG_PFB % (str(cap), fc, fs))
+    ready = tmp_path / "ready.json"
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "radiocapture-rf_amd"), ROOT]))
+    log = open(tmp_path / "daemon.log", "w")
+    proc = subprocess.Popen([sys.executable, "-m", "rcf.frontend", "-i", "0", "--config", str(cfg), "--transport", "tcp",
+                             "--registry", "dir:%s" % (tmp_path / "reg"), "--bind", "127.0.0.1", "--ready-file", str(ready)],
+                            env=env, cwd=str(tmp_path), stdout=log, stderr=subprocess.STDOUT)
+    try:
+        _wait(lambda: ready.exists() or proc.poll() is not None, 120, "daemon did not come up")
+        assert proc.poll() is None, open(tmp_path / "daemon.log").read()
+        reg = transport.DirRegistryClient(str(tmp_path / "reg"))
+        mgr = registry.redis_channelizer_manager(index=0, clients=[reg], start_thread=False)
+        _wait(lambda: (mgr.poll_once(), mgr.channelizers)[1], 10, "no registry record")
+        clients, got, chans = [], {}, {}
+        n_out = 12000
+        for name, f_off in (("bank", 25 * 12500), ("direct", -31 * 12500 + 300)):
+            fc_ = FC.frontend_connector("gpu-test-%s" % name, mgr, transport_factory=transport.tcp_req_factory)
+            chan, port = fc_.create_channel(CR, fc + f_off)
+            assert chan, name
+            sub = transport.TcpSubSocket(fc_.host, port)
+            got[name] = np.frombuffer(sub.recv_exact(8 * n_out), dtype=np.complex64)
+            sub.close()
+            clients.append(fc_)
+            chans[name] = (chan, f_off)
+        def record_with_starts():
+            mgr.poll_once()
+            r = next(iter(mgr.channelizers.values()))
+            return r if all(c in r.get("rcf_channel_starts", {}) for c, _ in chans.values()) else None
+        rec = _wait(record_with_starts, 6, "channel starts never reached the registry")
+        assert rec["rcf_pfb_served_by_bank"] == 1 and rec["rcf_pfb_direct_off_grid"] == 1 and rec["rcf_pfb_direct_parity_budget"] == 0
+        for name, (chan, f_off) in chans.items():
+            start, decim = rec["rcf_channel_starts"][chan]
+            # a bank tap's start counts the bank's FRAMES (decim 200 samples each); the direct channel's, samples
+            s0 = start * D if name == "bank" else start
+            need = (n_out + 60000) * D
+            reps = (s0 % n + need) // n + 2
+            if name == "bank":
+                # a bin comes with the filter's history in it (the bank was running before the tap was opened): give the
+                # oracle the samples before the tap's first frame too, and drop the outputs they produce
+                lead = (len(taps) // D + 2) * D
+                xs = np.tile(tile, reps + 1)[n + s0 % n - lead:][:need + lead]
+                skip = lead // D
+            else:
+                xs, skip = np.tile(tile, reps)[s0 % n:][:need], 0
+            ct, incr = OC.xlating_composite(taps, D, float(f_off), float(fs))
+            want, _ = OC.channel_bank(xs, D, ct[None, :], np.array([incr]), gains=[1.0])
+            want = want[0][skip:]
+            probe = 64
+            win = np.lib.stride_tricks.sliding_window_view(np.abs(want[: len(want) - n_out + probe]), probe)
+            k0 = int(np.argmin(np.abs(win - np.abs(got[name][:probe])).sum(axis=1)))
+            ref = want[k0:k0 + n_out]
+            # the bank tap's rotator starts at the tap's opening (GNU Radio's would have started with the flowgraph):
+            # a constant phase between the two streams; remove it, then compare
+            rot = np.vdot(ref, got[name]) / np.vdot(ref, ref)
+            err = float(np.sqrt(np.mean(np.abs(got[name] - rot * ref) ** 2) / np.mean(np.abs(ref) ** 2)))
+            assert abs(abs(rot) - 1) < 1e-4 and err < (1e-4 if name == "bank" else 1e-5), (name, k0, abs(rot), err)
+        for c in clients:
+            c.release_channel()
+            c.exit()
+        proc.send_signal(signal.SIGTERM)
+        proc.wait(timeout=30)
+        assert proc.returncode == 0
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+        log.close()

@@ -141,3 +141,61 @@ def test_python2_decimation_rule_opens_the_10p67_msps_channels(gpu_required):
     assert len(y) == len(yo[0])
     assert np.sqrt(np.mean(np.abs(y - yo[0]) ** 2) / np.mean(np.abs(yo[0]) ** 2)) < 1e-5
     assert np.sqrt(np.mean((fm - fo[0]) ** 2)) < 1e-4
+
+
+def test_a_block_whose_planning_fails_leaves_no_trace(gpu_required, tmp_path):
+    """planning advances every channel's counters and can still fail afterwards (allocation, launch arena).
+    Run in a child process with RCF_FAIL_PLAN_AT=3: the third block is refused -- and refused cleanly: counters where
+    they were, and the same block pushed again continues the streams as if nothing had happened (direct channels with
+    the exact rotator, a filterbank with a tapped bin and a stage-2 channel: all against the uninterrupted run)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path[:0] = ["radiocapture-rf_amd", "."]
+from rcf import native, synth
+from oracle import grspec as G
+fs = 5e6
+rng = np.random.default_rng(9)
+D, taps = G.channel_params(fs, 12500)
+x = synth.awgn(rng, D * 600 + 13)
+cuts = [0, D * 100 + 7, D * 250, D * 251 + 3, D * 420, len(x)]
+def run(fail):
+    out = {}
+    with native.Frontend(fs, hist_capacity=1 << 14, out_capacity=1 << 11) as fe:
+        fe.set_rotator(True)
+        a = fe.chan_open(12500, 312500.0)
+        fe.pfb_open(400, D, taps)
+        b = fe.pfb_tap_open(21, gr_phase=True)
+        refused = 0
+        for k, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+            before = (fe.chan_produced(a), fe.chan_produced(b), fe.pfb_produced(), fe.samples_in)
+            try:
+                fe.push(x[lo:hi])
+            except native.RcfError as e:
+                assert fail and e.code == native.RCF_ENOMEM, e
+                refused += 1
+                assert (fe.chan_produced(a), fe.chan_produced(b), fe.pfb_produced(), fe.samples_in) == before
+                fe.push(x[lo:hi])
+        out = (fe.chan_read_iq(a), fe.chan_read_fm(a, 5.0), fe.chan_read_iq(b), fe.pfb_read_bin(3))
+    return refused, out
+import os
+refused, got = run(True)
+assert refused == 1, refused
+np.savez(sys.argv[1], *got)
+"""
+    env = dict(os.environ, RCF_FAIL_PLAN_AT="3")
+    out_fail = str(tmp_path / "fail.npz")
+    r = subprocess.run([sys.executable, "-c", code, out_fail], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-2000:]
+    env.pop("RCF_FAIL_PLAN_AT")
+    out_ok = str(tmp_path / "ok.npz")
+    r = subprocess.run([sys.executable, "-c", code.replace("run(True)", "run(False)").replace("assert refused == 1, refused", "assert refused == 0"),
+                        out_ok], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = np.load(out_fail), np.load(out_ok)
+    for k in a.files:
+        assert len(a[k]) == len(b[k]) > 0 and np.array_equal(a[k], b[k]), k
