@@ -54,7 +54,8 @@ class Daemon:
     """Everything `receiver.py -i <index>` runs, as an object (so that tests can run it in-process too)."""
 
     def __init__(self, config, index=None, device=None, transport=None, registry=None, bind="0.0.0.0", port=0,
-                 egress_period=0.01, fm_gain=None, block_ms=20.0, frontend_factory=None, start_sources=True):
+                 egress_period=0.01, fm_gain=None, block_ms=20.0, frontend_factory=None, start_sources=True,
+                 kernel_metrics=32):
         from . import egress, protocol, receiver, registry as registry_mod, sources, transport as tr
         self.log = logging.getLogger("frontend" if index is None else "frontend-%s" % index)
         transport = transport or ("zmq" if have("zmq") else "tcp")
@@ -72,6 +73,10 @@ class Daemon:
         self.pump = egress.EgressPump(self.tb, socket_factory=egress.zmq_pub_factory() if transport == "zmq"
                                       else tr.tcp_pub_factory(), period=egress_period, fm_gain=fm_gain)
         self.server = protocol.FrontendServer(self.tb)
+        self.last_metrics = {}
+        self.server.status_extra = lambda: {k: v for k, v in self.last_metrics.items() if k != "rcf_channel_starts"}
+        if kernel_metrics and frontend_factory is None:
+            self.tb.enable_kernel_metrics(kernel_metrics)
         self.stop_flag = threading.Event()
         self.rep = None
         self._zmq_thread = None
@@ -114,6 +119,7 @@ class Daemon:
         with self.tb.access_lock:
             m["rcf_channel_starts"] = {b: [c.start_sample, c.decim] for b, c in self.tb.channels.items()
                                        if getattr(c, "start_sample", None) is not None}
+        self.last_metrics = m
         return m
 
     def serve_forever(self):
@@ -159,6 +165,8 @@ def main(argv=None):
     ap.add_argument("--port", type=int, default=0, help="control port (default: ephemeral, advertised through the registry)")
     ap.add_argument("--block-ms", type=float, default=20.0, help="block length of the paced 'synthetic' / 'file' sources")
     ap.add_argument("--fm-gain", type=float, default=None, help="also publish quadrature_demod_cf(gain) of every channel on port + 1")
+    ap.add_argument("--kernel-metrics", type=int, default=32,
+                    help="time every n-th kernel launch for the status line / registry record (0 = off)")
     ap.add_argument("--ready-file", default=None, help="write {'port':..,'pid':..} here once the control port is bound")
     args = ap.parse_args(argv)
 
@@ -172,7 +180,7 @@ def main(argv=None):
 
     config = load_config(args.config)
     d = Daemon(config, index=args.index, device=args.device, transport=args.transport, registry=args.registry,
-               bind=args.bind, port=args.port, fm_gain=args.fm_gain, block_ms=args.block_ms)
+               bind=args.bind, port=args.port, fm_gain=args.fm_gain, block_ms=args.block_ms, kernel_metrics=args.kernel_metrics)
     signal.signal(signal.SIGTERM, d.stop)
     signal.signal(signal.SIGINT, d.stop)
     if args.ready_file:

@@ -198,3 +198,44 @@ class frontend_connector():
                 self.socket.close()
             except Exception:
                 pass
+
+
+def main(argv=None):
+    """The reference's own smoke / speed test of this API (frontend_connector.py:232-251: it cannot run there any more --
+    the constructor grew arguments), working: create + release one channel, then time 100 x create / release, against a
+    running channelizer found through the registry.
+        python -m rcf.frontend_connector [--registry redis | dir:<path>] [--transport zmq | tcp] [--freq 855000000] [--rate 25000]"""
+    import argparse
+    import sys
+    from . import registry, transport
+    ap = argparse.ArgumentParser(prog="python -m rcf.frontend_connector")
+    ap.add_argument("--registry", default="redis")
+    ap.add_argument("--transport", choices=["zmq", "tcp"], default="zmq")
+    ap.add_argument("--freq", type=int, default=855000000)
+    ap.add_argument("--rate", type=int, default=25000)
+    ap.add_argument("-n", type=int, default=100)
+    a = ap.parse_args(argv)
+    mgr = registry.redis_channelizer_manager(clients=[transport.registry_client(a.registry)], start_thread=False)
+    t0 = time.time()
+    while not mgr.channelizers and time.time() - t0 < 10:
+        mgr.poll_once()
+        time.sleep(0.1)
+    factory = transport.tcp_req_factory if a.transport == "tcp" else None
+    test = frontend_connector("smoke-test", mgr, transport_factory=factory, heartbeat=False)
+    channel_id, port = test.create_channel(a.rate, a.freq)
+    if channel_id is False:
+        raise Exception("test failed: create")
+    if test.release_channel() is False:
+        raise Exception("test failed: release")
+    print("function test pass")
+    start = time.time()
+    for _ in range(a.n):
+        test.create_channel(a.rate, a.freq)
+        test.release_channel()
+    print("speed test %s" % (time.time() - start))
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(main())

@@ -24,6 +24,7 @@ class FrontendServer:
         self.clock = clock
         self.start_time = clock()
         self.last_status = clock()
+        self.status_extra = None          # callable -> dict appended to the 10 s status line (the daemon sets it)
 
     # ------------------------------------------------------------------ receiver.py:503-614
     def handle(self, msg):
@@ -105,6 +106,14 @@ class FrontendServer:
         now = self.clock() if now is None else now
         tb = self.tb
         if now - self.last_status > 10:
+            # receiver.py:622-625, the 10 s status line (+ what SURVEY 5 asks to add to it: Msps in, kernel time)
+            log.info("Frontend Status: client: %s client_hb: %s channels: %s uptime: %s" % (
+                len(self.clients), len(self.client_hb), len(tb.channels), int(now - self.start_time)))
+            if self.status_extra is not None:
+                try:
+                    log.info("Frontend Status: %s" % self.status_extra())
+                except Exception as e:
+                    log.error("status metrics failed: %s" % e)
             self.last_status = now
             if now - tb.last_channel_cleanup > tb.channel_idle_timeout * 2:
                 tb.sweep_idle_channels(now)

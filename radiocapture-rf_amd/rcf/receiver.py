@@ -208,6 +208,44 @@ class receiver:
             raise
         self._fed[source_id] = self._fed.get(source_id, 0) + n
 
+    def enable_kernel_metrics(self, stride=32):
+        """kernel time and HBM rate in the status line and the registry record.  Every `stride`-th
+        launch of each kernel class is bracketed with HIP events on the front-end's own stream (rcf_timing_*: an event
+        record costs ~6 us of queue gap, hence the stride); metrics() turns them into per-class average launch times, the
+        estimated GPU-busy share and the input bytes per second of kernel time."""
+        self._kernel_stride = int(stride)
+        for fe in {id(s["block"]): s["block"] for s in self.sources.values()}.values():
+            if hasattr(fe, "timing_enable"):
+                fe.timing_enable(True)
+                fe.timing_stride(self._kernel_stride)
+        self._kernel_mark = time.time()
+
+    def _kernel_metrics(self, d_samples):
+        from . import native
+        names = {native.T_FIR: "fir", native.T_FIR_MFMA: "fir_mfma", native.T_PFB: "pfb", native.T_FIR_DERIVED: "fir_stage2",
+                 native.T_DISC: "disc", native.T_TAPS: "tap_finalize", native.T_SCAN_FFT: "scan_fft",
+                 native.T_SCAN_MOVSUM: "scan_sum", native.T_AUDIO: "audio", native.T_HISTORY: "copies"}
+        now = time.time()
+        wall = max(now - self._kernel_mark, 1e-9)
+        self._kernel_mark = now
+        per, est_ms = {}, 0.0
+        for fe in {id(s["block"]): s["block"] for s in self.sources.values()}.values():
+            for cls, name in names.items():
+                try:
+                    ms, n = fe.timing_read(cls)
+                except Exception:
+                    continue
+                if n:
+                    a = per.setdefault(name, [0.0, 0])
+                    a[0] += ms
+                    a[1] += n
+                    est_ms += ms * self._kernel_stride        # every stride-th launch was timed
+        out = {"rcf_kernel_us": {k: v[0] / v[1] * 1e3 for k, v in per.items()},
+               "rcf_gpu_busy_fraction_est": est_ms * 1e-3 / wall}
+        if est_ms > 0:
+            out["rcf_input_GBps_of_kernel_time"] = d_samples * 8.0 / (est_ms * 1e-3) / 1e9
+        return out
+
     def healthy(self):
         """False once a push has failed (GPU / driver error).  The reference has no such signal: a dead flowgraph
         keeps publishing; here the heartbeat stops (registry.redis_channel_publisher(health=...))."""
@@ -221,6 +259,7 @@ class receiver:
         t_prev, n_prev = self._fed_mark
         rate = (total - n_prev) / (now - t_prev) / 1e6 if now > t_prev else 0.0
         self._fed_mark = (now, total)
+        kernel = self._kernel_metrics(total - n_prev) if getattr(self, "_kernel_stride", 0) else {}
         with self.access_lock:
             in_use = sum(1 for c in self.channels.values() if getattr(c, "in_use", False))
             n_chan = len(self.channels)
@@ -234,6 +273,7 @@ class receiver:
             out["rcf_pfb_direct_off_grid"] = sum(1 for r in routes if "off the bank" in r)
         if self.fault is not None:
             out["rcf_fault"] = self.fault
+        out.update(kernel)
         return out
 
     # ------------------------------------------------------------------ control plane

@@ -285,3 +285,14 @@ def test_registry_against_a_real_redis_server():
     assert mgr.channelizers[pub.instance_uuid]["port"] == 12345
     mgr.poll_once(now=time.time() + 6)
     assert pub.instance_uuid not in mgr.channelizers
+
+
+def test_the_references_own_smoke_and_speed_test_of_the_api_runs_again(daemon, capsys):
+    """frontend_connector.py:232-251 (create + release, then 100 x timed) cannot run in the reference any more; its working
+    equivalent ships as `python -m rcf.frontend_connector` and runs here against the daemon over real sockets"""
+    d, reg = daemon
+    _manager(reg)
+    assert FC.main(["--registry", "dir:%s" % reg.root, "--transport", "tcp", "--freq", str(FC0 + 12500), "--rate", str(CR),
+                    "-n", "20"]) == 0
+    out = capsys.readouterr().out
+    assert "function test pass" in out and "speed test" in out

@@ -100,6 +100,8 @@ def test_channelizer_process_serves_a_backend(gpu_required, tmp_path, wire):
         rec = (mgr.poll_once(), next(iter(mgr.channelizers.values())))[1]
         assert rec["rcf_channels_in_use"] == 1 and rec["rcf_healthy"] and rec["rcf_msps_in"] > 0.5 * FS / 1e6
         assert rec["rcf_source_late_blocks"] == 0
+        # kernel time in the record -- every 32nd launch of each kernel class is timed
+        assert rec["rcf_kernel_us"].get("fir", 0) > 0 and 0 < rec["rcf_gpu_busy_fraction_est"] < 1
         # the client dies without 'release' / 'quit': 5 s later the daemon has released its channel (receiver.py:654-668)
         fc.continue_running = False                                # stops the heartbeat thread ...
         fc.my_client_id = 10 ** 6                                   # ... whose parting 'quit' names nobody
