@@ -935,7 +935,7 @@ def main():
             # prove the communicator BEFORE anything is timed: one ncclAllGather of the rank numbers and one
             # ncclAllReduce(max) over all `world` GPUs; a run whose RCCL ring does not work fails here, loudly
             rccl_ranks = fe.comm_size()
-            parts = fe.allgather_peaks(np.array([rank], dtype=np.int64), 8)
+            parts = fe.allgather_peaks(np.array([rank], dtype=np.int64), multigpu.PEAK_CAP)   # the capacity the real gather uses
             seen = [int(p[0]) if len(p) else -1 for p in parts]
             top = fe.allreduce_max(float(rank))
             if rccl_ranks != world or seen != list(range(world)) or top != float(world - 1):

@@ -296,3 +296,40 @@ def test_the_references_own_smoke_and_speed_test_of_the_api_runs_again(daemon, c
                     "-n", "20"]) == 0
     out = capsys.readouterr().out
     assert "function test pass" in out and "speed test" in out
+
+
+def test_control_wire_survives_garbage_and_serves_many_clients_at_once(daemon):
+    """a client that sends an impossible frame length, or half a frame and hangs up, costs itself its connection and
+    nobody else anything; requests of several connections interleave (receiver.py:686-699 answers one request per
+    turn of its loop, whoever sent it)"""
+    import socket
+    import struct
+    d, reg = daemon
+    good = [transport.TcpReqSocket("127.0.0.1", d.port) for _ in range(4)]
+    bad = socket.create_connection(("127.0.0.1", d.port))
+    bad.sendall(struct.pack("<I", 0x7fffffff) + b"x" * 64)        # 2 GiB frame announced
+    half = socket.create_connection(("127.0.0.1", d.port))
+    half.sendall(struct.pack("<I", 100) + b"conn")                 # then silence
+    ids = []
+    for s in good:
+        s.send_string("connect")
+    for s in good:
+        verb, cid = s.recv_string().split(",")
+        assert verb == "connect"
+        ids.append(cid)
+    assert len(set(ids)) == 4
+    half.close()
+    for s, cid in zip(good, ids):
+        s.send_string("hb,%s" % cid)
+        assert s.recv_string() == "hb,%s" % cid
+    good[0].send_string("create,x")                                 # malformed: the reference logs and keeps serving
+    assert good[0].recv_string() == "na"
+    good[1].send_string("nonsense")                                 # unknown verb: empty reply, as the reference's handler returns None
+    assert good[1].recv_string() == ""
+    bad.settimeout(2.0)
+    assert bad.recv(16) == b""                                      # the daemon hung up on the garbage sender
+    for s, cid in zip(good, ids):
+        s.send_string("quit,%s" % cid)
+        assert s.recv_string() == "quit,%s" % cid
+        s.close()
+    bad.close()

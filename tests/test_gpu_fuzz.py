@@ -1411,3 +1411,60 @@ def test_device_picker_names_the_frequencies_the_reference_found(gpu_required):
             _hip_memcpy_h2d(dev.value, x)
             idx, _, _ = fe.scan_find_peaks(cap=4096)
         assert [nat.peak_frequency(int(l), fs, N, fc) for l in idx] == want, i
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_batched_reads_equal_single_reads_under_churn(gpu_required, seed):
+    """rcf_chan_read_many (round 4: the egress pump's read -- one gather launch into pinned memory, one sync) against
+    rcf_chan_read_iq / _fm channel by channel on a twin front-end fed the same stream: random channel sets (direct,
+    filterbank taps, stage-2 channels), opened and closed at random block boundaries, ragged pushes, small rings (wraps
+    and lagging readers), random capacities per call, ids of closed channels left in the list.  Bit for bit."""
+    nat = gpu_required
+    rng = np.random.default_rng(31000 + seed)
+    fs = 5e6
+    D, taps = G.channel_params(fs, 12500)
+    n_blocks = int(rng.integers(6, 14))
+    sizes = [int(rng.integers(1, 3 * D)) if rng.random() < 0.2 else int(rng.integers(2000, 30 * D)) for _ in range(n_blocks)]
+    x = synth.awgn(rng, int(np.sum(sizes)))
+    cap_log2 = int(rng.integers(8, 11))
+    with nat.Frontend(fs, block_capacity=max(sizes) + 16, hist_capacity=1 << 14, out_capacity=1 << cap_log2) as a, \
+            nat.Frontend(fs, block_capacity=max(sizes) + 16, hist_capacity=1 << 14, out_capacity=1 << cap_log2) as b:
+        for fe in (a, b):
+            fe.pfb_open(400, D, taps)
+        ia, ib, dead = [], [], []
+
+        at = 0
+        for blk, n in enumerate(sizes):
+            for _ in range(int(rng.integers(0, 4))):
+                u = rng.random()
+                if u < 0.6 or not ia:
+                    r = rng.random()
+                    if r < 0.5:
+                        f = float(rng.integers(-190, 190)) * 12500.0 + float(rng.choice([0.0, 300.0]))
+                        ia.append(a.chan_open(12500, f)); ib.append(b.chan_open(12500, f))
+                    elif r < 0.8:
+                        k, g = int(rng.integers(0, 400)), bool(rng.integers(0, 2))
+                        ia.append(a.pfb_tap_open(k, gr_phase=g)); ib.append(b.pfb_tap_open(k, gr_phase=g))
+                    else:
+                        k = int(rng.integers(0, 400))
+                        ia.append(a.pfb_chan_open(k, 6250, 100.0)); ib.append(b.pfb_chan_open(k, 6250, 100.0))
+                else:
+                    j = int(rng.integers(0, len(ia)))
+                    a.chan_close(ia[j]); b.chan_close(ib[j])
+                    dead.append(ib[j])
+                    del ia[j]; del ib[j]
+            a.push(x[at:at + n]); b.push(x[at:at + n])
+            at += n
+            if rng.random() < 0.3:
+                continue                                        # nobody reads this block: lag, perhaps past the ring
+            cap = int(rng.choice([64, 257, 1 << cap_log2, 1 << 12]))
+            what = "iq" if rng.random() < 0.6 else "fm"
+            ids = list(ib) + ([dead[-1]] if dead and rng.random() < 0.5 else [])
+            order = rng.permutation(len(ids))
+            got = b.chan_read_many([ids[i] for i in order], what, gain=2.5, cap_each=cap)
+            for pos, i in enumerate(order):
+                if i >= len(ib):
+                    assert got[pos] is None
+                    continue
+                one = a.chan_read_iq(ia[i], cap) if what == "iq" else a.chan_read_fm(ia[i], 2.5, cap)
+                assert len(one) == len(got[pos]) and np.array_equal(one, got[pos]), (seed, blk, what, cap, i, len(one), len(got[pos]))
