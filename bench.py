@@ -594,7 +594,7 @@ def read_gpu_busy_percent():
     return best
 
 
-def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_ms, n_threads):
+def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_ms, n_threads, stagger=True):
     """K independent 20 Msps front-ends on ONE GPU (the reference's deployment shape: ten sources per host,
     configs/config_denver_dev_den817.py:25-118, one channelizer process each), every one fed its own u8 stream --
     what an SDR link delivers, 2 bytes per sample -- at exactly 20 Msps of WALL-CLOCK time in blocks of `block_ms`
@@ -633,29 +633,47 @@ def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_
         mine = list(range(w, K, n_threads))
         outs = {i: np.empty((len(chans[i]), 1024), dtype=np.float32) for i in mine}
         st, ls = stats[w], lat[w]
+        # staggered (default): front-end i's blocks complete at t0 + (k + 1) period + (i / K) period -- independent SDRs
+        # are not synchronised, and the GPU then sees a steady flow; burst: every front-end ticks at the same instant
+        phase = {i: (i / K) * period if stagger else 0.0 for i in mine}
+
+        def drain(i, k, due):
+            t_ = time.perf_counter()
+            got = fes[i].chan_read_many(chans[i], "fm", gain=1.0, cap_each=1024, out=outs[i])
+            st["read"] += sum(len(g) for g in got)
+            done = time.perf_counter()
+            st["drain_ms"] += (done - t_) * 1e3
+            if k >= warm:
+                ls.append(done - due)
+                if done - due > period:
+                    st["miss"] += 1
+
         try:
             for k in range(n_ticks):
-                due = t0 + (k + 1) * period                       # block k's last sample exists now
-                now = time.perf_counter()
-                if now < due:
-                    time.sleep(due - now)
-                elif now - due > period and k >= warm:
-                    st["overrun"] += 1
-                ta = time.perf_counter()
+                pending = None                                   # pushed, not yet drained (pipelined by one front-end)
+                first = True
                 for i in mine:
+                    due = t0 + (k + 1) * period + phase[i]       # block k's last sample exists now
+                    now = time.perf_counter()
+                    if now < due:
+                        if pending is not None:                  # use the wait
+                            drain(*pending)
+                            pending = None
+                            now = time.perf_counter()
+                        if now < due:
+                            time.sleep(due - now)
+                    elif now - due > period and k >= warm and (stagger or first):
+                        st["overrun"] += 1
+                    first = False
+                    ta = time.perf_counter()
                     at = ((i * 7919 + k) * blk) % (n_tile - blk)
                     fes[i].push_raw(raw_tile[2 * at: 2 * (at + blk)], native.FMT_U8, 1.0 / 32, 127.4)
-                tb_ = time.perf_counter()
-                for i in mine:
-                    got = fes[i].chan_read_many(chans[i], "fm", gain=1.0, cap_each=1024, out=outs[i])
-                    st["read"] += sum(len(g) for g in got)
-                    done = time.perf_counter()
-                    if k >= warm:
-                        ls.append(done - due)
-                        if done - due > period:
-                            st["miss"] += 1
-                st["push_ms"] += (tb_ - ta) * 1e3
-                st["drain_ms"] += (time.perf_counter() - tb_) * 1e3
+                    st["push_ms"] += (time.perf_counter() - ta) * 1e3
+                    if pending is not None:
+                        drain(*pending)
+                    pending = (i, k, due)
+                if pending is not None:
+                    drain(*pending)
         except Exception as e:
             errors.append("%s: %s" % (type(e).__name__, e))
 
@@ -693,13 +711,15 @@ def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_
     pct = lambda p: alll[min(len(alll) - 1, int(p * len(alll)))] * 1e3 if alll else None
     n_ch = len(chans[0]) if chans else 0
     return {
-        "front_ends": K, "seconds": wall, "blocks_per_front_end": n_ticks - warm, "warmup_blocks_not_judged": warm,
+        "front_ends": K, "staggered": bool(stagger), "seconds": wall, "blocks_per_front_end": n_ticks - warm,
+        "warmup_blocks_not_judged": warm,
         "block_ms": period * 1e3,
         "deadline_misses": sum(s["miss"] for s in stats), "ring_overruns": sum(s["overrun"] for s in stats),
         "output_samples_lost": int(produced - read), "errors": errors,
         "latency_ms_p50": pct(0.50), "latency_ms_p99": pct(0.99), "latency_ms_max": alll[-1] * 1e3 if alll else None,
         "host_push_ms_per_tick_slowest_thread": max(s["push_ms"] for s in stats) / n_ticks,
         "host_drain_ms_per_tick_slowest_thread": max(s["drain_ms"] for s in stats) / n_ticks,
+        "host_busy_fraction_slowest_thread": max(s["push_ms"] + s["drain_ms"] for s in stats) / n_ticks / (period * 1e3),
         "gpu_busy_percent_mean": sum(busy) / len(busy) if busy else None,
         "gpu_busy_percent_max": max(busy) if busy else None,
         "pcie_GBps_in": K * FS * 2 / 1e9, "pcie_GBps_out": K * n_ch * (FS / NB / 3 if shape == "pfb256" else 25000.0) * 4 / 1e9,
@@ -709,7 +729,8 @@ def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_
     }
 
 
-def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_first=16, k_cap=512, shapes=("pfb256", "grid1600")):
+def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_first=16, k_cap=1024,
+                 shapes=("pfb256", "grid1600"), stagger=True):
     """`sustained`, as the metric means it: how many 20 Msps front-ends one MI355X keeps up with in real time.  K is
     doubled from k_first until a point misses a deadline (or k_cap), then the midpoint between the last good and the first
     bad K is tried once.  Per shape: pfb256 = BASELINE configs[1] per front-end (256-bin bank + 32 FM channels);
@@ -723,13 +744,16 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
         n_threads = 4
     out = {"what": "K independent 20 Msps u8 front-ends on one GPU, paced at wall-clock rate in %.0f ms blocks through "
                    "rcf_push_raw (pinned), every channel's discriminator output drained to the host after each block "
-                   "(rcf_chan_read_many); %d host threads share the front-ends" % (block_ms, n_threads),
-           "host_threads": n_threads, "seconds_per_point": seconds}
+                   "(rcf_chan_read_many); %d host threads share the front-ends; %s" % (
+                       block_ms, n_threads,
+                       "the front-ends' block boundaries are spread evenly over the block period (independent SDRs are not "
+                       "synchronised)" if stagger else "every front-end's block completes at the same instant (worst case)"),
+           "host_threads": n_threads, "seconds_per_point": seconds, "staggered": bool(stagger)}
     for shape in shapes:
         pts, good, bad = [], None, None
         K = k_first
         def point(K):
-            p = realtime_point(native, K, shape, raw.array, carriers, device, seconds, block_ms, min(n_threads, K))
+            p = realtime_point(native, K, shape, raw.array, carriers, device, seconds, block_ms, min(n_threads, K), stagger)
             pts.append(p)
             n_blocks = K * p["blocks_per_front_end"]
             if not p["ok"] and not p["errors"] and p["ring_overruns"] == 0 and p["output_samples_lost"] == 0 \
@@ -737,7 +761,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
                 # at most one tick's worth of late blocks (or 1 %): one hiccup of a shared host, or the limit?  Once more,
                 # both attempts stay in `points`
                 p["retried"] = True
-                p = realtime_point(native, K, shape, raw.array, carriers, device, seconds, block_ms, min(n_threads, K))
+                p = realtime_point(native, K, shape, raw.array, carriers, device, seconds, block_ms, min(n_threads, K), stagger)
                 p["second_attempt"] = True
                 pts.append(p)
             return p
@@ -869,7 +893,9 @@ def main():
     ap.add_argument("--sweep-max", type=int, default=196608, help="largest direct-bank channel count to open")
     ap.add_argument("--rt-seconds", type=float, default=10.0, help="seconds per point of the paced real-time leg (0 = skip it)")
     ap.add_argument("--rt-block-ms", type=float, default=20.0, help="block length of the paced real-time leg")
-    ap.add_argument("--rt-k-first", type=int, default=32, help="front-end count the real-time search starts at")
+    ap.add_argument("--rt-k-first", type=int, default=64, help="front-end count the real-time search starts at")
+    ap.add_argument("--rt-burst", action="store_true",
+                    help="real-time leg: every front-end's block completes at the same instant (default: spread over the period)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -1185,7 +1211,7 @@ def main():
         out["end_to_end"] = end_to_end_leg(native, tile, local_rank)
         if args.rt_seconds > 0:
             out["realtime"] = realtime_leg(native, tile, meta["carriers"], local_rank, seconds=args.rt_seconds,
-                                           block_ms=args.rt_block_ms, k_first=args.rt_k_first)
+                                           block_ms=args.rt_block_ms, k_first=args.rt_k_first, stagger=not args.rt_burst)
         out["control_plane"] = control_plane_leg(local_rank)
         counts = [c for c in (256, 1024, 4096, 16384, 65536, 131072, 196608) if c <= args.sweep_max]
         out["channels"]["direct_bank"] = direct_bank_sweep(native, tile, local_rank, counts)
