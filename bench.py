@@ -580,20 +580,6 @@ def measure_traffic_live(cfg5, block, kernel_substr, timeout_s=150):
 
 
 # ------------------------------------------------------------------------------------------- paced real-time leg
-def read_gpu_busy_percent():
-    """amdgpu's own utilisation figure from sysfs (the busiest card: nothing maps a HIP device to its card index
-    without the PCI bus id); None where the node does not expose it"""
-    import glob
-    best = None
-    for f in glob.glob("/sys/class/drm/card*/device/gpu_busy_percent"):
-        try:
-            v = float(open(f).read().strip())
-            best = v if best is None else max(best, v)
-        except Exception:
-            continue
-    return best
-
-
 def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_ms, n_threads, stagger=True):
     """K independent 20 Msps front-ends on ONE GPU (the reference's deployment shape: ten sources per host,
     configs/config_denver_dev_den817.py:25-118, one channelizer process each), every one fed its own u8 stream --
@@ -606,7 +592,7 @@ def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_
     import threading
     blk = int(round(FS * block_ms * 1e-3))
     period = blk / FS
-    warm = max(2, int(round(0.3 / period)))               # first ticks (lazy allocations, module loads): run, not judged
+    warm = max(2, int(round(1.0 / period)))               # the first second (lazy allocations, module loads, clocks): run, not judged
     n_ticks = max(4, int(round(seconds / period))) + warm
     fes, chans = [], []
     t_setup = time.perf_counter()
@@ -677,23 +663,19 @@ def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_
         except Exception as e:
             errors.append("%s: %s" % (type(e).__name__, e))
 
-    busy = []
-    stop = threading.Event()
-
-    def sampler():
-        while not stop.is_set():
-            v = read_gpu_busy_percent()
-            if v is not None:
-                busy.append(v)
-            stop.wait(0.25)
-
+    # GPU share of the filterbank / stage-2 / tap kernels, from HIP events around every 4th launch of front-end 0 (sysfs
+    # gpu_busy_percent counts any queued work -- it read ~100 % from K = 16 on -- and a sysfs read asks the SMU: not
+    # something to do inside a run that is judged on 20 ms deadlines)
+    t_classes = [native.T_PFB, native.T_FIR_DERIVED, native.T_TAPS, native.T_DISC]
+    fes[0].timing_enable(True, classes=t_classes)
+    fes[0].timing_stride(4)
+    for c_ in t_classes:
+        fes[0].timing_read(c_)
     import gc
     ths = [threading.Thread(target=worker, args=(w,)) for w in range(n_threads)]
-    smp = threading.Thread(target=sampler)
     gc.collect()
     gc.disable()                                         # a generation-2 collection of this process is a 20 ms block
     try:
-        smp.start()
         for t in ths:
             t.start()
         for t in ths:
@@ -701,8 +683,11 @@ def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_
     finally:
         gc.enable()
     wall = time.perf_counter() - t0
-    stop.set()
-    smp.join()
+    per_block_ms = 0.0
+    for c_ in t_classes:
+        ms_, n_ = fes[0].timing_read(c_)
+        per_block_ms += ms_ / n_ if n_ else 0.0
+    fes[0].timing_enable(False)
     produced = sum(fes[i].chan_produced(c) for i in range(K) for c in chans[i])
     read = sum(s["read"] for s in stats)
     for fe in fes:
@@ -720,8 +705,10 @@ def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_
         "host_push_ms_per_tick_slowest_thread": max(s["push_ms"] for s in stats) / n_ticks,
         "host_drain_ms_per_tick_slowest_thread": max(s["drain_ms"] for s in stats) / n_ticks,
         "host_busy_fraction_slowest_thread": max(s["push_ms"] + s["drain_ms"] for s in stats) / n_ticks / (period * 1e3),
-        "gpu_busy_percent_mean": sum(busy) / len(busy) if busy else None,
-        "gpu_busy_percent_max": max(busy) if busy else None,
+        "gpu_kernel_us_per_block_front_end_0": per_block_ms * 1e3,
+        "gpu_busy_percent_est": 100.0 * K * per_block_ms / (period * 1e3),
+        "gpu_busy_note": "filterbank + stage-2 / tap-finalize kernels of front-end 0 (HIP events, every 4th launch) x K / block "
+                         "period; the u8 conversion, the gather of the read and the H2D copy are not in it",
         "pcie_GBps_in": K * FS * 2 / 1e9, "pcie_GBps_out": K * n_ch * (FS / NB / 3 if shape == "pfb256" else 25000.0) * 4 / 1e9,
         "input_Msps_sustained": K * FS / 1e6, "setup_s": setup_s,
         "ok": not errors and sum(s["miss"] for s in stats) == 0 and sum(s["overrun"] for s in stats) == 0
@@ -756,10 +743,11 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
             p = realtime_point(native, K, shape, raw.array, carriers, device, seconds, block_ms, min(n_threads, K), stagger)
             pts.append(p)
             n_blocks = K * p["blocks_per_front_end"]
-            if not p["ok"] and not p["errors"] and p["ring_overruns"] == 0 and p["output_samples_lost"] == 0 \
-                    and p["deadline_misses"] <= max(K, n_blocks // 100):
-                # at most one tick's worth of late blocks (or 1 %): one hiccup of a shared host, or the limit?  Once more,
-                # both attempts stay in `points`
+            if not p["ok"] and not p["errors"] and p["output_samples_lost"] == 0 \
+                    and p["deadline_misses"] + p["ring_overruns"] <= max(2 * K, n_blocks // 100):
+                # at most a tick or two's worth of late blocks (or 1 %): one hiccup of a shared host (the front-ends of a
+                # worker all miss together when its thread is descheduled for > 20 ms), or the limit?  Once more; both
+                # attempts stay in `points`
                 p["retried"] = True
                 p = realtime_point(native, K, shape, raw.array, carriers, device, seconds, block_ms, min(n_threads, K), stagger)
                 p["second_attempt"] = True
@@ -774,6 +762,12 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
             else:
                 bad = K
                 break
+        while good is None and bad is not None and bad > 4:          # the starting point itself failed: search downwards
+            K = bad // 2
+            if point(K)["ok"]:
+                good = K
+            else:
+                bad = K
         if good is not None and bad is not None and bad - good > max(8, good // 4):
             mid = (good + bad) // 2
             if point(mid)["ok"]:
@@ -785,7 +779,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
             "channels_sustained": (good or 0) * bins, "fm_channels_sustained": (good or 0) * demod,
             "input_Msps_sustained": (good or 0) * FS / 1e6,
             "at_K_max": best, "points": [{k: p[k] for k in ("front_ends", "ok", "deadline_misses", "ring_overruns",
-                                                            "latency_ms_p50", "latency_ms_p99", "gpu_busy_percent_mean",
+                                                            "latency_ms_p50", "latency_ms_p99", "gpu_busy_percent_est",
                                                             "host_push_ms_per_tick_slowest_thread",
                                                             "host_drain_ms_per_tick_slowest_thread", "errors")} | {k: p[k] for k in ("retried", "second_attempt") if k in p}
                                          for p in pts],
