@@ -57,3 +57,26 @@ def test_one_gpu_line_is_unchanged_by_the_launcher():
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout)
     assert d["n_gpus"] == 1 and d["transport"].startswith("none") and d["rccl_ranks"] == 1
+
+
+def test_the_drivers_torchrun_invocation_for_n_gt_1():
+    """the contract's other launch form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher,
+    bench.py must NOT spawn again, rank 0 prints the one line"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RCF_BENCH_NATIVE="stub_native", RCF_BENCH_TRANSPORT="host",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), os.environ.get("PYTHONPATH", "")]))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2"] + FLAGS, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_started_by"].startswith("the launcher") and len(d["ms_per_step_by_rank"]) == 2
