@@ -167,7 +167,11 @@ int rcf_commit(rcf_t *h, size_t n_samples);
  * instead of 8 over PCIe) and the conversion the reference leaves to gr-osmosdr / gr-uhd on the host
  * (rc_frontend/receiver.py:74-98,170-191) runs on the GPU: x = (float(raw) - offset) * scale per
  * component, then the block is processed like rcf_push_iq.  rtl-sdr: RCF_FMT_U8, offset 127.4,
- * scale 1/128; sc16 (USRP wire, bladeRF Q11): RCF_FMT_S16, offset 0, scale 1/32768 or 1/2048. */
+ * scale 1/128; sc16 (USRP wire, bladeRF Q11): RCF_FMT_S16, offset 0, scale 1/32768 or 1/2048.
+ * A block of up to 4 MiB in pinned memory (rcf_host_alloc) is converted straight out of host memory -- one launch, no
+ * staging copy: the shape of a real-time SDR block; larger ones go through a staged copy that overlaps the previous
+ * block's kernels (RCF_RAW_DIRECT=<bytes> moves the threshold, 0 = always staged).  Either way the call returns once
+ * the caller's buffer has been read. */
 #define RCF_FMT_U8   1   /* unsigned 8-bit I,Q interleaved */
 #define RCF_FMT_S8   2   /* signed 8-bit I,Q interleaved */
 #define RCF_FMT_S16  3   /* signed 16-bit little-endian I,Q interleaved */

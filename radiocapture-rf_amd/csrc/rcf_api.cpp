@@ -1766,6 +1766,25 @@ int rcf_push_raw(rcf_t *h, const void *iq_raw, size_t n, int fmt, float scale, f
     if (n > h->block_cap) { set_error("push of %zu samples exceeds block capacity %zu", n, h->block_cap); return RCF_ECAP; }
     std::lock_guard<std::mutex> g(h->mu);
     if (set_dev(h)) return RCF_EHIP;
+    {
+        // Pinned caller memory (rcf_host_alloc): the conversion kernel reads the wire-format block straight out of host
+        // memory across PCIe -- no staging copy, no second stream, no cross-stream event waits: one event instead of
+        // two and two barrier packets fewer per block, which is what a real-time-sized block (a handful of ~5 us
+        // kernels) is made of: 256 front-ends of the bench's real-time leg p99 1.9 -> 0.2 ms, 384 sustained instead
+        // of missing.  Blocks above RCF_RAW_DIRECT bytes (default 4 MiB; 0 = never) keep the staged copy: in a bulk
+        // replay the copy of block n + 1 then overlaps the kernels of block n, which a PCIe-bound kernel on the
+        // compute stream would not.
+        static const int direct = [] { const char *e = getenv("RCF_RAW_DIRECT"); return e ? atoi(e) : (4 << 20); }();
+        void *dv = nullptr;
+        if (direct && n * bps <= (size_t)direct && hipHostGetDevicePointer(&dv, const_cast<void *>(iq_raw), 0) == hipSuccess && dv) {
+            launch_convert(fmt, dv, h->d_buf[h->cur] + h->hist_cap, n, scale, offset, h->stream);
+            RCF_HIP(hipEventRecord(h->copy_ev, h->stream));
+            int rc = process_block(h, n);
+            (void)hipEventSynchronize(h->copy_ev);  // the caller may reuse its buffer once the conversion has read it
+            return rc;
+        }
+        (void)hipGetLastError();                    // (pageable memory: not an error)
+    }
     if (!h->d_raw) RCF_HIP(hipMalloc(&h->d_raw, h->block_cap * 4));       // staging for the widest format
     if (h->raw_done_set) RCF_HIP(hipStreamWaitEvent(h->copy_stream, h->raw_done, 0));   // previous conversion read it
     RCF_HIP(hipMemcpyAsync(h->d_raw, iq_raw, n * bps, hipMemcpyHostToDevice, h->copy_stream));
