@@ -152,7 +152,10 @@ int rcf_timing_read(rcf_t *h, int what, double *total_ms, int64_t *launches, int
 /* ------------------------------------------------------------------ wideband ingest */
 /* Host buffer in: copies n_samples H2D behind the history and runs every consumer (channels, PFB,
  * armed scan) over the new block.  Replaces the source -> pub_sink broadcast (receiver.py:201-202)
- * and every channel's sub_source (rc_frontend/channel.py:29). */
+ * and every channel's sub_source (rc_frontend/channel.py:29).  Pageable or large blocks are copied on a second stream
+ * (the copy of block n + 1 overlaps the kernels of block n); a block of <= 4 MiB in pinned memory (rcf_host_alloc) is
+ * fetched by a kernel on the compute stream straight out of host memory -- no second stream, no cross-stream waits:
+ * what a real-time block wants (RCF_RAW_DIRECT moves the threshold).  Returns once the caller's buffer has been read. */
 int rcf_push_iq(rcf_t *h, const float *iq_interleaved, size_t n_samples);
 /* Zero-copy ingest: *dev_ptr is where the producer (SDR DMA, generator kernel, hipMemcpy) must put
  * the next block (device memory, room for *max_samples); rcf_commit(n) then processes the n samples

@@ -1742,6 +1742,22 @@ int rcf_push_iq(rcf_t *h, const float *iq, size_t n)
     if (n > h->block_cap) { set_error("push of %zu samples exceeds block capacity %zu", n, h->block_cap); return RCF_ECAP; }
     std::lock_guard<std::mutex> g(h->mu);
     if (set_dev(h)) return RCF_EHIP;
+    {
+        // a real-time-sized block in pinned memory (see rcf_push_raw): copied by a kernel on the compute stream straight
+        // out of host memory -- no second stream, no cross-stream waits.  In order behind every kernel that read this
+        // buffer, so no buf_done bookkeeping either.
+        static const int direct = [] { const char *e = getenv("RCF_RAW_DIRECT"); return e ? atoi(e) : (4 << 20); }();
+        void *dv = nullptr;
+        if (direct && n * sizeof(float2) <= (size_t)direct && h->copy_kernels &&
+            hipHostGetDevicePointer(&dv, const_cast<float *>(iq), 0) == hipSuccess && dv) {
+            launch_copy8(h->d_buf[h->cur] + h->hist_cap, dv, sizeof(float2) * n, h->stream);
+            RCF_HIP(hipEventRecord(h->copy_ev, h->stream));
+            int rc = process_block(h, n);
+            (void)hipEventSynchronize(h->copy_ev);
+            return rc;
+        }
+        (void)hipGetLastError();                              // (pageable memory: not an error)
+    }
     h->eager_buf_done = true;
     if (h->buf_dirty[h->cur]) {                               // blocks committed in place read this buffer since
         RCF_HIP(hipEventRecord(h->buf_done[h->cur], h->stream));

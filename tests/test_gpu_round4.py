@@ -199,3 +199,53 @@ np.savez(sys.argv[1], *got)
     a, b = np.load(out_fail), np.load(out_ok)
     for k in a.files:
         assert len(a[k]) == len(b[k]) > 0 and np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("fmt_name", ["u8", "s16"])
+def test_raw_blocks_from_pinned_memory_are_converted_in_place_and_equal_the_staged_copy(gpu_required, fmt_name):
+    """rcf_push_raw has two ingest paths since round 4: a pinned block of <= 4 MiB is converted straight out of host
+    memory (one launch, no staging copy), anything else goes through the staged copy.  Same samples, three ways --
+    pinned (direct), pageable (staged), and cf32 converted on the host with the same float32 operations -- mixed with
+    cf32 pushes on the same handle: channel and filterbank outputs bit for bit the same."""
+    nat = gpu_required
+    from rcf import sources
+    fs = 2.4e6
+    rng = np.random.default_rng(808)
+    n = 96 * 700 + 33
+    x = synth.awgn(rng, n) * np.float32(1.5)
+    raw = sources.to_wire(x, fmt_name)
+    scale, off = sources.WIRE_SCALE[fmt_name]
+    fmt = {"u8": nat.FMT_U8, "s16": nat.FMT_S16}[fmt_name]
+    host = ((raw.astype(np.float32) - np.float32(off)) * np.float32(scale)).view(np.complex64)
+    cuts = [0, 96 * 100 + 7, 96 * 101, 96 * 350 + 1, 96 * 351, n]
+    taps = G.low_pass_2(1.0, fs, fs / 64 * 0.4, fs / 64 * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS)
+
+    def run(mode):
+        pin = nat.PinnedArray(2 * n, raw.dtype)
+        pin.array[:] = raw
+        with nat.Frontend(fs) as fe:
+            c = fe.chan_open(12500, -62500.0)
+            fe.pfb_open(64, 64, taps)
+            for k, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+                if k == 2:                                      # one block as cf32 in between: the paths interleave
+                    if mode == "pinned":                        # ... from pinned memory too (rcf_push_iq's in-place copy)
+                        pc = nat.PinnedArray(hi - lo, np.complex64)
+                        pc.array[:] = host[lo:hi]
+                        fe.push(pc.array)
+                        pc.free()
+                    else:
+                        fe.push(host[lo:hi])
+                elif mode == "pinned":
+                    fe.push_raw(pin.array[2 * lo:2 * hi], fmt, scale, off)
+                elif mode == "pageable":
+                    fe.push_raw(raw[2 * lo:2 * hi].copy(), fmt, scale, off)
+                else:
+                    fe.push(host[lo:hi])
+            out = (fe.chan_read_iq(c), fe.chan_read_fm(c, 5.0), fe.pfb_read_bin(5))
+        pin.free()
+        return out
+
+    a, b, c = run("pinned"), run("pageable"), run("host")
+    for u, v, w in zip(a, b, c):
+        assert len(u) == len(v) == len(w) > 0
+        assert np.array_equal(u, v) and np.array_equal(u, w)
