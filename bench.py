@@ -547,6 +547,8 @@ def measure_traffic_live(cfg5, block, kernel_substr, timeout_s=150):
     rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if rp is None:
         return None
+    if any(k.startswith("ROCPROF") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None                                          # this run is itself being profiled: no profiler inside a profiler
     out = {}
     child = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "1", "--block", str(block), "--no-extras",
              "--no-cpu-baseline", "--no-sustained", "--no-live-traffic", "--prewarm-seconds", "0.2"]
