@@ -170,12 +170,15 @@ def main(argv=None):
     ap.add_argument("--ready-file", default=None, help="write {'port':..,'pid':..} here once the control port is bound")
     args = ap.parse_args(argv)
 
-    for cand in ("config.logging.json",):
-        if os.path.exists(cand):
-            with open(cand, "rt") as f:
-                logging.config.dictConfig(json.load(f))         # receiver.py:478-487
-            break
-    else:
+    configured = False
+    if os.path.exists("config.logging.json"):                   # receiver.py:478-487
+        try:
+            with open("config.logging.json", "rt") as f:
+                logging.config.dictConfig(json.load(f))
+            configured = True
+        except Exception as e:                                   # e.g. its rotating-file handler's ../logs/ is not there:
+            sys.stderr.write("config.logging.json not usable (%s): logging to stderr\n" % e)   # the reference dies here
+    if not configured:
         logging.basicConfig(level=logging.INFO, format="%(asctime)s %(name)s %(levelname)s %(message)s")
 
     config = load_config(args.config)
