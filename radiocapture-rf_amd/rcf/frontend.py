@@ -33,12 +33,25 @@ import time
 def load_config(spec="config"):
     """`from config import rc_config` (receiver.py:23) -- `spec` is a module name on sys.path or a path to a .py file
     (configs/*.py in the reference); returns rc_config()."""
-    if spec.endswith(".py") or os.sep in spec:
-        s = importlib.util.spec_from_file_location("config", spec)
-        mod = importlib.util.module_from_spec(s)
-        s.loader.exec_module(mod)
-    else:
-        mod = importlib.import_module(spec)
+    path = spec if (spec.endswith(".py") or os.sep in spec) else None
+    if path is None:
+        try:
+            return importlib.import_module(spec).rc_config()
+        except TabError:
+            path = importlib.util.find_spec(spec).origin
+    # Most of the reference's configs/*.py mix tabs and spaces the way Python 2 allowed (a tab = the next multiple of
+    # eight columns) and do not import under Python 3 -- the reference itself cannot load them any more.  Read them the
+    # Python-2 way instead of asking the operator to re-indent a site's configuration.
+    import types
+    with open(path, "rt") as fh:
+        src = fh.read()
+    try:
+        code = compile(src, path, "exec")
+    except TabError:
+        code = compile(src.expandtabs(8), path, "exec")
+    mod = types.ModuleType("config")
+    mod.__file__ = path
+    exec(code, mod.__dict__)
     return mod.rc_config()
 
 

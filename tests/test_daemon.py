@@ -333,3 +333,41 @@ def test_control_wire_survives_garbage_and_serves_many_clients_at_once(daemon):
         assert s.recv_string() == "quit,%s" % cid
         s.close()
     bad.close()
+
+
+def test_python2_indented_site_configs_load(tmp_path):
+    """20 of the reference's 22 configs/*.py mix tabs and spaces the way Python 2 allowed (tab = next multiple of eight)
+    and raise TabError under Python 3 -- the reference itself cannot import them any more; the channelizer process
+    reads them the Python-2 way"""
+    p = tmp_path / "config.py"
+    p.write_text("class rc_config:\n\tdef __init__(self):\n                self.receiver_split2 = False\n"
+                 "\t\tself.sources = {\n\t\t\t0:{\n                                'type': 'rtlsdr',\n"
+                 "\t\t\t\t'center_freq': 855500000,\n                                'samp_rate': 10666666,\n\t\t\t}\n\t\t}\n")
+    with pytest.raises(TabError):
+        compile(p.read_text(), str(p), "exec")
+    c = frontend.load_config(str(p))
+    assert c.receiver_split2 is False and c.sources[0]["samp_rate"] == 10666666
+
+
+def test_every_site_config_of_the_reference_can_open_its_channels():
+    """tests/golden/reference_configs.json (what configs/*.py ask for, read in the build container): every source of
+    every site configuration opens 12.5 kHz channels -- with channel.py:31's rule as Python 3 reads it, or, for the two
+    10 666 666 sps deployments, as Python 2 read it (py2_decim / RCF_DECIM_FLOOR)"""
+    import json
+    from rcf import native
+    cfgs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_configs.json")))
+    assert len(cfgs) == 22 and sum(not c["imports_under_python3"] for c in cfgs.values()) == 20
+    need_floor = set()
+    for name, c in cfgs.items():
+        for s in c["sources"]:
+            if s["samp_rate"] is None:
+                continue                                     # (one file leaves the rate to its device discovery)
+            rate = s["samp_rate"] / (2 if c["receiver_split2"] else 1)
+            try:
+                D, T = native.channel_params(rate, 12500)
+            except native.RcfError as e:
+                assert e.code == native.RCF_ERANGE
+                D, T = native.channel_params(rate, 12500, native.DECIM_FLOOR)
+                need_floor.add(name)
+            assert D == int(rate / 12500) // 2 and T % 2 == 1
+    assert need_floor == {"config_denver_massive_p25.py", "config_denver_usrp.py"}
