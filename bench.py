@@ -582,7 +582,7 @@ def measure_traffic_live(cfg5, block, kernel_substr, timeout_s=150):
 
 
 # ------------------------------------------------------------------------------------------- paced real-time leg
-def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_ms, n_threads, stagger=True):
+def realtime_point(native, pool, K, shape, raw_tile, carriers, device, seconds, block_ms, n_threads, stagger=True):
     """K independent 20 Msps front-ends on ONE GPU (the reference's deployment shape: ten sources per host,
     configs/config_denver_dev_den817.py:25-118, one channelizer process each), every one fed its own u8 stream --
     what an SDR link delivers, 2 bytes per sample -- at exactly 20 Msps of WALL-CLOCK time in blocks of `block_ms`
@@ -596,9 +596,11 @@ def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_
     period = blk / FS
     warm = max(2, int(round(1.0 / period)))               # the first second (lazy allocations, module loads, clocks): run, not judged
     n_ticks = max(4, int(round(seconds / period))) + warm
-    fes, chans = [], []
+    # the front-ends live in a pool that the points of one shape share (opening 768 of them takes longer than running
+    # them for ten seconds); a point uses the first K and starts from drained rings
     t_setup = time.perf_counter()
-    for i in range(K):
+    fes, chans = pool["fes"], pool["chans"]
+    while len(fes) < K:
         if shape == "pfb256":
             fe = native.Frontend(FS, 0.0, device=device, block_capacity=blk, hist_capacity=1 << 14, out_capacity=1 << 12)
             fe.pfb_open(NB, NB, proto_taps(native))
@@ -610,6 +612,11 @@ def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_
             ids = [fe.pfb_tap_open((7 + 6 * j) % 1600, gr_phase=True) for j in range(256)]
         fes.append(fe)
         chans.append(ids)
+    fes, chans = fes[:K], chans[:K]
+    for i in range(K):                                   # whatever an earlier point left unread
+        while sum(len(g) for g in fes[i].chan_read_many(chans[i], "fm", cap_each=1 << 12) if g is not None):
+            pass
+    produced0 = sum(fes[i].chan_produced(c) for i in range(K) for c in chans[i])
     setup_s = time.perf_counter() - t_setup
     n_tile = len(raw_tile) // 2
     lat = [[] for _ in range(n_threads)]
@@ -619,7 +626,9 @@ def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_
 
     def worker(w):
         mine = list(range(w, K, n_threads))
-        outs = {i: np.empty((len(chans[i]), 1024), dtype=np.float32) for i in mine}
+        # (the read's ctypes arguments are built once per front-end: with 256 channels a list-building wrapper costs
+        # ~0.15 ms of interpreter time per call, and sixteen threads share one interpreter lock)
+        plans = {i: fes[i].chan_read_many_plan(chans[i], "fm", gain=1.0, cap_each=1024) for i in mine}
         st, ls = stats[w], lat[w]
         # staggered (default): front-end i's blocks complete at t0 + (k + 1) period + (i / K) period -- independent SDRs
         # are not synchronised, and the GPU then sees a steady flow; burst: every front-end ticks at the same instant
@@ -627,8 +636,8 @@ def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_
 
         def drain(i, k, due):
             t_ = time.perf_counter()
-            got = fes[i].chan_read_many(chans[i], "fm", gain=1.0, cap_each=1024, out=outs[i])
-            st["read"] += sum(len(g) for g in got)
+            counts, _ = plans[i]()
+            st["read"] += int(counts.sum())
             done = time.perf_counter()
             st["drain_ms"] += (done - t_) * 1e3
             if k >= warm:
@@ -690,10 +699,8 @@ def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_
         ms_, n_ = fes[0].timing_read(c_)
         per_block_ms += ms_ / n_ if n_ else 0.0
     fes[0].timing_enable(False)
-    produced = sum(fes[i].chan_produced(c) for i in range(K) for c in chans[i])
+    produced = sum(fes[i].chan_produced(c) for i in range(K) for c in chans[i]) - produced0
     read = sum(s["read"] for s in stats)
-    for fe in fes:
-        fe.close()
     alll = sorted(x for l in lat for x in l)
     pct = lambda p: alll[min(len(alll) - 1, int(p * len(alll)))] * 1e3 if alll else None
     n_ch = len(chans[0]) if chans else 0
@@ -718,7 +725,7 @@ def realtime_point(native, K, shape, raw_tile, carriers, device, seconds, block_
     }
 
 
-def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_first=16, k_cap=1024,
+def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_first=16, k_cap=768,
                  shapes=("pfb256", "grid1600"), stagger=True):
     """`sustained`, as the metric means it: how many 20 Msps front-ends one MI355X keeps up with in real time.  K is
     doubled from k_first until a point misses a deadline (or k_cap), then the midpoint between the last good and the first
@@ -737,12 +744,17 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
                        block_ms, n_threads,
                        "the front-ends' block boundaries are spread evenly over the block period (independent SDRs are not "
                        "synchronised)" if stagger else "every front-end's block completes at the same instant (worst case)"),
-           "host_threads": n_threads, "seconds_per_point": seconds, "staggered": bool(stagger)}
+           "host_threads": n_threads, "seconds_of_the_confirmation_run_at_K_max": seconds,
+           "seconds_per_search_point": min(4.0, seconds), "staggered": bool(stagger)}
     for shape in shapes:
         pts, good, bad = [], None, None
+        pool = {"fes": [], "chans": []}
         K = k_first
-        def point(K):
-            p = realtime_point(native, K, shape, raw.array, carriers, device, seconds, block_ms, min(n_threads, K), stagger)
+        search_s = min(4.0, seconds)                     # the search runs short points; K_max is then CONFIRMED over `seconds`
+
+        def point(K, secs=None):
+            secs = search_s if secs is None else secs
+            p = realtime_point(native, pool, K, shape, raw.array, carriers, device, secs, block_ms, min(n_threads, K), stagger)
             pts.append(p)
             n_blocks = K * p["blocks_per_front_end"]
             if not p["ok"] and not p["errors"] and p["output_samples_lost"] == 0 \
@@ -751,7 +763,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
                 # worker all miss together when its thread is descheduled for > 20 ms), or the limit?  Once more; both
                 # attempts stay in `points`
                 p["retried"] = True
-                p = realtime_point(native, K, shape, raw.array, carriers, device, seconds, block_ms, min(n_threads, K), stagger)
+                p = realtime_point(native, pool, K, shape, raw.array, carriers, device, secs, block_ms, min(n_threads, K), stagger)
                 p["second_attempt"] = True
                 pts.append(p)
             return p
@@ -760,7 +772,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
             p = point(K)
             if p["ok"]:
                 good = K
-                K *= 2
+                K = K * 2 if K * 2 <= k_cap or K == k_cap else k_cap      # the cap itself is the last point of the search
             else:
                 bad = K
                 break
@@ -774,8 +786,24 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
             mid = (good + bad) // 2
             if point(mid)["ok"]:
                 good = mid
+        # confirmation: the K the short points found, over the full `seconds`; if it does not hold, three quarters of it
+        best = None
+        for _ in range(3):
+            if not good or seconds <= search_s:
+                break
+            p = point(good, seconds)
+            p["confirmation_run"] = True
+            if p["ok"]:
+                best = p
+                break
+            bad, good = good, max(1, (3 * good) // 4)
+        if best is None:
+            best = next((p for p in reversed(pts) if p["front_ends"] == good and p["ok"]), None)
+            if best is None:
+                good = 0
+        for fe in pool["fes"]:
+            fe.close()
         bins, demod = (NB, len(carriers)) if shape == "pfb256" else (1600, 256)
-        best = next((p for p in pts if p["front_ends"] == good and p["ok"]), None)
         out[shape] = {
             "K_max": good or 0, "first_K_that_missed": bad, "bins_per_front_end": bins, "demodulated_per_front_end": demod,
             "channels_sustained": (good or 0) * bins, "fm_channels_sustained": (good or 0) * demod,
@@ -783,7 +811,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
             "at_K_max": best, "points": [{k: p[k] for k in ("front_ends", "ok", "deadline_misses", "ring_overruns",
                                                             "latency_ms_p50", "latency_ms_p99", "gpu_busy_percent_est",
                                                             "host_push_ms_per_tick_slowest_thread",
-                                                            "host_drain_ms_per_tick_slowest_thread", "errors")} | {k: p[k] for k in ("retried", "second_attempt") if k in p}
+                                                            "host_drain_ms_per_tick_slowest_thread", "errors", "seconds")} | {k: p[k] for k in ("retried", "second_attempt", "confirmation_run") if k in p}
                                          for p in pts],
         }
     raw.free()
@@ -889,7 +917,8 @@ def main():
     ap.add_argument("--sweep-max", type=int, default=196608, help="largest direct-bank channel count to open")
     ap.add_argument("--rt-seconds", type=float, default=10.0, help="seconds per point of the paced real-time leg (0 = skip it)")
     ap.add_argument("--rt-block-ms", type=float, default=20.0, help="block length of the paced real-time leg")
-    ap.add_argument("--rt-k-first", type=int, default=64, help="front-end count the real-time search starts at")
+    ap.add_argument("--rt-k-first", type=int, default=256, help="front-end count the real-time search starts at")
+    ap.add_argument("--rt-k-cap", type=int, default=768, help="largest front-end count the real-time search tries")
     ap.add_argument("--rt-burst", action="store_true",
                     help="real-time leg: every front-end's block completes at the same instant (default: spread over the period)")
     args = ap.parse_args()
@@ -1207,7 +1236,8 @@ def main():
         out["end_to_end"] = end_to_end_leg(native, tile, local_rank)
         if args.rt_seconds > 0:
             out["realtime"] = realtime_leg(native, tile, meta["carriers"], local_rank, seconds=args.rt_seconds,
-                                           block_ms=args.rt_block_ms, k_first=args.rt_k_first, stagger=not args.rt_burst)
+                                           block_ms=args.rt_block_ms, k_first=args.rt_k_first, k_cap=args.rt_k_cap,
+                                           stagger=not args.rt_burst)
         out["control_plane"] = control_plane_leg(local_rank)
         counts = [c for c in (256, 1024, 4096, 16384, 65536, 131072, 196608) if c <= args.sweep_max]
         out["channels"]["direct_bank"] = direct_bank_sweep(native, tile, local_rank, counts)

@@ -37,6 +37,7 @@ class EgressPump:
         self.period = period
         self.fm_gain = fm_gain
         self.fm_port_offset = fm_port_offset
+        self._plans = {}
         self.batch_cap = 1 << 13                         # samples per channel and pass in the batched read (0.3 s at 25 kS/s)
         self.socks = {}
         self.fm_socks = {}
@@ -107,10 +108,9 @@ class EgressPump:
                 if len(items) > 1 and hasattr(fe, "chan_read_many"):
                     # all channels of one front-end behind ONE device synchronisation (rcf_chan_read_many)
                     try:
-                        ids = [ch.chan_id for _, ch in items]
-                        iqs = fe.chan_read_many(ids, "iq", cap_each=self.batch_cap)
-                        fms = fe.chan_read_many(ids, "fm", gain=self.fm_gain, cap_each=self.batch_cap) \
-                            if self.fm_gain is not None else [None] * len(ids)
+                        ids = tuple(ch.chan_id for _, ch in items)
+                        iqs = self._read_many(fe, ids, "iq", 1.0)
+                        fms = self._read_many(fe, ids, "fm", self.fm_gain) if self.fm_gain is not None else [None] * len(ids)
                         got = list(zip(iqs, fms))
                     except Exception as e:
                         log.error("batched egress read failed (%s): reading channel by channel" % e)
@@ -136,6 +136,19 @@ class EgressPump:
                 self._fail(block_id, e)
         for block_id in [b for b in self.socks if b not in chans]:   # destroyed channels
             self._drop(block_id)
+
+    def _read_many(self, fe, ids, what, gain):
+        """all channels of one front-end behind one device synchronisation; the call's arguments are kept while the
+        channel set stays the same (native.Frontend.chan_read_many_plan)"""
+        if not hasattr(fe, "chan_read_many_plan"):
+            return fe.chan_read_many(list(ids), what, gain=gain, cap_each=self.batch_cap)
+        key = (id(fe), what)
+        plan = self._plans.get(key)
+        if plan is None or plan[0] != (ids, gain):
+            plan = ((ids, gain), fe.chan_read_many_plan(list(ids), what, gain=gain, cap_each=self.batch_cap))
+            self._plans[key] = plan
+        counts, out = plan[1]()
+        return [None if counts[i] < 0 else out[i, :counts[i]].copy() for i in range(len(ids))]
 
     def _fail(self, block_id, e):
         self.errors += 1

@@ -482,6 +482,28 @@ class Frontend:
                                         out.ctypes.data_as(C.c_void_p), int(cap_each), counts))
         return [None if counts[i] < 0 else out[i, :counts[i]] for i in range(n)]
 
+    def chan_read_many_plan(self, cids, what="iq", gain=1.0, cap_each=1 << 14, out=None):
+        """chan_read_many for a FIXED channel list called over and over (an egress pump, a real-time loop): the ctypes
+        arguments are built once; the returned callable performs one rcf_chan_read_many and returns (counts, out) --
+        counts an int64 array (negative: that channel is gone), out the [len(cids), cap_each] array the samples are in.
+        Costs ~10 us of interpreter time per call instead of ~1 us per channel."""
+        n = len(cids)
+        dt = np.complex64 if what == "iq" else np.float32
+        if out is None:
+            out = np.empty((max(n, 1), cap_each), dtype=dt)
+        out2 = out.reshape(-1, cap_each)
+        ids = (C.c_int * max(n, 1))(*[int(c) for c in cids])
+        counts = np.zeros(max(n, 1), dtype=np.int64)
+        f = lib().rcf_chan_read_many
+        args = (self._h, 0 if what == "iq" else 1, ids, n, C.c_float(float(gain)), out2.ctypes.data_as(C.c_void_p),
+                C.c_size_t(int(cap_each)), counts.ctypes.data_as(C.POINTER(C.c_int64)))
+
+        def call():
+            _check(f(*args))
+            return counts, out2
+        call.keep = (ids, counts, out2)                     # the buffers the C call writes into live as long as the plan
+        return call
+
     def chan_fm_filter(self, cid, gain, taps):
         taps = np.ascontiguousarray(taps, dtype=np.float32)
         _check(lib().rcf_chan_fm_filter(self._h, cid, float(gain), _fp(taps), len(taps)))
