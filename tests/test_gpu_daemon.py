@@ -217,3 +217,87 @@ def test_channelizer_process_in_pfb_mode_replaying_a_capture_file(gpu_required, 
         if proc.poll() is None:
             proc.kill()
         log.close()
+
+
+CONFIG_20M = '''
+class rc_config:
+    def __init__(self):
+        self.receiver_split2 = False
+        self.frontend_mode = 'xlat'
+        self.sources = {0: {'type': 'synthetic', 'center_freq': 860000000, 'samp_rate': 20000000, 'seed': 5, 'tile_samples': 1 << 22,
+                            'wire': 'u8', 'block_ms': 20.0, 'carriers': []}}
+'''
+
+
+def test_channelizer_process_keeps_up_with_one_20_msps_source_and_64_subscribed_channels(gpu_required, tmp_path):
+    """the deployment shape at the BASELINE rate: ONE channelizer process, one 20 Msps source paced at wall-clock rate
+    (u8 wire, 20 ms blocks), 64 reference-shaped 12.5 kHz channels (2909-tap xlating FIR /800 each: the matrix-core
+    bank) created by 64 clients and every one of them subscribed to -- for eight seconds: no late source block, every
+    subscriber receives its 25 kS/s, the registry says so."""
+    cfg = tmp_path / "config.py"
+    cfg.write_text(CONFIG_20M)
+    ready = tmp_path / "ready.json"
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "radiocapture-rf_amd"), ROOT]))
+    log = open(tmp_path / "daemon.log", "w")
+    proc = subprocess.Popen([sys.executable, "-m", "rcf.frontend", "-i", "0", "--config", str(cfg), "--transport", "tcp",
+                             "--registry", "dir:%s" % (tmp_path / "reg"), "--bind", "127.0.0.1", "--ready-file", str(ready)],
+                            env=env, cwd=str(tmp_path), stdout=log, stderr=subprocess.STDOUT)
+    import socket
+    import threading
+    try:
+        _wait(lambda: ready.exists() or proc.poll() is not None, 120, "daemon did not come up")
+        assert proc.poll() is None, open(tmp_path / "daemon.log").read()
+        reg = transport.DirRegistryClient(str(tmp_path / "reg"))
+        mgr = registry.redis_channelizer_manager(index=0, clients=[reg], start_thread=False)
+        _wait(lambda: (mgr.poll_once(), mgr.channelizers)[1], 10, "no registry record")
+        clients, subs = [], []
+        for i in range(64):
+            fc_ = FC.frontend_connector("load-%d" % i, mgr, transport_factory=transport.tcp_req_factory)
+            chan, port = fc_.create_channel(CR, 860000000 + (i - 32) * 250000 + 12500)
+            assert chan, i
+            subs.append(transport.TcpSubSocket(fc_.host, port))
+            clients.append(fc_)
+        got = [0] * 64
+        stop = threading.Event()
+
+        def reader(lo, hi):
+            for s in subs[lo:hi]:
+                s.sock.settimeout(0.05)
+            while not stop.is_set():
+                for i in range(lo, hi):
+                    try:
+                        got[i] += len(subs[i].sock.recv(1 << 16))
+                    except (socket.timeout, BlockingIOError):
+                        pass
+        ths = [threading.Thread(target=reader, args=(k, k + 16)) for k in range(0, 64, 16)]
+        for t_ in ths:
+            t_.start()
+        time.sleep(1.5)                                           # everybody connected, rings drained
+        base = list(got)
+        mgr.poll_once()
+        r0 = next(iter(mgr.channelizers.values()))
+        t0 = time.time()
+        time.sleep(8.0)
+        now = list(got)
+        wall = time.time() - t0
+        mgr.poll_once()
+        r1 = next(iter(mgr.channelizers.values()))
+        stop.set()
+        for t_ in ths:
+            t_.join()
+        assert r1["rcf_channels_in_use"] == 64 and r1["rcf_healthy"]
+        assert r1["rcf_source_late_blocks"] == r0["rcf_source_late_blocks"], (r0["rcf_source_late_blocks"], r1["rcf_source_late_blocks"])
+        assert abs(r1["rcf_msps_in"] - 20.0) < 0.5, r1["rcf_msps_in"]
+        rates = [(b - a) / 8.0 / wall for a, b in zip(base, now)]            # cf32 samples per second per subscriber
+        assert min(rates) > 0.97 * 25000 and max(rates) < 1.03 * 25000, (min(rates), max(rates))
+        assert r1["rcf_egress_errors"] == 0
+        for s in subs:
+            s.close()
+        for c in clients:
+            c.exit()
+        proc.send_signal(signal.SIGTERM)
+        proc.wait(timeout=30)
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+        log.close()
