@@ -1235,9 +1235,12 @@ def main():
         out["scan"] = scan_leg(native, synth, local_rank)
         out["end_to_end"] = end_to_end_leg(native, tile, local_rank)
         if args.rt_seconds > 0:
-            out["realtime"] = realtime_leg(native, tile, meta["carriers"], local_rank, seconds=args.rt_seconds,
-                                           block_ms=args.rt_block_ms, k_first=args.rt_k_first, k_cap=args.rt_k_cap,
-                                           stagger=not args.rt_burst)
+            try:
+                out["realtime"] = realtime_leg(native, tile, meta["carriers"], local_rank, seconds=args.rt_seconds,
+                                               block_ms=args.rt_block_ms, k_first=args.rt_k_first, k_cap=args.rt_k_cap,
+                                               stagger=not args.rt_burst)
+            except Exception as e:                       # a leg outside the timed region must not cost the run its line
+                out["realtime"] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["control_plane"] = control_plane_leg(local_rank)
         counts = [c for c in (256, 1024, 4096, 16384, 65536, 131072, 196608) if c <= args.sweep_max]
         out["channels"]["direct_bank"] = direct_bank_sweep(native, tile, local_rank, counts)
