@@ -371,3 +371,48 @@ def test_every_site_config_of_the_reference_can_open_its_channels():
                 need_floor.add(name)
             assert D == int(rate / 12500) // 2 and T % 2 == 1
     assert need_floor == {"config_denver_massive_p25.py", "config_denver_usrp.py"}
+
+
+def test_data_wire_drops_whole_messages_for_a_slow_subscriber_and_stays_item_aligned():
+    """channel.py:36's PUB socket is lossy at its high-water mark and never blocks the flowgraph; the TCP stand-in behaves
+    the same way: a subscriber that stops reading loses WHOLE sends (never part of one: the cf32 stream stays item-aligned
+    and every surviving send arrives intact and in order), a fast subscriber next to it loses nothing, and the publisher
+    never blocks"""
+    import socket
+    pub = transport.TcpPubSocket(0, host="127.0.0.1", sndbuf=1 << 16)
+    fast = transport.TcpSubSocket("127.0.0.1", pub.port)
+    slow = transport.TcpSubSocket("127.0.0.1", pub.port)
+    n_msg, items = 400, 2048
+    msgs = [np.full(items, k, dtype=np.complex64).tobytes() for k in range(n_msg)]
+    got_fast = bytearray()
+    fast.sock.settimeout(0.2)
+    t0 = time.time()
+    for m in msgs:
+        pub.send(m)                                           # the slow subscriber's buffers fill up after a few dozen
+        try:
+            while len(got_fast) < (msgs.index(m) + 1) * len(m):
+                got_fast += fast.sock.recv(1 << 20)
+        except socket.timeout:
+            pass
+    assert time.time() - t0 < 20                              # never blocked on the stuck subscriber
+    assert bytes(got_fast) == b"".join(msgs)                  # the reader that keeps up has everything
+    assert pub.dropped > 0
+    slow.sock.settimeout(0.3)
+    got = bytearray()
+    try:
+        while True:
+            pub.send(b"")                                     # lets a pending tail out
+            chunk = slow.sock.recv(1 << 20)
+            if not chunk:
+                break
+            got += chunk
+    except socket.timeout:
+        pass
+    assert len(got) % (items * 8) == 0 and len(got) < n_msg * items * 8
+    seq = np.frombuffer(bytes(got), dtype=np.complex64).reshape(-1, items)
+    assert np.all(seq == seq[:, :1])                          # every surviving message intact ...
+    ks = seq[:, 0].real.astype(int)
+    assert np.all(np.diff(ks) > 0)                            # ... and in order, with gaps where sends were dropped
+    for s in (fast, slow):
+        s.close()
+    pub.close()
