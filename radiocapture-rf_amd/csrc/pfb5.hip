@@ -128,6 +128,23 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
 
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<cf *>(p.src.base), 0, (int)(p.src_len * (int64_t)sizeof(cf)), 0x00020000);
+    // Phase B's twiddle seeds (one table entry per second-pass butterfly, one per finish sweep: dependent-address loads
+    // from L2) requested NOW, at kernel entry, for the 3200-bin banks: 0.487 -> 0.54 of the HBM peak (D = 800), 0.478 ->
+    // 0.51 (D = 1600).  NOT for
+    // the smaller banks: the same change costs the 1600-bin kernel 18 % (0.598 -> 0.49: 98 instead of 73 VGPRs and a
+    // phase A that starts behind six more loads per thread).
+    // (800 bins, R3 = 2: 0.606 -> 0.47 with it; 400 bins, R3 = 1, where there is only the one seed: 0.650 -> 0.660)
+    constexpr bool SE = R3 == 8 || R3 == 1;
+    cf seed2 = make_float2(0.f, 0.f), seedf[(R + R3 - 1) / R3];
+    if constexpr (SE) {
+        const int g_ = (tid / F) % R3, k_ = tid / (F * R3);
+        seed2 = p.tw[k_ * R3];
+#pragma unroll
+        for (int s_ = 0; s_ < (R + R3 - 1) / R3; ++s_) {
+            const int i_ = g_ + R3 * s_;
+            seedf[s_] = p.tw[(k_ + R * (i_ < R ? i_ : 0)) % NB];
+        }
+    }
 
     // ---- phase A: branch FIR + first radix-20 pass.  u[t] = sum_q h[NB q + rho_t] x[(n - OS q) D - rho_t],
     // rho_t = j + BPF t; X[f] -> buf[20 j + f]
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
                 // W_{R R}^{k t}, t < R, from ONE table entry by binary powering (depth <= 5 multiplications, a few
                 // 1e-7 of error): nineteen table loads per thread were a third of the kernel's L2 traffic
                 cf w[R];
-                twiddle_powers<R>(p.tw[k * R3], w);
+                twiddle_powers<R>(SE ? seed2 : p.tw[k * R3], w);
 #pragma unroll
                 for (int t = 1; t < R; ++t) vv[t] = cmul(vv[t], w[t]);
             }
@@ -326,7 +343,7 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
             if (R3 > 1) {
                 {
                     cf wp[R3 > 1 ? R3 : 2];
-                    twiddle_powers<(R3 > 1 ? R3 : 2)>(p.tw[jj], wp);       // W_NB^{jj t} from one entry
+                    twiddle_powers<(R3 > 1 ? R3 : 2)>(SE ? seedf[s] : p.tw[jj], wp);       // W_NB^{jj t} from one entry
 #pragma unroll
                     for (int t = 1; t < R3; ++t) w[t] = cmul(w[t], wp[t]);
                 }
