@@ -129,11 +129,10 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<cf *>(p.src.base), 0, (int)(p.src_len * (int64_t)sizeof(cf)), 0x00020000);
     // Phase B's twiddle seeds (one table entry per second-pass butterfly, one per finish sweep: dependent-address loads
-    // from L2) requested NOW, at kernel entry, for the 3200-bin banks: 0.487 -> 0.54 of the HBM peak (D = 800), 0.478 ->
-    // 0.51 (D = 1600).  NOT for
-    // the smaller banks: the same change costs the 1600-bin kernel 18 % (0.598 -> 0.49: 98 instead of 73 VGPRs and a
-    // phase A that starts behind six more loads per thread).
-    // (800 bins, R3 = 2: 0.606 -> 0.47 with it; 400 bins, R3 = 1, where there is only the one seed: 0.650 -> 0.660)
+    // from L2) requested NOW, at kernel entry, a whole phase A ahead of their use -- for the 3200-bin banks (0.487 ->
+    // 0.54 of the HBM peak at D = 800, 0.478 -> 0.51 at D = 1600) and the 400-bin one (one seed: 0.650 -> 0.660).
+    // NOT for 800 / 1600 bins: measured 0.606 -> 0.47 and 0.598 -> 0.49 there (phase A then starts behind six more
+    // loads per thread).
     constexpr bool SE = R3 == 8 || R3 == 1;
     cf seed2 = make_float2(0.f, 0.f), seedf[(R + R3 - 1) / R3];
     if constexpr (SE) {
