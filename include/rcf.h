@@ -224,7 +224,8 @@ int64_t rcf_chan_read_fm(rcf_t *h, int chan_id, float gain, float *out, size_t m
 /* The same reads for MANY channels behind one stream synchronisation -- what an egress pump that serves hundreds of
  * channel.py:36 PUB sockets needs per pass (a single-channel read costs a device round trip each).  what: RCF_READ_IQ
  * (out = float2[n_chans][cap_each]) or RCF_READ_FM (out = float[n_chans][cap_each], scaled by gain); counts[i] = samples
- * copied for chan_ids[i] (0: nothing new; RCF_ENOCHAN: no such channel, the others are still served).  `out` may be
+ * copied for chan_ids[i] (0: nothing new; RCF_ENOCHAN: no such channel, RCF_EINVAL: a channel listed a second time -- it
+ * has one reader position per stream; the others are still served).  `out` may be
  * pinned memory (rcf_host_alloc): the copies then overlap each other. */
 #define RCF_READ_IQ 0
 #define RCF_READ_FM 1

@@ -57,6 +57,7 @@ static size_t pow2_at_least(size_t v)
 
 struct Chan {
     int id = -1;
+    uint64_t many_stamp = 0;      // the rcf_chan_read_many call that last listed this channel
     int src = -1;                 // -1 wideband; RCF_SRC_PFB_BIN0 + bin; else source channel id
     int D = 0, T = 0;
     double src_rate = 0, offset_hz = 0;
@@ -195,6 +196,7 @@ struct rcf {
     // rcf_chan_read_many: pinned staging the gather kernel writes (and reads its records from) across PCIe
     unsigned char *h_many = nullptr, *h_many_dev = nullptr;
     size_t many_cap = 0;
+    uint64_t many_stamp = 0;
     // optional per-kernel-class HIP-event timing (rcf_timing_*)
     bool timing = false;
     unsigned timing_mask = ~0u;
@@ -2047,12 +2049,15 @@ int rcf_chan_read_many(rcf_t *h, int what, const int *chan_ids, int n_chans, flo
     std::vector<Item> items((size_t)n_chans);
     size_t total = 0;
     uint32_t max_w = 0;
+    const uint64_t stamp = ++h->many_stamp;
     for (int i = 0; i < n_chans; ++i) {
         Item &it = items[(size_t)i];
         it = Item{nullptr, nullptr, nullptr, 0, 0};
         auto f = h->chans.find(chan_ids[i]);
         if (f == h->chans.end()) { counts[i] = RCF_ENOCHAN; continue; }
         Chan *c = f->second.get();
+        if (c->many_stamp == stamp) { counts[i] = RCF_EINVAL; continue; }   // listed twice: one reader position per channel
+        c->many_stamp = stamp;
         it.c = c;
         it.cur = what == RCF_READ_IQ ? &c->rd_iq : &c->rd_fm;
         it.ring = what == RCF_READ_IQ ? (const void *)c->d_iq : (const void *)c->d_fm;
@@ -2073,7 +2078,7 @@ int rcf_chan_read_many(rcf_t *h, int what, const int *chan_ids, int n_chans, flo
     // tapped bins of ten front-ends are 25 ms per pass.)
     const size_t rec_bytes = ((size_t)n_chans * sizeof(GatherRec) + 255) & ~(size_t)255;
     const size_t need = rec_bytes + total * elem;
-    if (need > h->many_cap) {
+    if (need > h->many_cap && (uint64_t)total * ew <= 0xffffffffull) {
         if (h->h_many) { (void)hipStreamSynchronize(h->stream); (void)hipHostFree(h->h_many); h->h_many = nullptr; h->many_cap = 0; }
         size_t cap = 1 << 16;
         while (cap < need) cap <<= 1;
@@ -2086,7 +2091,7 @@ int rcf_chan_read_many(rcf_t *h, int what, const int *chan_ids, int n_chans, flo
             (void)hipHostFree(p);
         }
     }
-    if (h->h_many && need <= h->many_cap) {
+    if (h->h_many && need <= h->many_cap && (uint64_t)total * ew <= 0xffffffffull) {     // (GatherRec counts 32-bit words)
         GatherRec *recs = reinterpret_cast<GatherRec *>(h->h_many);
         uint32_t at_w = 0;
         int n_recs = 0;

@@ -112,6 +112,14 @@ def test_batched_read_equals_channel_by_channel_reads(gpu_required):
         first = b.chan_read_many([ib[0]], "iq", cap_each=100)[0].copy()
         rest = b.chan_read_many([ib[0]], "iq", cap_each=4096)[0].copy()
         assert len(first) == 100 and np.array_equal(np.concatenate([first, rest]), a.chan_read_iq(ia[0]))
+        # a channel listed twice has one reader position: the second mention is refused, nothing is skipped or repeated
+        a.push(x[: 96 * 300])
+        b.push(x[: 96 * 300])
+        twice = b.chan_read_many([ib[0], ib[2], ib[0]], "iq", cap_each=4096)
+        assert twice[2] is None and np.array_equal(twice[0], a.chan_read_iq(ia[0])) and np.array_equal(twice[1], a.chan_read_iq(ia[2]))
+        a.push(x[: 96 * 300])
+        b.push(x[: 96 * 300])
+        assert np.array_equal(b.chan_read_many([ib[0]], "iq", cap_each=4096)[0], a.chan_read_iq(ia[0]))
 
 
 def test_python2_decimation_rule_opens_the_10p67_msps_channels(gpu_required):
