@@ -27,9 +27,9 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kThreads = 256;
+constexpr int kSmallPerThread = 2;   // outputs per thread of the small-T kernel (fir_small_outputs <= 256 n - 1): 1 -> 2 took the stage-2 launch of the timed configuration from 0.030 to 0.025 ms, 3 and 4 are not faster
 constexpr int CT = 2;   // channels per wave item
 constexpr int KR = 8;   // outputs per wave item
-constexpr int kSmallPerThread = 2;   // outputs per thread of the small-T kernel (fir_small_outputs <= 256 n - 1): 1 -> 2 took the stage-2 launch of the timed configuration from 0.030 to 0.025 ms, 4 is slower again
 
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -164,17 +164,38 @@ __global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *_
     const int j0 = blockIdx.y * KB;
     if (j0 >= L.n_k) return;
     const int nj = min(KB, L.n_k - j0);
-    for (int i = tid; i < 257; i += kThreads) tab[i] = atan_tab[i];
-    for (int i = tid; i < T; i += kThreads) cts[i] = L.ctaps[i];
     // samples (k0 - 1) D - (T - 1) .. (k0 + nj - 1) D, zero before the channel's start (GR zero history)
     const int64_t k0 = L.k_lo + j0;
     const int64_t s_first = (k0 - 1) * (int64_t)D - (T - 1);
     const int len = nj * D + T;
     const StreamView sv = L.src;
-    // all of a thread's tile loads are issued before the first LDS store: a load -> store loop exposes the full
-    // memory latency once per iteration (measured: that, not arithmetic, was this kernel's time)
+    // EVERY load of the workgroup's prologue -- the arctangent table, the composite taps, the first LU samples per
+    // thread -- is issued before the first LDS store: table -> taps -> samples as three load -> store loops were three
+    // memory latencies in a row in a kernel that is nothing but a chain of them (and a load -> store loop over the
+    // samples exposes the latency once per iteration: measured, that, not arithmetic, was this kernel's time)
     constexpr int LU = 8;     // the stage-2 shape of the timed configuration (D = 3, T = 11: 1544 samples) needs 7 per thread
-    for (int p0 = tid; p0 < len; p0 += kThreads * LU) {
+    static_assert(kThreads == 256, "one table entry per thread, the 257th on thread 0");
+    const float tab_a = atan_tab[tid], tab_b = atan_tab[256];
+    const float2 ct_a = tid < T ? L.ctaps[tid] : make_float2(0.f, 0.f);
+    {
+        float2 v[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int p = tid + u * kThreads;
+            const int64_t sidx = s_first + (p < len ? p : len - 1);
+            v[u] = sidx >= L.start_sample ? sv.base[sv.at(sidx)] : make_float2(0.f, 0.f);
+        }
+        tab[tid] = tab_a;
+        if (tid == 0) tab[256] = tab_b;
+        if (tid < T) cts[tid] = ct_a;
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int p = tid + u * kThreads;
+            if (p < len) xs[p] = v[u];
+        }
+    }
+    for (int i = tid + kThreads; i < T; i += kThreads) cts[i] = L.ctaps[i];
+    for (int p0 = tid + kThreads * LU; p0 < len; p0 += kThreads * LU) {
         float2 v[LU];
 #pragma unroll
         for (int u = 0; u < LU; ++u) {
@@ -192,8 +213,10 @@ __global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *_
     __syncthreads();
     // slot j = tid + 256 o holds y[k0 - 1 + j]: j = 0 is the predecessor the discriminator needs (it belongs to the
     // previous workgroup or launch and is only recomputed, not stored), j = 1 .. nj are this workgroup's outputs.
-    // Up to kSmallPerThread outputs per thread: the whole launch then fits the GPU in one or two waves of
-    // workgroups, and this latency-bound kernel costs about one load -> FIR -> store chain per wave.
+    // Up to kSmallPerThread outputs per thread: the whole launch then fits the GPU in one or two rounds of
+    // workgroups.  (Three per thread with the tile chosen so that the launch is exactly ONE round of resident
+    // workgroups -- 32 x 64 of 683 outputs instead of 32 x 86 of 511 -- measured the same, 19.7 against 19.2 us:
+    // it is the memory system's rate for 128-byte pieces, not the rounds.)
     float2 y[kSmallPerThread];
 #pragma unroll
     for (int o = 0; o < kSmallPerThread; ++o) {
