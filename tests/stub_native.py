@@ -19,6 +19,8 @@ def design_low_pass_2(gain, fs, fc, tw, att, window=WIN_HAMMING):
 
 
 def comm_unique_id():
+    if os.environ.get("STUB_RCCL") == "1":              # a pretend ncclUniqueId: 128 bytes, like the real one
+        return bytes(range(128))
     raise RuntimeError("stub: no RCCL")
 
 
@@ -75,14 +77,32 @@ class Frontend:
     def scan_find_peaks(self, cap=1024):
         return np.array([100 + self.device], dtype=np.int64), 0.0, None
 
+    # STUB_RCCL=1: a pretend communicator (a second host rendezvous) with the semantics of rcf_comm_init /
+    # rcf_allgather_peaks / rcf_allreduce_max, so that the RCCL branch of bench.py's protocol -- id broadcast, every
+    # rank joins, the proof before anything is timed, barrier and gather through the communicator -- runs on CPU
+    _comm = None
+
     def comm_init(self, rank, n, uid=None):
-        raise RuntimeError("stub: no RCCL")
+        if os.environ.get("STUB_RCCL") != "1" or os.environ.get("STUB_RCCL_INIT_FAILS") == "1":
+            raise RuntimeError("stub: no RCCL")
+        assert uid == bytes(range(128))
+        from rcf import multigpu
+        self._comm = multigpu.HostGroup(rank, n, "127.0.0.1", int(os.environ["MASTER_PORT"]) + 202)
 
     def comm_destroy(self):
-        pass
+        if self._comm is not None:
+            self._comm.close()
+            self._comm = None
 
     def comm_size(self):
-        return 1
+        return self._comm.world if self._comm is not None else 1
+
+    def allgather_peaks(self, mine, cap=1024):
+        mine = np.ascontiguousarray(mine, dtype=np.int64)[:cap]
+        return [np.frombuffer(b, dtype=np.int64).copy() for b in self._comm.all_gather(mine.tobytes())]
+
+    def allreduce_max(self, value):
+        return self._comm.max(float(value)) if self._comm is not None else float(value)
 
     def close(self):
         pass

@@ -80,3 +80,28 @@ def test_the_drivers_torchrun_invocation_for_n_gt_1():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_started_by"].startswith("the launcher") and len(d["ms_per_step_by_rank"]) == 2
+
+
+def test_eight_ranks_through_the_communicator_branch():
+    """N = 8, the way the driver's scaling run starts it, with the stub's pretend communicator: rank 0 draws the id, the
+    host rendezvous carries it, every rank joins, the all-gather + all-reduce proof runs BEFORE the warm-up, and the
+    barrier / peak gather go through the communicator (bench.py's `use_rccl` branch, which a 1-GPU box cannot reach)."""
+    r = _run(8, {"STUB_RCCL": "1", "STUB_DEVICES": "8", "RCF_BENCH_TRANSPORT": "rccl"}, timeout=300)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["n_gpus"] == 8 and d["transport"] == "rccl" and d["rccl_ranks"] == 8
+    assert d["rccl_proof"]["allgather_of_rank_numbers"] == list(range(8))
+    assert d["rccl_proof"]["allreduce_max_of_rank_numbers"] == 7.0
+    assert len(d["ms_per_step_by_rank"]) == 8 and d["ms_per_step"] >= max(d["ms_per_step_by_rank"]) * 0.999
+    assert abs(d["value"] - 8 * 6 * (1 << 16) / (d["ms_per_step"] * 6e-3) / 1e6) / d["value"] < 1e-6
+    assert d["peaks_allgather"]["ranks"] == 8 and d["peaks_allgather"]["values_gathered"] >= 8
+
+
+def test_ranks_that_cannot_join_fall_back_to_the_host_transport_together():
+    """the id is drawn and broadcast, but ncclCommInitRank fails (on every rank: a box whose RCCL cannot start): the
+    ranks agree on the host transport and the line says so"""
+    r = _run(4, {"STUB_RCCL": "1", "STUB_RCCL_INIT_FAILS": "1", "STUB_DEVICES": "4", "RCF_BENCH_TRANSPORT": "rccl"}, timeout=300)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["n_gpus"] == 4 and d["transport"] == "host-tcp" and d["rccl_proof"] is None
+    assert "could not join" in r.stderr
