@@ -158,7 +158,7 @@ class PacedSource:
         self.continue_running = False
         if self._thread is not None:
             self._thread.join(timeout=5)
-        if self._pin:
+        if self._pin and not (self._thread is not None and self._thread.is_alive()):   # (a push still in flight keeps its buffers)
             for p in self._pin:
                 p.free()
             self._pin = None

@@ -75,8 +75,14 @@ class TcpRepServer:
         socks = [self.lsock] + list(self.conns)
         try:
             ready, _, _ = select.select(socks, [], [], timeout)
-        except (OSError, ValueError):
+        except (OSError, ValueError):                      # a connection went bad under us: find it, serve the rest
             ready = []
+            for c in list(self.conns):
+                try:
+                    if select.select([c], [], [], 0)[0]:
+                        ready.append(c)
+                except (OSError, ValueError):
+                    self._drop(c)
         served = 0
         for s in ready:
             if s is self.lsock:
