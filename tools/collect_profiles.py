@@ -137,12 +137,12 @@ if len(ser) > 400:
     print("clock: first 100 %.3f GHz, last 100 %.3f GHz over %d dispatches" % (
         w([c for c, _ in ser[:100]]), w([c for c, _ in ser[-100:]]), len(ser)))
 
-for tag in ("bench", "bench_cfg5", "bench_head_under_rocprof", "bench_2ranks_1gpu", "unpinned_bounds"):
+for tag in ("bench", "bench_cfg5", "bench_head_under_rocprof", "bench_2ranks_1gpu", "unpinned_bounds", "hbm_mix_probe"):
     src = "gpurun_out/%s_%s.json" % (R, tag)
     if os.path.exists(src):
         text = open(src).read()
         lines = [l for l in text.splitlines() if l.startswith("{") and l.rstrip().endswith("}")]
-        if tag == "unpinned_bounds" and text.strip():
+        if tag in ("unpinned_bounds", "hbm_mix_probe") and text.strip():
             open("profiles/%s_%s.json" % (R, tag), "w").write(text)
         elif lines:
             open("profiles/%s_%s.json" % (R, tag), "w").write(lines[-1] + "\n")

@@ -175,6 +175,24 @@ def measured_block(R):
                ub["atan_table"]["max_fm_change_p25_gain"],
                max(v["largest_between_two_float32_orders"] for v in ub["summation"].values()),
                ub["rotator_fma"]["max_step_difference_rad"], ub["rotator_fma"]["max_phase_difference"], R))
+    mp = _j("%s_hbm_mix_probe.json" % R)
+    if mp:
+        best = mp["best"]
+        cells = []
+        cells.append("256 bins (1 : 1) %s / %s = %.2f" % (f3(ro["frac"]), f3(best["1:1"]["frac_of_peak"]), ro["frac"] / best["1:1"]["frac_of_peak"]))
+        if c5:
+            cells.append("512 bins (1 : 1) %s / %s = %.2f" % (f3(c5["roofline"]["frac"]), f3(best["1:1"]["frac_of_peak"]),
+                                                               c5["roofline"]["frac"] / best["1:1"]["frac_of_peak"]))
+        if g:
+            cells.append("1600 bins (1 : 2) %s / %s = %.2f" % (f3(g["roofline"]["frac"]), f3(best["1:2"]["frac_of_peak"]),
+                                                                g["roofline"]["frac"] / best["1:2"]["frac_of_peak"]))
+            for x in g.get("grid_6k25", []):
+                mix = "1:2" if x["decim"] == 1600 else "1:4"
+                cells.append("3200 bins, decim %d (%s) %s / %s = %.2f" % (x["decim"], mix.replace(":", " : "), f3(x["frac_of_hbm_peak"]),
+                                                                          f3(best[mix]["frac_of_peak"]), x["frac_of_hbm_peak"] / best[mix]["frac_of_peak"]))
+        add("| what the memory system sustains for the same read : write mix with NO arithmetic (`tools/hbm_mix_probe.hip`: coalesced 16-byte accesses, ping-pong 268 MB blocks, best variant per mix) | read only %s, 1 : 1 %s, 1 : 2 %s, 1 : 4 %s, write only %s of 8 TB/s ⇒ kernel / ceiling: %s | `%s_hbm_mix_probe.json`: `best` |"
+            % (f3(best["1:0"]["frac_of_peak"]), f3(best["1:1"]["frac_of_peak"]), f3(best["1:2"]["frac_of_peak"]),
+               f3(best["1:4"]["frac_of_peak"]), f3(best["0:1"]["frac_of_peak"]), "; ".join(cells), R))
     return "\n".join(L)
 
 

@@ -9,6 +9,7 @@
 #      --config cfg5 -> profiles/pfb512_traffic.json
 #   5. counters of the matrix-core FIR bank at 4096 channels -> profiles/<R>_fir_mfma_pmc.json
 #   6. counters + traffic of the 512-, 1024- and 1600-bin filterbanks
+#   7. tools/hbm_mix_probe: copy rates for the kernels' read : write mixes (the practical ceiling of each roofline fraction)
 # gpurun merges only gpurun_out/ back: run `python tools/collect_profiles.py <R>` locally afterwards.
 # Counter passes never share a run with trace domains other than --kernel-trace.
 set -u
@@ -46,4 +47,7 @@ tools/fir_pmc.sh ${R}_fir4096 C=4096 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb_kernel tools/fir_pmc.sh ${R}_pfb512 NB=512 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb_kernel tools/fir_pmc.sh ${R}_pfb1024 NB=1024 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb5_kernel tools/fir_pmc.sh ${R}_pfb1600 NB=1600 BLOCK=33554432 > /dev/null 2>&1
+# what the memory system sustains for the kernels' read : write mixes with no arithmetic at all
+[ -x tools/hbm_mix_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/hbm_mix_probe tools/hbm_mix_probe.hip
+timeout 300 tools/hbm_mix_probe json > gpurun_out/${R}_hbm_mix_probe.json 2> /dev/null
 echo done
