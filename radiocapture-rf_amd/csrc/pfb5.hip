@@ -56,6 +56,9 @@ namespace {
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef RCF_P5_STORE_AUX
+#define RCF_P5_STORE_AUX 2          // non-temporal
+#endif
 constexpr int kThreads5 = 320;
 
 // padded extent of one frame in LDS: pad5(NB - 1) + 1
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
             u32x2 o;
             o.x = __float_as_uint(z.x);
             o.y = __float_as_uint(z.y);
-            __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, bin * (int)sizeof(cf), so, 2);
+            __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, bin * (int)sizeof(cf), so, RCF_P5_STORE_AUX);
         }
         if (NB % kThreads5 != 0) {
             const int bin = tid + (NB / kThreads5) * kThreads5;
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
                 u32x2 o;
                 o.x = __float_as_uint(z.x);
                 o.y = __float_as_uint(z.y);
-                __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, bin * (int)sizeof(cf), so, 2);
+                __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, bin * (int)sizeof(cf), so, RCF_P5_STORE_AUX);
             }
         }
     }

@@ -13,9 +13,10 @@ D = nb // osf
 bw = fs / nb
 if nb % 25 == 0:
     # the reference's own channel filter (channel.py:31-33): every bin is one of its 25 kS/s channels
-    D, T = native.channel_params(fs, 12500)
+    cr = int(os.environ.get("CR", 12500))                 # CR=6250: the 6.25 kHz channel (D = 1600 at 20 Msps)
+    D, T = native.channel_params(fs, cr)
     osf = nb // D
-    taps = native.design_low_pass_2(1.0, fs, 6250.0, 6250.0, 20.0)
+    taps = native.design_low_pass_2(1.0, fs, cr / 2.0, cr / 2.0, 20.0)
 else:
     taps = native.design_low_pass_2(1.0, fs, 0.4 * bw, 0.2 * bw, 60.0, native.WIN_BLACKMAN_HARRIS) if osf == 1 \
         else native.design_low_pass_2(1.0, fs, bw / 4, bw / 4, 20.0)
