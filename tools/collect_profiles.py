@@ -105,6 +105,14 @@ pmc_record("%s_pfb1600" % R, "pfb5_kernel", "profiles/%s_pfb1600_pmc.json" % R, 
     "workload": "tools/pfb_probe.py NB=1600 BLOCK=2^25: 1600-bin bank, D = 800, 2909 taps; algorithmic 24 B/sample = 805.3 MB",
     "algorithmic_read_bytes": 8.0 * (1 << 25), "algorithmic_bytes": 24.0 * (1 << 25),
     "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
+pmc_record("%s_pfb3200a" % R, "pfb5_kernel", "profiles/%s_pfb3200_d1600_pmc.json" % R, {
+    "workload": "tools/pfb_probe.py NB=3200 CR=6250 BLOCK=2^25: 3200-bin bank, D = 1600, 5819 taps (3 launches after idling: the duration here is not the steady-state one); algorithmic 24 B/sample = 805.3 MB",
+    "algorithmic_read_bytes": 8.0 * (1 << 25), "algorithmic_bytes": 24.0 * (1 << 25),
+    "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
+pmc_record("%s_pfb3200b" % R, "pfb5_kernel", "profiles/%s_pfb3200_d800_pmc.json" % R, {
+    "workload": "tools/pfb_probe.py NB=3200 CR=12500 BLOCK=2^25: 3200-bin bank, D = 800, 2909 taps (3 launches after idling); algorithmic 40 B/sample = 1342.2 MB",
+    "algorithmic_read_bytes": 8.0 * (1 << 25), "algorithmic_bytes": 40.0 * (1 << 25),
+    "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
 
 # ---- shader clock of the filterbank launches over the sustained leg (first / last 100 dispatches)
 def clock_series(d, kernel):

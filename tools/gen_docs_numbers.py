@@ -116,6 +116,11 @@ def measured_block(R):
         for pt in g.get("with_taps", {}).get("points", []):
             add("| … with %d bins tapped and demodulated | bank %.4f ms (%.2f × untapped), finalize %.4f ms | `…with_taps.points[]` |"
                 % (pt["bins_tapped"], pt["pfb_ms_per_block"], pt["pfb_over_untapped"], pt["tap_finalize_ms_per_block"]))
+    t32 = [(_j("%s_pfb3200_d1600_pmc.json" % R), 1600), (_j("%s_pfb3200_d800_pmc.json" % R), 800)]
+    if all(t and "fetch_x2_over_algorithmic_read" in t for t, _ in t32):
+        add("| 3200-bin banks, PMC passes of `tools/pfb_probe.py` | %s | `%s_pfb3200_d1600_pmc.json`, `%s_pfb3200_d800_pmc.json` |"
+            % ("; ".join("decim %d: FETCH×2 = %.3f × algorithmic read, FETCH×2 + WRITE = %.3f × algorithmic" % (
+                dd, t["fetch_x2_over_algorithmic_read"], t["hbm_bytes_over_algorithmic"]) for t, dd in t32), R, R))
     db = b.get("channels", {}).get("direct_bank")
     if db:
         top = db["points"][-1]
