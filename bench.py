@@ -934,6 +934,8 @@ def main():
     if args.gpus != n_gpus and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
 
+    # (the host driver only supports dmabuf IPC: without this RCCL's peer mappings fail -- set before the HIP runtime loads)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from rcf import multigpu, synth
     native = load_native()
     if native.device_count() < 1:
