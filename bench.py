@@ -1032,10 +1032,12 @@ def main():
         for _ in range(32):
             fe.commit(B)
         n_prewarm += 32
-    # HIP events only around the kernel the roofline reports, and only around every 4th launch of it: an event record
-    # is a barrier packet, ~6 us of queue gap each (rocprof trace, tools/gap_probe.py), 12 us per bracketed launch of
-    # a 0.13 ms step that would otherwise be charged to `value`.  Switched on BEFORE the warm-up steps, so that nothing
-    # but the barrier and one counter reset lies between them and the timed region.
+    # HIP events only on the kernel the roofline reports, and only on every 4th launch of it.  The two events are ATTACHED
+    # to the filterbank's dispatch (hipExtLaunchKernelGGL), not recorded around it: one barrier packet less inside the
+    # measured interval (bracket 102.9 us, attached 101.1-102.2 on one box; RCF_TIMING_BRACKET=1 keeps the bracket;
+    # rocprofv3's kernel trace reads another 2.5-5 us less for the same launches).  A timed launch costs the step ~4 us
+    # (all 20 timed: 0.1232 instead of 0.1193 ms), hence every 4th.  Switched on BEFORE the warm-up steps, so that
+    # nothing but the barrier and one counter reset lies between them and the timed region.
     fe.timing_enable(True, classes=[native.T_PFB])
     time_every = args.time_every if args.steps >= 2 * args.time_every else 1     # a short run times every launch
     fe.timing_stride(time_every)
@@ -1201,6 +1203,8 @@ def main():
                 "traffic_from_tracked_file": traffic_file if live is not None else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_pfb_s * 1e3, "launches": pfb_n, "timed_every": time_every,
+                "timed_how": "bracket of two hipEventRecord (RCF_TIMING_BRACKET)" if os.environ.get("RCF_TIMING_BRACKET", "0") not in ("", "0")
+                else "HIP events attached to the kernel's dispatch (hipExtLaunchKernelGGL start / stop events), on the launch stream",
                 "avg_launch_ms_slowest_rank": pfb_avg_ms_max,
                 "frac_slowest_rank": alg_bytes / (pfb_avg_ms_max * 1e-3) / 1e9 / HBM_PEAK_GBS if pfb_avg_ms_max > 0 else 0.0,
             },

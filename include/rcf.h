@@ -140,7 +140,9 @@ int rcf_device(rcf_t *h);
 #define RCF_T_TAPS         9   /* filterbank taps: tap matrix -> channel rings, rotator + discriminator fused */
 #define RCF_T_COUNT        10
 /* on = 0: off; 1: every class; otherwise a mask with bit (class + 1) set for each class to time -- every timed
- * launch costs two event records on the stream (~10 us of gap), so a throughput run times only what it reports */
+ * launch costs two event records on the stream (~10 us of gap), so a throughput run times only what it reports.  The
+ * filterbank's launch carries its two events attached to the dispatch (one barrier packet less inside the measured
+ * interval; ~4 us per timed launch); RCF_TIMING_BRACKET=1 brackets it like the other classes. */
 int rcf_timing_enable(rcf_t *h, int on);
 /* events around every `every`-th launch of a timed class only (default 1 = every launch).  An event record is a
  * barrier packet: ~6 us of queue gap each on MI355X, two per timed launch -- at a 0.13 ms step that is 9 % of the

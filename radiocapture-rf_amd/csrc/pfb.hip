@@ -31,6 +31,7 @@
 #include <cstdlib>
 
 #include "fft_core.hpp"
+#include <hip/hip_ext.h>
 #include "rcf_internal.h"
 
 namespace rcfx {
@@ -621,10 +622,10 @@ void launch_os(const PfbLaunch &p, hipStream_t s)
             static DynLdsAttr attr_zh, attr;
             if (zh) {
                 attr_zh.ensure((const void *)pfb_kernel_2b<NH, P, 2, true>, lds2);
-                hipLaunchKernelGGL((pfb_kernel_2b<NH, P, 2, true>), dim3(n_wg), dim3(NH), lds2, s, p, arg);
+                RCF_PFB_LAUNCH(p, (pfb_kernel_2b<NH, P, 2, true>), dim3(n_wg), dim3(NH), lds2, s, p, arg);
             } else {
                 attr.ensure((const void *)pfb_kernel_2b<NH, P, MW2, false>, lds2);
-                hipLaunchKernelGGL((pfb_kernel_2b<NH, P, MW2, false>), dim3(n_wg), dim3(NH), lds2, s, p, arg);
+                RCF_PFB_LAUNCH(p, (pfb_kernel_2b<NH, P, MW2, false>), dim3(n_wg), dim3(NH), lds2, s, p, arg);
             }
             return;
         }
@@ -643,11 +644,11 @@ void launch_os(const PfbLaunch &p, hipStream_t s)
         }();
         int grid = 8 * (cus / 8) * wg_per_cu;                 // one resident round, the same count on every XCD
         if (grid > ((n_wg + 7) / 8) * 8) grid = ((n_wg + 7) / 8) * 8;
-        hipLaunchKernelGGL((pfb_kernel_pp<NB, OS, P, MINW, false, PF>), dim3(grid), dim3(NB), lds, s, p, n_wg);
+        RCF_PFB_LAUNCH(p, (pfb_kernel_pp<NB, OS, P, MINW, false, PF>), dim3(grid), dim3(NB), lds, s, p, n_wg);
         return;
     }
-    if (zh) hipLaunchKernelGGL((pfb_kernel_os<NB, OS, P, MINW, true>), dim3(n_wg), dim3(NB), lds, s, p, arg);
-    else    hipLaunchKernelGGL((pfb_kernel_os<NB, OS, P, MINW, false>), dim3(n_wg), dim3(NB), lds, s, p, arg);
+    if (zh) RCF_PFB_LAUNCH(p, (pfb_kernel_os<NB, OS, P, MINW, true>), dim3(n_wg), dim3(NB), lds, s, p, arg);
+    else    RCF_PFB_LAUNCH(p, (pfb_kernel_os<NB, OS, P, MINW, false>), dim3(n_wg), dim3(NB), lds, s, p, arg);
 }
 
 // taps per branch the kernels are instantiated for.  14 is what the reference's own low_pass_2 rule with a

@@ -48,6 +48,7 @@
 
 #define RCF_EXPLICIT_FMA 1
 #include "fft_core.hpp"
+#include <hip/hip_ext.h>
 #include "rcf_internal.h"
 
 namespace rcfx {
@@ -443,8 +444,8 @@ void launch5(const PfbLaunch &p, hipStream_t s)
     attr_f.ensure(reinterpret_cast<const void *>(pfb5_kernel<R, R3, OS, P, false>), lds);
     attr_t.ensure(reinterpret_cast<const void *>(pfb5_kernel<R, R3, OS, P, true>), lds);
     const bool zh = (p.n_lo - (int64_t)OS * (P - 1)) * (NB / OS) - (NB - 1) < p.start_sample;
-    if (zh) hipLaunchKernelGGL((pfb5_kernel<R, R3, OS, P, true>), dim3(n_wg), dim3(kThreads5), lds, s, p, n_wg);
-    else    hipLaunchKernelGGL((pfb5_kernel<R, R3, OS, P, false>), dim3(n_wg), dim3(kThreads5), lds, s, p, n_wg);
+    if (zh) RCF_PFB_LAUNCH(p, (pfb5_kernel<R, R3, OS, P, true>), dim3(n_wg), dim3(kThreads5), lds, s, p, n_wg);
+    else    RCF_PFB_LAUNCH(p, (pfb5_kernel<R, R3, OS, P, false>), dim3(n_wg), dim3(kThreads5), lds, s, p, n_wg);
 }
 
 }  // namespace

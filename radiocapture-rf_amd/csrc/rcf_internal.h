@@ -304,7 +304,16 @@ struct PfbLaunch {
     unsigned long long *rider_dst[2];
     const unsigned long long *rider_src[2];
     uint32_t rider_n8[2];
+    // host side only (the kernels never look): events ATTACHED to the bank's dispatch (hipExtLaunchKernelGGL) instead of
+    // a bracket of two event records around it (one barrier packet less inside the measured interval).  nullptr: plain launch.
+    hipEvent_t ev_start, ev_stop;
 };
+// launch `kernel` with the launch's attached events if it has them
+#define RCF_PFB_LAUNCH(p_, kernel, grid, block, lds, s, ...)                                                       \
+    do {                                                                                                           \
+        if ((p_).ev_start) hipExtLaunchKernelGGL(kernel, grid, block, lds, s, (p_).ev_start, (p_).ev_stop, 0, __VA_ARGS__); \
+        else               hipLaunchKernelGGL(kernel, grid, block, lds, s, __VA_ARGS__);                            \
+    } while (0)
 constexpr int kPfbRiderWgs = 64;    // of thousands: the few microseconds the pinned-memory reads take are lost in the first round
 // whether this launch's kernel takes the rider (pfb_kernel_os does: step of the timed configuration 128.5 -> 124.5 us,
 // kernel unchanged): the persistent form of the 512 / 1024-bin banks does not -- its

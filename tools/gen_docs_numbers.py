@@ -63,7 +63,7 @@ def measured_block(R):
     add("|---|---|---|")
     add("| headline `value` (BASELINE configs[1], N = 1) | %.0f Msamples/s, step %.4f ms | `%s_bench.json`: `value`, `ms_per_step` |"
         % (b["value"], b["ms_per_step"], R))
-    add("| filterbank launch, HIP events in the timed region | %.1f µs over %d bracketed launches ⇒ %.0f GB/s = **%s** of 8 TB/s | `%s_bench.json`: `roofline.avg_launch_ms`, `.launches`, `.achieved`, `.frac` |"
+    add("| filterbank launch, HIP events in the timed region | %.1f µs over %d timed launches ⇒ %.0f GB/s = **%s** of 8 TB/s | `%s_bench.json`: `roofline.avg_launch_ms`, `.launches`, `.achieved`, `.frac` |"
         % (ro["avg_launch_ms"] * 1e3, ro["launches"], ro["achieved"], f3(ro["frac"]), R))
     st = _stats("%s_bench_kernel_stats.csv" % R, r"pfb_kernel_os<256, 1, 14, 4, false>")
     hu = _j("%s_bench_head_under_rocprof.json" % R)
