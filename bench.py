@@ -963,6 +963,17 @@ def main():
     if world > 1:
         group = multigpu.HostGroup(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
                                    int(os.environ.get("MASTER_PORT", "29500")) + 101)
+        # a communicator that never comes up (a rank missing, a fabric problem) must not hang the run for an hour: if the
+        # join + proof below are not through in RCF_BENCH_RCCL_TIMEOUT seconds (default 300) this rank says so and exits
+        import threading
+        rccl_done = threading.Event()
+
+        def _watchdog(limit=float(os.environ.get("RCF_BENCH_RCCL_TIMEOUT", "300"))):
+            if not rccl_done.wait(limit):
+                print("bench.py: rank %d: communicator set-up / proof not finished after %.0f s -- giving up "
+                      "(RCF_BENCH_TRANSPORT=host runs without RCCL)" % (rank, limit), file=sys.stderr, flush=True)
+                os._exit(3)
+        threading.Thread(target=_watchdog, daemon=True).start()
         if use_rccl:
             # ncclCommInitRank on this rank's GPU.  If any rank cannot (no librccl, two ranks told to share one
             # GPU, ...) every rank falls back to the host rendezvous for the barrier and the gather -- the data
@@ -996,6 +1007,7 @@ def main():
                                    % (rank, rccl_ranks, world, seen, top))
             rccl_proof = {"allgather_of_rank_numbers": seen, "allreduce_max_of_rank_numbers": top,
                           "when": "before the warm-up steps"}
+        rccl_done.set()
     taps = proto_taps(native, fs, nb)
     fe.pfb_open(nb, nb, taps)
     if cfg5:

@@ -86,6 +86,8 @@ class Frontend:
         if os.environ.get("STUB_RCCL") != "1" or os.environ.get("STUB_RCCL_INIT_FAILS") == "1":
             raise RuntimeError("stub: no RCCL")
         assert uid == bytes(range(128))
+        if os.environ.get("STUB_RCCL_HANGS") == "1":
+            time.sleep(120)                               # a join that never completes
         from rcf import multigpu
         self._comm = multigpu.HostGroup(rank, n, "127.0.0.1", int(os.environ["MASTER_PORT"]) + 202)
 

@@ -105,3 +105,9 @@ def test_ranks_that_cannot_join_fall_back_to_the_host_transport_together():
     d = json.loads(r.stdout)
     assert d["n_gpus"] == 4 and d["transport"] == "host-tcp" and d["rccl_proof"] is None
     assert "could not join" in r.stderr
+
+
+def test_a_communicator_that_never_comes_up_ends_the_run_instead_of_hanging_it():
+    r = _run(2, {"STUB_RCCL": "1", "STUB_RCCL_HANGS": "1", "RCF_BENCH_TRANSPORT": "rccl", "RCF_BENCH_RCCL_TIMEOUT": "2"}, timeout=120)
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert "giving up" in r.stderr
