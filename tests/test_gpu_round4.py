@@ -257,3 +257,38 @@ def test_raw_blocks_from_pinned_memory_are_converted_in_place_and_equal_the_stag
     for u, v, w in zip(a, b, c):
         assert len(u) == len(v) == len(w) > 0
         assert np.array_equal(u, v) and np.array_equal(u, w)
+
+
+def test_filterbank_launch_timing_with_attached_events(gpu_required):
+    """rcf_timing_*: the filterbank launch carries its two HIP events attached to the dispatch (PfbLaunch::ev_start /
+    ev_stop): every timed launch is counted once, the time is a kernel's (microseconds, not zero, not the wall clock of
+    the loop), the stride picks every n-th launch, and outputs are the same bits with timing on or off -- for a
+    power-of-two bank and for a frame-major one."""
+    nat = gpu_required
+    rng = np.random.default_rng(44)
+    for nb, fs in ((256, 20e6), (400, 5e6)):
+        if nb == 256:
+            D = nb
+            taps = nat.design_low_pass_2(1.0, fs, 0.4 * fs / nb, 0.2 * fs / nb, 60.0, nat.WIN_BLACKMAN_HARRIS)
+        else:
+            D, _ = nat.channel_params(fs, 12500)
+            taps = nat.design_low_pass_2(1.0, fs, 6250.0, 6250.0, 20.0)
+        x = (rng.standard_normal(D * 640) + 1j * rng.standard_normal(D * 640)).astype(np.complex64)
+        outs = []
+        for timed in (False, True):
+            with nat.Frontend(fs, block_capacity=len(x), out_capacity=1 << 12) as fe:
+                fe.pfb_open(nb, D, taps)
+                if timed:
+                    fe.timing_enable(True, classes=[nat.T_PFB])
+                for _ in range(6):
+                    fe.push(x)
+                outs.append(fe.pfb_read_bin(3, 1 << 12))
+                if timed:
+                    ms, n = fe.timing_read(nat.T_PFB, reset=True)
+                    assert n == 6 and 0.0 < ms / n < 5.0, (nb, ms, n)
+                    fe.timing_stride(3)
+                    for _ in range(6):
+                        fe.push(x)
+                    ms, n = fe.timing_read(nat.T_PFB)
+                    assert n == 2 and 0.0 < ms / n < 5.0, (nb, ms, n)
+        assert len(outs[0]) > 0 and np.array_equal(outs[0], outs[1])
