@@ -122,7 +122,7 @@ def sustained_leg(fe, native, B, alg_bytes, seconds=2.0, window=100):
         "wall_ms_per_step": wall / (len(wins) * window) * 1e3,
         "sclk_mhz_first": ck[0] if ck else None, "sclk_mhz_last": ck[-1] if ck else None,
         "kernel_us_by_window": [round(w * 1e3, 2) for w in wins[:: max(1, len(wins) // 32)]],
-        "note": "HIP events around every filterbank launch, read back per window of %d launches; sclk from "
+        "note": "HIP events on every filterbank launch, read back per window of %d launches; sclk from "
                 "/sys/class/drm/card*/device/pp_dpm_sclk while the queue is full" % window,
     }
 
@@ -906,6 +906,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs (sweep, scan, end-to-end, ...)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained leg")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="length of the sustained leg of the timed configuration (profiles/rNN_sustained_60s.json: 60)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run")
     ap.add_argument("--time-every", type=int, default=4,
@@ -1091,7 +1093,7 @@ def main():
     alg_bytes = 16.0 * B                              # 8 B read + 8 B written per input sample (critically sampled)
     sustained = None
     if not args.no_sustained:                         # every rank runs it (the ranks stay in step); rank 0 reports
-        sustained = sustained_leg(fe, native, B, alg_bytes)
+        sustained = sustained_leg(fe, native, B, alg_bytes, seconds=args.sustained_seconds)
         if group is not None:
             sustained["kernel_us_last_window_max_over_ranks"] = barrier_max(sustained["kernel_us_last_window"])
 

@@ -145,7 +145,7 @@ if len(ser) > 400:
     print("clock: first 100 %.3f GHz, last 100 %.3f GHz over %d dispatches" % (
         w([c for c, _ in ser[:100]]), w([c for c, _ in ser[-100:]]), len(ser)))
 
-for tag in ("bench", "bench_cfg5", "bench_head_under_rocprof", "bench_2ranks_1gpu", "unpinned_bounds", "hbm_mix_probe"):
+for tag in ("bench", "bench_cfg5", "bench_head_under_rocprof", "bench_2ranks_1gpu", "sustained_60s", "unpinned_bounds", "hbm_mix_probe"):
     src = "gpurun_out/%s_%s.json" % (R, tag)
     if os.path.exists(src):
         text = open(src).read()

@@ -78,6 +78,12 @@ def measured_block(R):
     if su:
         add("| sustained leg, %.1f s / %d launches | first window %s, last %s, slowest %s of the peak | `%s_bench.json`: `sustained.frac_*_window` |"
             % (su["seconds"], su["launches"], f3(su["frac_first_window"]), f3(su["frac_last_window"]), f3(su["frac_slowest_window"]), R))
+    s60 = _j("%s_sustained_60s.json" % R)
+    if s60 and s60.get("sustained"):
+        q = s60["sustained"]
+        add("| the same, %.0f s / %d launches (`--sustained-seconds 60`) | first window %s, last %s, slowest %s; launch %.1f–%.1f µs over the sampled windows; wall %.4f ms per step | `%s_sustained_60s.json`: `sustained` |"
+            % (q["seconds"], q["launches"], f3(q["frac_first_window"]), f3(q["frac_last_window"]), f3(q["frac_slowest_window"]),
+               min(q["kernel_us_by_window"]), max(q["kernel_us_by_window"]), q["wall_ms_per_step"], R))
     if ro.get("traffic") and ro.get("traffic_fetch_x2_bytes"):
         add("| HBM traffic per launch, PMC child passes of the SAME run | FETCH×2 %.1f MB + WRITE %.1f MB = %.1f MB = %.3f × algorithmic | `%s_bench.json`: `roofline.traffic`, `.traffic_fetch_x2_bytes`, `.traffic_write_bytes` |"
             % (ro["traffic_fetch_x2_bytes"] / 1e6, ro["traffic_write_bytes"] / 1e6, ro["traffic"] / 1e6,

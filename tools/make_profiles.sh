@@ -49,6 +49,8 @@ PROBE=tools/pfb_probe.py KERNEL=pfb_kernel tools/fir_pmc.sh ${R}_pfb1024 NB=1024
 PROBE=tools/pfb_probe.py KERNEL=pfb5_kernel tools/fir_pmc.sh ${R}_pfb1600 NB=1600 BLOCK=33554432 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb5_kernel tools/fir_pmc.sh ${R}_pfb3200a NB=3200 CR=6250 BLOCK=33554432 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb5_kernel tools/fir_pmc.sh ${R}_pfb3200b NB=3200 CR=12500 BLOCK=33554432 > /dev/null 2>&1
+# one minute of back-to-back commits of the timed configuration (the "sustained" of the metric, at length)
+python bench.py --no-extras --no-cpu-baseline --no-live-traffic --rt-seconds 0 --sustained-seconds 60 > gpurun_out/${R}_sustained_60s.json 2> /dev/null
 # what the memory system sustains for the kernels' read : write mixes with no arithmetic at all
 [ -x tools/hbm_mix_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/hbm_mix_probe tools/hbm_mix_probe.hip
 timeout 300 tools/hbm_mix_probe json > gpurun_out/${R}_hbm_mix_probe.json 2> /dev/null
