@@ -32,6 +32,12 @@
 
 #include "fft_core.hpp"
 #include <hip/hip_ext.h>
+#ifndef RCF_PFB_LOAD_AUX
+#define RCF_PFB_LOAD_AUX 0
+#endif
+#ifndef RCF_PFB_STORE_AUX
+#define RCF_PFB_STORE_AUX 18       // nt | sc1 (bits 1 and 4).  256 / 512 / 1024 bins, two alternating runs each, of the HBM peak: plain 0.658-0.663 / 0.626-0.629 / -, sc0 0.660 / 0.627-0.630 / -, sc1 0.664 / 0.641-0.643 / -, nt 0.669-0.673 / 0.661-0.669 / 0.600, nt sc0 0.670 / 0.660-0.664 / 0.598, sc0 sc1 0.659-0.661 / 0.637 / 0.562, nt sc1 0.675-0.679 / 0.676-0.681 / 0.602-0.607, all three 0.675-0.676 / 0.672-0.679 / 0.606
+#endif
 #include "rcf_internal.h"
 
 namespace rcfx {
@@ -164,7 +170,7 @@ __device__ __forceinline__ void pfb_epilogue(const cf *buf, const cf *tw_lds, co
         u32x2 o;
         o.x = __float_as_uint(v.x);
         o.y = __float_as_uint(v.y);
-        __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, vo, i * out_so_step, 2);   // nt: +4 %
+        __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, vo, i * out_so_step, RCF_PFB_STORE_AUX);   // nt: +4 %
     }
 }
 
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
             for (int g = 0; g < GX; ++g) {
                 x[g] = (v2f)(0.f);
                 if (j0 + g < W) {
-                    const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, vo_in, (j0 + g) * D * (int)sizeof(cf), 0);
+                    const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, vo_in, (j0 + g) * D * (int)sizeof(cf), RCF_PFB_LOAD_AUX);
                     x[g].x = __uint_as_float(r.x);
                     x[g].y = __uint_as_float(r.y);
                     if (ZH && m0 + j0 + g < m_min) x[g] = (v2f)(0.f);
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(NH, MINW) void pfb_kernel_2b(PfbLaunch p, int n_wg)
         for (int g = 0; g < G; ++g) {
             x[g] = (v4f)(0.f);
             if (j0 + g < W) {
-                const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, vo_in, (j0 + g) * D * (int)sizeof(cf), 0);
+                const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, vo_in, (j0 + g) * D * (int)sizeof(cf), RCF_PFB_LOAD_AUX);
                 x[g].x = __uint_as_float(r.x);
                 x[g].y = __uint_as_float(r.y);
                 x[g].z = __uint_as_float(r.z);
@@ -577,10 +583,10 @@ __global__ __launch_bounds__(NH, MINW) void pfb_kernel_2b(PfbLaunch p, int n_wg)
         u32x2 o;
         o.x = __float_as_uint(lo.x);
         o.y = __float_as_uint(lo.y);
-        __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, vo, i * out_so_step, 2);
+        __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, vo, i * out_so_step, RCF_PFB_STORE_AUX);
         o.x = __float_as_uint(hi.x);
         o.y = __float_as_uint(hi.y);
-        __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, vo, out_so_half + i * out_so_step, 2);
+        __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, vo, out_so_half + i * out_so_step, RCF_PFB_STORE_AUX);
     }
 }
 
