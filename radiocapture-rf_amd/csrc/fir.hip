@@ -240,7 +240,9 @@ __global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *_
                 ai = fmaf(c.y, xv.x, ai);
             }
             y[o] = rotate_value(L, n, ar, ai);
-            if (j >= 1) L.iq_ring[(uint64_t)n & ring_mask] = y[o];
+            // (ring stores non-temporal: 20.6 -> 19.7 us for the timed configuration's 32 channels)
+            if (j >= 1) { typedef float v2f_ __attribute__((ext_vector_type(2))); v2f_ o_; o_.x = y[o].x; o_.y = y[o].y;
+                          __builtin_nontemporal_store(o_, reinterpret_cast<v2f_ *>(L.iq_ring + ((uint64_t)n & ring_mask))); }
         }
         if (j <= nj) ys[j] = y[o];                               // n < 0: quadrature_demod's zero history
     }
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *_
             // volk_32fc_x2_multiply_conjugate_32fc: a * conj(b), unfused
             const float tr = __fadd_rn(__fmul_rn(y[o].x, b.x), __fmul_rn(y[o].y, b.y));
             const float ti = __fsub_rn(__fmul_rn(y[o].y, b.x), __fmul_rn(y[o].x, b.y));
-            L.fm_ring[(uint64_t)(k0 - 1 + j - L.k_abs0) & ring_mask] = fast_atan2f_gr(ti, tr, tab);
+            __builtin_nontemporal_store(fast_atan2f_gr(ti, tr, tab), L.fm_ring + ((uint64_t)(k0 - 1 + j - L.k_abs0) & ring_mask));
         }
     }
 }
@@ -676,8 +678,12 @@ __global__ __launch_bounds__(kThreads) void tap_finalize_kernel(const TapLaunch 
             const float2 yb0 = na + 1 > 0 ? ya : make_float2(0.f, 0.f);
             const uint64_t ia = (uint64_t)na & ring_mask;
             if (va && vb) {                                          // na is even and the ring a power of two: no wrap inside the pair
-                *reinterpret_cast<float4 *>(L.iq_ring + ia) = make_float4(ya.x, ya.y, yb.x, yb.y);
-                *reinterpret_cast<float2 *>(L.fm_ring + ia) = make_float2(fm_of(ya, ym), fm_of(yb, yb0));
+                // (non-temporal: 256 taps 55.4 -> 53.1 us, 1600 taps 308 -> 302 us per 2^25-sample block)
+                { typedef float v4f_ __attribute__((ext_vector_type(4))); typedef float v2f_ __attribute__((ext_vector_type(2)));
+                  v4f_ a_; a_.x = ya.x; a_.y = ya.y; a_.z = yb.x; a_.w = yb.y;
+                  v2f_ b_; b_.x = fm_of(ya, ym); b_.y = fm_of(yb, yb0);
+                  __builtin_nontemporal_store(a_, reinterpret_cast<v4f_ *>(L.iq_ring + ia));
+                  __builtin_nontemporal_store(b_, reinterpret_cast<v2f_ *>(L.fm_ring + ia)); }
             } else if (va) {
                 L.iq_ring[ia] = ya;
                 L.fm_ring[ia] = fm_of(ya, ym);

@@ -116,7 +116,14 @@ __global__ __launch_bounds__(N1) void scan4_cols(Scan4Args a)
 #pragma unroll
         for (int i = 0; i < CW; ++i) {
             const int k1 = k10 + i * (N1 / CW);
-            scr[(size_t)k1 * N2 + c0 + c] = cmul(buf[c * RS + lds_pad(k1)], w);
+            {
+                // streamed out: the row pass reads it back a whole launch (268 MB) later (non-temporal: FFT pair 6.39 ->
+                // 6.29 ms per 1000 frames; the row pass's own stores measured 2 % SLOWER that way)
+                const cf z_ = cmul(buf[c * RS + lds_pad(k1)], w);
+                typedef float v2f_ __attribute__((ext_vector_type(2)));
+                v2f_ o_; o_.x = z_.x; o_.y = z_.y;
+                __builtin_nontemporal_store(o_, reinterpret_cast<v2f_ *>(scr + (size_t)k1 * N2 + c0 + c));
+            }
             w = cmul(w, step);
         }
     }
