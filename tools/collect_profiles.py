@@ -113,6 +113,10 @@ pmc_record("%s_pfb3200b" % R, "pfb5_kernel", "profiles/%s_pfb3200_d800_pmc.json"
     "workload": "tools/pfb_probe.py NB=3200 CR=12500 BLOCK=2^25: 3200-bin bank, D = 800, 2909 taps (3 launches after idling); algorithmic 40 B/sample = 1342.2 MB",
     "algorithmic_read_bytes": 8.0 * (1 << 25), "algorithmic_bytes": 40.0 * (1 << 25),
     "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
+pmc_record("%s_tapfin" % R, "tap_finalize", "profiles/%s_tap_finalize_pmc.json" % R, {
+    "workload": "tools/pfb_probe.py NB=1600 TAPS=1600 BLOCK=2^25: tap_finalize_kernel with every bin of the 1600-bin bank open as a channel (41943 frames x 1600 taps per launch; 3 launches after idling)",
+    "algorithmic_read_bytes": 8.0 * 1600 * 41943, "algorithmic_bytes": 20.0 * 1600 * 41943,
+    "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024; the kernel reads 161 rows per 128 outputs (32-aligned tiles): 1.26 x the algorithmic read"})
 
 # ---- shader clock of the filterbank launches over the sustained leg (first / last 100 dispatches)
 def clock_series(d, kernel):

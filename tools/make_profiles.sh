@@ -47,6 +47,7 @@ tools/fir_pmc.sh ${R}_fir4096 C=4096 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb_kernel tools/fir_pmc.sh ${R}_pfb512 NB=512 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb_kernel tools/fir_pmc.sh ${R}_pfb1024 NB=1024 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb5_kernel tools/fir_pmc.sh ${R}_pfb1600 NB=1600 BLOCK=33554432 > /dev/null 2>&1
+PROBE=tools/pfb_probe.py KERNEL=tap_finalize tools/fir_pmc.sh ${R}_tapfin NB=1600 BLOCK=33554432 TAPS=1600 TIME_ALL=1 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb5_kernel tools/fir_pmc.sh ${R}_pfb3200a NB=3200 CR=6250 BLOCK=33554432 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb5_kernel tools/fir_pmc.sh ${R}_pfb3200b NB=3200 CR=12500 BLOCK=33554432 > /dev/null 2>&1
 # one minute of back-to-back commits of the timed configuration (the "sustained" of the metric, at length)
