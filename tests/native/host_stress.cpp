@@ -15,7 +15,7 @@
 #include "../../radiocapture-rf_amd/csrc/rcf_internal.h"
 
 namespace rcfx {
-// the two symbols the design / peak sources expect from rcf_api.cpp
+// the two symbols the design / peak sources expect from rcf_handle.cpp
 static thread_local char g_err[256];
 void set_error(const char *fmt, ...) { (void)fmt; g_err[0] = 0; }
 bool hip_ok(hipError_t e, const char *) { return e == hipSuccess; }

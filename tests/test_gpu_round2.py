@@ -123,7 +123,7 @@ def test_scan_1m_point_reference_lengths_bit_exact(gpu_required):
 
 def test_matrix_core_bank_membership_churn(gpu_required):
     """Channels join and leave a matrix-core class between blocks: only the groups of 32 whose membership changed
-    are repacked (rcf_api.cpp) -- every survivor's stream must stay equal to the oracle's, sample for sample."""
+    are repacked (rcf_plan.cpp) -- every survivor's stream must stay equal to the oracle's, sample for sample."""
     nat = gpu_required
     fs, cr = 2.4e6, 12500
     D, taps = G.channel_params(fs, cr)

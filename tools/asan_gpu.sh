@@ -1,5 +1,5 @@
 #!/bin/bash
-# The whole C ABI host layer (rcf_api.cpp: mutexes, deferred frees, slab pools, double-buffered arenas, bank-matrix
+# The whole C ABI host layer (rcf_handle / rcf_plan / rcf_launch / rcf_chan / rcf_group ...: mutexes, deferred frees, slab pools, double-buffered arenas, bank-matrix
 # cache) under AddressSanitizer on a GPU box, over the whole GPU suite (every test but the one that loads librccl).
 #   make -C radiocapture-rf_amd/csrc asan      (here: the .so travels with the snapshot)
 #   gpurun -- tools/asan_gpu.sh                -> gpurun_out/asan_gpu.txt
