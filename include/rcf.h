@@ -177,6 +177,7 @@ int rcf_commit(rcf_t *h, size_t n_samples);
  * staging copy: the shape of a real-time SDR block; larger ones go through a staged copy that overlaps the previous
  * block's kernels (RCF_RAW_DIRECT=<bytes> moves the threshold, 0 = always staged).  Either way the call returns once
  * the caller's buffer has been read. */
+#define RCF_FMT_CF32 0   /* float32 I,Q interleaved (rcf_group_push only: rcf_push_iq is the single-front-end form) */
 #define RCF_FMT_U8   1   /* unsigned 8-bit I,Q interleaved */
 #define RCF_FMT_S8   2   /* signed 8-bit I,Q interleaved */
 #define RCF_FMT_S16  3   /* signed 16-bit little-endian I,Q interleaved */

@@ -110,8 +110,10 @@ static __global__ __launch_bounds__(256) void gather_rings_kernel(const GatherRe
 {
     const GatherRec r = recs[blockIdx.y];
     const uint32_t stride = gridDim.x * 256;
+    // the destination is either linear (dst_mask_w = ~0: rows packed back to back, rcf_chan_read_many) or a ring of its own
+    // (the real-time pump's per-channel host rings: dst_w = the ring's first word, dst_pos_w where this segment starts)
     for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < r.n_w; w += stride)
-        dst[r.dst_w + w] = r.ring[(r.pos_w + w) & r.mask_w];
+        dst[r.dst_w + ((r.dst_pos_w + w) & r.dst_mask_w)] = r.ring[(r.pos_w + w) & r.mask_w];
 }
 
 void launch_gather_rings(const GatherRec *d_recs, int n_recs, uint32_t *d_dst, uint32_t max_words, hipStream_t s)
@@ -125,6 +127,102 @@ void launch_gather_view(const StreamView &v, int64_t first, float2 *dst, size_t 
 {
     if (n == 0) return;
     hipLaunchKernelGGL(gather_view_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, first, dst, n);
+}
+
+// ---------------------------------------------------------------- grouped ingest (rcf_group.cpp)
+// ONE launch for the blocks of G front-ends: wire-format (or cf32) samples -> each front-end's wideband buffer, the
+// history tail of every block behind the OTHER buffer of its front-end (dual-written on the way, so no copy launch
+// follows), and plain 8-byte copies (the group's launch records host -> device arena; the part of a history that is
+// older than a short block).  grid = (tiles, records); the records themselves are read where the host wrote them
+// (pinned, device-mapped arena): 64 bytes once per workgroup.
+namespace {
+
+constexpr int kPrepTile = 2048;      // samples (or 8-byte words) per workgroup: 256 threads x 2 x 4
+
+template <typename T, int NV>
+__device__ __forceinline__ void prep_load(const PrepRec &r, uint32_t i, float (&v)[4])
+{
+    // two complex samples = four raw values starting at sample i (i even, i + 1 < n)
+    const T *p = static_cast<const T *>(r.src) + 2 * (size_t)i;
+    T raw[4];
+    if (r.aligned) {
+        typedef T vec_t __attribute__((ext_vector_type(4)));
+        const vec_t q = *reinterpret_cast<const vec_t *>(p);            // ONE 4 / 8-byte load per lane
+        raw[0] = q.x; raw[1] = q.y; raw[2] = q.z; raw[3] = q.w;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raw[u] = p[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = conv1(raw[u], r.scale, r.offset);
+}
+
+__device__ __forceinline__ void prep_store(const PrepRec &r, uint32_t i, int cnt, const float (&v)[4])
+{
+    float2 *d = r.dst + i;
+    if (cnt == 2 && r.dst_aligned) *reinterpret_cast<float4 *>(d) = make_float4(v[0], v[1], v[2], v[3]);
+    else { d[0] = make_float2(v[0], v[1]); if (cnt == 2) d[1] = make_float2(v[2], v[3]); }
+    if (r.hist_dst) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (u < cnt && i + u >= r.hist_from) r.hist_dst[i + u - r.hist_from] = make_float2(v[2 * u], v[2 * u + 1]);
+    }
+}
+
+__global__ __launch_bounds__(256) void group_prep_kernel(const PrepRec *__restrict__ recs)
+{
+    const PrepRec r = recs[blockIdx.y];
+    const uint32_t base = blockIdx.x * (uint32_t)kPrepTile;
+    if (base >= r.n) return;
+    const int tid = threadIdx.x;
+    if (r.fmt < 0) {                                   // plain copy, n 8-byte words
+        const unsigned long long *s = static_cast<const unsigned long long *>(r.src);
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(r.dst);
+        unsigned long long w[kPrepTile / 256];
+#pragma unroll
+        for (int u = 0; u < kPrepTile / 256; ++u) { const uint32_t i = base + u * 256 + tid; w[u] = i < r.n ? s[i] : 0ull; }
+#pragma unroll
+        for (int u = 0; u < kPrepTile / 256; ++u) { const uint32_t i = base + u * 256 + tid; if (i < r.n) d[i] = w[u]; }
+        return;
+    }
+    float v[4][4];
+    int cnt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                      // all four loads of the lane before the first store
+        const uint32_t i = base + 2 * (u * 256 + tid);
+        cnt[u] = i + 1 < r.n ? 2 : (i < r.n ? 1 : 0);
+        if (cnt[u] == 2) {
+            switch (r.fmt) {
+                case RCF_FMT_U8:  prep_load<uint8_t, 4>(r, i, v[u]); break;
+                case RCF_FMT_S8:  prep_load<int8_t, 4>(r, i, v[u]); break;
+                case RCF_FMT_S16: prep_load<int16_t, 4>(r, i, v[u]); break;
+                default: {
+                    const float *p = static_cast<const float *>(r.src) + 2 * (size_t)i;
+                    if (r.aligned) { const float4 q = *reinterpret_cast<const float4 *>(p); v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w; }
+                    else { v[u][0] = p[0]; v[u][1] = p[1]; v[u][2] = p[2]; v[u][3] = p[3]; }
+                }
+            }
+        } else if (cnt[u] == 1) {                      // the odd last sample of a block
+            v[u][2] = v[u][3] = 0.f;
+            switch (r.fmt) {
+                case RCF_FMT_U8:  { const uint8_t *p = static_cast<const uint8_t *>(r.src) + 2 * (size_t)i; v[u][0] = conv1(p[0], r.scale, r.offset); v[u][1] = conv1(p[1], r.scale, r.offset); break; }
+                case RCF_FMT_S8:  { const int8_t *p = static_cast<const int8_t *>(r.src) + 2 * (size_t)i; v[u][0] = conv1(p[0], r.scale, r.offset); v[u][1] = conv1(p[1], r.scale, r.offset); break; }
+                case RCF_FMT_S16: { const int16_t *p = static_cast<const int16_t *>(r.src) + 2 * (size_t)i; v[u][0] = conv1(p[0], r.scale, r.offset); v[u][1] = conv1(p[1], r.scale, r.offset); break; }
+                default:          { const float *p = static_cast<const float *>(r.src) + 2 * (size_t)i; v[u][0] = p[0]; v[u][1] = p[1]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (cnt[u]) prep_store(r, base + 2 * (u * 256 + tid), cnt[u], v[u]);
+}
+
+}  // namespace
+
+void launch_group_prep(const PrepRec *d_recs, int n_recs, uint32_t max_n, hipStream_t s)
+{
+    if (n_recs <= 0 || max_n == 0) return;
+    hipLaunchKernelGGL(group_prep_kernel, dim3((max_n + kPrepTile - 1) / kPrepTile, (unsigned)n_recs), dim3(256), 0, s, d_recs);
 }
 
 size_t raw_sample_bytes(int fmt)

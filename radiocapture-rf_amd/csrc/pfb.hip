@@ -174,28 +174,16 @@ __device__ __forceinline__ void pfb_epilogue(const cf *buf, const cf *tw_lds, co
     }
 }
 
-// n_wg < 0: probe without the XCD-aware block -> chunk map (RCF_PFB_NOREMAP=1)
-template <int NB, int OS, int P, int MINW, bool ZH>
-__global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
+// one chunk (16 frames) of one front-end's bank: everything the workgroup does once it knows WHICH chunk is its own.
+// Shared by the single-front-end kernel (launch record in the kernel arguments) and the grouped one (records of G
+// front-ends in the arena): the same instructions in the same order, so the bins are the same bits either way.
+template <int NB, int OS, int P, bool ZH>
+__device__ __forceinline__ void pfb_os_chunk(const PfbLaunch &p, const int wg, const int tid, cf *buf, cf *tw_lds)
 {
     constexpr int D = NB / OS;
     constexpr int HALO = OS * (P - 1);
     constexpr int W = F + HALO;
     constexpr int RS = row_stride<NB>();
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf *buf = reinterpret_cast<cf *>(smem_raw);
-    cf *tw_lds = buf + F * RS;
-
-    const int tid = threadIdx.x;
-    if (p.rider_n8[0] + p.rider_n8[1] && (int)blockIdx.x < kPfbRiderWgs)
-        pfb_copy_rider(p, blockIdx.x, min(kPfbRiderWgs, (int)gridDim.x), tid, NB);
-    int wg;
-    if (n_wg < 0) {
-        wg = blockIdx.x;                                   // probe: no XCD remap
-    } else {
-        const int b = blockIdx.x, q = n_wg / 8, r = n_wg % 8, xcd = b % 8;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-    }
     const int fb0 = wg * F;
     if (fb0 >= p.n_frames) return;
     const int nf = min(F, p.n_frames - fb0);
@@ -280,6 +268,45 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
     __syncthreads();
     pfb_fft<NB>(buf, tw_lds, tid);
     pfb_epilogue<NB, OS>(buf, tw_lds, p, out_rsrc, n0, nf, tid);
+}
+
+// n_wg < 0: probe without the XCD-aware block -> chunk map (RCF_PFB_NOREMAP=1)
+template <int NB, int OS, int P, int MINW, bool ZH>
+__global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
+{
+    constexpr int RS = row_stride<NB>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+    cf *tw_lds = buf + F * RS;
+
+    const int tid = threadIdx.x;
+    if (p.rider_n8[0] + p.rider_n8[1] && (int)blockIdx.x < kPfbRiderWgs)
+        pfb_copy_rider(p, blockIdx.x, min(kPfbRiderWgs, (int)gridDim.x), tid, NB);
+    int wg;
+    if (n_wg < 0) {
+        wg = blockIdx.x;                                   // probe: no XCD remap
+    } else {
+        const int b = blockIdx.x, q = n_wg / 8, r = n_wg % 8, xcd = b % 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    }
+    pfb_os_chunk<NB, OS, P, ZH>(p, wg, tid, buf, tw_lds);
+}
+
+// The banks of G front-ends in ONE launch (rcf_group.cpp): grid = the chunks of all of them, the XCD-aware map runs over
+// the whole grid (neighbouring chunks of one front-end stay on one XCD), a prefix table says whose chunk a workgroup
+// has.  The launch record comes out of the arena by scalar loads -- the address is uniform -- instead of the kernel
+// arguments; steady state only (a front-end that still sees zero history is launched on its own).
+template <int NB, int OS, int P, int MINW>
+__global__ __launch_bounds__(NB, MINW) void pfb_group_kernel_os(const PfbLaunch *__restrict__ pls, GroupMap gm)
+{
+    constexpr int RS = row_stride<NB>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+    cf *tw_lds = buf + F * RS;
+    int fe, wg;
+    group_resolve(gm, blockIdx.x, fe, wg);
+    const PfbLaunch p = pls[fe];
+    pfb_os_chunk<NB, OS, P, false>(p, wg, threadIdx.x, buf, tw_lds);
 }
 
 // Persistent form of the kernel above: the grid is one resident round of workgroups (8 XCDs x wg_per_xcd), each
@@ -440,8 +467,8 @@ __device__ __forceinline__ void pfb2_read_bins(const cf *buf, const cf *tw_lds, 
     }
 }
 
-template <int NH, int P, int MINW, bool ZH>
-__global__ __launch_bounds__(NH, MINW) void pfb_kernel_2b(PfbLaunch p, int n_wg)
+template <int NH, int P, bool ZH>
+__device__ __forceinline__ void pfb_2b_chunk(const PfbLaunch &p, const int wg, const int tid, cf *buf, cf *tw_lds)
 {
     constexpr int NB = 2 * NH, D = NB;
     constexpr int HALO = P - 1;
@@ -453,20 +480,6 @@ __global__ __launch_bounds__(NH, MINW) void pfb_kernel_2b(PfbLaunch p, int n_wg)
     constexpr int G = ZH ? 4 : (NH == 256 ? 8 : 4);
     constexpr bool DB = !ZH;
     constexpr int RS = row_stride<NH>();
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf *buf = reinterpret_cast<cf *>(smem_raw);
-    cf *tw_lds = buf + F * RS;                       // e^{+2 pi i n / NB}, n < NB
-
-    const int tid = threadIdx.x;
-    if (p.rider_n8[0] + p.rider_n8[1] && (int)blockIdx.x < kPfbRiderWgs)
-        pfb_copy_rider(p, blockIdx.x, min(kPfbRiderWgs, (int)gridDim.x), tid, NH);
-    int wg;
-    if (n_wg < 0) {
-        wg = blockIdx.x;
-    } else {
-        const int b = blockIdx.x, q = n_wg / 8, r = n_wg % 8, xcd = b % 8;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-    }
     const int fb0 = wg * F;
     if (fb0 >= p.n_frames) return;
     const int nf = min(F, p.n_frames - fb0);
@@ -590,6 +603,41 @@ __global__ __launch_bounds__(NH, MINW) void pfb_kernel_2b(PfbLaunch p, int n_wg)
     }
 }
 
+template <int NH, int P, int MINW, bool ZH>
+__global__ __launch_bounds__(NH, MINW) void pfb_kernel_2b(PfbLaunch p, int n_wg)
+{
+    constexpr int RS = row_stride<NH>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+    cf *tw_lds = buf + F * RS;                       // e^{+2 pi i n / NB}, n < NB
+
+    const int tid = threadIdx.x;
+    if (p.rider_n8[0] + p.rider_n8[1] && (int)blockIdx.x < kPfbRiderWgs)
+        pfb_copy_rider(p, blockIdx.x, min(kPfbRiderWgs, (int)gridDim.x), tid, NH);
+    int wg;
+    if (n_wg < 0) {
+        wg = blockIdx.x;
+    } else {
+        const int b = blockIdx.x, q = n_wg / 8, r = n_wg % 8, xcd = b % 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    }
+    pfb_2b_chunk<NH, P, ZH>(p, wg, tid, buf, tw_lds);
+}
+
+// grouped form (see pfb_group_kernel_os)
+template <int NH, int P, int MINW>
+__global__ __launch_bounds__(NH, MINW) void pfb_group_kernel_2b(const PfbLaunch *__restrict__ pls, GroupMap gm)
+{
+    constexpr int RS = row_stride<NH>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+    cf *tw_lds = buf + F * RS;
+    int fe, wg;
+    group_resolve(gm, blockIdx.x, fe, wg);
+    const PfbLaunch p = pls[fe];
+    pfb_2b_chunk<NH, P, false>(p, wg, threadIdx.x, buf, tw_lds);
+}
+
 int env_int(const char *name, int dflt)
 {
     const char *e = getenv(name);
@@ -657,6 +705,28 @@ void launch_os(const PfbLaunch &p, hipStream_t s)
     else    RCF_PFB_LAUNCH(p, (pfb_kernel_os<NB, OS, P, MINW, false>), dim3(n_wg), dim3(NB), lds, s, p, arg);
 }
 
+// grouped launch of one shape; false: this shape has no grouped form (the oversampled persistent kernels), the caller
+// launches its members one by one
+template <int NB, int OS, int P, int MINW>
+bool launch_os_group(const PfbLaunch *d_pls, const GroupMap &gm, hipStream_t s)
+{
+    if constexpr (OS == 1 && NB >= 512) {
+        if (!pfb_two_branch(NB, OS)) return false;
+        constexpr int NH = NB / 2;
+        constexpr int MW2 = NH == 256 ? 3 : 4;
+        const size_t lds2 = ((size_t)F * row_stride<NH>() + NB) * sizeof(cf);
+        static DynLdsAttr attr;
+        attr.ensure((const void *)pfb_group_kernel_2b<NH, P, MW2>, lds2);
+        hipLaunchKernelGGL((pfb_group_kernel_2b<NH, P, MW2>), dim3(gm.total_wg), dim3(NH), lds2, s, d_pls, gm);
+        return true;
+    } else {
+        if (pfb_persistent(NB)) return false;
+        const size_t lds = ((size_t)F * row_stride<NB>() + NB) * sizeof(cf);
+        hipLaunchKernelGGL((pfb_group_kernel_os<NB, OS, P, MINW>), dim3(gm.total_wg), dim3(NB), lds, s, d_pls, gm);
+        return true;
+    }
+}
+
 // taps per branch the kernels are instantiated for.  14 is what the reference's own low_pass_2 rule with a
 // Blackman-Harris window gives a critically sampled bank of ANY size (transition 0.2 bin, 60 dB -> 13.6 taps
 // per branch), so that case gets its exact row count instead of 16.
@@ -668,14 +738,25 @@ int round_p(int P, int OS)
     return 0;
 }
 
+// d_pls != nullptr: the grouped launch of this shape (p is the members' common shape; gm the chunk map)
 template <int NB>
-bool dispatch_nb(const PfbLaunch &p, int OS, int P, bool probe, hipStream_t s)
+bool dispatch_nb(const PfbLaunch &p, int OS, int P, bool probe, hipStream_t s, const PfbLaunch *d_pls = nullptr,
+                 const GroupMap *gm = nullptr)
 {
     const int PR = round_p(P, OS);
     if (PR == 0 || (OS != 1 && OS != 2)) return false;
     if (probe) return true;
     // waves per SIMD the register allocator must allow: 4 workgroups per CU is the LDS limit
     constexpr int MW = NB >= 1024 ? 4 : (NB >= 512 ? 4 : 4 * NB / 256 > 0 ? (4 * NB / 256 > 8 ? 8 : (4 * NB / 256 < 1 ? 1 : 4 * NB / 256)) : 1);
+    if (d_pls) {
+        if (OS == 1) {
+            if (PR == 4) return launch_os_group<NB, 1, 4, MW>(d_pls, *gm, s);
+            if (PR == 14) return launch_os_group<NB, 1, 14, MW>(d_pls, *gm, s);
+            return launch_os_group<NB, 1, 16, MW>(d_pls, *gm, s);
+        }
+        if (PR == 4) return launch_os_group<NB, 2, 4, MW>(d_pls, *gm, s);
+        return launch_os_group<NB, 2, 16, MW>(d_pls, *gm, s);
+    }
     if (OS == 1) {
         if (PR == 4) launch_os<NB, 1, 4, MW>(p, s);
         else if (PR == 14) launch_os<NB, 1, 14, MW>(p, s);
@@ -685,17 +766,17 @@ bool dispatch_nb(const PfbLaunch &p, int OS, int P, bool probe, hipStream_t s)
     return true;
 }
 
-bool dispatch(const PfbLaunch &p, bool probe, hipStream_t s)
+bool dispatch(const PfbLaunch &p, bool probe, hipStream_t s, const PfbLaunch *d_pls = nullptr, const GroupMap *gm = nullptr)
 {
     if (p.D <= 0 || p.NB % p.D) return false;
     const int OS = p.NB / p.D;
     switch (p.NB) {
-        case 64:   return dispatch_nb<64>(p, OS, p.P, probe, s);
-        case 128:  return dispatch_nb<128>(p, OS, p.P, probe, s);
-        case 256:  return dispatch_nb<256>(p, OS, p.P, probe, s);
-        case 512:  return dispatch_nb<512>(p, OS, p.P, probe, s);
-        case 1024: return dispatch_nb<1024>(p, OS, p.P, probe, s);
-        default:   return pfb5_dispatch(p, probe, s);      // 400 / 800 / 1600 / 3200 bins (pfb5.hip)
+        case 64:   return dispatch_nb<64>(p, OS, p.P, probe, s, d_pls, gm);
+        case 128:  return dispatch_nb<128>(p, OS, p.P, probe, s, d_pls, gm);
+        case 256:  return dispatch_nb<256>(p, OS, p.P, probe, s, d_pls, gm);
+        case 512:  return dispatch_nb<512>(p, OS, p.P, probe, s, d_pls, gm);
+        case 1024: return dispatch_nb<1024>(p, OS, p.P, probe, s, d_pls, gm);
+        default:   return d_pls ? pfb5_dispatch_group(p, d_pls, *gm, s) : pfb5_dispatch(p, probe, s);      // 400 / 800 / 1600 / 3200 bins (pfb5.hip)
     }
 }
 
@@ -727,6 +808,23 @@ void launch_pfb(const PfbLaunch &p, hipStream_t s)
 {
     if (p.n_frames <= 0) return;
     dispatch(p, false, s);
+}
+
+// whether this launch still reaches samples before the bank's start (it then runs the masking instantiation, alone)
+bool pfb_sees_zero_history(const PfbLaunch &p)
+{
+    const int OS = p.D > 0 ? p.NB / p.D : 1;
+    const int P = pfb_padded_p(p.NB, p.D, p.P);
+    return (p.n_lo - (int64_t)OS * (P - 1)) * (int64_t)p.D - (p.NB - 1) < p.start_sample;
+}
+
+// frames per chunk (= per workgroup) of this shape's kernel
+int pfb_chunk_frames(int NB) { return pfb_frame_major(NB) ? 16 / (NB / 400) : F; }
+
+bool launch_pfb_group(const PfbLaunch &shape, const PfbLaunch *d_pls, const GroupMap &gm, hipStream_t s)
+{
+    if (gm.total_wg <= 0) return true;
+    return dispatch(shape, false, s, d_pls, &gm);
 }
 
 }  // namespace rcfx

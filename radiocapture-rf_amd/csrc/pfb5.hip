@@ -89,8 +89,9 @@ __device__ __forceinline__ void wave_sync5()
     __builtin_amdgcn_wave_barrier();
 }
 
+// one chunk of one front-end's bank (shared by the single-front-end kernel and the grouped one: same instructions, same bits)
 template <int R, int R3, int OS, int P, bool ZH>
-__global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_wg)
+__device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, const int tid, cf *buf)
 {
     constexpr int NB = R * R * R3;
     constexpr int N2 = R * R;                  // W_{N2}^n = e^{+2 pi i n / (R R)} = tw[n R3]
@@ -109,10 +110,6 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
     static_assert((size_t)BUF * sizeof(cf) <= 64 * 1280, "at least two workgroups per CU");
     static_assert(R == 20 && F * BPF == kThreads5, "one butterfly per thread and pass");
     static_assert(OS == 1 || OS == 2 || OS == 4, "bin phase factor must be a power of -j");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf *buf = reinterpret_cast<cf *>(smem_raw);
-
-    const int tid = threadIdx.x;
     // -DRCF_PFB5_TRACE: two workgroups print the cycle counts of their phases (how the time of this kernel was found:
     // phase A ~45 % before the window was staged through LDS, phase B ~30 %; hipcc ... -DRCF_PFB5_TRACE -c pfb5.hip, link as another librcf, RCF_LIBRCF=...)
 #ifdef RCF_PFB5_TRACE
@@ -122,9 +119,6 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
 #else
 #define TS(i)
 #endif
-    // neighbouring chunks (they share input rows and complete each other's 128-byte output lines) on one XCD
-    const int b = blockIdx.x, q8 = n_wg / 8, r8 = n_wg % 8, xcd = b % 8;
-    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
     const int fb0 = wg * F;
     if (fb0 >= p.n_frames) return;
     const int nf = min(F, p.n_frames - fb0);
@@ -434,6 +428,39 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
 #endif
 }
 
+template <int R, int R3, int OS, int P, bool ZH>
+__global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+    // neighbouring chunks (they share input rows and complete each other's 128-byte output lines) on one XCD
+    const int b = blockIdx.x, q8 = n_wg / 8, r8 = n_wg % 8, xcd = b % 8;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    pfb5_chunk<R, R3, OS, P, ZH>(p, wg, threadIdx.x, buf);
+}
+
+// The banks of G front-ends in ONE launch (rcf_group.cpp; see pfb_group_kernel_os in pfb.hip): steady state only
+template <int R, int R3, int OS, int P>
+__global__ __launch_bounds__(kThreads5, 3) void pfb5_group_kernel(const PfbLaunch *__restrict__ pls, GroupMap gm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+    int fe, wg;
+    group_resolve(gm, blockIdx.x, fe, wg);
+    const PfbLaunch p = pls[fe];
+    pfb5_chunk<R, R3, OS, P, false>(p, wg, threadIdx.x, buf);
+}
+
+template <int R, int R3, int OS, int P>
+void launch5_group(const PfbLaunch *d_pls, const GroupMap &gm, hipStream_t s)
+{
+    constexpr int NB = R * R * R3, F = 16 / R3;
+    const size_t lds = (size_t)pfb5_buf(NB, R, F, OS, P) * sizeof(cf);
+    static DynLdsAttr attr;
+    attr.ensure(reinterpret_cast<const void *>(pfb5_group_kernel<R, R3, OS, P>), lds);
+    hipLaunchKernelGGL((pfb5_group_kernel<R, R3, OS, P>), dim3(gm.total_wg), dim3(kThreads5), lds, s, d_pls, gm);
+}
+
 template <int R, int R3, int OS, int P>
 void launch5(const PfbLaunch &p, hipStream_t s)
 {
@@ -468,6 +495,23 @@ bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s)
     RCF_PFB5(20, 2, 2, 2) RCF_PFB5(20, 2, 2, 1) RCF_PFB5(20, 2, 1, 4) RCF_PFB5(20, 2, 4, 1)      // 800 bins
     RCF_PFB5(20, 1, 2, 2) RCF_PFB5(20, 1, 2, 1) RCF_PFB5(20, 1, 1, 4) RCF_PFB5(20, 1, 4, 1)      // 400 bins
 #undef RCF_PFB5
+    return false;
+}
+
+bool pfb5_dispatch_group(const PfbLaunch &p, const PfbLaunch *d_pls, const GroupMap &gm, hipStream_t s)
+{
+    if (p.D <= 0 || p.NB % p.D) return false;
+    const int OS = p.NB / p.D;
+    const int PR = pfb5_padded_p(p.NB, p.D, p.P);
+    if (PR == 0) return false;
+#define RCF_PFB5G(R_, R3_, OS_, P_)                                 \
+    if (p.NB == R_ * R_ * R3_ && OS == OS_ && PR == P_) {            \
+        launch5_group<R_, R3_, OS_, P_>(d_pls, gm, s);               \
+        return true;                                                 \
+    }
+    // the shapes the reference's channel rule produces (OS = 2: 12.5 kHz raster, OS = 4: 6.25 kHz) -- the others run one by one
+    RCF_PFB5G(20, 4, 2, 2) RCF_PFB5G(20, 8, 4, 1) RCF_PFB5G(20, 8, 2, 2) RCF_PFB5G(20, 2, 2, 2) RCF_PFB5G(20, 1, 2, 2)
+#undef RCF_PFB5G
     return false;
 }
 

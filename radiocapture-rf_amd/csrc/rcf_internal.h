@@ -358,6 +358,40 @@ struct TapLaunch {           // one tapped bin, consumed by tap_finalize_kernel
 void launch_tap_finalize(const TapLaunch *d_taps, int n_taps, const float2 *tap_mat, int tap_pitch, int n_rows,
                          int64_t k_first, uint64_t ring_mask, const float *d_atan_table, const int32_t *d_group_bin0,
                          int tap_first, const float2 *bins_ring, int n_bins, hipStream_t s);
+// ---- grouped filterbank launch: the chunks of G front-ends (same shape) in one grid
+// virtual chunk v (after the XCD-aware map over the whole grid) belongs to front-end fe with wg_first[fe] <= v <
+// wg_first[fe + 1]; uniform_nwg > 0: every front-end has that many chunks (the real-time case), no table walk
+struct GroupMap {
+    const int32_t *wg_first;     // n_fe + 1 entries (device)
+    int32_t n_fe, total_wg, uniform_nwg;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ void group_resolve(const GroupMap &m, int b, int &fe, int &wg)
+{
+    const int q = m.total_wg / 8, r = m.total_wg % 8, xcd = b % 8;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    if (m.uniform_nwg > 0) {
+        fe = v / m.uniform_nwg;
+        wg = v - fe * m.uniform_nwg;
+    } else {
+        int lo = 0, hi = m.n_fe;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (m.wg_first[mid] <= v) lo = mid; else hi = mid;
+        }
+        fe = lo;
+        wg = v - m.wg_first[lo];
+    }
+    fe = __builtin_amdgcn_readfirstlane(fe);
+    wg = __builtin_amdgcn_readfirstlane(wg);
+}
+#endif
+// d_pls: the members' launch records (device); shape: any member's record (NB, D, P select the kernel).  false: this shape
+// has no grouped kernel -- launch the members one by one
+bool launch_pfb_group(const PfbLaunch &shape, const PfbLaunch *d_pls, const GroupMap &gm, hipStream_t s);
+bool pfb5_dispatch_group(const PfbLaunch &p, const PfbLaunch *d_pls, const GroupMap &gm, hipStream_t s);
+bool pfb_sees_zero_history(const PfbLaunch &p);
+int pfb_chunk_frames(int NB);
 bool pfb_supported(int NB, int D, int P);
 int pfb_padded_p(int NB, int D, int P);   // rows the kernel instantiation reads from ptaps (zero padded)
 void launch_pfb(const PfbLaunch &p, hipStream_t s);
@@ -367,11 +401,29 @@ inline bool pfb_frame_major(int NB) { return NB % 25 == 0; }
 // dst[i] = view sample (first + i), i < n (one bin's samples out of a bank ring; ingest.hip)
 void launch_gather_view(const StreamView &v, int64_t first, float2 *dst, size_t n, hipStream_t s);
 // one ring segment of a batched read (rcf_chan_read_many), in 4-byte words: dst[dst_w + w] = ring[(pos_w + w) & mask_w], w < n_w
+//   dst_mask_w = ~0u, dst_pos_w = 0: rows packed back to back; otherwise the destination is a ring of dst_mask_w + 1 words that
+//   starts at word dst_w (the real-time pump's per-channel host rings), written from dst_pos_w on
 struct GatherRec {
     const uint32_t *ring;
     uint32_t pos_w, n_w, mask_w, dst_w;
+    uint32_t dst_pos_w, dst_mask_w;
 };
 void launch_gather_rings(const GatherRec *d_recs, int n_recs, uint32_t *d_dst, uint32_t max_words, hipStream_t s);
+// one record of the grouped ingest launch (group_prep_kernel, ingest.hip): a block of one front-end, or a plain copy
+struct PrepRec {
+    const void *src;         // wire-format / cf32 samples (pinned host memory as the device sees it, or device memory)
+    float2 *dst;             // the block's place in the front-end's wideband buffer (copy: destination words)
+    float2 *hist_dst;        // where block sample hist_from lands in the OTHER buffer's history; nullptr: no dual write
+    uint32_t n;              // samples (copy: 8-byte words)
+    uint32_t hist_from;      // block samples i >= hist_from are also written to hist_dst[i - hist_from]
+    int32_t fmt;             // RCF_FMT_CF32 / U8 / S8 / S16; < 0: plain 8-byte copy
+    float scale, offset;
+    int32_t aligned;         // src allows one vector load per two samples (4 / 8 / 16-byte aligned for 8 / 16 / 32-bit items)
+    int32_t dst_aligned;     // dst is 16-byte aligned
+    int32_t pad_[3];
+};
+static_assert(sizeof(PrepRec) == 64, "one record = one 64-byte line of the pinned arena");
+void launch_group_prep(const PrepRec *d_recs, int n_recs, uint32_t max_n, hipStream_t s);
 // dst[0, bytes) = src[0, bytes), both 8-byte aligned, bytes rounded up to 8; src may be pinned (device-mapped) host memory
 void launch_copy8(void *dst, const void *src, size_t bytes, hipStream_t s);
 void launch_copy8x2(void *d0, const void *s0, size_t bytes0, void *d1, const void *s1, size_t bytes1, hipStream_t s);
