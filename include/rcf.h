@@ -392,6 +392,99 @@ int rcf_comm_size(rcf_t *h);
 int rcf_allgather_peaks(rcf_t *h, const int64_t *mine, int n, int64_t *all, int cap, int *counts);
 int rcf_allreduce_max(rcf_t *h, double *value);
 
+/* ------------------------------------------------------------------ groups of front-ends */
+/*
+ * The reference's receiver holds ALL configured SDR sources in one top block when no -i is given
+ * (rc_frontend/receiver.py:67-70,170-204; ten sources per host in configs/config_denver_dev_den817.py:25-118).  A group
+ * is that: G front-ends of one device whose blocks are processed by ONE launch per stage -- one conversion (wire format
+ * -> cf32, the history tails dual-written on the way), one filterbank launch over the chunks of every member (members of
+ * the same bank shape; the others follow one by one), one stage-2 FIR + discriminator launch per (decimation, taps)
+ * class, one tap-finalize launch, one gather for the read -- instead of G of each.  A real-time block is a handful of
+ * ~5 us kernels: launched per front-end, one MI355X is launch-bound at a few hundred front-ends; grouped, the PCIe link
+ * is what bounds it.  Outputs are the same bits as the members run one by one (tests/test_gpu_group.py).
+ *   - members must live on one device and have the same out_capacity; a handle belongs to at most one group; while it
+ *     does, it runs on the group's stream (every single-handle call keeps working) and rcf_close() on it is refused.
+ *   - a call processes any SUBSET of the members: n_samples[i] = 0 (or blocks[i] = NULL) skips member i this time --
+ *     independent SDRs are not synchronised, a pump takes whichever blocks are complete.
+ *   - rcf_group_push returns once the callers' buffers have been read; pinned buffers (rcf_host_alloc) are read in
+ *     place across PCIe, pageable ones are staged by the runtime first.
+ *   - on a planning failure (a ring too small, an exhausted arena) nothing is queued and no member has advanced.
+ */
+typedef struct rcf_group rcf_group_t;
+int rcf_group_open(rcf_t *const *handles, int n, rcf_group_t **out);
+/* the members stay open and go back to their own streams */
+int rcf_group_close(rcf_group_t *g);
+int rcf_group_size(rcf_group_t *g);
+/* blocks[i]: n_samples[i] samples of member i in `fmt` (RCF_FMT_CF32 / U8 / S8 / S16; scale and offset as rcf_push_raw) */
+int rcf_group_push(rcf_group_t *g, const void *const *blocks, const size_t *n_samples, int fmt, float scale, float offset);
+/* rcf_commit for every member with n_samples[i] > 0: the data is already where rcf_ingest_ptr said */
+int rcf_group_commit(rcf_group_t *g, const size_t *n_samples);
+/* rcf_chan_read_many over channels of several members: entry j is channel chan_ids[j] of member members[j] */
+int rcf_group_read_many(rcf_group_t *g, int what, const int *members, const int *chan_ids, int n, float gain, void *out,
+                        size_t cap_each, int64_t *counts);
+int rcf_group_sync(rcf_group_t *g);
+
+/* ------------------------------------------------------------------ real-time pump (native thread) */
+/*
+ * What moves the samples in a channelizer process -- in the reference GNU Radio's scheduler threads, started by
+ * receiver.start() (rc_frontend/receiver.py:271) and channel.start() (:336) -- as ONE native thread per group with no
+ * interpreter in it: whenever blocks
+ * of some members are complete it pushes them as one group block, gathers the new output of their subscribed channels
+ * with one launch into per-channel HOST rings (pinned memory the gather kernel writes across PCIe -- no host copy), and
+ * publishes the counts once the launch has finished.  Two group blocks are in flight at most: the next one is planned
+ * and queued while the previous one runs.
+ *   Sources are rings of whole blocks in pinned memory (rcf_host_alloc), ring_blocks[i] blocks of block_samples each:
+ *   written[i] != NULL: *written[i] counts the blocks the producer (an SDR driver thread) has completed -- block k is
+ *     taken from slot k % ring_blocks[i] once *written[i] > k;
+ *   written == NULL or written[i] == NULL: paced by the wall clock -- block k of member i is complete at
+ *     t0 + (k + 1) * block_samples / samp_rate + phase_s[i] (a recorded or synthetic stream replayed at its rate).
+ *   Latency of a block = from that instant (or from the moment the pump saw the counter) to its outputs being in host
+ *   memory; late = latency above one block period; overrun = the pump got to a block more than a period after it was due.
+ */
+typedef struct rcf_pump rcf_pump_t;
+typedef struct rcf_pump_config {
+    size_t block_samples;
+    int fmt;                             /* RCF_FMT_* of the source rings */
+    float scale, offset;
+    double samp_rate;                    /* pacing rate (samples per second of every member) */
+    const void *const *rings;            /* [group size] */
+    const size_t *ring_blocks;           /* [group size] */
+    const double *phase_s;               /* [group size] or NULL */
+    const volatile uint64_t *const *written;   /* [group size] or NULL */
+    int what;                            /* RCF_READ_IQ / RCF_READ_FM: what the subscribed channels deliver */
+    float gain;                          /* RCF_READ_FM: quadrature_demod_cf gain */
+    const int *read_members;             /* [n_read] subscribed channels: member index ... */
+    const int *read_chans;               /* ... and channel id */
+    int n_read;
+    size_t out_ring_samples;             /* host ring per subscribed channel, rounded up to a power of two (0: 4096) */
+    int64_t n_blocks;                    /* blocks per member, then the pump stops by itself (0: until rcf_pump_stop) */
+    int64_t warm_blocks;                 /* first blocks of every member that the statistics do not judge */
+    int max_batch;                       /* most members per group block (0: all that are ready) */
+    int cpu;                             /* pin the thread to this CPU (-1: leave it to the scheduler) */
+    double start_delay_s;                /* t0 = now + this */
+} rcf_pump_config_t;
+typedef struct rcf_pump_stats {
+    int64_t blocks_done;                 /* member blocks whose outputs are in host memory */
+    int64_t blocks_judged, late, overruns;
+    int64_t group_blocks;                /* launches of the group (batches) */
+    int64_t max_batch;
+    int64_t samples_out;                 /* output samples written to the host rings */
+    double latency_ms_p50, latency_ms_p99, latency_ms_max;
+    double host_plan_ms, host_wait_ms;   /* thread time spent planning + queueing / waiting for the device */
+    double elapsed_s;
+    int running;                         /* 0 once the thread has finished */
+    int error;                           /* RCF_E* that stopped it (0: none) */
+} rcf_pump_stats_t;
+int rcf_pump_start(rcf_group_t *g, const rcf_pump_config_t *cfg, rcf_pump_t **out);
+int rcf_pump_stats(rcf_pump_t *p, rcf_pump_stats_t *st);
+/* samples of subscribed channel `entry` (index into read_members / read_chans) in its host ring so far */
+int64_t rcf_pump_written(rcf_pump_t *p, int entry);
+/* copies up to max_items new items (cf32 pairs or floats) from *cursor on; a reader that fell more than the ring behind
+ * loses the oldest (as a PUB socket at its HWM does) */
+int64_t rcf_pump_read(rcf_pump_t *p, int entry, int64_t *cursor, void *out, size_t max_items);
+/* stops the thread (if still running), waits for it, releases the pump */
+int rcf_pump_stop(rcf_pump_t *p);
+
 #ifdef __cplusplus
 }
 #endif

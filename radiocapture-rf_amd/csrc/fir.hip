@@ -598,20 +598,21 @@ __global__ __launch_bounds__(64) void rot_fill_kernel(const RotFill *__restrict_
 // (32-byte pieces measured 4-5x slower than lines).  The price is the 32 extra rows a tile loads.
 constexpr int kTapOut = 128, kTapCols = 16, kTapAlign = 32, kTapLdsRows = kTapOut + kTapAlign + 1,
               kTapLdsPitch = kTapCols + 1;
-__global__ __launch_bounds__(kThreads) void tap_finalize_kernel(const TapLaunch *__restrict__ taps, int n_taps,
-                                                                const float2 *__restrict__ mat, int pitch, int n_rows,
-                                                                int64_t k_first, uint64_t ring_mask,
-                                                                const float *__restrict__ atan_tab,
-                                                                const int32_t *__restrict__ group_bin0, int tap_first,
-                                                                const float2 *__restrict__ bins_ring, int n_bins)
+// one tile (16 taps x 128 outputs) of one front-end's taps; shared by the single-front-end kernel and the grouped one
+__device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int bx, const int by, const uint64_t ring_mask,
+                                                  const float *__restrict__ atan_tab, float *tab, float2 *ys)
 {
     static_assert(kThreads == kTapCols * 16, "16 x 16 lanes");
-    __shared__ float tab[260];
-    __shared__ float2 ys[kTapLdsRows * kTapLdsPitch];
+    const TapLaunch *__restrict__ taps = A.taps;
+    const int n_taps = A.n_taps, pitch = A.pitch, n_rows = A.n_rows, tap_first = A.tap_first, n_bins = A.n_bins;
+    const float2 *__restrict__ mat = A.mat;
+    const int64_t k_first = A.k_first;
+    const int32_t *__restrict__ group_bin0 = A.group_bin0;
+    const float2 *__restrict__ bins_ring = A.bins_ring;
     const int tid = threadIdx.x;
     // grid: x = group of 16 taps (fastest), y = tile of rows -- workgroups dispatched together read neighbouring
     // 128-byte pieces of the SAME matrix rows (whole rows between them), not one piece from each of 161 rows apart
-    const int s0 = blockIdx.x * kTapCols, r0 = blockIdx.y * kTapOut;
+    const int s0 = bx * kTapCols, r0 = by * kTapOut;
     const int r_lds0 = r0 - kTapAlign - 1;                   // matrix row of LDS row 0
     for (int i = tid; i < 257; i += kThreads) tab[i] = atan_tab[i];
     {
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(kThreads) void tap_finalize_kernel(const TapLaunch 
         if (slot < n_taps) {
             const TapLaunch L = taps[slot];
             const bool idle = L.dangle == 0.0 && L.dlogmag == 0.0 && L.angle0 == 0.0 && L.logmag0 == 0.0;
-            const int b0 = group_bin0[blockIdx.x];              // >= 0: this group's taps are 16 consecutive bins of the ring
+            const int b0 = group_bin0[bx];                      // >= 0: this group's taps are 16 consecutive bins of the ring
             // all of a lane's rows are requested before the first is used (the loop below would otherwise pay one
             // memory round trip per row: 11 in a row)
             constexpr int NIT = (kTapLdsRows + 15) / 16;
@@ -696,6 +697,25 @@ __global__ __launch_bounds__(kThreads) void tap_finalize_kernel(const TapLaunch 
     }
 }
 
+__global__ __launch_bounds__(kThreads) void tap_finalize_kernel(TapFinArgs A, uint64_t ring_mask,
+                                                                const float *__restrict__ atan_tab)
+{
+    __shared__ float tab[260];
+    __shared__ float2 ys[kTapLdsRows * kTapLdsPitch];
+    tap_finalize_tile(A, blockIdx.x, blockIdx.y, ring_mask, atan_tab, tab, ys);
+}
+
+// the taps of G front-ends in one launch: grid.z = front-end, x / y sized for the largest of them
+__global__ __launch_bounds__(kThreads) void tap_finalize_group_kernel(const TapFinArgs *__restrict__ args, uint64_t ring_mask,
+                                                                      const float *__restrict__ atan_tab)
+{
+    __shared__ float tab[260];
+    __shared__ float2 ys[kTapLdsRows * kTapLdsPitch];
+    const TapFinArgs A = args[blockIdx.z];
+    if ((int)blockIdx.x * kTapCols >= A.n_taps || (int)blockIdx.y * kTapOut >= A.n_rows + kTapAlign - 1) return;
+    tap_finalize_tile(A, blockIdx.x, blockIdx.y, ring_mask, atan_tab, tab, ys);
+}
+
 // P25 symbol filter and friends: a short real FIR over gain * fm (float32, taps in order)
 __global__ __launch_bounds__(kThreads) void fm_fir_kernel(const FmFirLaunch *__restrict__ items, uint64_t ring_mask)
 {
@@ -752,10 +772,19 @@ void launch_tap_finalize(const TapLaunch *d_taps, int n_taps, const float2 *tap_
                          int tap_first, const float2 *bins_ring, int n_bins, hipStream_t s)
 {
     if (n_taps <= 0 || n_rows <= 0) return;
+    const TapFinArgs A{d_taps, tap_mat, d_group_bin0, bins_ring, k_first, n_taps, tap_pitch, n_rows, tap_first, n_bins, 0};
     hipLaunchKernelGGL(tap_finalize_kernel,
                        dim3((n_taps + kTapCols - 1) / kTapCols, (n_rows + kTapAlign - 1 + kTapOut - 1) / kTapOut),
-                       dim3(kThreads), 0, s, d_taps, n_taps, tap_mat, tap_pitch, n_rows, k_first, ring_mask,
-                       d_atan_table, d_group_bin0, tap_first, bins_ring, n_bins);
+                       dim3(kThreads), 0, s, A, ring_mask, d_atan_table);
+}
+
+void launch_tap_finalize_group(const TapFinArgs *d_args, int n_args, int max_taps, int max_rows, uint64_t ring_mask,
+                               const float *d_atan_table, hipStream_t s)
+{
+    if (n_args <= 0 || max_taps <= 0 || max_rows <= 0) return;
+    hipLaunchKernelGGL(tap_finalize_group_kernel,
+                       dim3((max_taps + kTapCols - 1) / kTapCols, (max_rows + kTapAlign - 1 + kTapOut - 1) / kTapOut, n_args),
+                       dim3(kThreads), 0, s, d_args, ring_mask, d_atan_table);
 }
 
 void launch_fm_level(const float *fm_ring, int64_t n_end, int window, float gain, uint64_t ring_mask, float *d_out,

@@ -112,8 +112,11 @@ static __global__ __launch_bounds__(256) void gather_rings_kernel(const GatherRe
     const uint32_t stride = gridDim.x * 256;
     // the destination is either linear (dst_mask_w = ~0: rows packed back to back, rcf_chan_read_many) or a ring of its own
     // (the real-time pump's per-channel host rings: dst_w = the ring's first word, dst_pos_w where this segment starts)
-    for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < r.n_w; w += stride)
-        dst[r.dst_w + ((r.dst_pos_w + w) & r.dst_mask_w)] = r.ring[(r.pos_w + w) & r.mask_w];
+    for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < r.n_w; w += stride) {
+        uint32_t v = r.ring[(r.pos_w + w) & r.mask_w];
+        if (r.flags & 1u) v = __float_as_uint(__fmul_rn(r.gain, __uint_as_float(v)));
+        dst[r.dst_w + ((r.dst_pos_w + w) & r.dst_mask_w)] = v;
+    }
 }
 
 void launch_gather_rings(const GatherRec *d_recs, int n_recs, uint32_t *d_dst, uint32_t max_words, hipStream_t s)

@@ -420,7 +420,7 @@ int rcf_chan_read_many(rcf_t *h, int what, const int *chan_ids, int n_chans, flo
             const Item &it = items[(size_t)i];
             if (it.n <= 0) continue;
             recs[n_recs++] = GatherRec{static_cast<const uint32_t *>(it.ring), (uint32_t)(it.pos * ew), (uint32_t)it.n * ew,
-                                       (uint32_t)(h->out_cap * ew - 1), at_w, 0u, ~0u};
+                                       (uint32_t)(h->out_cap * ew - 1), at_w, 0u, ~0u, 1.0f, 0u};
             at_w += (uint32_t)it.n * ew;
         }
         launch_gather_rings(reinterpret_cast<const GatherRec *>(h->h_many_dev), n_recs,

@@ -57,6 +57,65 @@ void drain_graveyard(rcf_t *h)
     free_graveyard_idle(h);
 }
 
+int ArenaSet::create()
+{
+    for (int i = 0; i < 2; ++i) {
+        RCF_HIP(hipHostMalloc(&h[i], cap, hipHostMallocDefault));
+        RCF_HIP(hipMalloc(&d[i], cap));
+        void *dv = nullptr;
+        h_dev[i] = hipHostGetDevicePointer(&dv, h[i], 0) == hipSuccess ? static_cast<unsigned char *>(dv) : nullptr;
+        if (!h_dev[i]) mapped = false;
+        RCF_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    }
+    return RCF_OK;
+}
+
+void ArenaSet::destroy()
+{
+    for (int i = 0; i < 2; ++i) {
+        if (d[i]) (void)hipFree(d[i]);
+        if (h[i]) (void)hipHostFree(h[i]);
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+        d[i] = h[i] = h_dev[i] = nullptr;
+        ev[i] = nullptr;
+    }
+}
+
+int ArenaSet::reserve(size_t need, hipStream_t stream)
+{
+    if (!h[0] && create() != RCF_OK) return RCF_EHIP;
+    if (need > cap) {
+        RCF_HIP(hipStreamSynchronize(stream));
+        size_t ncap = cap;
+        while (ncap < need) ncap *= 2;
+        for (int i = 0; i < 2; ++i) {
+            unsigned char *nh = nullptr, *nd = nullptr;
+            RCF_HIP(hipHostMalloc(&nh, ncap, hipHostMallocDefault));
+            RCF_HIP(hipMalloc(&nd, ncap));
+            (void)hipHostFree(h[i]);
+            (void)hipFree(d[i]);
+            h[i] = nh;
+            d[i] = nd;
+            used[i] = false;
+            void *dv = nullptr;
+            h_dev[i] = hipHostGetDevicePointer(&dv, nh, 0) == hipSuccess ? static_cast<unsigned char *>(dv) : nullptr;
+            if (!h_dev[i]) mapped = false;
+        }
+        cap = ncap;
+        fill = 0;
+    }
+    if (fill + need > cap) {
+        // this arena is full: everything queued so far may still read it -- one event now guards its reuse -- and the
+        // other one must have been drained
+        RCF_HIP(hipEventRecord(ev[cur], stream));
+        used[cur] = true;
+        cur ^= 1;
+        fill = 0;
+        if (used[cur]) RCF_HIP(hipEventSynchronize(ev[cur]));
+    }
+    return RCF_OK;
+}
+
 size_t slice_round(size_t bytes) { return (bytes + 255) & ~size_t(255); }
 
 // one slice of `bytes` (a multiple of 256) from the handle's pools; nullptr + error set on failure
@@ -131,15 +190,9 @@ int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_c
     for (int i = 0; i < 2; ++i) {
         RCF_HIP(hipMalloc(&h->d_buf[i], sizeof(float2) * buf_samples));
         RCF_HIP(hipMemsetAsync(h->d_buf[i], 0, sizeof(float2) * buf_samples, h->stream));
-        RCF_HIP(hipHostMalloc(&h->h_arena[i], h->arena_cap, hipHostMallocDefault));
-        RCF_HIP(hipMalloc(&h->d_arena[i], h->arena_cap));
-        {
-            void *dv = nullptr;
-            h->h_arena_dev[i] = hipHostGetDevicePointer(&dv, h->h_arena[i], 0) == hipSuccess ? static_cast<unsigned char *>(dv) : nullptr;
-            if (!h->h_arena_dev[i]) h->copy_kernels = false;
-        }
-        RCF_HIP(hipEventCreateWithFlags(&h->arena_ev[i], hipEventDisableTiming));
     }
+    // (the launch-record arenas -- 2 x 8 MiB pinned + 2 x 8 MiB device -- come with the first block the handle processes on
+    // its own: a member of a group plans into the group's arena and never needs them)
     RCF_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) RCF_HIP(hipEventCreateWithFlags(&h->buf_done[i], hipEventDisableTiming));
     RCF_HIP(hipEventCreateWithFlags(&h->copy_ev, hipEventDisableTiming));
@@ -154,6 +207,7 @@ int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_c
 int rcf_close(rcf_t *h)
 {
     if (!h) return RCF_EINVAL;
+    if (h->group) { set_error("the handle belongs to a group: rcf_group_close first"); return RCF_ESTATE; }
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (auto &kv : h->chans) free_channel(h, kv.second.get());
@@ -170,15 +224,13 @@ int rcf_close(rcf_t *h)
     bury(h, h->d_level);
     for (int i = 0; i < 2; ++i) {
         bury(h, h->d_buf[i]);
-        bury(h, h->d_arena[i]);
-        if (h->h_arena[i]) (void)hipHostFree(h->h_arena[i]);
-        if (h->arena_ev[i]) (void)hipEventDestroy(h->arena_ev[i]);
     }
     bury(h, h->d_gather);
     if (h->h_many) (void)hipHostFree(h->h_many);
     bury(h, h->d_partial);
     bury(h, h->d_tapmat);
     drain_graveyard(h);
+    h->arenas.destroy();
     for (auto &kv : h->pools)
         for (void *slab : kv.second.slabs) (void)hipFree(slab);
     h->pools.clear();

@@ -352,6 +352,17 @@ struct TapLaunch {           // one tapped bin, consumed by tap_finalize_kernel
     int32_t bin;
     static constexpr bool kHasRotRing = false;
 };
+// what tap_finalize needs of ONE front-end (kernel argument of the single launch, arena record of the grouped one)
+struct TapFinArgs {
+    const TapLaunch *taps;
+    const float2 *mat;
+    const int32_t *group_bin0;
+    const float2 *bins_ring;
+    int64_t k_first;
+    int32_t n_taps, pitch, n_rows, tap_first, n_bins, pad_;
+};
+void launch_tap_finalize_group(const TapFinArgs *d_args, int n_args, int max_taps, int max_rows, uint64_t ring_mask,
+                               const float *d_atan_table, hipStream_t s);
 // mat row r = the bank's frame k_first + r (tap output index); rows [0, n_rows)
 // group_bin0[g] >= 0: the 16 taps of slot group g are the bins group_bin0[g] .. + 15 -- read from the bank's frame-major
 // ring (bins_ring[((k_first + r) & ring_mask) n_bins + bin]) instead of the matrix
@@ -407,6 +418,8 @@ struct GatherRec {
     const uint32_t *ring;
     uint32_t pos_w, n_w, mask_w, dst_w;
     uint32_t dst_pos_w, dst_mask_w;
+    float gain;              // flags & 1: the words are float32 and leave multiplied by gain (quadrature_demod_cf's gain, one
+    uint32_t flags;          // float32 multiply -- what rcf_chan_read_fm does on the host)
 };
 void launch_gather_rings(const GatherRec *d_recs, int n_recs, uint32_t *d_dst, uint32_t max_words, hipStream_t s);
 // one record of the grouped ingest launch (group_prep_kernel, ingest.hip): a block of one front-end, or a plain copy

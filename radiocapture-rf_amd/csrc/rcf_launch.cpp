@@ -7,7 +7,7 @@ namespace rcfx {
 int launch_plan(rcf_t *h, BlockPlan &bp)
 {
     hipStream_t st = h->stream;
-    Arena &ar = bp.ar;
+    Arena &ar = *bp.ar;
     const int a = bp.a;
     const size_t arena_base = bp.arena_base;
     auto &fir_by_depth = bp.fir_by_depth;
@@ -39,23 +39,23 @@ int launch_plan(rcf_t *h, BlockPlan &bp)
                           bytes / 8 < (1u << 31) && h->hist_cap < (1u << 28) && pfb_takes_rider(pl);
         if (ride) {
             pl.rider_dst[0] = reinterpret_cast<unsigned long long *>(ar.d + from);
-            pl.rider_src[0] = reinterpret_cast<const unsigned long long *>(h->h_arena_dev[a] + from);
+            pl.rider_src[0] = reinterpret_cast<const unsigned long long *>(h->arenas.h_dev[a] + from);
             pl.rider_n8[0] = (uint32_t)((bytes + 7) / 8);
             pl.rider_dst[1] = reinterpret_cast<unsigned long long *>(h->d_buf[h->cur ^ 1]);
             pl.rider_src[1] = reinterpret_cast<const unsigned long long *>(h->d_buf[h->cur] + bp.n);
             pl.rider_n8[1] = (uint32_t)(sizeof(float2) * h->hist_cap / 8);
             bp.history_done = true;
         } else if (h->copy_kernels && !merge) {
-            if (bytes) launch_copy8(ar.d + from, h->h_arena_dev[a] + from, bytes, st);
+            if (bytes) launch_copy8(ar.d + from, h->arenas.h_dev[a] + from, bytes, st);
         } else if (h->copy_kernels) {
             Timed t(h, RCF_T_HISTORY);
-            launch_copy8x2(ar.d + from, h->h_arena_dev[a] + from, bytes, h->d_buf[h->cur ^ 1], h->d_buf[h->cur] + bp.n,
+            launch_copy8x2(ar.d + from, h->arenas.h_dev[a] + from, bytes, h->d_buf[h->cur ^ 1], h->d_buf[h->cur] + bp.n,
                            sizeof(float2) * h->hist_cap, st);
             bp.history_done = true;
         } else if (bytes) {
             RCF_HIP(hipMemcpyAsync(ar.d + from, ar.h + from, bytes, hipMemcpyHostToDevice, st));
         }
-        if (bytes) h->arena_fill = (ar.used + 63) & ~size_t(63);
+        if (bytes) h->arenas.fill = (ar.used + 63) & ~size_t(63);
     }
     if (d_rot_fills) launch_rot_fill(d_rot_fills, (int)rot_fills.size(), h->ring_mask, st);
     if (!fir_by_depth.empty())

@@ -35,39 +35,13 @@ int plan_arena(rcf_t *h, BlockPlan &bp)
         }
         need += 64 * (h->chans.size() / 4 + 64);              // per-class alignment slack
         arena_need = need;
-        if (need > h->arena_cap) {
-            RCF_HIP(hipStreamSynchronize(h->stream));
-            size_t cap = h->arena_cap;
-            while (cap < need) cap *= 2;
-            for (int i = 0; i < 2; ++i) {
-                unsigned char *nh = nullptr, *nd = nullptr;
-                RCF_HIP(hipHostMalloc(&nh, cap, hipHostMallocDefault));
-                RCF_HIP(hipMalloc(&nd, cap));
-                (void)hipHostFree(h->h_arena[i]);
-                (void)hipFree(h->d_arena[i]);
-                h->h_arena[i] = nh;
-                h->d_arena[i] = nd;
-                h->arena_used[i] = false;
-                void *dv = nullptr;
-                h->h_arena_dev[i] = hipHostGetDevicePointer(&dv, nh, 0) == hipSuccess ? static_cast<unsigned char *>(dv) : nullptr;
-                if (!h->h_arena_dev[i]) h->copy_kernels = false;
-            }
-            h->arena_cap = cap;
-            h->arena_fill = 0;
-        }
     }
-    if (h->arena_fill + arena_need > h->arena_cap) {
-        // this arena is full: everything queued so far may still read it -- one event now guards its reuse -- and the
-        // other one must have been drained
-        RCF_HIP(hipEventRecord(h->arena_ev[h->arena_cur], h->stream));
-        h->arena_used[h->arena_cur] = true;
-        h->arena_cur ^= 1;
-        h->arena_fill = 0;
-        if (h->arena_used[h->arena_cur]) RCF_HIP(hipEventSynchronize(h->arena_ev[h->arena_cur]));
-    }
-    bp.a = h->arena_cur;
-    bp.arena_base = h->arena_fill;
-    bp.ar = Arena{h->h_arena[bp.a], h->d_arena[bp.a], bp.arena_base, h->arena_cap};
+    if (bp.ar != &bp.own_ar) return RCF_OK;        // a group's block: the group reserved its arena for all members
+    if (h->arenas.reserve(arena_need, h->stream) != RCF_OK) return RCF_EHIP;
+    if (!h->arenas.mapped) h->copy_kernels = false;
+    bp.a = h->arenas.cur;
+    bp.arena_base = h->arenas.fill;
+    bp.own_ar = Arena{h->arenas.h[bp.a], h->arenas.d[bp.a], bp.arena_base, h->arenas.cap};
     return RCF_OK;
 }
 
@@ -274,7 +248,7 @@ int plan_class_jobs(rcf_t *h, BlockPlan &bp, ClassPlan &cp, int depth, std::pair
 {
     const int D = cls_key.first, T = cls_key.second;
     const size_t n = bp.n;
-    Arena &ar = bp.ar;
+    Arena &ar = *bp.ar;
     auto &fir_by_depth = bp.fir_by_depth;
     auto &disc_jobs = bp.disc_jobs;
     auto &launches = cp.launches;
@@ -421,14 +395,18 @@ int plan_class_jobs(rcf_t *h, BlockPlan &bp, ClassPlan &cp, int depth, std::pair
     if (!rest.empty()) {
         job.dims.n_chans = (int)rest.size();
         job.dims.small = (!shared_src && fir_small_outputs(D, T) > 0) ? 1 : 0;
-        if (!ar.put(rest, &job.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
-        fir_by_depth[depth].push_back(job);
+        // a group's block: launches whose records are self-contained (every channel its own source view) are merged
+        // with the same class of the other front-ends -- the records stay on the host until the group has them all
+        if (bp.defer && job.dims.chans_per_wg == 1) job.host.swap(rest);
+        else if (!ar.put(rest, &job.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+        fir_by_depth[depth].push_back(std::move(job));
     }
     if (!(job.dims.small && clean.empty())) {   // the small-T kernel writes the discriminator ring itself
         DiscJob dj{};
         dj.n = (int)discs.size(); dj.max_n = max_n;
-        if (!ar.put(discs, &dj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
-        disc_jobs.push_back(dj);
+        if (bp.defer) dj.host.swap(discs);
+        else if (!ar.put(discs, &dj.dev)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+        disc_jobs.push_back(std::move(dj));
     }
     return RCF_OK;
 }
@@ -436,7 +414,7 @@ int plan_class_jobs(rcf_t *h, BlockPlan &bp, ClassPlan &cp, int depth, std::pair
 // filterbank taps (matrix + records) and the records that go out as one launch each
 int plan_tail(rcf_t *h, BlockPlan &bp)
 {
-    Arena &ar = bp.ar;
+    Arena &ar = *bp.ar;
     auto &tap_list = bp.tap_list;
     auto &tap_bins = bp.tap_bins;
     auto &rot_fills = bp.rot_fills;
@@ -498,8 +476,9 @@ int plan_tail(rcf_t *h, BlockPlan &bp)
         pl.tap_pitch = (int32_t)mat_pitch;
         pl.n_taps = (int32_t)tap_list.size();
     }
-    if (!rot_fills.empty() && !ar.put(rot_fills, &d_rot_fills)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
-    if (!symf.empty() && !ar.put(symf, &d_symf)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+    // (a group's block: the exact-rotator fills and the symbol filters of all members go out as one launch each)
+    if (!bp.defer && !rot_fills.empty() && !ar.put(rot_fills, &d_rot_fills)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
+    if (!bp.defer && !symf.empty() && !ar.put(symf, &d_symf)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
     if (!audf.empty() && !ar.put(audf, &d_audf)) { set_error("launch arena exhausted"); return RCF_ENOMEM; }
     return RCF_OK;
 }
@@ -552,10 +531,22 @@ int check_block_capacity(rcf_t *h, const BlockPlan &bp)
     return RCF_OK;
 }
 
-int process_block(rcf_t *h, size_t n)
+void undo_block(rcf_t *h, BlockUndo &u)
 {
-    if (h->graveyard.size() > 512) drain_graveyard(h);     // bounded even if nobody ever syncs or reads
-    BlockPlan bp;
+    if (!u.armed) return;
+    for (const BlockUndo::Saved &s : u.saved) {
+        s.c->produced = s.produced; s.c->n_seg0 = s.n_seg0; s.c->blk_before = s.blk_before; s.c->blk_after = s.blk_after;
+        s.c->blk_serial = s.blk_serial; s.c->angle0 = s.angle0; s.c->logmag0 = s.logmag0;
+    }
+    if (h->pfb.open) h->pfb.produced = h->pfb.produced_before;
+    h->blk_serial = u.serial_before;
+    u.armed = false;
+}
+
+// Everything of one block up to (not including) its launches.  On failure the handle is as it was before the call; on
+// success the channels' counters have advanced and `undo` can still take that back (a group whose LATER member fails).
+int plan_block(rcf_t *h, size_t n, BlockPlan &bp, BlockUndo &undo)
+{
     bp.S0 = h->total_in;
     bp.S1 = bp.S0 + (int64_t)n;
     bp.n = n;
@@ -575,23 +566,15 @@ int process_block(rcf_t *h, size_t n)
     // bank matrix, split-K slab or tap matrix that cannot be allocated, an exhausted launch arena.  Nothing has been
     // queued at that point: put the counters back, so that they never claim outputs nobody computed (and the exact
     // rotator's device state stays in step with them).
-    struct Saved { Chan *c; int64_t produced, n_seg0, blk_before, blk_after; uint64_t blk_serial; long double angle0; double logmag0; };
-    std::vector<Saved> saved;
-    saved.reserve(h->chans.size());
+    undo.saved.clear();
+    undo.saved.reserve(h->chans.size());
     for (auto &kv : h->chans) {
         Chan *c = kv.second.get();
-        saved.push_back(Saved{c, c->produced, c->n_seg0, c->blk_before, c->blk_after, c->blk_serial, c->angle0, c->logmag0});
+        undo.saved.push_back(BlockUndo::Saved{c, c->produced, c->n_seg0, c->blk_before, c->blk_after, c->blk_serial, c->angle0, c->logmag0});
     }
-    const uint64_t serial_before = h->blk_serial;
-    auto roll_back = [&](int code) {
-        for (const Saved &s : saved) {
-            s.c->produced = s.produced; s.c->n_seg0 = s.n_seg0; s.c->blk_before = s.blk_before; s.c->blk_after = s.blk_after;
-            s.c->blk_serial = s.blk_serial; s.c->angle0 = s.angle0; s.c->logmag0 = s.logmag0;
-        }
-        if (h->pfb.open) h->pfb.produced = h->pfb.produced_before;
-        h->blk_serial = serial_before;
-        return code;
-    };
+    undo.serial_before = h->blk_serial;
+    undo.armed = true;
+    auto roll_back = [&](int code) { undo_block(h, undo); return code; };
     // channels, by depth then by (D, T) class
     bp.fir_by_depth.resize(bp.max_depth + 1);
     bp.serial = ++h->blk_serial;
@@ -619,6 +602,16 @@ int process_block(rcf_t *h, size_t n)
             return roll_back(RCF_ENOMEM);
         }
     }
+    return RCF_OK;
+}
+
+int process_block(rcf_t *h, size_t n)
+{
+    if (h->graveyard.size() > 512) drain_graveyard(h);     // bounded even if nobody ever syncs or reads
+    BlockPlan bp;
+    BlockUndo undo;
+    int rc = plan_block(h, n, bp, undo);
+    if (rc != RCF_OK) return rc;
     if ((rc = launch_plan(h, bp)) != RCF_OK) return rc;      // kernels may be queued: the handle's stream state is undefined now
     if ((rc = run_scan(h, bp)) != RCF_OK) return rc;
     return finish_block(h, bp);

@@ -38,8 +38,9 @@ struct FirJob {
     // bank-matrix cache entry to mark current once the pack launch has been queued (not before: an error
     // return in between must not leave a key that claims a matrix nobody built)
     rcf::BankCache *bc; std::vector<std::pair<int, uint64_t>> key;
+    std::vector<ChanLaunch> host;      // BlockPlan::defer: records not yet in the arena (the group merges them first)
 };
-struct DiscJob { const DiscLaunch *dev; int n; int max_n; };
+struct DiscJob { const DiscLaunch *dev; int n; int max_n; std::vector<DiscLaunch> host; };
 
 struct BlockPlan {
     int64_t S0 = 0, S1 = 0;            // the block's samples [S0, S1)
@@ -58,7 +59,8 @@ struct BlockPlan {
     size_t arena_need = 0;
     int a = 0;                         // arena in use, and where this commit's records start in it
     size_t arena_base = 0;
-    Arena ar{nullptr, nullptr, 0, 0};
+    Arena own_ar{nullptr, nullptr, 0, 0};
+    Arena *ar = &own_ar;               // a member of a group plans into the group's arena instead
     uint64_t serial = 0;               // Chan::blk_before / blk_after of this block carry it
     std::vector<std::vector<FirJob>> fir_by_depth;
     std::vector<DiscJob> disc_jobs;
@@ -80,6 +82,7 @@ struct BlockPlan {
     const RotFill *d_rot_fills = nullptr;
     const FmFirLaunch *d_symf = nullptr;
     const AudioLaunch *d_audf = nullptr;
+    bool defer = false;                // a member of a group: mergeable records stay on the host (FirJob::host, DiscJob::host)
     bool history_done = false;         // launch_plan copied the history tail together with the launch records
 
     size_t reach(int id) const
@@ -99,7 +102,17 @@ struct ClassPlan {
     bool shared_src = true;
 };
 
+// what planning a block changed in the handle, so that it can be taken back while nothing has been queued
+struct BlockUndo {
+    struct Saved { Chan *c; int64_t produced, n_seg0, blk_before, blk_after; uint64_t blk_serial; long double angle0; double logmag0; };
+    std::vector<Saved> saved;
+    uint64_t serial_before = 0;
+    bool armed = false;
+};
+
 // rcf_plan.cpp
+int plan_block(rcf_t *h, size_t n, BlockPlan &bp, BlockUndo &undo);
+void undo_block(rcf_t *h, BlockUndo &undo);
 int plan_arena(rcf_t *h, BlockPlan &bp);
 int plan_pfb(rcf_t *h, BlockPlan &bp);
 int plan_channel(rcf_t *h, BlockPlan &bp, ClassPlan &cp, Chan *c, int D);

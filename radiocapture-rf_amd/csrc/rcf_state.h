@@ -112,6 +112,26 @@ struct Scan {
 
 }  // namespace rcfx
 
+namespace rcfx {
+// Launch-parameter arenas: two pinned host buffers with device twins.  The records of successive blocks are APPENDED to the
+// current one; only when it is full is an event recorded (every hipEventRecord costs ~6 us of queue gap: rocprof trace
+// of the timed configuration) and the other one taken, once the kernels that read it have finished.
+struct ArenaSet {
+    size_t cap = 8u << 20;
+    unsigned char *h[2] = {nullptr, nullptr};
+    unsigned char *h_dev[2] = {nullptr, nullptr};     // the same pinned memory as the device sees it
+    unsigned char *d[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
+    int cur = 0;
+    size_t fill = 0;              // bytes of the current arena taken by earlier commits
+    bool mapped = true;           // both pinned arenas are visible to the device (copy kernels can read them)
+    int create();
+    void destroy();               // the stream that read them is idle
+    int reserve(size_t need, hipStream_t stream);   // room for `need` more bytes in arena `cur` from `fill` on
+};
+}  // namespace rcfx
+
 using rcfx::Chan;
 using rcfx::Pfb;
 using rcfx::Scan;
@@ -131,17 +151,11 @@ struct rcf {
     float *d_level = nullptr;     // rcf_chan_fm_level result
     void *d_raw = nullptr;        // wire-format staging (rcf_push_raw), block_cap * 4 bytes, lazily allocated
     // launch-parameter arenas (pinned host + device), double buffered
-    size_t arena_cap = 8u << 20;
-    unsigned char *h_arena[2] = {nullptr, nullptr};
-    unsigned char *h_arena_dev[2] = {nullptr, nullptr};   // the same pinned memory as the device sees it
+    rcfx::ArenaSet arenas;
     bool copy_kernels = true;     // RCF_COPY_KERNELS=0: hipMemcpyAsync for the launch records and the history (A/B)
-    unsigned char *d_arena[2] = {nullptr, nullptr};
-    hipEvent_t arena_ev[2] = {nullptr, nullptr};
-    bool arena_used[2] = {false, false};
-    int arena_cur = 0;
-    size_t arena_fill = 0;        // bytes of the current arena taken by earlier commits (records are appended: the event
-                                  // that guards an arena's reuse is recorded when it is LEFT, not once per commit --
-                                  // every hipEventRecord costs ~6 us of queue gap, rocprof trace of the timed configuration)
+    // a handle that belongs to a group (rcf_group_open) runs on the group's stream; its own comes back at rcf_group_close
+    struct rcf_group *group = nullptr;
+    hipStream_t own_stream = nullptr;
     std::map<int, std::unique_ptr<Chan>> chans;
     int next_id = 1;
     Pfb pfb;

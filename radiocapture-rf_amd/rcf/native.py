@@ -38,8 +38,11 @@ SYMBOLS = [
     "rcf_host_alloc", "rcf_host_free", "rcf_comm_unique_id", "rcf_comm_init", "rcf_comm_destroy", "rcf_comm_size",
     "rcf_allgather_peaks", "rcf_allreduce_max", "rcf_pfb_tap_open", "rcf_pfb_shape_supported",
     "rcf_pfb_tap_leakage", "rcf_set_rotator", "rcf_timing_stride",
+    "rcf_group_open", "rcf_group_close", "rcf_group_size", "rcf_group_push", "rcf_group_commit", "rcf_group_read_many",
+    "rcf_group_sync", "rcf_pump_start", "rcf_pump_stats", "rcf_pump_written", "rcf_pump_read", "rcf_pump_stop",
 ]
-FMT_U8, FMT_S8, FMT_S16 = 1, 2, 3
+FMT_CF32, FMT_U8, FMT_S8, FMT_S16 = 0, 1, 2, 3
+READ_IQ, READ_FM = 0, 1
 T_FIR, T_PFB, T_FIR_DERIVED, T_DISC, T_SCAN_FFT, T_SCAN_MOVSUM, T_HISTORY, T_FIR_MFMA, T_AUDIO, T_TAPS = range(10)
 
 
@@ -50,6 +53,25 @@ class AudioParams(C.Structure):
                 ("lpf_taps", C.POINTER(C.c_float)), ("n_lpf", C.c_int), ("n_hpf", C.c_int),
                 ("hpf_taps", C.POINTER(C.c_float)), ("rs_taps", C.POINTER(C.c_float)), ("n_rs", C.c_int),
                 ("interpolation", C.c_int), ("decimation", C.c_int), ("reserved2_", C.c_int)]
+
+
+class PumpConfig(C.Structure):
+    """rcf_pump_config_t (include/rcf.h)"""
+    _fields_ = [("block_samples", C.c_size_t), ("fmt", C.c_int), ("scale", C.c_float), ("offset", C.c_float),
+                ("samp_rate", C.c_double), ("rings", C.POINTER(C.c_void_p)), ("ring_blocks", C.POINTER(C.c_size_t)),
+                ("phase_s", C.POINTER(C.c_double)), ("written", C.POINTER(C.c_void_p)), ("what", C.c_int),
+                ("gain", C.c_float), ("read_members", C.POINTER(C.c_int)), ("read_chans", C.POINTER(C.c_int)),
+                ("n_read", C.c_int), ("out_ring_samples", C.c_size_t), ("n_blocks", C.c_int64),
+                ("warm_blocks", C.c_int64), ("max_batch", C.c_int), ("cpu", C.c_int), ("start_delay_s", C.c_double)]
+
+
+class PumpStats(C.Structure):
+    """rcf_pump_stats_t (include/rcf.h)"""
+    _fields_ = [("blocks_done", C.c_int64), ("blocks_judged", C.c_int64), ("late", C.c_int64), ("overruns", C.c_int64),
+                ("group_blocks", C.c_int64), ("max_batch", C.c_int64), ("samples_out", C.c_int64),
+                ("latency_ms_p50", C.c_double), ("latency_ms_p99", C.c_double), ("latency_ms_max", C.c_double),
+                ("host_plan_ms", C.c_double), ("host_wait_ms", C.c_double), ("elapsed_s", C.c_double),
+                ("running", C.c_int), ("error", C.c_int)]
 
 
 class RcfError(RuntimeError):
@@ -144,6 +166,18 @@ def lib():
         "rcf_comm_size": (C.c_int, [vp]),
         "rcf_allgather_peaks": (C.c_int, [vp, C.POINTER(i64), C.c_int, C.POINTER(i64), C.c_int, ip]),
         "rcf_allreduce_max": (C.c_int, [vp, C.POINTER(C.c_double)]),
+        "rcf_group_open": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp)]),
+        "rcf_group_close": (C.c_int, [vp]),
+        "rcf_group_size": (C.c_int, [vp]),
+        "rcf_group_push": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz), C.c_int, C.c_float, C.c_float]),
+        "rcf_group_commit": (C.c_int, [vp, C.POINTER(sz)]),
+        "rcf_group_read_many": (C.c_int, [vp, C.c_int, ip, ip, C.c_int, C.c_float, vp, sz, C.POINTER(i64)]),
+        "rcf_group_sync": (C.c_int, [vp]),
+        "rcf_pump_start": (C.c_int, [vp, C.POINTER(PumpConfig), C.POINTER(vp)]),
+        "rcf_pump_stats": (C.c_int, [vp, C.POINTER(PumpStats)]),
+        "rcf_pump_written": (i64, [vp, C.c_int]),
+        "rcf_pump_read": (i64, [vp, C.c_int, C.POINTER(i64), vp, sz]),
+        "rcf_pump_stop": (C.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -593,3 +627,163 @@ class Frontend:
         _check(lib().rcf_scan_find_peaks(self._h, prominence, idx.ctypes.data_as(C.POINTER(C.c_int64)), cap,
                                          C.byref(cnt), C.byref(mean), C.byref(dev) if want_device else None))
         return idx[:min(cnt.value, cap)].copy(), mean.value, dev.value
+
+
+_WIRE_DTYPE = {FMT_CF32: np.complex64, FMT_U8: np.uint8, FMT_S8: np.int8, FMT_S16: np.int16}
+
+
+class Group:
+    """G front-ends of one device whose blocks go out as ONE launch per stage (rcf_group_t): the reference's receiver with
+    all its sources in one top block (rc_frontend/receiver.py:67-70,170-204).  The members stay usable one by one (channel
+    control, reads); close the group before closing them."""
+
+    def __init__(self, frontends):
+        self.frontends = list(frontends)
+        self._g = C.c_void_p()
+        arr = (C.c_void_p * len(self.frontends))(*[fe._h for fe in self.frontends])
+        _check(lib().rcf_group_open(arr, len(self.frontends), C.byref(self._g)))
+
+    def close(self):
+        if self._g:
+            _check(lib().rcf_group_close(self._g))
+            self._g = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return len(self.frontends)
+
+    def push(self, blocks, fmt=FMT_CF32, scale=1.0, offset=0.0):
+        """blocks[i]: member i's next block (complex64 for FMT_CF32, interleaved I,Q in the wire type otherwise), or
+        None / empty to skip the member this time."""
+        n = len(self.frontends)
+        if len(blocks) != n:
+            raise ValueError("one block (or None) per member")
+        dt = _WIRE_DTYPE[fmt]
+        keep, ptrs, cnt = [], (C.c_void_p * n)(), (C.c_size_t * n)()
+        for i, b in enumerate(blocks):
+            if b is None or len(b) == 0:
+                ptrs[i], cnt[i] = None, 0
+                continue
+            b = np.ascontiguousarray(b, dtype=dt)
+            keep.append(b)
+            ptrs[i] = b.ctypes.data
+            cnt[i] = len(b) if fmt == FMT_CF32 else b.size // 2
+        _check(lib().rcf_group_push(self._g, ptrs, cnt, int(fmt), float(scale), float(offset)))
+
+    def commit(self, counts):
+        n = len(self.frontends)
+        cnt = (C.c_size_t * n)(*[int(c) for c in counts])
+        _check(lib().rcf_group_commit(self._g, cnt))
+
+    def sync(self):
+        _check(lib().rcf_group_sync(self._g))
+
+    def read_many(self, pairs, what="iq", gain=1.0, cap_each=1 << 14):
+        """pairs: [(member index, channel id), ...] -> list of arrays (None where the channel is gone), ONE gather launch
+        and one synchronisation for all of them (rcf_group_read_many)"""
+        n = len(pairs)
+        dt = np.complex64 if what == "iq" else np.float32
+        out = np.empty((max(n, 1), cap_each), dtype=dt)
+        ms = (C.c_int * max(n, 1))(*[int(m) for m, _ in pairs])
+        cs = (C.c_int * max(n, 1))(*[int(c) for _, c in pairs])
+        counts = (C.c_int64 * max(n, 1))()
+        _check(lib().rcf_group_read_many(self._g, READ_IQ if what == "iq" else READ_FM, ms, cs, n, float(gain),
+                                         out.ctypes.data_as(C.c_void_p), int(cap_each), counts))
+        return [None if counts[i] < 0 else out[i, :counts[i]].copy() for i in range(n)]
+
+
+class Pump:
+    """The native real-time loop of a group (rcf_pump_t): one C++ thread takes whichever members' blocks are complete,
+    pushes them as one group block, gathers the subscribed channels' new output into pinned host rings.  `rings[i]`: a
+    PinnedArray (or any pinned uint8 / int8 / int16 / complex64 array) holding whole blocks of member i, replayed
+    cyclically at `samp_rate` of wall-clock time, block boundaries shifted by phase_s[i]."""
+
+    def __init__(self, group, rings, block_samples, samp_rate, subscriptions, fmt=FMT_U8, scale=1.0, offset=0.0,
+                 what="fm", gain=1.0, phase_s=None, out_ring_samples=4096, n_blocks=0, warm_blocks=0, max_batch=0,
+                 cpu=-1, start_delay_s=0.05):
+        self.group = group
+        n = len(group)
+        if len(rings) != n:
+            raise ValueError("one source ring per member")
+        self._keep = []
+        bps = {FMT_CF32: 8, FMT_U8: 2, FMT_S8: 2, FMT_S16: 4}[fmt]
+        rp, rb = (C.c_void_p * n)(), (C.c_size_t * n)()
+        for i, r in enumerate(rings):
+            a = r.array if isinstance(r, PinnedArray) else r
+            self._keep.append(r)
+            rp[i] = a.ctypes.data
+            rb[i] = a.nbytes // (bps * int(block_samples))
+            if rb[i] < 1:
+                raise ValueError("source ring %d is shorter than one block" % i)
+        ph = (C.c_double * n)(*([0.0] * n if phase_s is None else [float(x) for x in phase_s]))
+        ne = len(subscriptions)
+        ms = (C.c_int * max(ne, 1))(*[int(m) for m, _ in subscriptions])
+        cs = (C.c_int * max(ne, 1))(*[int(c) for _, c in subscriptions])
+        cfg = PumpConfig()
+        cfg.block_samples, cfg.fmt, cfg.scale, cfg.offset = int(block_samples), int(fmt), float(scale), float(offset)
+        cfg.samp_rate = float(samp_rate)
+        cfg.rings, cfg.ring_blocks, cfg.phase_s, cfg.written = rp, rb, ph, None
+        cfg.what, cfg.gain = (READ_IQ if what == "iq" else READ_FM), float(gain)
+        cfg.read_members, cfg.read_chans, cfg.n_read = ms, cs, ne
+        cfg.out_ring_samples, cfg.n_blocks, cfg.warm_blocks = int(out_ring_samples), int(n_blocks), int(warm_blocks)
+        cfg.max_batch, cfg.cpu, cfg.start_delay_s = int(max_batch), int(cpu), float(start_delay_s)
+        self.what = what
+        self.n_entries = ne
+        self._cursors = [C.c_int64(0) for _ in range(ne)]
+        self._p = C.c_void_p()
+        _check(lib().rcf_pump_start(group._g, C.byref(cfg), C.byref(self._p)))
+
+    def stats(self):
+        st = PumpStats()
+        lib().rcf_pump_stats(self._p, C.byref(st))
+        d = {k: getattr(st, k) for k, _ in PumpStats._fields_}
+        if st.error:
+            d["error_text"] = lib().rcf_last_error().decode("utf-8", "replace")
+        return d
+
+    def running(self):
+        return bool(self.stats()["running"])
+
+    def wait(self, timeout_s=60.0, poll_s=0.02):
+        """until the pump has finished its n_blocks (or timeout) -> stats"""
+        import time
+        t_end = time.monotonic() + timeout_s
+        while time.monotonic() < t_end:
+            st = self.stats()
+            if not st["running"]:
+                return st
+            time.sleep(poll_s)
+        return self.stats()
+
+    def written(self, entry):
+        return _check(lib().rcf_pump_written(self._p, int(entry)))
+
+    def read(self, entry, max_items=1 << 16):
+        dt = np.complex64 if self.what == "iq" else np.float32
+        out = np.empty(max_items, dtype=dt)
+        n = _check(lib().rcf_pump_read(self._p, int(entry), C.byref(self._cursors[entry]),
+                                       out.ctypes.data_as(C.c_void_p), int(max_items)))
+        return out[:n].copy()
+
+    def stop(self):
+        if self._p:
+            lib().rcf_pump_stop(self._p)
+            self._p = C.c_void_p()
+            self._keep = []
+
+    def __del__(self):
+        try:
+            self.stop()
+        except Exception:
+            pass
