@@ -22,10 +22,11 @@ Outside the timed region, rank 0 at N = 1 also reports:
   scan                   BASELINE configs[2]: 1M-point FFT x 1000 frames / 100-frame average + peak pick
   end_to_end             PCIe-inclusive ingest (pinned cf32 rcf_push_iq, u8 rcf_push_raw), copy overlapped
   realtime               the paced leg: K independent 20 Msps u8 front-ends on this GPU fed at WALL-CLOCK rate in
-                         20 ms blocks (rcf_push_raw from pinned memory) and drained after every block
-                         (rcf_chan_read_many); K doubled until a block misses its deadline -> K_max, channels sustained,
-                         per-block latency p50 / p99, overruns; for the 256-bin + 32 FM shape and for the 1600-bin
-                         reference-grid bank with 256 bins demodulated
+                         20 ms blocks by native pump threads (rcf_pump_*), each driving a GROUP of front-ends
+                         (rcf_group_*: one conversion / filterbank / stage-2 / gather launch for all blocks that are
+                         complete), outputs in pinned host rings; K raised until a block misses its deadline -> K_max
+                         (one attempt per point), channels sustained, per-block latency p50 / p99 / max, overruns; for the
+                         256-bin + 32 FM shape and for the 1600-bin reference-grid bank with 256 bins demodulated
   control_plane          100 x create / release through the frontend_connector protocol
   cpu_baseline           the oracle's C port of the reference path on the host cores: one channel on one core, every
                          physical core busy (pinned, private first-touched streams, 2 s of signal per channel), SURVEY's
@@ -582,22 +583,21 @@ def measure_traffic_live(cfg5, block, kernel_substr, timeout_s=150):
 
 
 # ------------------------------------------------------------------------------------------- paced real-time leg
-def realtime_point(native, pool, K, shape, raw_tile, carriers, device, seconds, block_ms, n_threads, stagger=True):
+def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block_ms, n_pumps, stagger=True):
     """K independent 20 Msps front-ends on ONE GPU (the reference's deployment shape: ten sources per host,
-    configs/config_denver_dev_den817.py:25-118, one channelizer process each), every one fed its own u8 stream --
-    what an SDR link delivers, 2 bytes per sample -- at exactly 20 Msps of WALL-CLOCK time in blocks of `block_ms`
-    through rcf_push_raw from pinned memory, and drained: after each block every front-end's channel outputs are read
-    back to the host (rcf_chan_read_many, the egress pump's read).  Latency of a block = from the instant its last
-    sample exists (the tick) to its channels' outputs being in host memory.  A deadline is missed when that exceeds
-    the block period; an overrun is a tick that STARTS more than one period late (the source's double buffer would
-    have been overwritten)."""
-    import threading
+    configs/config_denver_dev_den817.py:25-118, all of them inside one receiver when no -i is given,
+    rc_frontend/receiver.py:67-70), every one fed its own u8 stream -- what an SDR link delivers, 2 bytes per sample --
+    at exactly 20 Msps of WALL-CLOCK time in blocks of `block_ms`.  The front-ends are shared out over `n_pumps` groups
+    (rcf_group_*), each driven by ONE native thread (rcf_pump_*; no interpreter in the loop): whenever blocks of some of its
+    members are complete the pump pushes them as one group block -- one conversion, one filterbank, one stage-2 / tap and
+    one gather launch for all of them -- and every subscribed channel's discriminator output lands in its pinned host ring.
+    Latency of a block = from the instant its last sample exists to its channels' outputs being in host memory.  A
+    deadline is missed when that exceeds the block period; an overrun is a block the pump only got to more than one
+    period after it was complete (the source's double buffer would have been overwritten)."""
     blk = int(round(FS * block_ms * 1e-3))
     period = blk / FS
     warm = max(2, int(round(1.0 / period)))               # the first second (lazy allocations, module loads, clocks): run, not judged
-    n_ticks = max(4, int(round(seconds / period))) + warm
-    # the front-ends live in a pool that the points of one shape share (opening 768 of them takes longer than running
-    # them for ten seconds); a point uses the first K and starts from drained rings
+    n_blocks = max(4, int(round(seconds / period))) + warm
     t_setup = time.perf_counter()
     fes, chans = pool["fes"], pool["chans"]
     while len(fes) < K:
@@ -613,180 +613,148 @@ def realtime_point(native, pool, K, shape, raw_tile, carriers, device, seconds, 
         fes.append(fe)
         chans.append(ids)
     fes, chans = fes[:K], chans[:K]
-    for i in range(K):                                   # whatever an earlier point left unread
-        while sum(len(g) for g in fes[i].chan_read_many(chans[i], "fm", cap_each=1 << 12) if g is not None):
-            pass
     produced0 = sum(fes[i].chan_produced(c) for i in range(K) for c in chans[i])
-    setup_s = time.perf_counter() - t_setup
-    n_tile = len(raw_tile) // 2
-    lat = [[] for _ in range(n_threads)]
-    stats = [dict(miss=0, overrun=0, read=0, push_ms=0.0, drain_ms=0.0) for _ in range(n_threads)]
-    errors = []
-    t0 = time.perf_counter() + 0.25
-
-    def worker(w):
-        mine = list(range(w, K, n_threads))
-        # (the read's ctypes arguments are built once per front-end: with 256 channels a list-building wrapper costs
-        # ~0.15 ms of interpreter time per call, and sixteen threads share one interpreter lock)
-        plans = {i: fes[i].chan_read_many_plan(chans[i], "fm", gain=1.0, cap_each=1024) for i in mine}
-        st, ls = stats[w], lat[w]
-        # staggered (default): front-end i's blocks complete at t0 + (k + 1) period + (i / K) period -- independent SDRs
-        # are not synchronised, and the GPU then sees a steady flow; burst: every front-end ticks at the same instant
-        phase = {i: (i / K) * period if stagger else 0.0 for i in mine}
-
-        def drain(i, k, due):
-            t_ = time.perf_counter()
-            counts, _ = plans[i]()
-            st["read"] += int(counts.sum())
-            done = time.perf_counter()
-            st["drain_ms"] += (done - t_) * 1e3
-            if k >= warm:
-                ls.append(done - due)
-                if done - due > period:
-                    st["miss"] += 1
-
-        try:
-            for k in range(n_ticks):
-                pending = None                                   # pushed, not yet drained (pipelined by one front-end)
-                first = True
-                for i in mine:
-                    due = t0 + (k + 1) * period + phase[i]       # block k's last sample exists now
-                    now = time.perf_counter()
-                    if now < due:
-                        if pending is not None:                  # use the wait
-                            drain(*pending)
-                            pending = None
-                            now = time.perf_counter()
-                        if now < due:
-                            time.sleep(due - now)
-                    elif now - due > period and k >= warm and (stagger or first):
-                        st["overrun"] += 1
-                    first = False
-                    ta = time.perf_counter()
-                    at = ((i * 7919 + k) * blk) % (n_tile - blk)
-                    fes[i].push_raw(raw_tile[2 * at: 2 * (at + blk)], native.FMT_U8, 1.0 / 32, 127.4)
-                    st["push_ms"] += (time.perf_counter() - ta) * 1e3
-                    if pending is not None:
-                        drain(*pending)
-                    pending = (i, k, due)
-                if pending is not None:
-                    drain(*pending)
-        except Exception as e:
-            errors.append("%s: %s" % (type(e).__name__, e))
-
-    # GPU share of the filterbank / stage-2 / tap kernels, from HIP events around every 4th launch of front-end 0 (sysfs
-    # gpu_busy_percent counts any queued work -- it read ~100 % from K = 16 on -- and a sysfs read asks the SMU: not
-    # something to do inside a run that is judged on 20 ms deadlines)
+    n_ch = len(chans[0]) if chans else 0
+    out_rate = FS / NB / 3 if shape == "pfb256" else 25000.0
+    out_ring = 1 << max(10, int(np.ceil(np.log2(4 * out_rate * period))))   # four blocks of output per channel
+    NP = max(1, min(n_pumps, K))
+    groups, pumps = [], []
+    # every front-end replays its own stretch of the pinned source (src["blocks"] whole blocks, 32 of them per front-end
+    # from a start of its own); staggered: front-end i's blocks complete (i / K) of a period after front-end 0's --
+    # independent SDRs are not synchronised, and the GPU then sees a steady flow; burst: all at the same instant
+    src_arr, n_src = src["array"], src["blocks"]
     t_classes = [native.T_PFB, native.T_FIR_DERIVED, native.T_TAPS, native.T_DISC]
-    fes[0].timing_enable(True, classes=t_classes)
-    fes[0].timing_stride(4)
-    for c_ in t_classes:
-        fes[0].timing_read(c_)
-    import gc
-    ths = [threading.Thread(target=worker, args=(w,)) for w in range(n_threads)]
-    gc.collect()
-    gc.disable()                                         # a generation-2 collection of this process is a 20 ms block
     try:
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
+        for j in range(NP):
+            mine = list(range(j, K, NP))
+            grp = native.Group([fes[i] for i in mine])
+            groups.append(grp)
+        fes[0].timing_enable(True, classes=t_classes)     # (the grouped launches of group 0 are timed on its first member)
+        fes[0].timing_stride(4)
+        for c_ in t_classes:
+            fes[0].timing_read(c_)
+        setup_s = time.perf_counter() - t_setup
+        for j in range(NP):
+            mine = list(range(j, K, NP))
+            rings = [src_arr[2 * blk * ((i * 5) % (n_src - 32)): 2 * blk * ((i * 5) % (n_src - 32) + 32)] for i in mine]
+            subs = [(m, c) for m, i in enumerate(mine) for c in chans[i]]
+            pumps.append(native.Pump(groups[j], rings, blk, FS, subs, fmt=native.FMT_U8, scale=1.0 / 32, offset=127.4,
+                                     what="fm", gain=1.0, phase_s=[(i / K) * period if stagger else 0.0 for i in mine],
+                                     out_ring_samples=out_ring, n_blocks=n_blocks, warm_blocks=warm, start_delay_s=0.25))
+        t_end = time.perf_counter() + n_blocks * period + 0.25 + 10.0
+        stats = []
+        while time.perf_counter() < t_end:
+            stats = [p_.stats() for p_ in pumps]
+            if not any(s_["running"] for s_ in stats):
+                break
+            time.sleep(0.05)
+        stats = [p_.stats() for p_ in pumps]
+        hung = any(s_["running"] for s_ in stats)
     finally:
-        gc.enable()
-    wall = time.perf_counter() - t0
-    per_block_ms = 0.0
+        for p_ in pumps:
+            p_.stop()
+    per_batch_ms = 0.0
     for c_ in t_classes:
         ms_, n_ = fes[0].timing_read(c_)
-        per_block_ms += ms_ / n_ if n_ else 0.0
+        per_batch_ms += ms_ / n_ if n_ else 0.0
     fes[0].timing_enable(False)
+    for g_ in groups:
+        g_.close()
+    errors = [s_.get("error_text", "error %d" % s_["error"]) for s_ in stats if s_["error"]] + (["pump still running at the deadline"] if hung else [])
     produced = sum(fes[i].chan_produced(c) for i in range(K) for c in chans[i]) - produced0
-    read = sum(s["read"] for s in stats)
-    alll = sorted(x for l in lat for x in l)
-    pct = lambda p: alll[min(len(alll) - 1, int(p * len(alll)))] * 1e3 if alll else None
-    n_ch = len(chans[0]) if chans else 0
+    read = sum(s_["samples_out"] for s_ in stats)
+    wall = max(s_["elapsed_s"] for s_ in stats)
+    miss = sum(s_["late"] for s_ in stats)
+    over = sum(s_["overruns"] for s_ in stats)
+    judged = sum(s_["blocks_judged"] for s_ in stats)
+    batches = sum(s_["group_blocks"] for s_ in stats)
     return {
-        "front_ends": K, "staggered": bool(stagger), "seconds": wall, "blocks_per_front_end": n_ticks - warm,
-        "warmup_blocks_not_judged": warm,
-        "block_ms": period * 1e3,
-        "deadline_misses": sum(s["miss"] for s in stats), "ring_overruns": sum(s["overrun"] for s in stats),
+        "front_ends": K, "staggered": bool(stagger), "seconds": wall, "blocks_per_front_end": n_blocks - warm,
+        "warmup_blocks_not_judged": warm, "block_ms": period * 1e3, "pump_threads": NP,
+        "blocks_judged": judged, "deadline_misses": miss, "ring_overruns": over,
         "output_samples_lost": int(produced - read), "errors": errors,
-        "latency_ms_p50": pct(0.50), "latency_ms_p99": pct(0.99), "latency_ms_max": alll[-1] * 1e3 if alll else None,
-        "host_push_ms_per_tick_slowest_thread": max(s["push_ms"] for s in stats) / n_ticks,
-        "host_drain_ms_per_tick_slowest_thread": max(s["drain_ms"] for s in stats) / n_ticks,
-        "host_busy_fraction_slowest_thread": max(s["push_ms"] + s["drain_ms"] for s in stats) / n_ticks / (period * 1e3),
-        "gpu_kernel_us_per_block_front_end_0": per_block_ms * 1e3,
-        "gpu_busy_percent_est": 100.0 * K * per_block_ms / (period * 1e3),
-        "gpu_busy_note": "filterbank + stage-2 / tap-finalize kernels of front-end 0 (HIP events, every 4th launch) x K / block "
-                         "period; the u8 conversion, the gather of the read and the H2D copy are not in it",
-        "pcie_GBps_in": K * FS * 2 / 1e9, "pcie_GBps_out": K * n_ch * (FS / NB / 3 if shape == "pfb256" else 25000.0) * 4 / 1e9,
+        "latency_ms_p50": float(np.median([s_["latency_ms_p50"] for s_ in stats])),
+        "latency_ms_p99": max(s_["latency_ms_p99"] for s_ in stats),
+        "latency_ms_max": max(s_["latency_ms_max"] for s_ in stats),
+        "latency_note": "p50: median over the pump threads; p99 / max: the worst pump thread's",
+        "group_blocks": batches, "front_ends_per_group_block_mean": (judged + K * warm) / max(1, batches),
+        "front_ends_per_group_block_max": max(s_["max_batch"] for s_ in stats),
+        "host_plan_fraction_busiest_pump": max(s_["host_plan_ms"] for s_ in stats) * 1e-3 / wall,
+        "gpu_kernel_us_per_group_block_of_group_0": per_batch_ms * 1e3,
+        "gpu_busy_percent_est": 100.0 * per_batch_ms * 1e-3 * batches / wall,
+        "gpu_busy_note": "filterbank + stage-2 / tap-finalize launches of pump 0's group blocks (HIP events, every 4th) x all "
+                         "group blocks / elapsed; the conversion and the gather launch are not in it",
+        "pcie_GBps_in": K * FS * 2 / 1e9, "pcie_GBps_out": K * n_ch * out_rate * 4 / 1e9,
         "input_Msps_sustained": K * FS / 1e6, "setup_s": setup_s,
-        "ok": not errors and sum(s["miss"] for s in stats) == 0 and sum(s["overrun"] for s in stats) == 0
-              and produced == read,
+        "ok": not errors and miss == 0 and over == 0 and produced == read and judged == K * (n_blocks - warm),
     }
 
 
-def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_first=16, k_cap=768,
-                 shapes=("pfb256", "grid1600"), stagger=True):
-    """`sustained`, as the metric means it: how many 20 Msps front-ends one MI355X keeps up with in real time.  K is
-    doubled from k_first until a point misses a deadline (or k_cap), then the midpoint between the last good and the first
-    bad K is tried once.  Per shape: pfb256 = BASELINE configs[1] per front-end (256-bin bank + 32 FM channels);
-    grid1600 = the 1600-bin reference-grid bank (every bin one of channel.py's 25 kS/s channels) with 256 bins tapped
-    and demodulated."""
-    raw = native.PinnedArray(2 * len(tile), np.uint8)
-    raw.array[:] = np.clip(np.round(tile.view(np.float32) * 32 + 127.4), 0, 255).astype(np.uint8)
-    try:
-        n_threads = max(1, min(16, (os.cpu_count() or 8) // 4))
-    except Exception:
-        n_threads = 4
-    out = {"what": "K independent 20 Msps u8 front-ends on one GPU, paced at wall-clock rate in %.0f ms blocks through "
-                   "rcf_push_raw (pinned), every channel's discriminator output drained to the host after each block "
-                   "(rcf_chan_read_many); %d host threads share the front-ends; %s" % (
-                       block_ms, n_threads,
+def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_first=512, k_cap=1280,
+                 shapes=("pfb256", "grid1600"), stagger=True, n_pumps=0):
+    """`sustained`, as the metric means it: how many 20 Msps front-ends one MI355X keeps up with in real time.  Short
+    points (4 s judged) from k_first upwards in steps of k_first / 2 until one misses a deadline (or k_cap), downwards if
+    the first one already misses; the K found is then CONFIRMED over `seconds`.  EVERY point is one attempt: a point that
+    misses is a miss (`K_max_first_attempt` = the largest K whose FIRST run was clean, which is what `K_max` is too unless
+    the confirmation run disagrees).  Per shape: pfb256 = BASELINE configs[1] per front-end (256-bin bank + 32 FM
+    channels); grid1600 = the 1600-bin reference-grid bank (every bin one of channel.py's 25 kS/s channels) with 256
+    bins tapped and demodulated."""
+    blk = int(round(FS * block_ms * 1e-3))
+    n_src = 64
+    raw = native.PinnedArray(2 * blk * n_src, np.uint8)
+    t8 = np.clip(np.round(tile.view(np.float32) * 32 + 127.4), 0, 255).astype(np.uint8)
+    for b in range(n_src):                               # 64 different blocks: the tile read from 64 different starts
+        at = 2 * ((b * 40961) % (len(tile) - blk))
+        raw.array[2 * blk * b: 2 * blk * (b + 1)] = t8[at: at + 2 * blk] if at + 2 * blk <= len(t8) else np.resize(t8[at:], 2 * blk)
+    src = {"array": raw.array, "blocks": n_src}
+    if not n_pumps:
+        try:
+            n_pumps = max(1, min(8, (os.cpu_count() or 8) // 8))
+        except Exception:
+            n_pumps = 4
+    out = {"what": "K independent 20 Msps u8 front-ends on one GPU, paced at wall-clock rate in %.0f ms blocks; %d native "
+                   "pump threads (rcf_pump_*), each driving one group of front-ends (rcf_group_*): the blocks that are "
+                   "complete go out as ONE conversion / filterbank / stage-2 or tap-finalize / gather launch, every channel's "
+                   "discriminator output lands in its pinned host ring; %s" % (
+                       block_ms, n_pumps,
                        "the front-ends' block boundaries are spread evenly over the block period (independent SDRs are not "
                        "synchronised)" if stagger else "every front-end's block completes at the same instant (worst case)"),
-           "host_threads": n_threads, "seconds_of_the_confirmation_run_at_K_max": seconds,
-           "seconds_per_search_point": min(4.0, seconds), "staggered": bool(stagger)}
+           "pump_threads": n_pumps, "seconds_of_the_confirmation_run_at_K_max": seconds,
+           "seconds_per_search_point": min(4.0, seconds), "staggered": bool(stagger),
+           "attempts_per_point": 1}
     for shape in shapes:
         pts, good, bad = [], None, None
         pool = {"fes": [], "chans": []}
-        K = k_first
         search_s = min(4.0, seconds)                     # the search runs short points; K_max is then CONFIRMED over `seconds`
+        step = max(16, k_first // 2)
 
         def point(K, secs=None):
             secs = search_s if secs is None else secs
-            p = realtime_point(native, pool, K, shape, raw.array, carriers, device, secs, block_ms, min(n_threads, K), stagger)
+            try:
+                p = realtime_point(native, pool, K, shape, src, carriers, device, secs, block_ms, n_pumps, stagger)
+            except Exception as e:                       # (out of memory opening front-end K, ...): a failed point, not a failed leg
+                p = {"front_ends": K, "ok": False, "errors": ["%s: %s" % (type(e).__name__, e)], "seconds": 0.0}
             pts.append(p)
-            n_blocks = K * p["blocks_per_front_end"]
-            if not p["ok"] and not p["errors"] and p["output_samples_lost"] == 0 \
-                    and p["deadline_misses"] + p["ring_overruns"] <= max(2 * K, n_blocks // 100):
-                # at most a tick or two's worth of late blocks (or 1 %): one hiccup of a shared host (the front-ends of a
-                # worker all miss together when its thread is descheduled for > 20 ms), or the limit?  Once more; both
-                # attempts stay in `points`
-                p["retried"] = True
-                p = realtime_point(native, pool, K, shape, raw.array, carriers, device, secs, block_ms, min(n_threads, K), stagger)
-                p["second_attempt"] = True
-                pts.append(p)
             return p
 
+        K = min(k_first, k_cap)
         while K <= k_cap:
-            p = point(K)
-            if p["ok"]:
+            if point(K)["ok"]:
                 good = K
-                K = K * 2 if K * 2 <= k_cap or K == k_cap else k_cap      # the cap itself is the last point of the search
+                if K == k_cap:
+                    break
+                K = min(K + step, k_cap)
             else:
                 bad = K
                 break
-        while good is None and bad is not None and bad > 4:          # the starting point itself failed: search downwards
+        while good is None and bad is not None and bad > 16:           # the starting point itself failed: search downwards
             K = bad // 2
             if point(K)["ok"]:
                 good = K
             else:
                 bad = K
-        if good is not None and bad is not None and bad - good > max(8, good // 4):
-            mid = (good + bad) // 2
-            if point(mid)["ok"]:
-                good = mid
-        # confirmation: the K the short points found, over the full `seconds`; if it does not hold, three quarters of it
+        first_attempt = good or 0
+        # confirmation: the K the short points found, over the full `seconds`; if it does not hold, one step less
         best = None
         for _ in range(3):
             if not good or seconds <= search_s:
@@ -796,7 +764,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
             if p["ok"]:
                 best = p
                 break
-            bad, good = good, max(1, (3 * good) // 4)
+            bad, good = good, max(1, good - step)
         if best is None:
             best = next((p for p in reversed(pts) if p["front_ends"] == good and p["ok"]), None)
             if best is None:
@@ -804,15 +772,15 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
         for fe in pool["fes"]:
             fe.close()
         bins, demod = (NB, len(carriers)) if shape == "pfb256" else (1600, 256)
+        keys = ("front_ends", "ok", "deadline_misses", "ring_overruns", "latency_ms_p50", "latency_ms_p99", "latency_ms_max",
+                "gpu_busy_percent_est", "front_ends_per_group_block_mean", "host_plan_fraction_busiest_pump", "errors",
+                "seconds", "confirmation_run")
         out[shape] = {
-            "K_max": good or 0, "first_K_that_missed": bad, "bins_per_front_end": bins, "demodulated_per_front_end": demod,
+            "K_max": good or 0, "K_max_first_attempt": first_attempt, "first_K_that_missed": bad,
+            "bins_per_front_end": bins, "demodulated_per_front_end": demod,
             "channels_sustained": (good or 0) * bins, "fm_channels_sustained": (good or 0) * demod,
             "input_Msps_sustained": (good or 0) * FS / 1e6,
-            "at_K_max": best, "points": [{k: p[k] for k in ("front_ends", "ok", "deadline_misses", "ring_overruns",
-                                                            "latency_ms_p50", "latency_ms_p99", "gpu_busy_percent_est",
-                                                            "host_push_ms_per_tick_slowest_thread",
-                                                            "host_drain_ms_per_tick_slowest_thread", "errors", "seconds")} | {k: p[k] for k in ("retried", "second_attempt", "confirmation_run") if k in p}
-                                         for p in pts],
+            "at_K_max": best, "points": [{k: p[k] for k in keys if k in p} for p in pts],
         }
     raw.free()
     return out
@@ -919,8 +887,10 @@ def main():
     ap.add_argument("--sweep-max", type=int, default=196608, help="largest direct-bank channel count to open")
     ap.add_argument("--rt-seconds", type=float, default=10.0, help="seconds per point of the paced real-time leg (0 = skip it)")
     ap.add_argument("--rt-block-ms", type=float, default=20.0, help="block length of the paced real-time leg")
-    ap.add_argument("--rt-k-first", type=int, default=256, help="front-end count the real-time search starts at")
-    ap.add_argument("--rt-k-cap", type=int, default=768, help="largest front-end count the real-time search tries")
+    ap.add_argument("--rt-k-first", type=int, default=512, help="front-end count the real-time search starts at")
+    ap.add_argument("--rt-k-cap", type=int, default=1280, help="largest front-end count the real-time search tries")
+    ap.add_argument("--rt-pumps", type=int, default=0, help="native pump threads (groups) of the real-time leg (0: cores / 8, at most 8)")
+    ap.add_argument("--rt-shapes", default="pfb256,grid1600", help="shapes of the real-time leg")
     ap.add_argument("--rt-burst", action="store_true",
                     help="real-time leg: every front-end's block completes at the same instant (default: spread over the period)")
     args = ap.parse_args()
@@ -1258,7 +1228,8 @@ def main():
             try:
                 out["realtime"] = realtime_leg(native, tile, meta["carriers"], local_rank, seconds=args.rt_seconds,
                                                block_ms=args.rt_block_ms, k_first=args.rt_k_first, k_cap=args.rt_k_cap,
-                                               stagger=not args.rt_burst)
+                                               stagger=not args.rt_burst, n_pumps=args.rt_pumps,
+                                               shapes=tuple(x for x in args.rt_shapes.split(",") if x))
             except Exception as e:                       # a leg outside the timed region must not cost the run its line
                 out["realtime"] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["control_plane"] = control_plane_leg(local_rank)

@@ -76,7 +76,7 @@ int group_process(rcf_group *g, const std::vector<GroupItem> &items, int fmt, fl
     hipStream_t st = g->stream;
     const size_t bps = group_sample_bytes(fmt);
     const size_t NI = items.size();
-    rcf_t *h0 = g->members[(size_t)items[0].m];
+    rcf_t *h0 = g->members[0];                  // merged launches are timed on the first member (rcf_timing_* of that handle)
 
     // ---- 1. room in the group's arena for every member's records and the group's own
     size_t need = 16384 + NI * (3 * sizeof(PrepRec) + sizeof(PfbLaunch) + sizeof(TapFinArgs) + 4 * sizeof(int32_t) + 512);

@@ -282,11 +282,14 @@ def test_pump_feeds_a_group_in_real_time_and_delivers_the_same_bits(gpu_required
     fes, ids = open_all()
     k = 0
     for m in range(3):
+        want = [[] for _ in ids[m]]
         for b in range(n_blocks):
             fes[m].push_raw(srcs[m][2 * b * blk: 2 * (b + 1) * blk], nat.FMT_U8, 1.0 / 32, 127.4)
-        for c in ids[m]:
-            want = fes[m].chan_read_fm(c, 5.0)
-            assert len(want) > 1000 and _same_bits(got[k], want)
+            for j, c in enumerate(ids[m]):
+                want[j].append(fes[m].chan_read_fm(c, 5.0))
+        for j in range(len(ids[m])):
+            w = np.concatenate(want[j])
+            assert len(w) > 5000 and _same_bits(got[k], w)
             k += 1
         fes[m].close()
     for r in rings:
