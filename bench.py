@@ -583,7 +583,7 @@ def measure_traffic_live(cfg5, block, kernel_substr, timeout_s=150):
 
 
 # ------------------------------------------------------------------------------------------- paced real-time leg
-def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block_ms, n_pumps, stagger=True):
+def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block_ms, n_pumps, stagger=True, window_ms=1.0):
     """K independent 20 Msps front-ends on ONE GPU (the reference's deployment shape: ten sources per host,
     configs/config_denver_dev_den817.py:25-118, all of them inside one receiver when no -i is given,
     rc_frontend/receiver.py:67-70), every one fed its own u8 stream -- what an SDR link delivers, 2 bytes per sample --
@@ -619,10 +619,11 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
     out_ring = 1 << max(10, int(np.ceil(np.log2(4 * out_rate * period))))   # four blocks of output per channel
     NP = max(1, min(n_pumps, K))
     groups, pumps = [], []
-    # every front-end replays its own stretch of the pinned source (src["blocks"] whole blocks, 32 of them per front-end
-    # from a start of its own); staggered: front-end i's blocks complete (i / K) of a period after front-end 0's --
-    # independent SDRs are not synchronised, and the GPU then sees a steady flow; burst: all at the same instant
-    src_arr, n_src = src["array"], src["blocks"]
+    # every front-end replays its OWN two blocks of the pinned source (K x 1.6 MB: no cache between the host's DRAM and
+    # the GPU holds that); staggered: front-end i's blocks complete (i / K) of a period after front-end 0's -- independent
+    # SDRs are not synchronised, and the GPU then sees a steady flow; burst: all at the same instant
+    src_arr = src["array"]
+    assert len(src_arr) >= 2 * blk * 2 * K
     t_classes = [native.T_PFB, native.T_FIR_DERIVED, native.T_TAPS, native.T_DISC]
     try:
         for j in range(NP):
@@ -636,11 +637,12 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
         setup_s = time.perf_counter() - t_setup
         for j in range(NP):
             mine = list(range(j, K, NP))
-            rings = [src_arr[2 * blk * ((i * 5) % (n_src - 32)): 2 * blk * ((i * 5) % (n_src - 32) + 32)] for i in mine]
+            rings = [src_arr[2 * blk * 2 * i: 2 * blk * 2 * (i + 1)] for i in mine]
             subs = [(m, c) for m, i in enumerate(mine) for c in chans[i]]
             pumps.append(native.Pump(groups[j], rings, blk, FS, subs, fmt=native.FMT_U8, scale=1.0 / 32, offset=127.4,
                                      what="fm", gain=1.0, phase_s=[(i / K) * period if stagger else 0.0 for i in mine],
-                                     out_ring_samples=out_ring, n_blocks=n_blocks, warm_blocks=warm, start_delay_s=0.25))
+                                     out_ring_samples=out_ring, n_blocks=n_blocks, warm_blocks=warm, start_delay_s=0.25,
+                                     batch_window_s=window_ms * 1e-3))
         t_end = time.perf_counter() + n_blocks * period + 0.25 + 10.0
         stats = []
         while time.perf_counter() < t_end:
@@ -670,7 +672,7 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
     batches = sum(s_["group_blocks"] for s_ in stats)
     return {
         "front_ends": K, "staggered": bool(stagger), "seconds": wall, "blocks_per_front_end": n_blocks - warm,
-        "warmup_blocks_not_judged": warm, "block_ms": period * 1e3, "pump_threads": NP,
+        "warmup_blocks_not_judged": warm, "block_ms": period * 1e3, "pump_threads": NP, "batch_window_ms": window_ms,
         "blocks_judged": judged, "deadline_misses": miss, "ring_overruns": over,
         "output_samples_lost": int(produced - read), "errors": errors,
         "latency_ms_p50": float(np.median([s_["latency_ms_p50"] for s_ in stats])),
@@ -691,7 +693,7 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
 
 
 def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_first=512, k_cap=1280,
-                 shapes=("pfb256", "grid1600"), stagger=True, n_pumps=0):
+                 shapes=("pfb256", "grid1600"), stagger=True, n_pumps=0, window_ms=1.0):
     """`sustained`, as the metric means it: how many 20 Msps front-ends one MI355X keeps up with in real time.  Short
     points (4 s judged) from k_first upwards in steps of k_first / 2 until one misses a deadline (or k_cap), downwards if
     the first one already misses; the K found is then CONFIRMED over `seconds`.  EVERY point is one attempt: a point that
@@ -700,16 +702,15 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
     channels); grid1600 = the 1600-bin reference-grid bank (every bin one of channel.py's 25 kS/s channels) with 256
     bins tapped and demodulated."""
     blk = int(round(FS * block_ms * 1e-3))
-    n_src = 64
-    raw = native.PinnedArray(2 * blk * n_src, np.uint8)
+    raw = native.PinnedArray(2 * blk * 2 * k_cap, np.uint8)   # two blocks of its own per front-end
     t8 = np.clip(np.round(tile.view(np.float32) * 32 + 127.4), 0, 255).astype(np.uint8)
-    for b in range(n_src):                               # 64 different blocks: the tile read from 64 different starts
+    for b in range(2 * k_cap):                           # the tile read from a different start for every block
         at = 2 * ((b * 40961) % (len(tile) - blk))
-        raw.array[2 * blk * b: 2 * blk * (b + 1)] = t8[at: at + 2 * blk] if at + 2 * blk <= len(t8) else np.resize(t8[at:], 2 * blk)
-    src = {"array": raw.array, "blocks": n_src}
+        raw.array[2 * blk * b: 2 * blk * (b + 1)] = t8[at: at + 2 * blk]
+    src = {"array": raw.array}
     if not n_pumps:
         try:
-            n_pumps = max(1, min(8, (os.cpu_count() or 8) // 8))
+            n_pumps = max(1, min(2, (os.cpu_count() or 8) // 8))
         except Exception:
             n_pumps = 4
     out = {"what": "K independent 20 Msps u8 front-ends on one GPU, paced at wall-clock rate in %.0f ms blocks; %d native "
@@ -721,7 +722,8 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
                        "synchronised)" if stagger else "every front-end's block completes at the same instant (worst case)"),
            "pump_threads": n_pumps, "seconds_of_the_confirmation_run_at_K_max": seconds,
            "seconds_per_search_point": min(4.0, seconds), "staggered": bool(stagger),
-           "attempts_per_point": 1}
+           "attempts_per_point": 1, "batch_window_ms": window_ms,
+           "batch_window_note": "a complete block waits up to this long for the blocks that complete meanwhile: they share its launches"}
     for shape in shapes:
         pts, good, bad = [], None, None
         pool = {"fes": [], "chans": []}
@@ -731,7 +733,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
         def point(K, secs=None):
             secs = search_s if secs is None else secs
             try:
-                p = realtime_point(native, pool, K, shape, src, carriers, device, secs, block_ms, n_pumps, stagger)
+                p = realtime_point(native, pool, K, shape, src, carriers, device, secs, block_ms, n_pumps, stagger, window_ms)
             except Exception as e:                       # (out of memory opening front-end K, ...): a failed point, not a failed leg
                 p = {"front_ends": K, "ok": False, "errors": ["%s: %s" % (type(e).__name__, e)], "seconds": 0.0}
             pts.append(p)
@@ -889,7 +891,8 @@ def main():
     ap.add_argument("--rt-block-ms", type=float, default=20.0, help="block length of the paced real-time leg")
     ap.add_argument("--rt-k-first", type=int, default=512, help="front-end count the real-time search starts at")
     ap.add_argument("--rt-k-cap", type=int, default=1280, help="largest front-end count the real-time search tries")
-    ap.add_argument("--rt-pumps", type=int, default=0, help="native pump threads (groups) of the real-time leg (0: cores / 8, at most 8)")
+    ap.add_argument("--rt-pumps", type=int, default=0, help="native pump threads (groups) of the real-time leg (0: two)")
+    ap.add_argument("--rt-window-ms", type=float, default=1.0, help="batching window of the pumps: a complete block waits this long for company")
     ap.add_argument("--rt-shapes", default="pfb256,grid1600", help="shapes of the real-time leg")
     ap.add_argument("--rt-burst", action="store_true",
                     help="real-time leg: every front-end's block completes at the same instant (default: spread over the period)")
@@ -1228,7 +1231,7 @@ def main():
             try:
                 out["realtime"] = realtime_leg(native, tile, meta["carriers"], local_rank, seconds=args.rt_seconds,
                                                block_ms=args.rt_block_ms, k_first=args.rt_k_first, k_cap=args.rt_k_cap,
-                                               stagger=not args.rt_burst, n_pumps=args.rt_pumps,
+                                               stagger=not args.rt_burst, n_pumps=args.rt_pumps, window_ms=args.rt_window_ms,
                                                shapes=tuple(x for x in args.rt_shapes.split(",") if x))
             except Exception as e:                       # a leg outside the timed region must not cost the run its line
                 out["realtime"] = {"error": "%s: %s" % (type(e).__name__, e)}

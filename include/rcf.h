@@ -462,6 +462,7 @@ typedef struct rcf_pump_config {
     int max_batch;                       /* most members per group block (0: all that are ready) */
     int cpu;                             /* pin the thread to this CPU (-1: leave it to the scheduler) */
     double start_delay_s;                /* t0 = now + this */
+    double batch_window_s;               /* a complete block waits up to this long for others to share its launches (0: none) */
 } rcf_pump_config_t;
 typedef struct rcf_pump_stats {
     int64_t blocks_done;                 /* member blocks whose outputs are in host memory */

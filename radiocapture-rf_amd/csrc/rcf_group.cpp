@@ -529,7 +529,14 @@ void pump_main(rcf_pump *p)
             due.push_back(d);
         }
         if (all_finished && in_flight == 0) break;
-        if (!items.empty() && in_flight < 2) {
+        // batching window: the first block that is complete waits up to batch_window_s for company -- every block that
+        // completes meanwhile rides in the same launches (at K front-ends a block completes every period / K)
+        bool hold = false;
+        if (!items.empty() && cfg.batch_window_s > 0 && !(cfg.max_batch > 0 && (int)items.size() >= cfg.max_batch)) {
+            const double oldest = *std::min_element(due.begin(), due.end());
+            if (now_s - oldest < cfg.batch_window_s) { hold = true; next_due = std::min(next_due, oldest + cfg.batch_window_s); }
+        }
+        if (!items.empty() && !hold && in_flight < 2) {
             const Clock::time_point p0 = Clock::now();
             const int slot = head ^ (in_flight & 1);
             InFlight &s = slots[slot];
@@ -598,7 +605,7 @@ void pump_main(rcf_pump *p)
         }
         if (in_flight > 0) {
             // nothing to queue (or both slots taken): the oldest batch's outputs are what the host waits for
-            if (!items.empty() || next_due - now_s > 200e-6) { (void)complete_oldest(true); continue; }
+            if ((!items.empty() && !hold) || next_due - now_s > 200e-6) { (void)complete_oldest(true); continue; }
             if (complete_oldest(false)) continue;
         }
         const double wait_s = next_due - secs(Clock::now() - t0);
