@@ -7,6 +7,7 @@
 //   x = (float(raw) - offset) * scale     (float32, unfused: the drivers' lookup-table semantics)
 // Bound: HBM, 2|4 B read + 8 B written per sample; 16 bytes stored per lane.
 #include <algorithm>
+#include <cstdlib>
 
 #include "rcf_internal.h"
 
@@ -140,7 +141,7 @@ void launch_gather_view(const StreamView &v, int64_t first, float2 *dst, size_t 
 // (pinned, device-mapped arena): 64 bytes once per workgroup.
 namespace {
 
-constexpr int kPrepTile = 2048;      // samples (or 8-byte words) per workgroup: 256 threads x 2 x 4
+constexpr int kPrepTile = 2048;      // samples (or 8-byte words) per tile: 256 threads x 2 x 4
 
 template <typename T, int NV>
 __device__ __forceinline__ void prep_load(const PrepRec &r, uint32_t i, float (&v)[4])
@@ -172,12 +173,10 @@ __device__ __forceinline__ void prep_store(const PrepRec &r, uint32_t i, int cnt
     }
 }
 
-__global__ __launch_bounds__(256) void group_prep_kernel(const PrepRec *__restrict__ recs)
+// one tile (kPrepTile samples or words from `base` on) of one record
+__device__ __forceinline__ void prep_tile(const PrepRec &r, const uint32_t base, const int tid)
 {
-    const PrepRec r = recs[blockIdx.y];
-    const uint32_t base = blockIdx.x * (uint32_t)kPrepTile;
     if (base >= r.n) return;
-    const int tid = threadIdx.x;
     if (r.fmt < 0) {                                   // plain copy, n 8-byte words
         const unsigned long long *s = static_cast<const unsigned long long *>(r.src);
         unsigned long long *d = reinterpret_cast<unsigned long long *>(r.dst);
@@ -220,12 +219,54 @@ __global__ __launch_bounds__(256) void group_prep_kernel(const PrepRec *__restri
         if (cnt[u]) prep_store(r, base + 2 * (u * 256 + tid), cnt[u], v[u]);
 }
 
+// A BOUNDED grid: the kernel is PCIe-bound (its loads cross the link), and a workgroup that waits for the link holds its
+// slot on a CU -- launched one workgroup per tile (thousands), the blocks of one group's ingest starved the OTHER groups'
+// filterbank launches of CUs (rocprof of the real-time leg: 27 front-ends' filterbank 132 us instead of ~40).  So
+// kPrepWgs workgroups (RCF_PREP_WGS) each walk a contiguous range of the launch's tiles; records[i].tile_first (host) says
+// where record i's tiles start, all of them are fetched into LDS once, the 64-byte record itself only when the range
+// crosses into the next record.
+__global__ __launch_bounds__(256) void group_prep_kernel(const PrepRec *__restrict__ recs, int n_recs, uint32_t total_tiles)
+{
+    __shared__ uint32_t tf[kPrepMaxRecs + 1];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n_recs; i += 256) tf[i] = recs[i].tile_first;
+    if (tid == 0) tf[n_recs] = total_tiles;
+    __syncthreads();
+    const uint32_t per = (total_tiles + gridDim.x - 1) / gridDim.x;
+    uint32_t t = blockIdx.x * per;
+    const uint32_t t_end = min(total_tiles, t + per);
+    if (t >= t_end) return;
+    int lo = 0, hi = n_recs;                           // record of tile t: tf[lo] <= t < tf[lo + 1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tf[mid] <= t) lo = mid; else hi = mid;
+    }
+    int ri = __builtin_amdgcn_readfirstlane(lo);
+    PrepRec r = recs[ri];
+    for (; t < t_end; ++t) {
+        while (t >= tf[ri + 1]) { ++ri; r = recs[ri]; }    // (records without tiles -- n = 0 -- are stepped over)
+        prep_tile(r, (t - tf[ri]) * (uint32_t)kPrepTile, tid);
+    }
+}
+
 }  // namespace
 
-void launch_group_prep(const PrepRec *d_recs, int n_recs, uint32_t max_n, hipStream_t s)
+// recs: as the DEVICE reads them (the pinned arena); tile_first filled in by fill_prep_tiles().  At most kPrepMaxRecs per launch.
+void launch_group_prep(const PrepRec *d_recs, int n_recs, uint32_t total_tiles, hipStream_t s)
 {
-    if (n_recs <= 0 || max_n == 0) return;
-    hipLaunchKernelGGL(group_prep_kernel, dim3((max_n + kPrepTile - 1) / kPrepTile, (unsigned)n_recs), dim3(256), 0, s, d_recs);
+    if (n_recs <= 0 || total_tiles == 0) return;
+    static const unsigned cap = [] { const char *e = getenv("RCF_PREP_WGS"); const int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 512); }();
+    hipLaunchKernelGGL(group_prep_kernel, dim3(std::min<unsigned>(cap, total_tiles)), dim3(256), 0, s, d_recs, n_recs, total_tiles);
+}
+
+uint32_t fill_prep_tiles(PrepRec *recs, int n_recs)
+{
+    uint32_t t = 0;
+    for (int i = 0; i < n_recs; ++i) {
+        recs[i].tile_first = t;
+        t += (recs[i].n + (uint32_t)kPrepTile - 1) / (uint32_t)kPrepTile;
+    }
+    return t;
 }
 
 size_t raw_sample_bytes(int fmt)

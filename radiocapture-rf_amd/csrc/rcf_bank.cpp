@@ -74,6 +74,7 @@ int rcf_pfb_close(rcf_t *h)
     }
     bury(h, p.d_ptaps); bury(h, p.d_tw); bury(h, p.d_bins); bury(h, p.d_stage);
     p = Pfb();
+    ++h->chans_epoch;
     return RCF_OK;
 }
 

@@ -117,6 +117,7 @@ int new_channel(rcf_t *h, int src, int D, const float *taps, int T, double offse
     c->id = h->next_id++;
     *chan_id = c->id;
     h->chans[c->id] = std::move(c);
+    ++h->chans_epoch;
     return RCF_OK;
 }
 
@@ -302,6 +303,7 @@ int rcf_chan_close(rcf_t *h, int chan_id)
     FIND_CHAN(h, chan_id, c);
     free_channel(h, c);
     h->chans.erase(chan_id);
+    ++h->chans_epoch;
     return RCF_OK;
 }
 

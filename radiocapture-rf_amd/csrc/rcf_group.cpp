@@ -83,12 +83,7 @@ int group_process(rcf_group *g, const std::vector<GroupItem> &items, int fmt, fl
     for (const GroupItem &it : items) {
         rcf_t *h = g->members[(size_t)it.m];
         if (h->graveyard.size() > 512) drain_graveyard(h);
-        BlockPlan tmp;
-        Arena dummy{nullptr, nullptr, 0, 0};
-        tmp.ar = &dummy;
-        int rc = plan_arena(h, tmp);
-        if (rc != RCF_OK) return rc;
-        need += tmp.arena_need;
+        need += arena_need_bound(h);
     }
     if (g->arenas.reserve(need, st) != RCF_OK) return RCF_EHIP;
     if (!g->arenas.mapped) { set_error("group launches need device-mapped pinned memory for their records"); return RCF_ESTATE; }
@@ -284,6 +279,10 @@ int group_process(rcf_group *g, const std::vector<GroupItem> &items, int fmt, fl
             prep_max = std::max(prep_max, c.n);
         }
     }
+    // (at most kPrepMaxRecs records per launch: more go out as further launches)
+    std::vector<uint32_t> prep_tiles;
+    for (size_t at = 0; at < prep.size(); at += kPrepMaxRecs)
+        prep_tiles.push_back(fill_prep_tiles(prep.data() + at, (int)std::min<size_t>(kPrepMaxRecs, prep.size() - at)));
     const PrepRec *d_prep = nullptr;
     if (!ga.put(prep, &d_prep)) return oom();
     // (the kernel reads ITS records where the host wrote them: the pinned arena as the device sees it)
@@ -292,7 +291,8 @@ int group_process(rcf_group *g, const std::vector<GroupItem> &items, int fmt, fl
     g->arenas.fill = (ga.used + 63) & ~size_t(63);
 
     // ---- 6. launches, in dependency order.  From here on a failure leaves queued work behind: no roll-back.
-    launch_group_prep(prep_mapped, (int)prep.size(), prep_max, st);
+    for (size_t at = 0, li = 0; at < prep.size(); at += kPrepMaxRecs, ++li)
+        launch_group_prep(prep_mapped + at, (int)std::min<size_t>(kPrepMaxRecs, prep.size() - at), prep_tiles[li], st);
     if (wait) RCF_HIP(hipEventRecord(g->ingest_ev, st));
     if (d_rots) launch_rot_fill(d_rots, (int)rots.size(), h0->ring_mask, st);
     auto launch_depth = [&](size_t d, int timing_class_default) {
@@ -471,6 +471,8 @@ void pump_main(rcf_pump *p)
     int head = 0, in_flight = 0;                   // slots[head] is the oldest busy one
     std::vector<GroupItem> items;
     std::vector<int64_t> queued(p->rd_member.size(), 0);   // items ever queued for the host ring of each subscribed channel
+    std::vector<Chan *> chan_of(p->rd_member.size(), nullptr);      // subscribed channels, resolved once per channel-set epoch
+    std::vector<uint64_t> epoch_of(G, ~0ull);
     const uint32_t ew = (uint32_t)(p->elem / 4);
 
     auto complete_oldest = [&](bool block) -> bool {
@@ -562,10 +564,16 @@ void pump_main(rcf_pump *p)
                     uint32_t max_w = 0;
                     for (const GroupItem &it : items) {
                         rcf_t *h = g->members[(size_t)it.m];
+                        if (epoch_of[(size_t)it.m] != h->chans_epoch) {            // channels were opened / closed: look them up again
+                            for (int e : p->entries_of[(size_t)it.m]) {
+                                auto f = h->chans.find(p->rd_chan[(size_t)e]);
+                                chan_of[(size_t)e] = f == h->chans.end() ? nullptr : f->second.get();
+                            }
+                            epoch_of[(size_t)it.m] = h->chans_epoch;
+                        }
                         for (int e : p->entries_of[(size_t)it.m]) {
-                            auto f = h->chans.find(p->rd_chan[(size_t)e]);
-                            if (f == h->chans.end()) continue;                     // closed under the pump: starves
-                            Chan *c = f->second.get();
+                            Chan *c = chan_of[(size_t)e];
+                            if (!c) continue;                                      // closed under the pump: starves
                             int64_t *cur = cfg.what == RCF_READ_IQ ? &c->rd_iq : &c->rd_fm;
                             int64_t avail = c->produced - *cur;
                             if (avail <= 0) continue;

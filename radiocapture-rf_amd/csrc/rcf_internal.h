@@ -433,10 +433,13 @@ struct PrepRec {
     float scale, offset;
     int32_t aligned;         // src allows one vector load per two samples (4 / 8 / 16-byte aligned for 8 / 16 / 32-bit items)
     int32_t dst_aligned;     // dst is 16-byte aligned
-    int32_t pad_[3];
+    uint32_t tile_first;     // first tile of this record among the launch's tiles (fill_prep_tiles)
+    int32_t pad_[2];
 };
+constexpr int kPrepMaxRecs = 1024;   // records per launch_group_prep
 static_assert(sizeof(PrepRec) == 64, "one record = one 64-byte line of the pinned arena");
-void launch_group_prep(const PrepRec *d_recs, int n_recs, uint32_t max_n, hipStream_t s);
+uint32_t fill_prep_tiles(PrepRec *recs, int n_recs);     // sets tile_first; returns the launch's tile count
+void launch_group_prep(const PrepRec *d_recs, int n_recs, uint32_t total_tiles, hipStream_t s);
 // dst[0, bytes) = src[0, bytes), both 8-byte aligned, bytes rounded up to 8; src may be pinned (device-mapped) host memory
 void launch_copy8(void *dst, const void *src, size_t bytes, hipStream_t s);
 void launch_copy8x2(void *d0, const void *s0, size_t bytes0, void *d1, const void *s1, size_t bytes1, hipStream_t s);

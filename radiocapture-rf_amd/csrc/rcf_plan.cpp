@@ -5,6 +5,15 @@
 
 namespace rcfx {
 
+// an upper bound of what plan_arena() will ask for, without walking the channels (a group sizes its arena for all of its
+// members before it plans any of them)
+size_t arena_need_bound(const rcf_t *h)
+{
+    const size_t n = h->chans.size();
+    return 4096 + n * (2 * sizeof(ChanLaunch) + sizeof(TapLaunch) + sizeof(DiscLaunch) + sizeof(RotFill) + 12 + 128 +
+                       sizeof(FmFirLaunch) + sizeof(AudioLaunch)) + 64 * (n / 4 + 64);
+}
+
 // arena for this commit: sized for every channel's launch records before anything is scheduled, so the schedule
 // cannot run out half way (it mutates channel state as it goes); also the consumers' reach and the deepest chain
 int plan_arena(rcf_t *h, BlockPlan &bp)

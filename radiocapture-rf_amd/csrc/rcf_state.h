@@ -157,6 +157,7 @@ struct rcf {
     struct rcf_group *group = nullptr;
     hipStream_t own_stream = nullptr;
     std::map<int, std::unique_ptr<Chan>> chans;
+    uint64_t chans_epoch = 0;     // bumped whenever a channel is opened or closed (cached Chan pointers: the pump's)
     int next_id = 1;
     Pfb pfb;
     Scan scan;
