@@ -25,7 +25,7 @@ int plan_arena(rcf_t *h, BlockPlan &bp)
     {
         // (one pass over the channel map for everything that needs one: at 196608 channels each pass is ~8 ms of
         // pointer chasing)
-        size_t need = 4096;
+        size_t need = 4096, pfb_reach = 0;
         for (auto &kv : h->chans) {
             const Chan &c = *kv.second;
             need += 2 * sizeof(ChanLaunch) + sizeof(TapLaunch) + sizeof(DiscLaunch) + sizeof(RotFill) + 12 + 128;
@@ -35,12 +35,19 @@ int plan_arena(rcf_t *h, BlockPlan &bp)
             if (c.src < 0 && (bp.min_d0 == 0 || c.D < bp.min_d0)) bp.min_d0 = c.D;
             if (c.audio) bp.max_reach = std::max<size_t>(bp.max_reach, (size_t)std::max(std::max(c.audio->n_lpf, c.audio->n_hpf), c.audio->nt_rs));
             if (c.d_sym) { size_t &own = reach_x[c.id]; own = std::max<size_t>(own, std::max<size_t>(1, (size_t)c.sym_ntaps)); }
-            if (c.src >= 0) {
-                size_t &r = reach_x[c.src >= RCF_SRC_PFB_BIN0 ? RCF_SRC_PFB_BIN0 : c.src];
+            if (c.src >= RCF_SRC_PFB_BIN0) {              // (the bank's ring: one entry for all of its consumers, set after the loop)
+                pfb_reach = std::max<size_t>(pfb_reach, (size_t)(c.T - 1 + c.D));
+            } else if (c.src >= 0) {
+                size_t &r = reach_x[c.src];
                 r = std::max<size_t>(r, (size_t)(c.T - 1 + c.D));
                 bp.max_reach = std::max(bp.max_reach, r);
             }
             if (c.d_sym) bp.max_reach = std::max<size_t>(bp.max_reach, (size_t)c.sym_ntaps);
+        }
+        if (pfb_reach) {
+            size_t &r = reach_x[RCF_SRC_PFB_BIN0];
+            r = std::max(r, pfb_reach);
+            bp.max_reach = std::max(bp.max_reach, r);
         }
         need += 64 * (h->chans.size() / 4 + 64);              // per-class alignment slack
         arena_need = need;
@@ -146,7 +153,19 @@ int plan_channel(rcf_t *h, BlockPlan &bp, ClassPlan &cp, Chan *c, int D)
                   (long long)cnt, reach(c->id), h->out_cap);
         return RCF_ECAP;
     }
+    if (c->is_tap) {                            // served through the tap matrix, not by a FIR launch: its own short record
+        TapLaunch tl{};
+        tl.iq_ring = c->d_iq;
+        tl.fm_ring = c->d_fm;
+        tl.k_lo = k_lo; tl.k_abs0 = c->k_abs0; tl.n_seg0 = c->n_seg0;
+        tl.angle0 = (double)c->angle0; tl.dangle = c->dangle; tl.logmag0 = c->logmag0; tl.dlogmag = c->dlogmag;
+        tl.n_k = (int32_t)cnt;
+        tl.bin = c->src - RCF_SRC_PFB_BIN0;
+        tap_list.push_back(tl);
+        tap_bins.push_back(tl.bin);
+    }
     ChanLaunch L{};
+    if (!c->is_tap) {
     L.ctaps = c->d_ctaps;
     L.fm_ring = c->d_fm;
     L.iq_ring = c->d_iq;
@@ -173,22 +192,13 @@ int plan_channel(rcf_t *h, BlockPlan &bp, ClassPlan &cp, Chan *c, int D)
         rf.incr_im = c->incr[1];
         rot_fills.push_back(rf);
     }
+    }
     DiscLaunch dl{};
     dl.iq_ring = c->d_iq;
     dl.fm_ring = c->d_fm;
     dl.n_lo = k_lo - c->k_abs0;
     dl.n_k = (int32_t)cnt;
-    if (c->is_tap) {                            // served through the tap matrix, not by a FIR launch
-        TapLaunch tl{};
-        tl.iq_ring = c->d_iq;
-        tl.fm_ring = c->d_fm;
-        tl.k_lo = L.k_lo; tl.k_abs0 = L.k_abs0; tl.n_seg0 = L.n_seg0;
-        tl.angle0 = L.angle0; tl.dangle = L.dangle; tl.logmag0 = L.logmag0; tl.dlogmag = L.dlogmag;
-        tl.n_k = L.n_k;
-        tl.bin = c->src - RCF_SRC_PFB_BIN0;
-        tap_list.push_back(tl);
-        tap_bins.push_back(tl.bin);
-    } else {
+    if (!c->is_tap) {
         launches.push_back(L);
         launched.push_back(c);
         discs.push_back(dl);
@@ -587,10 +597,22 @@ int plan_block(rcf_t *h, size_t n, BlockPlan &bp, BlockUndo &undo)
     // channels, by depth then by (D, T) class
     bp.fir_by_depth.resize(bp.max_depth + 1);
     bp.serial = ++h->blk_serial;
+    // (one pass over the channel map; a front-end has a handful of (D, T) classes: linear search, then sorted -- the
+    // order classes are launched in is the key order, as it always was)
+    typedef std::pair<std::pair<int, int>, std::vector<Chan *>> ClassBucket;
+    std::vector<std::vector<ClassBucket>> by_depth((size_t)bp.max_depth + 1);
+    for (auto &kv : h->chans) {
+        Chan *c = kv.second.get();
+        auto &lvl = by_depth[(size_t)c->depth];
+        const std::pair<int, int> key{c->D, c->T};
+        size_t q = 0;
+        while (q < lvl.size() && lvl[q].first != key) ++q;
+        if (q == lvl.size()) lvl.push_back(ClassBucket{key, {}});
+        lvl[q].second.push_back(c);
+    }
     for (int depth = 0; depth <= bp.max_depth; ++depth) {
-        std::map<std::pair<int, int>, std::vector<Chan *>> classes;
-        for (auto &kv : h->chans)
-            if (kv.second->depth == depth) classes[{kv.second->D, kv.second->T}].push_back(kv.second.get());
+        auto &classes = by_depth[(size_t)depth];
+        std::sort(classes.begin(), classes.end(), [](const ClassBucket &a, const ClassBucket &b) { return a.first < b.first; });
         for (auto &cls : classes) {
             ClassPlan cp;
             cp.launches.reserve(cls.second.size());
