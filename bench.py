@@ -750,7 +750,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
                 bad = K
                 break
         while good is None and bad is not None and bad > 16:           # the starting point itself failed: search downwards
-            K = bad // 2
+            K = bad - step if bad > step else bad // 2
             if point(K)["ok"]:
                 good = K
             else:

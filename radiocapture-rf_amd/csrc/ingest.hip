@@ -107,24 +107,33 @@ void launch_copy8(void *dst, const void *src, size_t bytes, hipStream_t s)
 // rcf_chan_read_many: the new samples of many channel rings packed back to back into ONE staging buffer (pinned host
 // memory the device writes across PCIe) -- one launch and one synchronisation per egress pass instead of a device
 // round trip per channel.  Records live in pinned host memory too.  Units: 4-byte words.
-static __global__ __launch_bounds__(256) void gather_rings_kernel(const GatherRec *__restrict__ recs, uint32_t *__restrict__ dst)
+// A BOUNDED grid, like group_prep_kernel's and for the same reason: its stores cross PCIe, a workgroup whose stores wait for the
+// link holds its CU slot, and launched one workgroup per (record, part) -- tens of thousands for a group's read -- it
+// starved the filterbank launches of the other groups (rocprof of the real-time leg: a 20 us pfb5 launch averaging 183 us).
+static __global__ __launch_bounds__(256) void gather_rings_kernel(const GatherRec *__restrict__ recs, uint32_t *__restrict__ dst,
+                                                                  uint32_t n_recs, uint32_t parts)
 {
-    const GatherRec r = recs[blockIdx.y];
-    const uint32_t stride = gridDim.x * 256;
-    // the destination is either linear (dst_mask_w = ~0: rows packed back to back, rcf_chan_read_many) or a ring of its own
-    // (the real-time pump's per-channel host rings: dst_w = the ring's first word, dst_pos_w where this segment starts)
-    for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < r.n_w; w += stride) {
-        uint32_t v = r.ring[(r.pos_w + w) & r.mask_w];
-        if (r.flags & 1u) v = __float_as_uint(__fmul_rn(r.gain, __uint_as_float(v)));
-        dst[r.dst_w + ((r.dst_pos_w + w) & r.dst_mask_w)] = v;
+    const uint32_t n_items = n_recs * parts;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const GatherRec r = recs[item / parts];
+        const uint32_t stride = parts * 256;
+        // the destination is either linear (dst_mask_w = ~0: rows packed back to back, rcf_chan_read_many) or a ring of its
+        // own (the real-time pump's per-channel host rings: dst_w = the ring's first word, dst_pos_w where this segment starts)
+        for (uint32_t w = (item % parts) * 256 + threadIdx.x; w < r.n_w; w += stride) {
+            uint32_t v = r.ring[(r.pos_w + w) & r.mask_w];
+            if (r.flags & 1u) v = __float_as_uint(__fmul_rn(r.gain, __uint_as_float(v)));
+            dst[r.dst_w + ((r.dst_pos_w + w) & r.dst_mask_w)] = v;
+        }
     }
 }
 
 void launch_gather_rings(const GatherRec *d_recs, int n_recs, uint32_t *d_dst, uint32_t max_words, hipStream_t s)
 {
     if (n_recs <= 0 || max_words == 0) return;
-    const unsigned gx = std::min<unsigned>((max_words + 255) / 256, 16);
-    hipLaunchKernelGGL(gather_rings_kernel, dim3(gx, (unsigned)n_recs), dim3(256), 0, s, d_recs, d_dst);
+    static const unsigned cap = [] { const char *e = getenv("RCF_GATHER_WGS"); const int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 512); }();
+    const unsigned parts = std::min<unsigned>((max_words + 255) / 256, 16);
+    const unsigned items = parts * (unsigned)n_recs;
+    hipLaunchKernelGGL(gather_rings_kernel, dim3(std::min(items, cap)), dim3(256), 0, s, d_recs, d_dst, (uint32_t)n_recs, parts);
 }
 
 void launch_gather_view(const StreamView &v, int64_t first, float2 *dst, size_t n, hipStream_t s)
