@@ -473,6 +473,8 @@ typedef struct rcf_pump_stats {
     double latency_ms_p50, latency_ms_p99, latency_ms_max;
     double host_plan_ms, host_wait_ms;   /* thread time spent planning + queueing / waiting for the device */
     double elapsed_s;
+    double max_plan_ms, max_wait_ms;     /* the longest single planning + queueing of a group block / wait for the device */
+    double max_sleep_overshoot_ms;       /* how much later than asked the thread ever came back from a sleep (host scheduling) */
     int running;                         /* 0 once the thread has finished */
     int error;                           /* RCF_E* that stopped it (0: none) */
 } rcf_pump_stats_t;

@@ -426,6 +426,7 @@ struct rcf_pump {
     std::vector<float> lat_ms;
     int64_t blocks_done = 0, judged = 0, late = 0, overruns = 0, group_blocks = 0, max_batch = 0, samples_out = 0;
     double plan_ms = 0, wait_ms = 0;
+    double max_plan_ms = 0, max_wait_ms = 0, max_idle_gap_ms = 0;   // longest single planning / device wait / sleep overshoot
     std::chrono::steady_clock::time_point t_start, t_end;
     char err_text[256] = "";
 };
@@ -488,6 +489,7 @@ void pump_main(rcf_pump *p)
         {
             std::lock_guard<std::mutex> l(p->st_mu);
             p->wait_ms += secs(now - w0) * 1e3;
+            p->max_wait_ms = std::max(p->max_wait_ms, secs(now - w0) * 1e3);
             p->samples_out += items_out;
             for (size_t i = 0; i < s.members.size(); ++i) {
                 ++p->blocks_done;
@@ -604,6 +606,7 @@ void pump_main(rcf_pump *p)
             {
                 std::lock_guard<std::mutex> l(p->st_mu);
                 p->plan_ms += secs(Clock::now() - p0) * 1e3;
+                p->max_plan_ms = std::max(p->max_plan_ms, secs(Clock::now() - p0) * 1e3);
                 ++p->group_blocks;
                 p->max_batch = std::max<int64_t>(p->max_batch, (int64_t)items.size());
                 p->overruns += n_over;
@@ -617,7 +620,13 @@ void pump_main(rcf_pump *p)
             if (complete_oldest(false)) continue;
         }
         const double wait_s = next_due - secs(Clock::now() - t0);
-        if (wait_s > 0) std::this_thread::sleep_for(std::chrono::duration<double>(std::min(wait_s, 1e-3)));
+        if (wait_s > 0) {
+            const double want = std::min(wait_s, 1e-3);
+            const Clock::time_point s0 = Clock::now();
+            std::this_thread::sleep_for(std::chrono::duration<double>(want));
+            const double over = (secs(Clock::now() - s0) - want) * 1e3;      // how much later than asked the thread came back
+            if (over > p->max_idle_gap_ms) { std::lock_guard<std::mutex> l(p->st_mu); p->max_idle_gap_ms = over; }
+        }
     }
     while (in_flight > 0 && !p->error.load()) (void)complete_oldest(true);
     (void)hipStreamSynchronize(g->stream);
@@ -886,6 +895,9 @@ int rcf_pump_stats(rcf_pump_t *p, rcf_pump_stats_t *st)
         st->samples_out = p->samples_out;
         st->host_plan_ms = p->plan_ms;
         st->host_wait_ms = p->wait_ms;
+        st->max_plan_ms = p->max_plan_ms;
+        st->max_wait_ms = p->max_wait_ms;
+        st->max_sleep_overshoot_ms = p->max_idle_gap_ms;
         const bool run = p->running.load();
         st->elapsed_s = secs((run ? Clock::now() : p->t_end) - p->t_start);
         st->running = run ? 1 : 0;

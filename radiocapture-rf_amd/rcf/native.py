@@ -72,6 +72,7 @@ class PumpStats(C.Structure):
                 ("group_blocks", C.c_int64), ("max_batch", C.c_int64), ("samples_out", C.c_int64),
                 ("latency_ms_p50", C.c_double), ("latency_ms_p99", C.c_double), ("latency_ms_max", C.c_double),
                 ("host_plan_ms", C.c_double), ("host_wait_ms", C.c_double), ("elapsed_s", C.c_double),
+                ("max_plan_ms", C.c_double), ("max_wait_ms", C.c_double), ("max_sleep_overshoot_ms", C.c_double),
                 ("running", C.c_int), ("error", C.c_int)]
 
 
