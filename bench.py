@@ -684,6 +684,7 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
         "host_plan_fraction_busiest_pump": max(s_["host_plan_ms"] for s_ in stats) * 1e-3 / wall,
         "host_longest_plan_ms": max(s_["max_plan_ms"] for s_ in stats), "host_longest_device_wait_ms": max(s_["max_wait_ms"] for s_ in stats),
         "host_longest_sleep_overshoot_ms": max(s_["max_sleep_overshoot_ms"] for s_ in stats),
+        "slow_plans_waits_sleeps": [sum(s_[k_] for s_ in stats) for k_ in ("slow_plans", "slow_waits", "slow_sleeps")],
         "gpu_kernel_us_per_group_block_of_group_0": per_batch_ms * 1e3,
         "gpu_busy_percent_est": 100.0 * per_batch_ms * 1e-3 * batches / wall,
         "gpu_busy_note": "filterbank + stage-2 / tap-finalize launches of pump 0's group blocks (HIP events, every 4th) x all "
@@ -778,7 +779,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
         bins, demod = (NB, len(carriers)) if shape == "pfb256" else (1600, 256)
         keys = ("front_ends", "ok", "deadline_misses", "ring_overruns", "latency_ms_p50", "latency_ms_p99", "latency_ms_max",
                 "gpu_busy_percent_est", "front_ends_per_group_block_mean", "host_plan_fraction_busiest_pump", "host_longest_plan_ms",
-                "host_longest_device_wait_ms", "host_longest_sleep_overshoot_ms", "errors",
+                "host_longest_device_wait_ms", "host_longest_sleep_overshoot_ms", "slow_plans_waits_sleeps", "errors",
                 "seconds", "confirmation_run")
         out[shape] = {
             "K_max": good or 0, "K_max_first_attempt": first_attempt, "first_K_that_missed": bad,

@@ -475,6 +475,7 @@ typedef struct rcf_pump_stats {
     double elapsed_s;
     double max_plan_ms, max_wait_ms;     /* the longest single planning + queueing of a group block / wait for the device */
     double max_sleep_overshoot_ms;       /* how much later than asked the thread ever came back from a sleep (host scheduling) */
+    int64_t slow_plans, slow_waits, slow_sleeps;   /* judged region: plans > 5 ms, device waits > 5 ms, sleeps that overshot by > 2 ms */
     int running;                         /* 0 once the thread has finished */
     int error;                           /* RCF_E* that stopped it (0: none) */
 } rcf_pump_stats_t;

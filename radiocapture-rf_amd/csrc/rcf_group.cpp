@@ -427,6 +427,8 @@ struct rcf_pump {
     int64_t blocks_done = 0, judged = 0, late = 0, overruns = 0, group_blocks = 0, max_batch = 0, samples_out = 0;
     double plan_ms = 0, wait_ms = 0;
     double max_plan_ms = 0, max_wait_ms = 0, max_idle_gap_ms = 0;   // longest single planning / device wait / sleep overshoot
+    int64_t slow_plans = 0, slow_waits = 0, slow_sleeps = 0;        // ... and how many of them exceeded 5 / 5 / 2 ms (after the warm-up)
+    bool warm_done = false;
     std::chrono::steady_clock::time_point t_start, t_end;
     char err_text[256] = "";
 };
@@ -489,7 +491,10 @@ void pump_main(rcf_pump *p)
         {
             std::lock_guard<std::mutex> l(p->st_mu);
             p->wait_ms += secs(now - w0) * 1e3;
-            p->max_wait_ms = std::max(p->max_wait_ms, secs(now - w0) * 1e3);
+            if (p->warm_done) {
+                p->max_wait_ms = std::max(p->max_wait_ms, secs(now - w0) * 1e3);
+                if (secs(now - w0) > 5e-3) ++p->slow_waits;
+            }
             p->samples_out += items_out;
             for (size_t i = 0; i < s.members.size(); ++i) {
                 ++p->blocks_done;
@@ -606,7 +611,11 @@ void pump_main(rcf_pump *p)
             {
                 std::lock_guard<std::mutex> l(p->st_mu);
                 p->plan_ms += secs(Clock::now() - p0) * 1e3;
-                p->max_plan_ms = std::max(p->max_plan_ms, secs(Clock::now() - p0) * 1e3);
+                if (!p->warm_done && *std::min_element(s.kidx.begin(), s.kidx.end()) >= cfg.warm_blocks) p->warm_done = true;
+                if (p->warm_done) {
+                    p->max_plan_ms = std::max(p->max_plan_ms, secs(Clock::now() - p0) * 1e3);
+                    if (secs(Clock::now() - p0) > 5e-3) ++p->slow_plans;
+                }
                 ++p->group_blocks;
                 p->max_batch = std::max<int64_t>(p->max_batch, (int64_t)items.size());
                 p->overruns += n_over;
@@ -625,7 +634,7 @@ void pump_main(rcf_pump *p)
             const Clock::time_point s0 = Clock::now();
             std::this_thread::sleep_for(std::chrono::duration<double>(want));
             const double over = (secs(Clock::now() - s0) - want) * 1e3;      // how much later than asked the thread came back
-            if (over > p->max_idle_gap_ms) { std::lock_guard<std::mutex> l(p->st_mu); p->max_idle_gap_ms = over; }
+            if (p->warm_done && over > 2.0) { std::lock_guard<std::mutex> l(p->st_mu); ++p->slow_sleeps; p->max_idle_gap_ms = std::max(p->max_idle_gap_ms, over); }
         }
     }
     while (in_flight > 0 && !p->error.load()) (void)complete_oldest(true);
@@ -861,7 +870,12 @@ int rcf_pump_start(rcf_group_t *g, const rcf_pump_config_t *cfg, rcf_pump_t **ou
     }
     p->h_recs = static_cast<unsigned char *>(hp);
     p->h_recs_dev = static_cast<unsigned char *>(dv);
-    for (int i = 0; i < 2; ++i) RCF_HIP(hipEventCreateWithFlags(&p->slot_ev[i], hipEventDisableTiming));
+    {
+        // RCF_PUMP_BLOCKING=1: the pump sleeps in the driver while it waits for a group block instead of spinning on the event
+        static const bool blocking = [] { const char *e = getenv("RCF_PUMP_BLOCKING"); return e && atoi(e) != 0; }();
+        for (int i = 0; i < 2; ++i)
+            RCF_HIP(hipEventCreateWithFlags(&p->slot_ev[i], hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
+    }
     // the subscribed channels' readers start at what has been produced so far
     {
         MemberLocks ml(g->members);
@@ -898,6 +912,9 @@ int rcf_pump_stats(rcf_pump_t *p, rcf_pump_stats_t *st)
         st->max_plan_ms = p->max_plan_ms;
         st->max_wait_ms = p->max_wait_ms;
         st->max_sleep_overshoot_ms = p->max_idle_gap_ms;
+        st->slow_plans = p->slow_plans;
+        st->slow_waits = p->slow_waits;
+        st->slow_sleeps = p->slow_sleeps;
         const bool run = p->running.load();
         st->elapsed_s = secs((run ? Clock::now() : p->t_end) - p->t_start);
         st->running = run ? 1 : 0;

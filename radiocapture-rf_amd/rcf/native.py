@@ -73,6 +73,7 @@ class PumpStats(C.Structure):
                 ("latency_ms_p50", C.c_double), ("latency_ms_p99", C.c_double), ("latency_ms_max", C.c_double),
                 ("host_plan_ms", C.c_double), ("host_wait_ms", C.c_double), ("elapsed_s", C.c_double),
                 ("max_plan_ms", C.c_double), ("max_wait_ms", C.c_double), ("max_sleep_overshoot_ms", C.c_double),
+                ("slow_plans", C.c_int64), ("slow_waits", C.c_int64), ("slow_sleeps", C.c_int64),
                 ("running", C.c_int), ("error", C.c_int)]
 
 
