@@ -474,6 +474,7 @@ int rcf_chan_fm_filter(rcf_t *h, int chan_id, float gain, const float *taps, int
     c->d_symtaps = fresh;
     c->sym_ntaps = ntaps;
     c->sym_gain = gain;
+    ++h->chans_epoch;
     if (!c->d_sym) {
         RCF_HIP(hipMalloc(&c->d_sym, sizeof(float) * h->out_cap));
         RCF_HIP(hipMemsetAsync(c->d_sym, 0, sizeof(float) * h->out_cap, h->stream));
@@ -530,6 +531,7 @@ int rcf_chan_audio_open(rcf_t *h, int chan_id, const rcf_audio_params_t *p)
     au->from = c->produced;                                      // a new flowgraph: zero state from here on
     if (c->audio) { bury(h, c->audio->d_state); bury(h, c->audio->d_rings); bury(h, c->audio->d_taps); }
     c->audio = std::move(au);
+    ++h->chans_epoch;
     return RCF_OK;
 }
 
@@ -540,6 +542,7 @@ int rcf_chan_audio_close(rcf_t *h, int chan_id)
     if (set_dev(h)) return RCF_EHIP;
     FIND_CHAN(h, chan_id, c);
     if (c->audio) { bury(h, c->audio->d_state); bury(h, c->audio->d_rings); bury(h, c->audio->d_taps); c->audio.reset(); }
+    ++h->chans_epoch;
     return RCF_OK;
 }
 

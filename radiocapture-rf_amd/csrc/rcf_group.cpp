@@ -42,6 +42,8 @@ struct rcf_group {
     size_t many_cap = 0;
     rcf_pump *pump = nullptr;
     std::mutex mu;
+    // RCF_PUMP_DEBUG=1: the longest time one group block spent in each part of group_process (printed by rcf_pump_stop)
+    double dbg_ms[6] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -72,6 +74,12 @@ struct MergedFir {
 int group_process(rcf_group *g, const std::vector<GroupItem> &items, int fmt, float scale, float offset, bool wait)
 {
     if (items.empty()) return RCF_OK;
+    const auto dbg_t0 = std::chrono::steady_clock::now();
+    auto dbg_mark = [&](int i, std::chrono::steady_clock::time_point from) {
+        const double ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - from).count() * 1e3;
+        if (ms > g->dbg_ms[i]) g->dbg_ms[i] = ms;
+        return std::chrono::steady_clock::now();
+    };
     RCF_HIP(hipSetDevice(g->device));
     hipStream_t st = g->stream;
     const size_t bps = group_sample_bytes(fmt);
@@ -87,6 +95,7 @@ int group_process(rcf_group *g, const std::vector<GroupItem> &items, int fmt, fl
     }
     if (g->arenas.reserve(need, st) != RCF_OK) return RCF_EHIP;
     if (!g->arenas.mapped) { set_error("group launches need device-mapped pinned memory for their records"); return RCF_ESTATE; }
+    auto dbg_t1 = dbg_mark(0, dbg_t0);                          // set device + arena reserve
     const int a = g->arenas.cur;
     const size_t base = g->arenas.fill;
     Arena ga{g->arenas.h[a], g->arenas.d[a], base, g->arenas.cap};
@@ -126,6 +135,7 @@ int group_process(rcf_group *g, const std::vector<GroupItem> &items, int fmt, fl
             return rc;
         }
     }
+    dbg_t1 = dbg_mark(1, dbg_t1);                               // planning
     auto fail_all = [&](int code) {
         for (size_t j = 0; j < NI; ++j) undo_block(g->members[(size_t)items[j].m], undo[j]);
         return code;
@@ -290,9 +300,11 @@ int group_process(rcf_group *g, const std::vector<GroupItem> &items, int fmt, fl
         g->arenas.h_dev[a] + (reinterpret_cast<const unsigned char *>(d_prep) - ga.d));
     g->arenas.fill = (ga.used + 63) & ~size_t(63);
 
+    dbg_t1 = dbg_mark(2, dbg_t1);                               // merging + records
     // ---- 6. launches, in dependency order.  From here on a failure leaves queued work behind: no roll-back.
     for (size_t at = 0, li = 0; at < prep.size(); at += kPrepMaxRecs, ++li)
         launch_group_prep(prep_mapped + at, (int)std::min<size_t>(kPrepMaxRecs, prep.size() - at), prep_tiles[li], st);
+    dbg_t1 = dbg_mark(3, dbg_t1);                               // the prep launch
     if (wait) RCF_HIP(hipEventRecord(g->ingest_ev, st));
     if (d_rots) launch_rot_fill(d_rots, (int)rots.size(), h0->ring_mask, st);
     auto launch_depth = [&](size_t d, int timing_class_default) {
@@ -346,6 +358,7 @@ int group_process(rcf_group *g, const std::vector<GroupItem> &items, int fmt, fl
         h->total_in = bp.S1;
     }
     RCF_HIP(hipGetLastError());
+    dbg_t1 = dbg_mark(4, dbg_t1);                               // the other launches
     if (wait) (void)hipEventSynchronize(g->ingest_ev);
     return RCF_OK;
 }
@@ -876,6 +889,15 @@ int rcf_pump_start(rcf_group_t *g, const rcf_pump_config_t *cfg, rcf_pump_t **ou
         for (int i = 0; i < 2; ++i)
             RCF_HIP(hipEventCreateWithFlags(&p->slot_ev[i], hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
     }
+    // room in the group's arena for a group block of ALL members at once (after a hiccup everything that is complete goes
+    // out together): growing the arena means a stream synchronisation and pinned allocations -- not in the middle of a run
+    {
+        MemberLocks ml(g->members);
+        size_t all = 65536;
+        for (rcf_t *h : g->members) all += arena_need_bound(h) + 1024;
+        if (!g->arenas.h[0] && g->arenas.cap < all) { size_t c_ = g->arenas.cap; while (c_ < all) c_ *= 2; g->arenas.cap = c_; }
+        if (g->arenas.reserve(all, g->stream) != RCF_OK) return RCF_EHIP;
+    }
     // the subscribed channels' readers start at what has been produced so far
     {
         MemberLocks ml(g->members);
@@ -961,6 +983,9 @@ int rcf_pump_stop(rcf_pump_t *p)
     p->stop.store(true);
     if (p->th.joinable()) p->th.join();
     rcf_group *g = p->g;
+    if (getenv("RCF_PUMP_DEBUG"))
+        fprintf(stderr, "pump: longest group block by part, ms: reserve %.2f plan %.2f merge %.2f prep-launch %.2f launches %.2f\n",
+                g->dbg_ms[0], g->dbg_ms[1], g->dbg_ms[2], g->dbg_ms[3], g->dbg_ms[4]);
     {
         std::lock_guard<std::mutex> gl(g->mu);
         (void)hipSetDevice(g->device);

@@ -7,11 +7,14 @@ namespace rcfx {
 
 // an upper bound of what plan_arena() will ask for, without walking the channels (a group sizes its arena for all of its
 // members before it plans any of them)
-size_t arena_need_bound(const rcf_t *h)
+size_t arena_need_bound(rcf_t *h)
 {
-    const size_t n = h->chans.size();
-    return 4096 + n * (2 * sizeof(ChanLaunch) + sizeof(TapLaunch) + sizeof(DiscLaunch) + sizeof(RotFill) + 12 + 128 +
-                       sizeof(FmFirLaunch) + sizeof(AudioLaunch)) + 64 * (n / 4 + 64);
+    if (h->arena_need_epoch == h->chans_epoch && h->arena_need_last) return h->arena_need_last;   // what plan_arena last computed
+    BlockPlan tmp;
+    Arena dummy{nullptr, nullptr, 0, 0};
+    tmp.ar = &dummy;
+    (void)plan_arena(h, tmp);
+    return tmp.arena_need;
 }
 
 // arena for this commit: sized for every channel's launch records before anything is scheduled, so the schedule
@@ -25,10 +28,13 @@ int plan_arena(rcf_t *h, BlockPlan &bp)
     {
         // (one pass over the channel map for everything that needs one: at 196608 channels each pass is ~8 ms of
         // pointer chasing)
-        size_t need = 4096, pfb_reach = 0;
+        size_t need = 4096, pfb_reach = 0, n_fir = 0;
         for (auto &kv : h->chans) {
             const Chan &c = *kv.second;
-            need += 2 * sizeof(ChanLaunch) + sizeof(TapLaunch) + sizeof(DiscLaunch) + sizeof(RotFill) + 12 + 128;
+            // (a filterbank tap has one short record; a FIR channel up to two launch records -- matrix-core launch and
+            // zero-history fix-up --, a discriminator record, an exact-rotator fill, its bank-matrix dirty flag)
+            need += c.is_tap ? sizeof(TapLaunch) + 8 : 2 * sizeof(ChanLaunch) + sizeof(DiscLaunch) + sizeof(RotFill) + 12 + 128;
+            n_fir += c.is_tap ? 0 : 1;
             if (c.d_sym) need += sizeof(FmFirLaunch);
             if (c.audio) need += sizeof(AudioLaunch);
             max_depth = std::max(max_depth, c.depth);
@@ -49,8 +55,10 @@ int plan_arena(rcf_t *h, BlockPlan &bp)
             r = std::max(r, pfb_reach);
             bp.max_reach = std::max(bp.max_reach, r);
         }
-        need += 64 * (h->chans.size() / 4 + 64);              // per-class alignment slack
+        need += 64 * (n_fir / 4 + 64);                        // per-class alignment slack
         arena_need = need;
+        h->arena_need_last = need;
+        h->arena_need_epoch = h->chans_epoch;
     }
     if (bp.ar != &bp.own_ar) return RCF_OK;        // a group's block: the group reserved its arena for all members
     if (h->arenas.reserve(arena_need, h->stream) != RCF_OK) return RCF_EHIP;

@@ -113,7 +113,7 @@ struct BlockUndo {
 // rcf_plan.cpp
 int plan_block(rcf_t *h, size_t n, BlockPlan &bp, BlockUndo &undo);
 void undo_block(rcf_t *h, BlockUndo &undo);
-size_t arena_need_bound(const rcf_t *h);
+size_t arena_need_bound(rcf_t *h);
 int plan_arena(rcf_t *h, BlockPlan &bp);
 int plan_pfb(rcf_t *h, BlockPlan &bp);
 int plan_channel(rcf_t *h, BlockPlan &bp, ClassPlan &cp, Chan *c, int D);

@@ -157,7 +157,10 @@ struct rcf {
     struct rcf_group *group = nullptr;
     hipStream_t own_stream = nullptr;
     std::map<int, std::unique_ptr<Chan>> chans;
-    uint64_t chans_epoch = 0;     // bumped whenever a channel is opened or closed (cached Chan pointers: the pump's)
+    uint64_t chans_epoch = 0;     // bumped whenever a channel is opened or closed or gains / loses a symbol filter or voice
+                                  // chain (cached Chan pointers: the pump's; the cached arena need below)
+    size_t arena_need_last = 0;   // what plan_arena last asked for, valid while arena_need_epoch == chans_epoch
+    uint64_t arena_need_epoch = ~0ull;
     int next_id = 1;
     Pfb pfb;
     Scan scan;

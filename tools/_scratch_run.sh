@@ -10,7 +10,10 @@ for k,v in r.items():
             print("   ", {a: (round(b,2) if isinstance(b,float) else b) for a,b in p.items() if a not in ("errors","seconds","gpu_busy_percent_est","ok") or (a=="errors" and b)})
 PY
 }
-for i in 1 2; do
-PUMPS=4 WINDOW_MS=1.0 SECONDS=4 KFIRST=768 KCAP=768 SHAPES=grid1600 timeout 500 python tools/rt_probe.py > gpurun_out/r05i/a$i.json 2> gpurun_out/r05i/err.txt || tail -3 gpurun_out/r05i/err.txt
-show gpurun_out/r05i/a$i.json
+for cfg in "grid1600 768 1024" "pfb256 1024 1280"; do
+set -- $cfg
+echo "== $cfg"
+RCF_PUMP_DEBUG=1 PUMPS=4 WINDOW_MS=1.0 SECONDS=4 KFIRST=$2 KCAP=$3 SHAPES=$1 timeout 600 python tools/rt_probe.py > gpurun_out/r05i/c_$1.json 2> gpurun_out/r05i/err.txt || tail -3 gpurun_out/r05i/err.txt
+grep "^pump:" gpurun_out/r05i/err.txt | sort | tail -3
+show gpurun_out/r05i/c_$1.json
 done
