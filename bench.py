@@ -582,6 +582,73 @@ def measure_traffic_live(cfg5, block, kernel_substr, timeout_s=150):
             "dispatches_averaged": min(out["FETCH_SIZE"][1], out["WRITE_SIZE"][1])}
 
 
+# ------------------------------------------------------------------------------------------- grouped launches, resident
+def group_capacity_leg(native, tile, carriers, device, G=80, blk=409600, seconds=1.5):
+    """What ONE grouped launch per stage is worth when the GPU is kept busy: G front-ends (each the BASELINE configs[1]
+    shape: 256-bin bank + 32 FM channels) with a real-time-sized block resident in HBM, committed back to back as one
+    group block (rcf_group_commit: one records + history launch, ONE filterbank launch over all G x 100 chunks, ONE stage-2
+    launch over all G x 32 channels), against the same G front-ends committed one after the other.  The paced real-time
+    leg runs the same launches at a duty cycle of a few per cent (the chip idles between group blocks and clocks down:
+    its launches are slower than these)."""
+    fes, ids = [], []
+    for i in range(G):
+        fe = native.Frontend(FS, 0.0, device=device, block_capacity=blk, hist_capacity=1 << 14, out_capacity=1 << 12)
+        fe.pfb_open(NB, NB, proto_taps(native))
+        ids.append([fe.pfb_chan_open(c["bin"] % NB, 12500, c["delta"]) for c in carriers])
+        fes.append(fe)
+    x = np.tile(tile, blk // len(tile) + 1)[:blk]
+    out = {"front_ends": G, "block_samples": blk, "samples_per_group_block": G * blk,
+           "algorithmic_bytes_per_filterbank_launch": 16.0 * G * blk}
+    for mode in ("one_by_one", "grouped"):
+        grp = native.Group(fes) if mode == "grouped" else None
+        for _ in range(2):                               # both ping-pong buffers of every member hold data
+            if grp is not None:
+                grp.push([np.roll(x, 977 * i) for i in range(G)], native.FMT_CF32)
+            else:
+                for i, fe in enumerate(fes):
+                    fe.push(np.roll(x, 977 * i))
+        step = (lambda: grp.commit([blk] * G)) if grp is not None else (lambda: [fe.commit(blk) for fe in fes])
+        sync = grp.sync if grp is not None else (lambda: [fe.sync() for fe in fes])
+        for _ in range(30):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < seconds / 2:
+            step()
+            n += 1
+        sync()
+        wall = (time.perf_counter() - t0) / n
+        e = {"wall_ms_per_group_block": wall * 1e3, "input_Msps": G * blk / wall / 1e6, "group_blocks": n}
+        # the filterbank launch itself, HIP events on the launch stream (the grouped launches are timed on member 0)
+        fes[0].timing_enable(True, classes=[native.T_PFB, native.T_FIR_DERIVED])
+        fes[0].timing_read(native.T_PFB)
+        fes[0].timing_read(native.T_FIR_DERIVED)
+        for _ in range(100):
+            step()
+        sync()
+        ms, k = fes[0].timing_read(native.T_PFB)
+        ms2, k2 = fes[0].timing_read(native.T_FIR_DERIVED)
+        fes[0].timing_enable(False)
+        if k:
+            per = (16.0 * G * blk) if grp is not None else 16.0 * blk
+            e["filterbank_launch_us"] = ms / k * 1e3
+            e["filterbank_launches_timed"] = k
+            e["filterbank_frac_of_hbm_peak"] = per / (ms / k * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if k2:
+            e["stage2_launch_us"] = ms2 / k2 * 1e3
+        out[mode] = e
+        if grp is not None:
+            # the grouped outputs are the one-by-one outputs (bit for bit: tests/test_gpu_group.py); here only that every
+            # channel produced the same count either way
+            e["outputs_per_channel"] = fes[G // 2].chan_produced(ids[G // 2][0])
+            grp.close()
+    out["grouped_over_one_by_one"] = out["one_by_one"]["wall_ms_per_group_block"] / out["grouped"]["wall_ms_per_group_block"]
+    for fe in fes:
+        fe.close()
+    return out
+
+
 # ------------------------------------------------------------------------------------------- paced real-time leg
 def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block_ms, n_pumps, stagger=True, window_ms=1.0):
     """K independent 20 Msps front-ends on ONE GPU (the reference's deployment shape: ten sources per host,
@@ -713,7 +780,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
     src = {"array": raw.array}
     if not n_pumps:
         try:
-            n_pumps = max(1, min(2, (os.cpu_count() or 8) // 8))
+            n_pumps = max(1, min(4, (os.cpu_count() or 8) // 8))
         except Exception:
             n_pumps = 4
     out = {"what": "K independent 20 Msps u8 front-ends on one GPU, paced at wall-clock rate in %.0f ms blocks; %d native "
@@ -728,6 +795,8 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
            "attempts_per_point": 1, "batch_window_ms": window_ms,
            "batch_window_note": "a complete block waits up to this long for the blocks that complete meanwhile: they share its launches"}
     for shape in shapes:
+        if shape == "grid1600":
+            k_cap = min(k_cap, 1024)                     # (256 tapped bins per front-end: a point above this does not pay for its setup time)
         pts, good, bad = [], None, None
         pool = {"fes": [], "chans": []}
         search_s = min(4.0, seconds)                     # the search runs short points; K_max is then CONFIRMED over `seconds`
@@ -895,7 +964,7 @@ def main():
     ap.add_argument("--rt-block-ms", type=float, default=20.0, help="block length of the paced real-time leg")
     ap.add_argument("--rt-k-first", type=int, default=512, help="front-end count the real-time search starts at")
     ap.add_argument("--rt-k-cap", type=int, default=1280, help="largest front-end count the real-time search tries")
-    ap.add_argument("--rt-pumps", type=int, default=0, help="native pump threads (groups) of the real-time leg (0: two)")
+    ap.add_argument("--rt-pumps", type=int, default=0, help="native pump threads (groups) of the real-time leg (0: four)")
     ap.add_argument("--rt-window-ms", type=float, default=1.0, help="batching window of the pumps: a complete block waits this long for company")
     ap.add_argument("--rt-shapes", default="pfb256,grid1600", help="shapes of the real-time leg")
     ap.add_argument("--rt-burst", action="store_true",
@@ -1231,6 +1300,10 @@ def main():
         out["channels"]["reference_grid_filterbank"] = reference_grid_leg(native, tile, local_rank)
         out["scan"] = scan_leg(native, synth, local_rank)
         out["end_to_end"] = end_to_end_leg(native, tile, local_rank)
+        try:
+            out["group_capacity"] = group_capacity_leg(native, tile, meta["carriers"], local_rank)
+        except Exception as e:
+            out["group_capacity"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if args.rt_seconds > 0:
             try:
                 out["realtime"] = realtime_leg(native, tile, meta["carriers"], local_rank, seconds=args.rt_seconds,

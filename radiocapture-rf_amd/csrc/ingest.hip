@@ -130,7 +130,7 @@ static __global__ __launch_bounds__(256) void gather_rings_kernel(const GatherRe
 void launch_gather_rings(const GatherRec *d_recs, int n_recs, uint32_t *d_dst, uint32_t max_words, hipStream_t s)
 {
     if (n_recs <= 0 || max_words == 0) return;
-    static const unsigned cap = [] { const char *e = getenv("RCF_GATHER_WGS"); const int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 512); }();
+    static const unsigned cap = [] { const char *e = getenv("RCF_GATHER_WGS"); const int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 128); }();
     const unsigned parts = std::min<unsigned>((max_words + 255) / 256, 16);
     const unsigned items = parts * (unsigned)n_recs;
     hipLaunchKernelGGL(gather_rings_kernel, dim3(std::min(items, cap)), dim3(256), 0, s, d_recs, d_dst, (uint32_t)n_recs, parts);
@@ -231,7 +231,7 @@ __device__ __forceinline__ void prep_tile(const PrepRec &r, const uint32_t base,
 // A BOUNDED grid: the kernel is PCIe-bound (its loads cross the link), and a workgroup that waits for the link holds its
 // slot on a CU -- launched one workgroup per tile (thousands), the blocks of one group's ingest starved the OTHER groups'
 // filterbank launches of CUs (rocprof of the real-time leg: 27 front-ends' filterbank 132 us instead of ~40).  So
-// kPrepWgs workgroups (RCF_PREP_WGS) each walk a contiguous range of the launch's tiles; records[i].tile_first (host) says
+// 128 workgroups (RCF_PREP_WGS) each walk a contiguous range of the launch's tiles; records[i].tile_first (host) says
 // where record i's tiles start, all of them are fetched into LDS once, the 64-byte record itself only when the range
 // crosses into the next record.
 __global__ __launch_bounds__(256) void group_prep_kernel(const PrepRec *__restrict__ recs, int n_recs, uint32_t total_tiles)
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void group_prep_kernel(const PrepRec *__restri
 void launch_group_prep(const PrepRec *d_recs, int n_recs, uint32_t total_tiles, hipStream_t s)
 {
     if (n_recs <= 0 || total_tiles == 0) return;
-    static const unsigned cap = [] { const char *e = getenv("RCF_PREP_WGS"); const int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 512); }();
+    static const unsigned cap = [] { const char *e = getenv("RCF_PREP_WGS"); const int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 128); }();   // 128: same PCIe rate as 512 (0.6 ms per 27 blocks), the filterbank launches beside it 96 -> 68 us
     hipLaunchKernelGGL(group_prep_kernel, dim3(std::min<unsigned>(cap, total_tiles)), dim3(256), 0, s, d_recs, n_recs, total_tiles);
 }
 
