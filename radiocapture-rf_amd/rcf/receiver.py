@@ -208,6 +208,59 @@ class receiver:
             raise
         self._fed[source_id] = self._fed.get(source_id, 0) + n
 
+    # ---- all sources at once: the reference's receiver holds EVERY configured source in one top block when no -i is
+    # given (receiver.py:67-70,170-204; ten of them in configs/config_denver_dev_den817.py:25-118) and GNU Radio's
+    # scheduler moves all their samples.  Here the front-ends of one receiver form a group (rcf_group_*): the blocks that
+    # are handed over together go out as ONE conversion / filterbank / stage-2 / tap launch instead of one set per source.
+    def _group_for_feed(self):
+        """the native group over this receiver's front-ends, built on first use; None when there is nothing to group (one
+        source, a stub front-end without the native handle, half-band sub-sources that are fed in pieces)"""
+        if getattr(self, "_group_tried", False):
+            return self._group
+        self._group_tried, self._group, self._group_index = True, None, {}
+        if any("parent_chan" in s_ for s_ in self.sources.values()):
+            return None
+        blocks = []
+        for sid in sorted(self.sources):
+            fe = self.sources[sid]["block"]
+            if not hasattr(fe, "_h"):
+                return None
+            self._group_index[sid] = len(blocks)
+            blocks.append(fe)
+        if len(blocks) < 2:
+            return None
+        try:
+            from . import native
+            self._group = native.Group(blocks)
+        except Exception as e:                               # (different devices / ring sizes): one by one, as before
+            self.log.warning("sources are fed one by one: %s" % e)
+            self._group = None
+        return self._group
+
+    def feed_all(self, blocks, fmt=None, scale=1.0, offset=0.0):
+        """blocks: {source_id: samples} for any subset of the sources -- complex64 (fmt None) or the SDR's wire format
+        (fmt = native.FMT_U8 / FMT_S8 / FMT_S16 with scale / offset as feed_raw).  One group block for all of them."""
+        grp = self._group_for_feed()
+        if grp is None:
+            for sid, b in blocks.items():
+                if fmt is None:
+                    self.feed(sid, b)
+                else:
+                    self.feed_raw(sid, b, fmt, scale, offset)
+            return
+        row = [None] * len(grp)
+        for sid, b in blocks.items():
+            row[self._group_index[sid]] = b
+        try:
+            grp.push(row, 0 if fmt is None else fmt, scale, offset)
+        except Exception as e:
+            if self.fault is None:
+                self.fault = "%s: %s" % (type(e).__name__, e)
+                self.log.error("data plane failed on a group block: %s" % self.fault)
+            raise
+        for sid, b in blocks.items():
+            self._fed[sid] = self._fed.get(sid, 0) + (len(b) if fmt is None else len(b) // 2)
+
     def enable_kernel_metrics(self, stride=32):
         """kernel time and HBM rate in the status line and the registry record.  Every `stride`-th
         launch of each kernel class is bracketed with HIP events on the front-end's own stream (rcf_timing_*: an event
@@ -406,6 +459,9 @@ class receiver:
 
     def close(self):
         with self.access_lock:
+            if getattr(self, "_group", None) is not None:
+                self._group.close()
+                self._group = None
             for c in list(self.channels):
                 self.channels[c].destroy()
             self.channels.clear()

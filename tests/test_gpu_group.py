@@ -294,3 +294,37 @@ def test_pump_feeds_a_group_in_real_time_and_delivers_the_same_bits(gpu_required
         fes[m].close()
     for r in rings:
         r.free()
+
+
+def test_receiver_feed_all_is_the_sources_fed_one_by_one(gpu_required):
+    """rcf.receiver with three sources (no -i: the reference's whole-host receiver, rc_frontend/receiver.py:67-70): the
+    channels its clients hold deliver the same bits whether the sources' blocks arrive together (feed_all: one group
+    block) or source by source (feed)"""
+    import types
+    from rcf import receiver
+    fs = 2.4e6
+    xs = [synth.cfg1(seconds=0.1, seed=1001 + m)[0] for m in range(3)]
+    res = []
+    for which in (0, 1):
+        cfg = types.SimpleNamespace(
+            sources={m: dict(type="synthetic", center_freq=855050000 + 3000000 * m, samp_rate=int(fs)) for m in range(3)},
+            frontend_mode="xlat")
+        tb = receiver.receiver(cfg)
+        try:
+            ids = [tb.connect_channel(12500, 854987500 + 3000000 * m)[0] for m in range(3)]
+            ids.append(tb.connect_channel(12500, 855100000)[0])
+            assert [tb.channels[c].source_id for c in ids] == [0, 1, 2, 0]
+            n = len(xs[0])
+            for a, b in ((0, n // 2 + 17), (n // 2 + 17, n)):
+                if which == 0:
+                    tb.feed_all({m: xs[m][a:b] for m in range(3)})
+                else:
+                    for m in range(3):
+                        tb.feed(m, xs[m][a:b])
+            assert (getattr(tb, "_group", None) is not None) == (which == 0)
+            res.append([(tb.channels[c].read_iq(), tb.channels[c].read_fm(5.0)) for c in ids])
+            assert tb.metrics()["rcf_samples_in"] == 3 * n
+        finally:
+            tb.close()
+    for (gi, gf), (si, sf) in zip(*res):
+        assert len(gi) > 2000 and _same_bits(gi, si) and _same_bits(gf, sf)

@@ -846,3 +846,19 @@ def test_server_tick_is_one_turn_of_the_references_main_loop(case):
     assert {str(k): list(v) for k, v in srv.clients.items()} == a["clients"]
     assert sorted(str(k) for k in srv.client_hb) == a["client_hb"]
     assert srv.last_status == a["last_status"] and tb.last_channel_cleanup == a["last_channel_cleanup"]
+
+
+def test_feed_all_without_native_front_ends_feeds_one_by_one():
+    """receiver.feed_all: the sources of one receiver as one group block (the reference holds all its sources in one top
+    block, rc_frontend/receiver.py:67-70); with front-ends that are not librcf handles -- these stubs -- it is feed() /
+    feed_raw() per source, the counters the same"""
+    rx = make_receiver()
+    got = {0: [], 1: []}
+    for i, fe in enumerate(StubFrontend.instances):
+        fe.push = (lambda i_: (lambda iq: got[i_].append(("cf32", len(iq)))))(i)
+        fe.push_raw = (lambda i_: (lambda raw, fmt, scale, offset=0.0: got[i_].append((fmt, len(raw) // 2, scale, offset))))(i)
+    rx.feed_all({0: np.zeros(100, np.complex64), 1: np.zeros(50, np.complex64)})
+    rx.feed_all({1: np.zeros(40, np.uint8)}, fmt=1, scale=1 / 128.0, offset=127.4)
+    assert got[0] == [("cf32", 100)] and got[1] == [("cf32", 50), (1, 20, 1 / 128.0, 127.4)]
+    assert rx.metrics()["rcf_samples_in"] == 170
+    rx.close()
