@@ -11,7 +11,7 @@ import time
 
 
 class channel:
-    def __init__(self, frontend, port, channel_rate, samp_rate, offset, parent_chan=None, pfb=None):
+    def __init__(self, frontend, port, channel_rate, samp_rate, offset, parent_chan=None, pfb=None, decim_rule=0):
         """frontend: rcf.native.Frontend (the HBM-resident source that replaces `parent_zmq_address`).
         parent_chan: channel id of a receiver_split2 half-band source (receiver.py:205-237) this channel
         reads instead of the wideband stream; samp_rate is then that half's rate.
@@ -27,6 +27,8 @@ class channel:
         self.block_id = None
         self.parent_chan = parent_chan
         self.pfb = pfb
+        self.decim_rule = int(decim_rule)    # native.DECIM_EXACT / DECIM_FLOOR (config.py2_decim): what THIS object does with an
+                                             # odd int(fs / cr) where it derives the decimation itself (split2 halves)
         self.pfb_bin = None
         self.chan_id = None
         self.route = "direct"
@@ -81,7 +83,7 @@ class channel:
             chan_id = frontend.chan_open(channel_rate, offset)
         else:
             from . import native
-            decim, ntaps = native.channel_params(samp_rate, channel_rate)
+            decim, ntaps = native.channel_params(samp_rate, channel_rate, self.decim_rule)
             taps = native.design_low_pass_2(1.0, samp_rate, channel_rate / 2, channel_rate / 2, 20.0)
             assert len(taps) == ntaps
             chan_id = frontend.chan_open_taps(self.parent_chan, decim, taps, offset)

@@ -104,22 +104,28 @@ class EgressPump:
                 except Exception as e:
                     self._fail(block_id, e)
             for fe, items in groups.values():
-                got = None
+                iqs = fms = None
                 if len(items) > 1 and hasattr(fe, "chan_read_many"):
-                    # all channels of one front-end behind ONE device synchronisation (rcf_chan_read_many)
+                    # all channels of one front-end behind ONE device synchronisation (rcf_chan_read_many).  The two
+                    # streams have independent reader positions: a batch that succeeded has ADVANCED its positions and
+                    # its samples are kept whatever happens to the other one -- only the stream whose batch failed is
+                    # read again channel by channel
+                    ids = tuple(ch.chan_id for _, ch in items)
                     try:
-                        ids = tuple(ch.chan_id for _, ch in items)
                         iqs = self._read_many(fe, ids, "iq", 1.0)
-                        fms = self._read_many(fe, ids, "fm", self.fm_gain) if self.fm_gain is not None else [None] * len(ids)
-                        got = list(zip(iqs, fms))
                     except Exception as e:
-                        log.error("batched egress read failed (%s): reading channel by channel" % e)
+                        log.error("batched IQ egress read failed (%s): reading channel by channel" % e)
+                    if self.fm_gain is not None:
+                        try:
+                            fms = self._read_many(fe, ids, "fm", self.fm_gain)
+                        except Exception as e:
+                            log.error("batched discriminator egress read failed (%s): reading channel by channel" % e)
                 for i, (block_id, ch) in enumerate(items):
                     try:
-                        if got is not None and got[i][0] is not None:
-                            iq, fm = got[i]
+                        iq = iqs[i] if iqs is not None and iqs[i] is not None else ch.read_iq()
+                        if fms is not None and fms[i] is not None:
+                            fm = fms[i]
                         else:
-                            iq = ch.read_iq()
                             fm = ch.read_fm(self.fm_gain) if block_id in self.fm_socks else None
                         ready.append((block_id, iq, fm))
                     except Exception as e:

@@ -118,7 +118,7 @@ class receiver:
         cr = int(getattr(self.config, "pfb_channel_rate", 12500))
         grid = float(getattr(self.config, "pfb_grid", cr))
         try:
-            decim, ntaps = native.channel_params(samp_rate, cr)
+            decim, ntaps = native.channel_params(samp_rate, cr, 1 if getattr(self.config, "py2_decim", False) else 0)
         except native.RcfError:
             return None
         n_bins = samp_rate / grid
@@ -384,7 +384,8 @@ class receiver:
                 try:
                     block = channel_mod.channel(frontend, port, channel_rate, source_samp_rate, offset,
                                                 parent_chan=self.sources[source_id].get("parent_chan"),
-                                                pfb=self.sources[source_id].get("pfb"))
+                                                pfb=self.sources[source_id].get("pfb"),
+                                                decim_rule=1 if getattr(self.config, "py2_decim", False) else 0)
                 except Exception:
                     if self.release_port is not None:      # the sockets bound above have no channel: close them
                         self.release_port(port)

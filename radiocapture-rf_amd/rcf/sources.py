@@ -11,8 +11,9 @@ the hardware clock pace the flowgraph).  Hardware drivers are out of scope here 
 
 A PacedSource is one thread per source: every `block_ms` it hands the next block -- staged in one of two pinned host
 buffers (rcf_host_alloc), so the copy of block n+1 overlaps the kernels of block n -- to receiver.feed /
-receiver.feed_raw, at t0 + k * block / samp_rate.  It never runs ahead of the clock, and when it falls behind it does
-not drop samples: it counts the block as `late` and catches up (a real SDR would have overrun its ring instead).
+receiver.feed_raw, at t0 + (k + 1) * block / samp_rate -- the instant the block's last sample exists.  It never runs
+ahead of the clock, and when it falls behind it does not drop samples: a block whose delivery starts more than one block
+period after that instant is counted as `late` and the source catches up (a real SDR would have overrun its ring instead).
 """
 from __future__ import annotations
 
@@ -128,7 +129,10 @@ class PacedSource:
                 blk = self.next_block(k)
                 if blk is None:
                     break
-                due = t0 + k * self.block / self.fs         # the block's LAST sample exists at due + block / fs
+                # block k is delivered once its LAST sample exists -- (k + 1) block periods after the start: a source
+                # never hands over samples that a real SDR would not have produced yet -- and it is late when the
+                # delivery starts more than a block period after that (the next block is then already complete)
+                due = t0 + (k + 1) * self.block / self.fs
                 now = self.clock()
                 if now < due:
                     self.sleep(due - now)

@@ -23,6 +23,7 @@ import errno
 import json
 import os
 import select
+import selectors
 import socket
 import struct
 import time
@@ -61,30 +62,54 @@ class TcpRepServer:
     serves whatever is ready and returns; `serve(server, stop)` is the reference's main loop around it (tick + recv +
     handle + send, receiver.py:620-699)."""
 
+    OUT_LIMIT = 1 << 20                                    # a client that does not read its replies is dropped at this backlog
+
     def __init__(self, host="0.0.0.0", port=0):
         self.lsock = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         self.lsock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         self.lsock.bind((host, port))
-        self.lsock.listen(64)
+        self.lsock.listen(256)
         self.lsock.setblocking(False)
         self.port = self.lsock.getsockname()[1]
         self.endpoint = "tcp://%s:%d" % (host, self.port)
-        self.conns = {}
+        self.conns = {}                                    # socket -> _FrameReader
+        self.out = {}                                      # socket -> bytearray of reply bytes not yet written
+        # epoll / kqueue where there is one: no limit of 1024 descriptors (select() raises above it), and the write set
+        # costs nothing while nobody has a backlog
+        self.sel = selectors.DefaultSelector()
+        self.sel.register(self.lsock, selectors.EVENT_READ)
+
+    def _flush(self, s):
+        """write what the socket takes of its pending replies, NEVER blocking: one client that stops reading must not
+        stall the control loop (heartbeat expiry, idle sweep, every other client) behind a send timeout"""
+        buf = self.out.get(s)
+        if not buf:
+            return
+        try:
+            n = s.send(buf)
+        except (BlockingIOError, InterruptedError):
+            n = 0
+        except OSError:
+            self._drop(s)
+            return
+        del buf[:n]
+        if len(buf) > self.OUT_LIMIT:
+            self._drop(s)
+            return
+        want = selectors.EVENT_READ | (selectors.EVENT_WRITE if buf else 0)
+        try:
+            self.sel.modify(s, want)
+        except (KeyError, ValueError, OSError):
+            self._drop(s)
 
     def poll(self, handler, timeout=0.001):
-        socks = [self.lsock] + list(self.conns)
         try:
-            ready, _, _ = select.select(socks, [], [], timeout)
-        except (OSError, ValueError):                      # a connection went bad under us: find it, serve the rest
-            ready = []
-            for c in list(self.conns):
-                try:
-                    if select.select([c], [], [], 0)[0]:
-                        ready.append(c)
-                except (OSError, ValueError):
-                    self._drop(c)
+            events = self.sel.select(timeout)
+        except (OSError, ValueError):
+            events = []
         served = 0
-        for s in ready:
+        for key, mask in events:
+            s = key.fileobj
             if s is self.lsock:
                 try:
                     c, _ = self.lsock.accept()
@@ -93,10 +118,23 @@ class TcpRepServer:
                 c.setblocking(False)
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 self.conns[c] = _FrameReader()
+                self.out[c] = bytearray()
+                try:
+                    self.sel.register(c, selectors.EVENT_READ)
+                except (ValueError, OSError):
+                    self._drop(c)
+                continue
+            if s not in self.conns:
+                continue
+            if mask & selectors.EVENT_WRITE:
+                self._flush(s)
+                if s not in self.conns:
+                    continue
+            if not (mask & selectors.EVENT_READ):
                 continue
             try:
                 chunk = s.recv(65536)
-            except BlockingIOError:
+            except (BlockingIOError, InterruptedError):
                 continue
             except OSError:
                 chunk = b""
@@ -111,17 +149,22 @@ class TcpRepServer:
                     if msg is None:
                         break
                     reply = handler(msg)
-                    s.setblocking(True)
-                    s.settimeout(1.0)
-                    _send_frame(s, reply if reply is not None else "")
-                    s.setblocking(False)
+                    data = (reply if reply is not None else "").encode("utf-8")
+                    self.out[s] += struct.pack("<I", len(data)) + data
                     served += 1
             except Exception:
                 self._drop(s)
+                continue
+            self._flush(s)
         return served
 
     def _drop(self, s):
         self.conns.pop(s, None)
+        self.out.pop(s, None)
+        try:
+            self.sel.unregister(s)
+        except (KeyError, ValueError, OSError):
+            pass
         try:
             s.close()
         except OSError:
@@ -130,6 +173,11 @@ class TcpRepServer:
     def close(self):
         for s in list(self.conns):
             self._drop(s)
+        try:
+            self.sel.unregister(self.lsock)
+        except (KeyError, ValueError, OSError):
+            pass
+        self.sel.close()
         self.lsock.close()
 
 

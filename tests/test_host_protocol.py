@@ -862,3 +862,53 @@ def test_feed_all_without_native_front_ends_feeds_one_by_one():
     assert got[0] == [("cf32", 100)] and got[1] == [("cf32", 50), (1, 20, 1 / 128.0, 127.4)]
     assert rx.metrics()["rcf_samples_in"] == 170
     rx.close()
+
+
+def test_egress_pump_keeps_the_iq_batch_when_only_the_fm_batch_fails():
+    """the batched IQ read advances every channel's reader position; when the batched discriminator read then
+    fails, the IQ samples of that pass must not be read a second time (from the advanced positions: they would be lost) --
+    only the discriminator stream falls back to channel-by-channel reads"""
+    calls = []
+
+    class FE:
+        def chan_read_many(self, ids, what, gain=1.0, cap_each=0):
+            calls.append(("many", what))
+            if what == "fm":
+                raise RuntimeError("gather failed")
+            return [np.full(3, 10 + i, dtype=np.complex64) for i in range(len(ids))]
+
+    fe = FE()
+
+    class Chan:
+        def __init__(self, port, cid):
+            self.port, self.chan_id, self.frontend = port, cid, fe
+
+        def read_iq(self):
+            calls.append(("iq", self.chan_id))
+            return np.zeros(1, dtype=np.complex64)
+
+        def read_fm(self, gain):
+            calls.append(("fm", self.chan_id))
+            return np.full(2, float(self.chan_id), dtype=np.float32)
+
+    sent = {}
+
+    class Sock:
+        def __init__(self, port):
+            self.port = port
+
+        def send(self, payload):
+            sent.setdefault(self.port, []).append(payload)
+
+        def close(self):
+            pass
+
+    import threading
+    from rcf import egress
+    tbx = types.SimpleNamespace(access_lock=threading.RLock(), channels={"a": Chan(20000, 1), "b": Chan(20002, 2)}, bind_port=None)
+    pump = egress.EgressPump(tbx, socket_factory=Sock, fm_gain=5.0)
+    pump.pump_once()
+    assert ("iq", 1) not in calls and ("iq", 2) not in calls          # the batch's IQ was used, not re-read
+    assert ("fm", 1) in calls and ("fm", 2) in calls                  # the discriminator stream fell back per channel
+    assert np.frombuffer(sent[20000][0], dtype=np.complex64)[0] == 10 and np.frombuffer(sent[20002][0], dtype=np.complex64)[0] == 11
+    assert np.frombuffer(sent[20000 + pump.fm_port_offset][0], dtype=np.float32)[0] == 1.0
