@@ -650,6 +650,27 @@ def group_capacity_leg(native, tile, carriers, device, G=80, blk=409600, seconds
 
 
 # ------------------------------------------------------------------------------------------- paced real-time leg
+def cgroup_cpu_stat():
+    """(nr_throttled, throttled_usec, usage_usec, quota cores or None) of this process's CPU cgroup: a paced run on a host
+    whose container is throttled by its CFS quota misses deadlines that are not the GPU's"""
+    out = {}
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            for line in open(path):
+                k, v = line.split()
+                out[k] = int(v)
+            break
+        except Exception:
+            continue
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else int(q) / int(per)
+    except Exception:
+        pass
+    return out.get("nr_throttled"), out.get("throttled_usec", out.get("throttled_time")), out.get("usage_usec"), quota
+
+
 def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block_ms, n_pumps, stagger=True, window_ms=1.0):
     """K independent 20 Msps front-ends on ONE GPU (the reference's deployment shape: ten sources per host,
     configs/config_denver_dev_den817.py:25-118, all of them inside one receiver when no -i is given,
@@ -686,6 +707,7 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
     out_ring = 1 << max(10, int(np.ceil(np.log2(4 * out_rate * period))))   # four blocks of output per channel
     NP = max(1, min(n_pumps, K))
     groups, pumps = [], []
+    cg0 = None
     # every front-end replays its OWN two blocks of the pinned source (K x 1.6 MB: no cache between the host's DRAM and
     # the GPU holds that); staggered: front-end i's blocks complete (i / K) of a period after front-end 0's -- independent
     # SDRs are not synchronised, and the GPU then sees a steady flow; burst: all at the same instant
@@ -712,12 +734,14 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
                                      batch_window_s=window_ms * 1e-3))
         t_end = time.perf_counter() + n_blocks * period + 0.25 + 10.0
         stats = []
+        cg0 = cgroup_cpu_stat()
         while time.perf_counter() < t_end:
             stats = [p_.stats() for p_ in pumps]
             if not any(s_["running"] for s_ in stats):
                 break
             time.sleep(0.05)
         stats = [p_.stats() for p_ in pumps]
+        cg1 = cgroup_cpu_stat()
         hung = any(s_["running"] for s_ in stats)
     finally:
         for p_ in pumps:
@@ -752,6 +776,10 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
         "host_longest_plan_ms": max(s_["max_plan_ms"] for s_ in stats), "host_longest_device_wait_ms": max(s_["max_wait_ms"] for s_ in stats),
         "host_longest_sleep_overshoot_ms": max(s_["max_sleep_overshoot_ms"] for s_ in stats),
         "slow_plans_waits_sleeps": [sum(s_[k_] for s_ in stats) for k_ in ("slow_plans", "slow_waits", "slow_sleeps")],
+        "host_cgroup": {"cpu_quota_cores": cg1[3],
+                        "throttled_periods": (cg1[0] - cg0[0]) if cg0 and cg0[0] is not None and cg1[0] is not None else None,
+                        "throttled_ms": (cg1[1] - cg0[1]) / 1e3 if cg0 and cg0[1] is not None and cg1[1] is not None else None,
+                        "cpu_cores_used_mean": (cg1[2] - cg0[2]) / 1e6 / wall if cg0 and cg0[2] is not None and cg1[2] is not None else None},
         "gpu_kernel_us_per_group_block_of_group_0": per_batch_ms * 1e3,
         "gpu_busy_percent_est": 100.0 * per_batch_ms * 1e-3 * batches / wall,
         "gpu_busy_note": "filterbank + stage-2 / tap-finalize launches of pump 0's group blocks (HIP events, every 4th) x all "
@@ -848,7 +876,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
         bins, demod = (NB, len(carriers)) if shape == "pfb256" else (1600, 256)
         keys = ("front_ends", "ok", "deadline_misses", "ring_overruns", "latency_ms_p50", "latency_ms_p99", "latency_ms_max",
                 "gpu_busy_percent_est", "front_ends_per_group_block_mean", "host_plan_fraction_busiest_pump", "host_longest_plan_ms",
-                "host_longest_device_wait_ms", "host_longest_sleep_overshoot_ms", "slow_plans_waits_sleeps", "errors",
+                "host_longest_device_wait_ms", "host_longest_sleep_overshoot_ms", "slow_plans_waits_sleeps", "host_cgroup", "errors",
                 "seconds", "confirmation_run")
         out[shape] = {
             "K_max": good or 0, "K_max_first_attempt": first_attempt, "first_K_that_missed": bad,

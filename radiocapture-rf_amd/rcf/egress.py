@@ -189,3 +189,10 @@ class EgressPump:
         self.continue_running = False
         if self._thread is not None:
             self._thread.join(timeout=2)
+        # the channels' sockets (and the ones bound ahead of a channel) go with the pump: a PUB socket left bound keeps
+        # its port for the life of the process (found by the ZeroMQ stand-in of tests/test_zmq_redis_branches.py)
+        if self._thread is None or not self._thread.is_alive():
+            for block_id in list(self.socks):
+                self._drop(block_id)
+            for port in list(self.prebound):
+                self.release_port(port)

@@ -137,21 +137,28 @@ class FrontendServer:
         sock = ctx.socket(zmq.REP)
         sock.bind(bind)
         self.endpoint = sock.getsockopt(zmq.LAST_ENDPOINT).decode("utf-8")
-        while not stop():
-            self.tick()
+        try:
+            while not stop():
+                self.tick()
+                try:
+                    msg = sock.recv_string(flags=zmq.NOBLOCK)
+                except zmq.Again:
+                    time.sleep(0.001)
+                    continue
+                # the reference's main loop catches and logs whatever its handler raises and keeps serving
+                # (receiver.py:686-699); a REP socket must also answer every request or it wedges
+                try:
+                    resp = self.handle(msg)
+                except Exception as e:                   # malformed request, failed retune, ...
+                    log.error("handler error on %r: %s" % (msg, e))
+                    resp = "na"
+                sock.send_string(resp if resp is not None else "")
+        finally:
+            # (the reference's loop never ends; this one does -- stop() -- and gives its port back)
             try:
-                msg = sock.recv_string(flags=zmq.NOBLOCK)
-            except zmq.Again:
-                time.sleep(0.001)
-                continue
-            # the reference's main loop catches and logs whatever its handler raises and keeps serving
-            # (receiver.py:686-699); a REP socket must also answer every request or it wedges
-            try:
-                resp = self.handle(msg)
-            except Exception as e:                       # malformed request, failed retune, ...
-                log.error("handler error on %r: %s" % (msg, e))
-                resp = "na"
-            sock.send_string(resp if resp is not None else "")
+                sock.close(0)
+            finally:
+                ctx.term()
 
 
 class LoopbackTransport:
