@@ -731,7 +731,7 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
             pumps.append(native.Pump(groups[j], rings, blk, FS, subs, fmt=native.FMT_U8, scale=1.0 / 32, offset=127.4,
                                      what="fm", gain=1.0, phase_s=[(i / K) * period if stagger else 0.0 for i in mine],
                                      out_ring_samples=out_ring, n_blocks=n_blocks, warm_blocks=warm, start_delay_s=0.25,
-                                     batch_window_s=window_ms * 1e-3))
+                                     batch_window_s=window_ms * 1e-3, rt_priority=int(os.environ.get("RCF_BENCH_RT_PRIORITY", "10"))))
         t_end = time.perf_counter() + n_blocks * period + 0.25 + 10.0
         stats = []
         cg0 = cgroup_cpu_stat()
@@ -775,6 +775,7 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
         "host_plan_fraction_busiest_pump": max(s_["host_plan_ms"] for s_ in stats) * 1e-3 / wall,
         "host_longest_plan_ms": max(s_["max_plan_ms"] for s_ in stats), "host_longest_device_wait_ms": max(s_["max_wait_ms"] for s_ in stats),
         "host_longest_sleep_overshoot_ms": max(s_["max_sleep_overshoot_ms"] for s_ in stats),
+        "pump_threads_sched_fifo": sum(s_["rt_priority_granted"] for s_ in stats),
         "slow_plans_waits_sleeps": [sum(s_[k_] for s_ in stats) for k_ in ("slow_plans", "slow_waits", "slow_sleeps")],
         "host_cgroup": {"cpu_quota_cores": cg1[3],
                         "throttled_periods": (cg1[0] - cg0[0]) if cg0 and cg0[0] is not None and cg1[0] is not None else None,
@@ -876,7 +877,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
         bins, demod = (NB, len(carriers)) if shape == "pfb256" else (1600, 256)
         keys = ("front_ends", "ok", "deadline_misses", "ring_overruns", "latency_ms_p50", "latency_ms_p99", "latency_ms_max",
                 "gpu_busy_percent_est", "front_ends_per_group_block_mean", "host_plan_fraction_busiest_pump", "host_longest_plan_ms",
-                "host_longest_device_wait_ms", "host_longest_sleep_overshoot_ms", "slow_plans_waits_sleeps", "host_cgroup", "errors",
+                "host_longest_device_wait_ms", "host_longest_sleep_overshoot_ms", "slow_plans_waits_sleeps", "host_cgroup", "pump_threads_sched_fifo", "errors",
                 "seconds", "confirmation_run")
         out[shape] = {
             "K_max": good or 0, "K_max_first_attempt": first_attempt, "first_K_that_missed": bad,

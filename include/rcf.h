@@ -463,6 +463,8 @@ typedef struct rcf_pump_config {
     int cpu;                             /* pin the thread to this CPU (-1: leave it to the scheduler) */
     double start_delay_s;                /* t0 = now + this */
     double batch_window_s;               /* a complete block waits up to this long for others to share its launches (0: none) */
+    int rt_priority;                     /* > 0: the thread asks for SCHED_FIFO at this priority (needs CAP_SYS_NICE; refused: it runs as it is) */
+    int reserved_;
 } rcf_pump_config_t;
 typedef struct rcf_pump_stats {
     int64_t blocks_done;                 /* member blocks whose outputs are in host memory */
@@ -476,6 +478,7 @@ typedef struct rcf_pump_stats {
     double max_plan_ms, max_wait_ms;     /* the longest single planning + queueing of a group block / wait for the device */
     double max_sleep_overshoot_ms;       /* how much later than asked the thread ever came back from a sleep (host scheduling) */
     int64_t slow_plans, slow_waits, slow_sleeps;   /* judged region: plans > 5 ms, device waits > 5 ms, sleeps that overshot by > 2 ms */
+    int rt_priority_granted;             /* 1 when the SCHED_FIFO request of rt_priority went through */
     int running;                         /* 0 once the thread has finished */
     int error;                           /* RCF_E* that stopped it (0: none) */
 } rcf_pump_stats_t;

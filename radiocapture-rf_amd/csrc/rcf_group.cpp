@@ -434,7 +434,7 @@ struct rcf_pump {
     hipEvent_t slot_ev[2] = {nullptr, nullptr};
     std::thread th;
     std::atomic<bool> stop{false}, running{false};
-    std::atomic<int> error{0};
+    std::atomic<int> error{0}, rt_granted{0};
     std::mutex st_mu;                              // the statistics below
     std::vector<float> lat_ms;
     int64_t blocks_done = 0, judged = 0, late = 0, overruns = 0, group_blocks = 0, max_batch = 0, samples_out = 0;
@@ -475,6 +475,11 @@ void pump_main(rcf_pump *p)
         CPU_ZERO(&set);
         CPU_SET(cfg.cpu, &set);
         (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+    }
+    if (cfg.rt_priority > 0) {
+        sched_param sp{};
+        sp.sched_priority = cfg.rt_priority;
+        p->rt_granted.store(pthread_setschedparam(pthread_self(), SCHED_FIFO, &sp) == 0 ? 1 : 0);
     }
     (void)hipSetDevice(g->device);
     const double period = (double)cfg.block_samples / cfg.samp_rate;
@@ -940,6 +945,7 @@ int rcf_pump_stats(rcf_pump_t *p, rcf_pump_stats_t *st)
         const bool run = p->running.load();
         st->elapsed_s = secs((run ? Clock::now() : p->t_end) - p->t_start);
         st->running = run ? 1 : 0;
+        st->rt_priority_granted = p->rt_granted.load();
         st->error = p->error.load();
         lat = p->lat_ms;
     }
