@@ -731,7 +731,8 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
             pumps.append(native.Pump(groups[j], rings, blk, FS, subs, fmt=native.FMT_U8, scale=1.0 / 32, offset=127.4,
                                      what="fm", gain=1.0, phase_s=[(i / K) * period if stagger else 0.0 for i in mine],
                                      out_ring_samples=out_ring, n_blocks=n_blocks, warm_blocks=warm, start_delay_s=0.25,
-                                     batch_window_s=window_ms * 1e-3, rt_priority=int(os.environ.get("RCF_BENCH_RT_PRIORITY", "10"))))
+                                     batch_window_s=window_ms * 1e-3, rt_priority=int(os.environ.get("RCF_BENCH_RT_PRIORITY", "10")),
+                                     spin_us=int(os.environ.get("RCF_BENCH_RT_SPIN_US", "1000"))))
         t_end = time.perf_counter() + n_blocks * period + 0.25 + 10.0
         stats = []
         cg0 = cgroup_cpu_stat()

@@ -464,7 +464,7 @@ typedef struct rcf_pump_config {
     double start_delay_s;                /* t0 = now + this */
     double batch_window_s;               /* a complete block waits up to this long for others to share its launches (0: none) */
     int rt_priority;                     /* > 0: the thread asks for SCHED_FIFO at this priority (needs CAP_SYS_NICE; refused: it runs as it is) */
-    int reserved_;
+    int spin_us;                         /* idle waits up to this long are spun instead of slept (a late wake-up is a late block) */
 } rcf_pump_config_t;
 typedef struct rcf_pump_stats {
     int64_t blocks_done;                 /* member blocks whose outputs are in host memory */

@@ -650,7 +650,12 @@ void pump_main(rcf_pump *p)
         if (wait_s > 0) {
             const double want = std::min(wait_s, 1e-3);
             const Clock::time_point s0 = Clock::now();
-            std::this_thread::sleep_for(std::chrono::duration<double>(want));
+            if (cfg.spin_us > 0 && want <= cfg.spin_us * 1e-6) {
+                while (secs(Clock::now() - s0) < want && !p->stop.load(std::memory_order_relaxed)) __builtin_ia32_pause();
+            } else {
+                std::this_thread::sleep_for(std::chrono::duration<double>(cfg.spin_us > 0 ? want - cfg.spin_us * 0.5e-6 : want));
+                while (secs(Clock::now() - s0) < want && cfg.spin_us > 0) __builtin_ia32_pause();
+            }
             const double over = (secs(Clock::now() - s0) - want) * 1e3;      // how much later than asked the thread came back
             if (p->warm_done && over > 2.0) { std::lock_guard<std::mutex> l(p->st_mu); ++p->slow_sleeps; p->max_idle_gap_ms = std::max(p->max_idle_gap_ms, over); }
         }

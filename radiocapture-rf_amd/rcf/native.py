@@ -63,7 +63,7 @@ class PumpConfig(C.Structure):
                 ("gain", C.c_float), ("read_members", C.POINTER(C.c_int)), ("read_chans", C.POINTER(C.c_int)),
                 ("n_read", C.c_int), ("out_ring_samples", C.c_size_t), ("n_blocks", C.c_int64),
                 ("warm_blocks", C.c_int64), ("max_batch", C.c_int), ("cpu", C.c_int), ("start_delay_s", C.c_double),
-                ("batch_window_s", C.c_double), ("rt_priority", C.c_int), ("reserved_", C.c_int)]
+                ("batch_window_s", C.c_double), ("rt_priority", C.c_int), ("spin_us", C.c_int)]
 
 
 class PumpStats(C.Structure):
@@ -715,7 +715,7 @@ class Pump:
 
     def __init__(self, group, rings, block_samples, samp_rate, subscriptions, fmt=FMT_U8, scale=1.0, offset=0.0,
                  what="fm", gain=1.0, phase_s=None, out_ring_samples=4096, n_blocks=0, warm_blocks=0, max_batch=0,
-                 cpu=-1, start_delay_s=0.05, batch_window_s=0.0, rt_priority=0):
+                 cpu=-1, start_delay_s=0.05, batch_window_s=0.0, rt_priority=0, spin_us=0):
         self.group = group
         n = len(group)
         if len(rings) != n:
@@ -744,6 +744,7 @@ class Pump:
         cfg.max_batch, cfg.cpu, cfg.start_delay_s = int(max_batch), int(cpu), float(start_delay_s)
         cfg.batch_window_s = float(batch_window_s)
         cfg.rt_priority = int(rt_priority)
+        cfg.spin_us = int(spin_us)
         self.what = what
         self.n_entries = ne
         self._cursors = [C.c_int64(0) for _ in range(ne)]
