@@ -732,7 +732,7 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
                                      what="fm", gain=1.0, phase_s=[(i / K) * period if stagger else 0.0 for i in mine],
                                      out_ring_samples=out_ring, n_blocks=n_blocks, warm_blocks=warm, start_delay_s=0.25,
                                      batch_window_s=window_ms * 1e-3, rt_priority=int(os.environ.get("RCF_BENCH_RT_PRIORITY", "10")),
-                                     spin_us=int(os.environ.get("RCF_BENCH_RT_SPIN_US", "1000"))))
+                                     spin_us=int(os.environ.get("RCF_BENCH_RT_SPIN_US", "0"))))   # (spinning the idle waits: measured WORSE -- 40 ms device stalls in both 10 s runs, none with sleeps)
         t_end = time.perf_counter() + n_blocks * period + 0.25 + 10.0
         stats = []
         cg0 = cgroup_cpu_stat()
@@ -868,7 +868,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
             if p["ok"]:
                 best = p
                 break
-            bad, good = good, max(1, good - step)
+            bad, good = good, max(step // 2, good - step // 2)
         if best is None:
             best = next((p for p in reversed(pts) if p["front_ends"] == good and p["ok"]), None)
             if best is None:
