@@ -892,6 +892,38 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
 
 
 # ------------------------------------------------------------------------------------------------ rank launcher
+def pin_to_gpu_numa(local_rank):
+    """N > 1: keep this rank's threads on the CPUs of its GPU's NUMA node (the pump threads of a per-GPU real-time leg and
+    the pinned buffers they touch then sit next to the GPU's PCIe root).  The AMD render nodes in PCI order are HIP's
+    device order; node -1 (no NUMA information) or any failure: no pinning.  -> {numa_node, cpus} for the line."""
+    try:
+        import glob
+        nodes = []
+        for d in sorted(glob.glob("/sys/class/drm/renderD*/device")):
+            try:
+                if open(os.path.join(d, "vendor")).read().strip() != "0x1002":
+                    continue
+                nodes.append((os.path.basename(os.path.realpath(d)), int(open(os.path.join(d, "numa_node")).read())))
+            except Exception:
+                continue
+        nodes.sort()
+        dev = int(os.environ.get("RCF_BENCH_DEVICE", local_rank))
+        if dev >= len(nodes) or nodes[dev][1] < 0:
+            return {"numa_node": None, "cpus": len(os.sched_getaffinity(0)), "pinned": False}
+        node = nodes[dev][1]
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return {"numa_node": node, "cpus": len(os.sched_getaffinity(0)), "pinned": False}
+        os.sched_setaffinity(0, cpus)
+        return {"numa_node": node, "cpus": len(cpus), "pinned": True, "pci": nodes[dev][0]}
+    except Exception as e:
+        return {"numa_node": None, "cpus": None, "pinned": False, "error": "%s: %s" % (type(e).__name__, e)}
+
+
 def load_native():
     """librcf's ctypes layer.  RCF_BENCH_NATIVE=<module> swaps in another module with the same surface: the CPU test of
     the launcher (tests/test_bench_launcher.py) runs the whole N-rank protocol over a stub Frontend that way."""
@@ -994,6 +1026,7 @@ def main():
     ap.add_argument("--rt-block-ms", type=float, default=20.0, help="block length of the paced real-time leg")
     ap.add_argument("--rt-k-first", type=int, default=512, help="front-end count the real-time search starts at")
     ap.add_argument("--rt-k-cap", type=int, default=1280, help="largest front-end count the real-time search tries")
+    ap.add_argument("--rt-k-per-gpu", type=int, default=512, help="N > 1: front-ends of the one paced real-time point every rank runs")
     ap.add_argument("--rt-pumps", type=int, default=0, help="native pump threads (groups) of the real-time leg (0: four)")
     ap.add_argument("--rt-window-ms", type=float, default=1.0, help="batching window of the pumps: a complete block waits this long for company")
     ap.add_argument("--rt-shapes", default="pfb256,grid1600", help="shapes of the real-time leg")
@@ -1012,6 +1045,8 @@ def main():
     if args.gpus != n_gpus and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
 
+    # N > 1: this rank's threads stay on the CPUs of its GPU's NUMA node (before the HIP runtime starts its own threads)
+    numa = pin_to_gpu_numa(local_rank) if world > 1 and os.environ.get("RCF_BENCH_NO_PIN", "0") in ("", "0") else None
     # (the host driver only supports dmabuf IPC: without this RCCL's peer mappings fail -- set before the HIP runtime loads)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from rcf import multigpu, synth
@@ -1147,6 +1182,13 @@ def main():
 
     pfb_ms, pfb_n = fe.timing_read(native.T_PFB)
     fe.timing_stride(1)
+    # ... and a second pass, NOT timed by the wall clock, in which EVERY launch of the same number of steps (at least 20)
+    # carries its two events: the large-sample launch time beside the every-4th one of the timed region
+    n_all = max(args.steps, 20)
+    for _ in range(n_all):
+        fe.commit(B)
+    fe.sync()
+    pfb_all_ms, pfb_all_n = fe.timing_read(native.T_PFB)
     # the FM channels' newest outputs, for the parity check against the oracle (done in the cpu_baseline leg)
     fm_check = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and chans:
@@ -1216,6 +1258,37 @@ def main():
         allgather_us = barrier_max((time.perf_counter() - ta) * 1e6)
         gathered_n = len(everyone)
     pfb_avg_ms_max = barrier_max(pfb_ms / max(pfb_n, 1)) if group is not None else pfb_ms / max(pfb_n, 1)
+    by_rank = None
+    if group is not None:
+        # what the line says about EVERY rank, not only the slowest: launch time / roofline fraction, the sustained leg's
+        # last window, the rank's peak count (their sum must be what the gather returned), its NUMA pinning -- and, with
+        # --rt-seconds > 0, one paced real-time point per GPU (K = --rt-k-per-gpu front-ends on every rank at the same time)
+        mine = {"rank": rank, "avg_launch_ms": pfb_ms / max(pfb_n, 1),
+                "frac": alg_bytes / (pfb_ms / max(pfb_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS if pfb_ms > 0 else None,
+                "sustained_frac_last_window": sustained["frac_last_window"] if sustained else None,
+                "peaks": len(freqs), "numa": numa}
+        if args.rt_seconds > 0 and not args.no_extras:
+            try:
+                barrier_max()
+                blk = int(round(FS * args.rt_block_ms * 1e-3))
+                raw = native.PinnedArray(2 * blk * 2 * args.rt_k_per_gpu, np.uint8)
+                t8 = np.clip(np.round(tile.view(np.float32) * 32 + 127.4), 0, 255).astype(np.uint8)
+                for b_ in range(2 * args.rt_k_per_gpu):
+                    at = 2 * ((b_ * 40961) % (len(tile) - blk))
+                    raw.array[2 * blk * b_: 2 * blk * (b_ + 1)] = t8[at: at + 2 * blk]
+                pool = {"fes": [], "chans": []}
+                p = realtime_point(native, pool, args.rt_k_per_gpu, "pfb256", {"array": raw.array},
+                                   meta["carriers"] if not cfg5 else synth.cfg2(n=1 << 16, seed=2002)[1]["carriers"], local_rank,
+                                   min(4.0, args.rt_seconds), args.rt_block_ms, args.rt_pumps or 4, not args.rt_burst, args.rt_window_ms)
+                for f_ in pool["fes"]:
+                    f_.close()
+                raw.free()
+                mine["realtime"] = {k_: p[k_] for k_ in ("front_ends", "ok", "deadline_misses", "ring_overruns", "latency_ms_p50",
+                                                         "latency_ms_p99", "latency_ms_max", "output_samples_lost", "errors")}
+            except Exception as e:
+                mine["realtime"] = {"front_ends": args.rt_k_per_gpu, "ok": False, "errors": ["%s: %s" % (type(e).__name__, e)]}
+        by_rank = sorted((json.loads(b.decode("utf-8")) for b in group.all_gather(json.dumps(mine).encode("utf-8"))),
+                         key=lambda r_: r_["rank"])
 
     if rank == 0:
         total_samples = float(B) * args.steps * n_gpus
@@ -1266,6 +1339,7 @@ def main():
                         "why": "steady state before the W warm-up steps (metric: sustained); see `sustained`"},
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_by_rank": per_rank_ms,
+            "by_rank": by_rank,
             "ranks_started_by": ("bench.py itself (one process per GPU)" if os.environ.get("RCF_BENCH_SPAWNED")
                                  else "the launcher's environment (RANK / WORLD_SIZE)") if world > 1 else "single process",
             "rccl_ranks": rccl_ranks if world > 1 else 1,
@@ -1293,6 +1367,11 @@ def main():
                 "traffic_from_tracked_file": traffic_file if live is not None else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_pfb_s * 1e3, "launches": pfb_n, "timed_every": time_every,
+                "avg_launch_ms_every_launch_pass": pfb_all_ms / max(pfb_all_n, 1), "launches_every_launch_pass": pfb_all_n,
+                "frac_every_launch_pass": alg_bytes / (pfb_all_ms / max(pfb_all_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS if pfb_all_ms > 0 else None,
+                "every_launch_pass_note": "a second, untimed pass of max(steps, 20) commits right behind the timed region with "
+                                          "events on EVERY filterbank launch (each costs the step ~4 us, which is why the timed "
+                                          "region itself times every 4th)",
                 "timed_how": "bracket of two hipEventRecord (RCF_TIMING_BRACKET)" if os.environ.get("RCF_TIMING_BRACKET", "0") not in ("", "0")
                 else "HIP events attached to the kernel's dispatch (hipExtLaunchKernelGGL start / stop events), on the launch stream",
                 "avg_launch_ms_slowest_rank": pfb_avg_ms_max,
@@ -1307,7 +1386,24 @@ def main():
                                                         "do both copies on the way in (PfbLaunch::rider_*)",
             },
         }
+        if by_rank is not None:
+            out["roofline"]["frac_by_rank"] = [r_["frac"] for r_ in by_rank]
+            out["numa_by_rank"] = [r_["numa"] for r_ in by_rank]
+            if any("realtime" in r_ for r_ in by_rank):
+                rts = [r_.get("realtime", {"ok": False}) for r_ in by_rank]
+                out["realtime_per_gpu"] = {
+                    "what": "one paced point per GPU, all GPUs at the same time: K 20 Msps u8 front-ends per GPU (256-bin bank + 32 "
+                            "FM channels each) in %.0f ms blocks through native pumps; no search at N > 1" % args.rt_block_ms,
+                    "front_ends_per_gpu": args.rt_k_per_gpu, "ok_by_rank": [bool(r_.get("ok")) for r_ in rts],
+                    "latency_ms_p99_by_rank": [r_.get("latency_ms_p99") for r_ in rts],
+                    "deadline_misses_by_rank": [r_.get("deadline_misses") for r_ in rts],
+                    "front_ends_sustained_total": sum(args.rt_k_per_gpu for r_ in rts if r_.get("ok")),
+                    "fm_channels_sustained_total": sum(args.rt_k_per_gpu * 32 for r_ in rts if r_.get("ok")),
+                    "input_Msps_sustained_total": sum(args.rt_k_per_gpu * FS / 1e6 for r_ in rts if r_.get("ok")),
+                    "errors": [e_ for r_ in rts for e_ in (r_.get("errors") or [])]}
         if sustained is not None:
+            if by_rank is not None:
+                sustained["frac_last_window_by_rank"] = [r_["sustained_frac_last_window"] for r_ in by_rank]
             out["sustained"] = sustained
         if scan_out is not None:
             out["scan"] = scan_out
@@ -1315,6 +1411,9 @@ def main():
             out["peaks_allgather_us"] = allgather_us
             out["peaks_allgather"] = {"transport": "ncclAllGather via rcf_allgather_peaks" if use_rccl else "host TCP",
                                       "values_gathered": gathered_n, "ranks": world,
+                                      "peaks_by_rank": [r_["peaks"] for r_ in by_rank] if by_rank else None,
+                                      "values_expected": sum(r_["peaks"] for r_ in by_rank) if by_rank else None,
+                                      "ok": (gathered_n == sum(r_["peaks"] for r_ in by_rank)) if by_rank else None,
                                       "peaks_from": "N=2^20 scan of each rank's slice" if cfg5 else
                                                     "16384-point scan / the tile's known carriers"}
     fe.close()

@@ -108,3 +108,48 @@ class Frontend:
 
     def close(self):
         pass
+
+
+# ---- what bench.py's per-GPU real-time point touches (N > 1): groups of front-ends and their native pumps
+FMT_CF32, FMT_U8, FMT_S8, FMT_S16 = 0, 1, 2, 3
+
+
+def channel_params(fs, cr, rule=0):
+    return int(fs / cr) // 2, 2909
+
+
+class PinnedArray:
+    def __init__(self, n, dtype):
+        self.array = np.zeros(int(n), dtype=dtype)
+
+    def free(self):
+        self.array = None
+
+
+class Group:
+    def __init__(self, frontends):
+        self.frontends = list(frontends)
+
+    def __len__(self):
+        return len(self.frontends)
+
+    def close(self):
+        pass
+
+
+class Pump:
+    """finishes at once: every block of every member judged, nothing late (STUB_RT_MISS=<rank>: that rank's pumps miss)"""
+
+    def __init__(self, group, rings, block_samples, samp_rate, subscriptions, n_blocks=0, warm_blocks=0, **kw):
+        assert len(rings) == len(group) and all(len(r) >= 2 * block_samples for r in rings)
+        self.n, self.judged = len(group), len(group) * (n_blocks - warm_blocks)
+        self.late = 3 if os.environ.get("STUB_RT_MISS") == os.environ.get("RANK", "0") else 0
+
+    def stats(self):
+        return dict(blocks_done=self.judged, blocks_judged=self.judged, late=self.late, overruns=0, group_blocks=max(1, self.judged // 4),
+                    max_batch=4, samples_out=0, latency_ms_p50=0.5, latency_ms_p99=1.0 + self.late, latency_ms_max=2.0,
+                    host_plan_ms=1.0, host_wait_ms=1.0, elapsed_s=0.1, max_plan_ms=0.1, max_wait_ms=0.1,
+                    max_sleep_overshoot_ms=0.0, slow_plans=0, slow_waits=0, slow_sleeps=0, rt_priority_granted=0, running=0, error=0)
+
+    def stop(self):
+        pass

@@ -111,3 +111,44 @@ def test_a_communicator_that_never_comes_up_ends_the_run_instead_of_hanging_it()
     r = _run(2, {"STUB_RCCL": "1", "STUB_RCCL_HANGS": "1", "RCF_BENCH_TRANSPORT": "rccl", "RCF_BENCH_RCCL_TIMEOUT": "2"}, timeout=120)
     assert r.returncode != 0 and not r.stdout.strip()
     assert "giving up" in r.stderr
+
+
+def test_eight_rank_line_carries_every_rank_and_a_real_time_point_per_gpu():
+    """VERDICT r04 item 5, the pre-flight of the first 8-GPU run: per-rank roofline fractions and sustained windows (not only
+    the slowest rank's), each rank's NUMA pinning, `--config cfg5` with the scan time over ranks, the gather time and the
+    gathered count checked against the sum of the ranks' peak counts, and one paced real-time point PER GPU so that the
+    line answers "channels sustained" at N = 8 too -- here on the stub, one rank told to miss its deadlines"""
+    flags = ["--steps", "6", "--warmup", "1", "--block", str(1 << 20), "--prewarm-seconds", "0", "--no-cpu-baseline",
+             "--sustained-seconds", "0.05", "--config", "cfg5", "--rt-seconds", "0.5", "--rt-k-per-gpu", "6", "--rt-pumps", "2"]
+    env = dict(os.environ, RCF_BENCH_NATIVE="stub_native", RCF_BENCH_TRANSPORT="rccl", STUB_RCCL="1", STUB_DEVICES="8", STUB_RT_MISS="5",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), os.environ.get("PYTHONPATH", "")]))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + flags, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout)
+    assert d["n_gpus"] == 8 and d["transport"] == "rccl"
+    assert len(d["roofline"]["frac_by_rank"]) == 8 and all(f > 0 for f in d["roofline"]["frac_by_rank"])
+    assert len(d["sustained"]["frac_last_window_by_rank"]) == 8
+    assert len(d["numa_by_rank"]) == 8 and all("pinned" in n for n in d["numa_by_rank"])
+    assert [b["rank"] for b in d["by_rank"]] == list(range(8))
+    pg = d["peaks_allgather"]
+    assert pg["peaks_by_rank"] == [1] * 8 and pg["values_expected"] == 8 == pg["values_gathered"] and pg["ok"] is True
+    assert d["scan"]["scan_ms_max_over_ranks"] > 0 and d["peaks_allgather_us"] > 0 and d["rccl_proof"] is not None
+    rt = d["realtime_per_gpu"]
+    assert rt["front_ends_per_gpu"] == 6 and rt["ok_by_rank"] == [True] * 5 + [False] + [True] * 2
+    assert rt["front_ends_sustained_total"] == 7 * 6 and rt["fm_channels_sustained_total"] == 7 * 6 * 32
+    assert rt["deadline_misses_by_rank"][5] == 3 * 2 and rt["errors"] == []
+
+
+def test_numa_pinning_reads_sysfs_and_survives_its_absence(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    before = os.sched_getaffinity(0)
+    try:
+        out = bench.pin_to_gpu_numa(0)                      # this container: no AMD render node, or one without NUMA info
+        assert out["pinned"] in (True, False) and "numa_node" in out
+        assert os.sched_getaffinity(0) <= before and len(os.sched_getaffinity(0)) >= 1
+    finally:
+        os.sched_setaffinity(0, before)
