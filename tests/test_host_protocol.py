@@ -523,15 +523,20 @@ def test_rep_loop_survives_handler_errors_and_egress_isolates_channels():
         def send_string(self, s):
             self.sent.append(s)
 
+        def close(self, linger=None):
+            self.closed = True
+
     sock = FakeSock(["connect", "create,x", "offset,1", "scan_mode_set_freq,notanumber", "hb,1", "quit,1"])
-    fake_zmq = types.SimpleNamespace(Context=lambda: types.SimpleNamespace(socket=lambda kind: sock), REP=4,
-                                     LAST_ENDPOINT=32, NOBLOCK=1, Again=Again)
+    termed = []
+    fake_zmq = types.SimpleNamespace(Context=lambda: types.SimpleNamespace(socket=lambda kind: sock, term=lambda: termed.append(1)),
+                                     REP=4, LAST_ENDPOINT=32, NOBLOCK=1, Again=Again)
     sys.modules["zmq"] = fake_zmq
     try:
         srv.serve_zmq(stop=lambda: not sock.inbox and len(sock.sent) >= 6)
     finally:
         del sys.modules["zmq"]
     assert len(sock.sent) == 6                                    # every request answered: the REP socket never wedges
+    assert sock.closed and termed == [1]                          # ... and the loop, once stopped, gives its socket back
     assert sock.sent[0].startswith("connect,") and sock.sent[-1] == "quit,1"
 
     # egress: channel A's socket raises on send, channel B keeps flowing
