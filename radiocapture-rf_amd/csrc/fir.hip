@@ -597,7 +597,12 @@ __global__ __launch_bounds__(64) void rot_fill_kernel(const RotFill *__restrict_
 // its own k_abs0), so that every store is whole lines: a partial line costs a read-modify-write in the memory system
 // (32-byte pieces measured 4-5x slower than lines).  The price is the 32 extra rows a tile loads.
 constexpr int kTapOut = 128, kTapCols = 16, kTapAlign = 32, kTapLdsRows = kTapOut + kTapAlign + 1,
-              kTapLdsPitch = kTapCols + 1;
+              kTapLdsPitch = kTapCols;
+// LDS position of (row lr, tap column sl): the column is rotated by half the row number, so that BOTH phases are free of
+// bank conflicts -- phase 1 writes 16 columns of one row (any rotation of 16 consecutive 8-byte words), phase 2 reads
+// rows 2 q + c, q = 0 .. 15, of ONE column: 16 different rotations = 16 different bank pairs.  (A pitch of 17 had the
+// second phase at stride 68 dwords: lanes q and q + 8 on the same banks, 8.9 M conflict cycles per 1600-tap launch.)
+__device__ __forceinline__ int tap_lds_at(int lr, int sl) { return lr * kTapLdsPitch + ((sl + (lr >> 1)) & (kTapCols - 1)); }
 // one tile (16 taps x 128 outputs) of one front-end's taps; shared by the single-front-end kernel and the grouped one
 __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int bx, const int by, const uint64_t ring_mask,
                                                   const float *__restrict__ atan_tab, float *tab, float2 *ys)
@@ -626,12 +631,17 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
             // memory round trip per row: 11 in a row)
             constexpr int NIT = (kTapLdsRows + 15) / 16;
             float2 z[NIT];
+            // the rows THIS tap's 128 outputs (and the output before them) come from: its tile starts a_own rows before r0
+            // (its ring index aligned to 32).  Rows outside are not requested: with the taps of a group opened together --
+            // one offset for all sixteen -- the 32 alignment rows are then never fetched (they were a quarter more traffic)
+            const int a_own = (int)((uint64_t)(k_first - L.k_abs0 + r0) & (kTapAlign - 1));
+            const int r_need_lo = r0 - a_own - 1, r_need_hi = r0 - a_own + kTapOut - 1;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int lr = rr + 16 * it, r = r_lds0 + lr;
                 const int64_t k = k_first + r, n = k - L.k_abs0;
                 z[it] = make_float2(0.f, 0.f);
-                if (lr < kTapLdsRows) {
+                if (lr < kTapLdsRows && r >= r_need_lo && r <= r_need_hi) {
                     if (r >= 0 && r < n_rows && k >= L.k_lo && k < L.k_lo + L.n_k && n >= 0)
                         z[it] = b0 >= 0 ? bins_ring[((uint64_t)k & ring_mask) * (uint64_t)n_bins + (unsigned)(b0 + sl)]
                                         : mat[(size_t)r * pitch + (slot - tap_first)];
@@ -647,7 +657,7 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
                 float2 v = z[it];
                 if (!idle && r >= 0) v = walk.rotate(L, v.x, v.y);     // (a zero stays zero: rows outside the tap's range)
                 walk.advance();
-                ys[lr * kTapLdsPitch + sl] = v;
+                ys[tap_lds_at(lr, sl)] = v;
             }
         }
     }
@@ -674,8 +684,8 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
             const bool vb = ra + 1 >= 0 && ra + 1 < n_rows && k_first + ra + 1 >= L.k_lo &&
                             k_first + ra + 1 < L.k_lo + L.n_k && na + 1 >= 0;
             if (!va && !vb) continue;
-            const float2 ym = na > 0 ? ys[(lr - 1) * kTapLdsPitch + sl] : make_float2(0.f, 0.f);
-            const float2 ya = ys[lr * kTapLdsPitch + sl], yb = ys[(lr + 1) * kTapLdsPitch + sl];
+            const float2 ym = na > 0 ? ys[tap_lds_at(lr - 1, sl)] : make_float2(0.f, 0.f);
+            const float2 ya = ys[tap_lds_at(lr, sl)], yb = ys[tap_lds_at(lr + 1, sl)];
             const float2 yb0 = na + 1 > 0 ? ya : make_float2(0.f, 0.f);
             const uint64_t ia = (uint64_t)na & ring_mask;
             if (va && vb) {                                          // na is even and the ring a power of two: no wrap inside the pair
