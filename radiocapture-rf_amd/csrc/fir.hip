@@ -655,7 +655,8 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
                 const int lr = rr + 16 * it, r = r_lds0 + lr;
                 if (lr >= kTapLdsRows) break;
                 float2 v = z[it];
-                if (!idle && r >= 0) v = walk.rotate(L, v.x, v.y);     // (a zero stays zero: rows outside the tap's range)
+                // (rows outside the tap's own range hold zeros nobody reads: no rotation spent on them)
+                if (!idle && r >= 0 && r >= r_need_lo && r <= r_need_hi) v = walk.rotate(L, v.x, v.y);
                 walk.advance();
                 ys[tap_lds_at(lr, sl)] = v;
             }
