@@ -1066,7 +1066,8 @@ def main():
     assert B % nb == 0 and (not cfg5 or B % SCAN_N == 0)
     frames = B // nb
     out_cap = 1
-    while out_cap < 2 * frames:
+    while out_cap < 2 * frames + 64:                  # two blocks of frames + the stage-2 channels' reach: the stage-2 launch of
+                                                      # block n rides in block n + 1's filterbank launch (rcf_set_stage2_lag)
         out_cap <<= 1
     fe = native.Frontend(fs, 0.0, device=local_rank, block_capacity=B, hist_capacity=SCAN_N if cfg5 else 1 << 16,
                          out_capacity=out_cap)
@@ -1208,7 +1209,26 @@ def main():
     if chans:
         assert fe.chan_produced(chans[0]) > 0        # the FM channels really produced output
 
-    alg_bytes = 16.0 * B                              # 8 B read + 8 B written per input sample (critically sampled)
+    alg_bytes_pfb = 16.0 * B                          # 8 B read + 8 B written per input sample (critically sampled)
+    # the stage-2 work of the previous block rides in the filterbank's launch (rcf_set_stage2_lag: 256-bin kernel only):
+    # the launch then also moves that work's algorithmic bytes -- SURVEY 8(d): per active bin 8 B read per frame of its
+    # stream, 8 B (IQ) + 4 B (fused discriminator) written per output at a third of the frame rate
+    s2_rides = bool(chans) and nb == 256 and os.environ.get("RCF_S2_LAG", "1") != "0" and hasattr(fe, "set_stage2_lag")
+    alg_bytes_s2 = len(chans) * (8.0 * (B // nb) + 12.0 * ((B // nb) // 3)) if s2_rides else 0.0
+    alg_bytes = alg_bytes_pfb + alg_bytes_s2
+    # ... and the filterbank kernel ALONE (the lag switched off for a pass of its own: every launch timed) -- the figure
+    # that compares with the rounds before the rider existed
+    pfb_alone_ms = pfb_alone_n = None
+    if s2_rides:
+        fe.set_stage2_lag(False)
+        fe.timing_enable(True, classes=[native.T_PFB])
+        fe.timing_read(native.T_PFB)
+        for _ in range(max(args.steps, 20)):
+            fe.commit(B)
+        fe.sync()
+        pfb_alone_ms, pfb_alone_n = fe.timing_read(native.T_PFB)
+        fe.timing_enable(False)
+        fe.set_stage2_lag(True)
     sustained = None
     if not args.no_sustained:                         # every rank runs it (the ranks stay in step); rank 0 reports
         sustained = sustained_leg(fe, native, B, alg_bytes, seconds=args.sustained_seconds)
@@ -1366,6 +1386,13 @@ def main():
                 "traffic_write_bytes": live["write_bytes"] if live else None,
                 "traffic_from_tracked_file": traffic_file if live is not None else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "algorithmic_bytes_filterbank": alg_bytes_pfb, "algorithmic_bytes_stage2_rider": alg_bytes_s2,
+                "stage2_rides_in_this_launch": s2_rides,
+                "filterbank_alone": ({"avg_launch_ms": pfb_alone_ms / max(pfb_alone_n, 1), "launches": pfb_alone_n,
+                                      "frac": alg_bytes_pfb / (pfb_alone_ms / max(pfb_alone_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "what": "the same kernel without the rider (rcf_set_stage2_lag off for a pass of its own, every "
+                                              "launch timed): 16 B x block / launch time, the figure of the rounds before the rider"}
+                                     if pfb_alone_n else None),
                 "avg_launch_ms": avg_pfb_s * 1e3, "launches": pfb_n, "timed_every": time_every,
                 "avg_launch_ms_every_launch_pass": pfb_all_ms / max(pfb_all_n, 1), "launches_every_launch_pass": pfb_all_n,
                 "frac_every_launch_pass": alg_bytes / (pfb_all_ms / max(pfb_all_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS if pfb_all_ms > 0 else None,
@@ -1380,6 +1407,8 @@ def main():
             "kernel_ms_per_step": {
                 "pfb": pfb_ms / max(pfb_n, 1),
                 "stage2_fir_with_fused_discriminator": fir2_ms / max(n_extra, 1),
+                "stage2_note": ("rides in the NEXT block's filterbank launch (its first workgroups): no launch of its own in steady "
+                                "state -- the figure above is the one flush the timing read forced, spread over the steps") if s2_rides else None,
                 "separate_discriminator_launches": disc_ms / max(n_extra, 1),
                 "launch_records_and_history_copy": hist_ms / max(n_extra, 1),
                 "launch_records_and_history_copy_note": "0 = no launch of its own: the filterbank kernel's first workgroups "

@@ -116,6 +116,13 @@ int rcf_close(rcf_t *h);
  *   bank's own phases).  Must be called before the first channel is opened (RCF_ESTATE otherwise); the environment
  *   variable RCF_ROTATOR=exact sets it at rcf_open. */
 int rcf_set_rotator(rcf_t *h, int exact);
+/* Stage-2 lag (default on; RCF_S2_LAG=0 at rcf_open or on = 0 here: off).  On a handle whose block is a power-of-two
+ * filterbank plus short stage-2 channels on its bins (rcf_pfb_chan_open: BASELINE configs[1]), the stage-2 launch of block
+ * n is not queued behind block n's filterbank launch -- a latency-bound tail of ~19 us behind a bandwidth-bound 100 us
+ * kernel -- but rides, as the first workgroups, in block n + 1's filterbank launch; every call that could observe its
+ * outputs (reads, rcf_sync, channel control, timing reads, a block that cannot carry it) queues it on its own first.
+ * Results are the same bits either way. */
+int rcf_set_stage2_lag(rcf_t *h, int on);
 /* The decimation rule rcf_chan_open / rcf_pfb_chan_open apply on this handle (rcf_channel_params_ex); default
  * RCF_DECIM_EXACT, or RCF_DECIM_FLOOR when the environment variable RCF_DECIM_FLOOR=1 is set at rcf_open. */
 int rcf_set_decim_rule(rcf_t *h, int decim_rule);

@@ -20,6 +20,7 @@
 
 #include "rcf_internal.h"
 #include "rotator.hpp"
+#include "fir_small.hpp"
 
 namespace rcfx {
 
@@ -27,7 +28,6 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kThreads = 256;
-constexpr int kSmallPerThread = 2;   // outputs per thread of the small-T kernel (fir_small_outputs <= 256 n - 1): 1 -> 2 took the stage-2 launch of the timed configuration from 0.030 to 0.025 ms, 3 and 4 are not faster
 constexpr int CT = 2;   // channels per wave item
 constexpr int KR = 8;   // outputs per wave item
 
@@ -36,35 +36,6 @@ __device__ __forceinline__ float wave_sum(float v)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
     return v;
-}
-
-// gr::fast_atan2f: 255-interval table + linear interpolation, octant fix-up (gr-runtime fast_atan2f.cc)
-__device__ __forceinline__ float fast_atan2f_gr(float y, float x, const float *tab)
-{
-    const float TAN_MAP_RES = 0.003921569f;
-    const float PI = 3.14159265358979323846f, PI_2 = 1.57079632679489661923f;
-    const float ya = fabsf(y), xa = fabsf(x);
-    if (!((ya > 0.0f) || (xa > 0.0f))) return 0.0f;
-    const float z = (ya < xa) ? __fdiv_rn(ya, xa) : __fdiv_rn(xa, ya);
-    float base;
-    if (z < TAN_MAP_RES) {
-        base = z;
-    } else {
-        float alpha = __fmul_rn(z, 255.0f);
-        const int index = ((int)alpha) & 0xff;
-        alpha = __fsub_rn(alpha, (float)index);
-        const float t0 = tab[index], t1 = tab[index + 1];
-        base = __fadd_rn(t0, __fmul_rn(__fsub_rn(t1, t0), alpha));
-    }
-    float angle;
-    if (xa > ya) {
-        if (x >= 0.0f) angle = (y >= 0.0f) ? base : -base;
-        else           angle = (y >= 0.0f) ? __fsub_rn(PI, base) : __fsub_rn(base, PI);
-    } else {
-        if (y >= 0.0f) angle = (x >= 0.0f) ? __fsub_rn(PI_2, base) : __fadd_rn(PI_2, base);
-        else           angle = (x >= 0.0f) ? __fadd_rn(-PI_2, base) : __fsub_rn(-PI_2, base);
-    }
-    return angle;
 }
 
 template <bool MASK>
@@ -142,122 +113,12 @@ __device__ __forceinline__ void fir_item(const float2 *xs, const ChanLaunch *__r
     }
 }
 
-// Small-T path (stage-2 FIRs on narrowband rings, e.g. D = 3, T = 11; the P25 69-tap pre-filter): one thread per
-// output (the lanes-over-taps kernel above would idle 53 of 64 lanes at T = 11).  A workgroup stages the
-// KB D + T input samples of its KB outputs (plus the output just before them) in LDS with coalesced loads,
-// taps come from the scalar cache, and the FM discriminator is fused in: outputs meet their predecessor in LDS,
-// thread 0 recomputes the one that belongs to the previous workgroup (the previous LAUNCH's is read back from the ring).  One launch and one pass over the channel
-// stream instead of two (the stage-2 FIR + discriminator pair was 22 % of the bench step).
+// Small-T path: fir_small_tile (fir_small.hpp), one (channel, tile) per workgroup
 __global__ __launch_bounds__(kThreads) void fir_small_kernel(const ChanLaunch *__restrict__ chans, int D, int T, int KB,
                                                              uint64_t ring_mask, const float *__restrict__ atan_tab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2 *xs = reinterpret_cast<float2 *>(smem_raw);          // KB D + T samples
-    float2 *ys = xs + (size_t)KB * D + T;                        // KB + 1 outputs: ys[t] = y[k0 - 1 + t]
-    float2 *cts = ys + KB + 1;                                   // T composite taps
-    float *tab = reinterpret_cast<float *>(cts + T);             // 257 + pad
-    // grid = (channels, output tiles): workgroups that run together work on the SAME stretch of time of different
-    // channels -- when the channels are bins of one filterbank ring (tiled or frame-major) their lines sit in the
-    // same tiles, i.e. the same pages
-    const ChanLaunch L = chans[blockIdx.x];     // by value: ONE batch of scalar loads (a reference is re-read after every global store -- 25 serialized scalar-memory waits per wave)
-    const int tid = threadIdx.x;
-    const int j0 = blockIdx.y * KB;
-    if (j0 >= L.n_k) return;
-    const int nj = min(KB, L.n_k - j0);
-    // samples (k0 - 1) D - (T - 1) .. (k0 + nj - 1) D, zero before the channel's start (GR zero history)
-    const int64_t k0 = L.k_lo + j0;
-    const int64_t s_first = (k0 - 1) * (int64_t)D - (T - 1);
-    const int len = nj * D + T;
-    const StreamView sv = L.src;
-    // EVERY load of the workgroup's prologue -- the arctangent table, the composite taps, the first LU samples per
-    // thread -- is issued before the first LDS store: table -> taps -> samples as three load -> store loops were three
-    // memory latencies in a row in a kernel that is nothing but a chain of them (and a load -> store loop over the
-    // samples exposes the latency once per iteration: measured, that, not arithmetic, was this kernel's time)
-    constexpr int LU = 8;     // the stage-2 shape of the timed configuration (D = 3, T = 11: 1544 samples) needs 7 per thread
-    static_assert(kThreads == 256, "one table entry per thread, the 257th on thread 0");
-    const float tab_a = atan_tab[tid], tab_b = atan_tab[256];
-    const float2 ct_a = tid < T ? L.ctaps[tid] : make_float2(0.f, 0.f);
-    {
-        float2 v[LU];
-#pragma unroll
-        for (int u = 0; u < LU; ++u) {
-            const int p = tid + u * kThreads;
-            const int64_t sidx = s_first + (p < len ? p : len - 1);
-            v[u] = sidx >= L.start_sample ? sv.base[sv.at(sidx)] : make_float2(0.f, 0.f);
-        }
-        tab[tid] = tab_a;
-        if (tid == 0) tab[256] = tab_b;
-        if (tid < T) cts[tid] = ct_a;
-#pragma unroll
-        for (int u = 0; u < LU; ++u) {
-            const int p = tid + u * kThreads;
-            if (p < len) xs[p] = v[u];
-        }
-    }
-    for (int i = tid + kThreads; i < T; i += kThreads) cts[i] = L.ctaps[i];
-    for (int p0 = tid + kThreads * LU; p0 < len; p0 += kThreads * LU) {
-        float2 v[LU];
-#pragma unroll
-        for (int u = 0; u < LU; ++u) {
-            const int p = p0 + u * kThreads;
-            const int64_t sidx = s_first + (p < len ? p : len - 1);
-            v[u] = sidx >= L.start_sample ? sv.base[sv.at(sidx)]
-                                          : make_float2(0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < LU; ++u) {
-            const int p = p0 + u * kThreads;
-            if (p < len) xs[p] = v[u];
-        }
-    }
-    __syncthreads();
-    // slot j = tid + 256 o holds y[k0 - 1 + j]: j = 0 is the predecessor the discriminator needs (it belongs to the
-    // previous workgroup or launch and is only recomputed, not stored), j = 1 .. nj are this workgroup's outputs.
-    // Up to kSmallPerThread outputs per thread: the whole launch then fits the GPU in one or two rounds of
-    // workgroups.  (Three per thread with the tile chosen so that the launch is exactly ONE round of resident
-    // workgroups -- 32 x 64 of 683 outputs instead of 32 x 86 of 511 -- measured the same, 19.7 against 19.2 us:
-    // it is the memory system's rate for 128-byte pieces, not the rounds.)
-    float2 y[kSmallPerThread];
-#pragma unroll
-    for (int o = 0; o < kSmallPerThread; ++o) {
-        const int j = tid + o * kThreads;
-        const int64_t n = k0 - 1 + j - L.k_abs0;               // relative output index
-        y[o] = make_float2(0.f, 0.f);
-        if (j == 0 && j0 == 0) {
-            // the launch's first output meets the output the PREVIOUS launch stored, not a recomputation of it: after a
-            // retune the taps and the rotator increment in force now are not the ones that made it (quadrature_demod
-            // sees the stream as it was emitted -- found by tests/test_gpu_fuzz.py: one discriminator sample per retune)
-            if (n >= 0) y[o] = L.iq_ring[(uint64_t)n & ring_mask];
-        } else if (j <= nj && n >= 0) {
-            const float2 *w = xs + (size_t)j * D + (T - 1);     // x[(k0 - 1 + j) D - i] = w[-i]
-            float ar = 0.f, ai = 0.f;
-            for (int i = 0; i < T; ++i) {
-                const float2 c = cts[i];
-                const float2 xv = w[-i];
-                ar = fmaf(c.x, xv.x, ar);
-                ar = fmaf(-c.y, xv.y, ar);
-                ai = fmaf(c.x, xv.y, ai);
-                ai = fmaf(c.y, xv.x, ai);
-            }
-            y[o] = rotate_value(L, n, ar, ai);
-            // (ring stores non-temporal: 20.6 -> 19.7 us for the timed configuration's 32 channels)
-            if (j >= 1) { typedef float v2f_ __attribute__((ext_vector_type(2))); v2f_ o_; o_.x = y[o].x; o_.y = y[o].y;
-                          __builtin_nontemporal_store(o_, reinterpret_cast<v2f_ *>(L.iq_ring + ((uint64_t)n & ring_mask))); }
-        }
-        if (j <= nj) ys[j] = y[o];                               // n < 0: quadrature_demod's zero history
-    }
-    __syncthreads();
-#pragma unroll
-    for (int o = 0; o < kSmallPerThread; ++o) {
-        const int j = tid + o * kThreads;
-        if (j >= 1 && j <= nj) {
-            const float2 b = ys[j - 1];
-            // volk_32fc_x2_multiply_conjugate_32fc: a * conj(b), unfused
-            const float tr = __fadd_rn(__fmul_rn(y[o].x, b.x), __fmul_rn(y[o].y, b.y));
-            const float ti = __fsub_rn(__fmul_rn(y[o].y, b.x), __fmul_rn(y[o].x, b.y));
-            __builtin_nontemporal_store(fast_atan2f_gr(ti, tr, tab), L.fm_ring + ((uint64_t)(k0 - 1 + j - L.k_abs0) & ring_mask));
-        }
-    }
+    fir_small_tile(chans, blockIdx.x, blockIdx.y, D, T, KB, ring_mask, atan_tab, smem_raw);
 }
 
 __global__ __launch_bounds__(kThreads) void fir_bank_kernel(const ChanLaunch *__restrict__ chans, FirLaunchDims d)

@@ -39,6 +39,7 @@
 #define RCF_PFB_STORE_AUX 18       // nt | sc1 (bits 1 and 4).  256 / 512 / 1024 bins, two alternating runs each, of the HBM peak: plain 0.658-0.663 / 0.626-0.629 / -, sc0 0.660 / 0.627-0.630 / -, sc1 0.664 / 0.641-0.643 / -, nt 0.669-0.673 / 0.661-0.669 / 0.600, nt sc0 0.670 / 0.660-0.664 / 0.598, sc0 sc1 0.659-0.661 / 0.637 / 0.562, nt sc1 0.675-0.679 / 0.676-0.681 / 0.602-0.607, all three 0.675-0.676 / 0.672-0.679 / 0.606
 #endif
 #include "rcf_internal.h"
+#include "fir_small.hpp"
 
 namespace rcfx {
 
@@ -271,22 +272,38 @@ __device__ __forceinline__ void pfb_os_chunk(const PfbLaunch &p, const int wg, c
 }
 
 // n_wg < 0: probe without the XCD-aware block -> chunk map (RCF_PFB_NOREMAP=1)
+// sr: the stage-2 rider.  The stage-2 launch of the PREVIOUS block (fir_small_tile: short xlating FIR + discriminator per
+// active bin) is a latency-bound tail of ~19 us behind a bandwidth-bound 100 us kernel -- 14 % of the step.  Its work
+// items are independent of this block's chunks (the frames they read were finished by the previous launch), so they are
+// the FIRST sr.n_wgs workgroups of this launch and run beside the first rounds of filterbank chunks: the tail costs its
+// 50 MB of traffic and nothing else.
 template <int NB, int OS, int P, int MINW, bool ZH>
-__global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg)
+__global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg, S2Rider sr)
 {
     constexpr int RS = row_stride<NB>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int bid = blockIdx.x;
+    if constexpr (NB == kSmallThreads && !ZH) {
+        if (sr.n_wgs > 0) {
+            if (bid < sr.n_wgs) {
+                if (bid < sr.n_chans * sr.n_tiles)
+                    fir_small_tile(sr.chans, bid % sr.n_chans, bid / sr.n_chans, sr.D, sr.T, sr.KB, sr.ring_mask, sr.atan_tab, smem_raw);
+                return;
+            }
+            bid -= sr.n_wgs;                               // (a multiple of 8: the chunks keep their XCDs)
+        }
+    }
     cf *buf = reinterpret_cast<cf *>(smem_raw);
     cf *tw_lds = buf + F * RS;
 
     const int tid = threadIdx.x;
-    if (p.rider_n8[0] + p.rider_n8[1] && (int)blockIdx.x < kPfbRiderWgs)
-        pfb_copy_rider(p, blockIdx.x, min(kPfbRiderWgs, (int)gridDim.x), tid, NB);
+    if (p.rider_n8[0] + p.rider_n8[1] && bid < kPfbRiderWgs)
+        pfb_copy_rider(p, bid, min(kPfbRiderWgs, (int)gridDim.x - (int)sr.n_wgs), tid, NB);
     int wg;
     if (n_wg < 0) {
-        wg = blockIdx.x;                                   // probe: no XCD remap
+        wg = bid;                                          // probe: no XCD remap
     } else {
-        const int b = blockIdx.x, q = n_wg / 8, r = n_wg % 8, xcd = b % 8;
+        const int b = bid, q = n_wg / 8, r = n_wg % 8, xcd = b % 8;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
     }
     pfb_os_chunk<NB, OS, P, ZH>(p, wg, tid, buf, tw_lds);
@@ -659,9 +676,11 @@ bool pfb_two_branch(int NB, int OS)
 }
 
 template <int NB, int OS, int P, int MINW>
-void launch_os(const PfbLaunch &p, hipStream_t s)
+void launch_os(const PfbLaunch &p, hipStream_t s, const S2Rider *sr_in)
 {
     const int n_wg = (p.n_frames + F - 1) / F;
+    S2Rider sr{};
+    if (sr_in) sr = *sr_in;
     static const int no_remap = env_int("RCF_PFB_NOREMAP", 0);
     const int arg = no_remap ? -n_wg : n_wg;
     const size_t lds = ((size_t)F * row_stride<NB>() + NB) * sizeof(cf);
@@ -701,8 +720,12 @@ void launch_os(const PfbLaunch &p, hipStream_t s)
         RCF_PFB_LAUNCH(p, (pfb_kernel_pp<NB, OS, P, MINW, false, PF>), dim3(grid), dim3(NB), lds, s, p, n_wg);
         return;
     }
-    if (zh) RCF_PFB_LAUNCH(p, (pfb_kernel_os<NB, OS, P, MINW, true>), dim3(n_wg), dim3(NB), lds, s, p, arg);
-    else    RCF_PFB_LAUNCH(p, (pfb_kernel_os<NB, OS, P, MINW, false>), dim3(n_wg), dim3(NB), lds, s, p, arg);
+    if (zh) { S2Rider none{}; RCF_PFB_LAUNCH(p, (pfb_kernel_os<NB, OS, P, MINW, true>), dim3(n_wg), dim3(NB), lds, s, p, arg, none); }
+    else {
+        size_t lds_s2 = 0;
+        if (sr.n_wgs > 0) lds_s2 = ((size_t)sr.KB * sr.D + 2 * sr.T + sr.KB + 1) * sizeof(float2) + 264 * sizeof(float);
+        RCF_PFB_LAUNCH(p, (pfb_kernel_os<NB, OS, P, MINW, false>), dim3(n_wg + sr.n_wgs), dim3(NB), std::max(lds, lds_s2), s, p, arg, sr);
+    }
 }
 
 // grouped launch of one shape; false: this shape has no grouped form (the oversampled persistent kernels), the caller
@@ -741,7 +764,7 @@ int round_p(int P, int OS)
 // d_pls != nullptr: the grouped launch of this shape (p is the members' common shape; gm the chunk map)
 template <int NB>
 bool dispatch_nb(const PfbLaunch &p, int OS, int P, bool probe, hipStream_t s, const PfbLaunch *d_pls = nullptr,
-                 const GroupMap *gm = nullptr)
+                 const GroupMap *gm = nullptr, const S2Rider *sr = nullptr)
 {
     const int PR = round_p(P, OS);
     if (PR == 0 || (OS != 1 && OS != 2)) return false;
@@ -758,24 +781,25 @@ bool dispatch_nb(const PfbLaunch &p, int OS, int P, bool probe, hipStream_t s, c
         return launch_os_group<NB, 2, 16, MW>(d_pls, *gm, s);
     }
     if (OS == 1) {
-        if (PR == 4) launch_os<NB, 1, 4, MW>(p, s);
-        else if (PR == 14) launch_os<NB, 1, 14, MW>(p, s);
-        else launch_os<NB, 1, 16, MW>(p, s);
+        if (PR == 4) launch_os<NB, 1, 4, MW>(p, s, sr);
+        else if (PR == 14) launch_os<NB, 1, 14, MW>(p, s, sr);
+        else launch_os<NB, 1, 16, MW>(p, s, sr);
     }
-    else         { if (PR == 4) launch_os<NB, 2, 4, MW>(p, s); else launch_os<NB, 2, 16, MW>(p, s); }
+    else         { if (PR == 4) launch_os<NB, 2, 4, MW>(p, s, sr); else launch_os<NB, 2, 16, MW>(p, s, sr); }
     return true;
 }
 
-bool dispatch(const PfbLaunch &p, bool probe, hipStream_t s, const PfbLaunch *d_pls = nullptr, const GroupMap *gm = nullptr)
+bool dispatch(const PfbLaunch &p, bool probe, hipStream_t s, const PfbLaunch *d_pls = nullptr, const GroupMap *gm = nullptr,
+              const S2Rider *sr = nullptr)
 {
     if (p.D <= 0 || p.NB % p.D) return false;
     const int OS = p.NB / p.D;
     switch (p.NB) {
-        case 64:   return dispatch_nb<64>(p, OS, p.P, probe, s, d_pls, gm);
-        case 128:  return dispatch_nb<128>(p, OS, p.P, probe, s, d_pls, gm);
-        case 256:  return dispatch_nb<256>(p, OS, p.P, probe, s, d_pls, gm);
-        case 512:  return dispatch_nb<512>(p, OS, p.P, probe, s, d_pls, gm);
-        case 1024: return dispatch_nb<1024>(p, OS, p.P, probe, s, d_pls, gm);
+        case 64:   return dispatch_nb<64>(p, OS, p.P, probe, s, d_pls, gm, sr);
+        case 128:  return dispatch_nb<128>(p, OS, p.P, probe, s, d_pls, gm, sr);
+        case 256:  return dispatch_nb<256>(p, OS, p.P, probe, s, d_pls, gm, sr);
+        case 512:  return dispatch_nb<512>(p, OS, p.P, probe, s, d_pls, gm, sr);
+        case 1024: return dispatch_nb<1024>(p, OS, p.P, probe, s, d_pls, gm, sr);
         default:   return d_pls ? pfb5_dispatch_group(p, d_pls, *gm, s) : pfb5_dispatch(p, probe, s);      // 400 / 800 / 1600 / 3200 bins (pfb5.hip)
     }
 }
@@ -804,10 +828,20 @@ bool pfb_takes_rider(const PfbLaunch &p)
     return pfb_two_branch(p.NB, p.D > 0 ? p.NB / p.D : 1) || !pfb_persistent(p.NB);
 }
 
-void launch_pfb(const PfbLaunch &p, hipStream_t s)
+void launch_pfb(const PfbLaunch &p, hipStream_t s, const S2Rider *sr)
 {
     if (p.n_frames <= 0) return;
-    dispatch(p, false, s);
+    dispatch(p, false, s, nullptr, nullptr, sr);
+}
+
+// whether THIS launch runs the kernel that can carry a stage-2 rider: the 256-bin steady-state kernel (its workgroups have
+// the small-T tile's 256 threads)
+bool pfb_can_carry_s2(const PfbLaunch &p)
+{
+    if (p.NB != kSmallThreads || pfb_frame_major(p.NB) || p.D <= 0 || p.n_frames <= 0) return false;
+    const int OS = p.NB / p.D;
+    if ((OS != 1 && OS != 2) || round_p(p.P, OS) == 0 || pfb_persistent(p.NB) || pfb_two_branch(p.NB, OS)) return false;
+    return !pfb_sees_zero_history(p);
 }
 
 // whether this launch still reaches samples before the bank's start (it then runs the masking instantiation, alone)

@@ -90,6 +90,7 @@ int group_process(rcf_group *g, const std::vector<GroupItem> &items, int fmt, fl
     size_t need = 16384 + NI * (3 * sizeof(PrepRec) + sizeof(PfbLaunch) + sizeof(TapFinArgs) + 4 * sizeof(int32_t) + 512);
     for (const GroupItem &it : items) {
         rcf_t *h = g->members[(size_t)it.m];
+        flush_lagged(h);                                       // (a member that was fed on its own before: nothing lags inside a group)
         if (h->graveyard.size() > 512) drain_graveyard(h);
         need += arena_need_bound(h);
     }
@@ -694,6 +695,7 @@ int rcf_group_open(rcf_t *const *handles, int n, rcf_group_t **out)
     g->stage_cap.assign((size_t)n, 0);
     for (rcf_t *h : g->members) {
         std::lock_guard<std::mutex> l(h->mu);
+        flush_lagged(h);
         RCF_HIP(hipStreamSynchronize(h->stream));          // whatever it queued on its own stream comes first
         time_collect(h);
         h->own_stream = h->stream;
@@ -769,6 +771,7 @@ int rcf_group_sync(rcf_group_t *g)
     std::lock_guard<std::mutex> gl(g->mu);
     MemberLocks ml(g->members);
     RCF_HIP(hipSetDevice(g->device));
+    for (rcf_t *h : g->members) flush_lagged(h);
     RCF_HIP(hipStreamSynchronize(g->stream));
     for (rcf_t *h : g->members) free_graveyard_idle(h);
     return RCF_OK;
@@ -784,6 +787,7 @@ int rcf_group_read_many(rcf_group_t *g, int what, const int *members, const int 
     std::lock_guard<std::mutex> gl(g->mu);
     MemberLocks ml(g->members);
     RCF_HIP(hipSetDevice(g->device));
+    for (rcf_t *h : g->members) flush_lagged(h);            // (a member that was fed on its own meanwhile)
     const size_t elem = what == RCF_READ_IQ ? sizeof(float2) : sizeof(float);
     const uint32_t ew = (uint32_t)(elem / 4);
     std::vector<uint64_t> stamps(g->members.size());

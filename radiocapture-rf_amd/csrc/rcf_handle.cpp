@@ -29,9 +29,16 @@ bool hip_ok(hipError_t e, const char *what)
     return false;
 }
 
+int set_dev_ingest(rcf_t *h)
+{
+    RCF_HIP(hipSetDevice(h->device));
+    return RCF_OK;
+}
+
 int set_dev(rcf_t *h)
 {
     RCF_HIP(hipSetDevice(h->device));
+    flush_lagged(h);
     return RCF_OK;
 }
 
@@ -180,6 +187,7 @@ int rcf_open_ex(int device, double samp_rate, double center_freq, size_t block_c
         if (const char *rm = getenv("RCF_ROTATOR")) h->exact_rot = std::strcmp(rm, "exact") == 0;
         if (const char *df = getenv("RCF_DECIM_FLOOR")) h->decim_rule = std::atoi(df) ? RCF_DECIM_FLOOR : RCF_DECIM_EXACT;
         if (const char *ck = getenv("RCF_COPY_KERNELS")) h->copy_kernels = h->copy_kernels && atoi(ck) != 0;
+        if (const char *lg = getenv("RCF_S2_LAG")) h->lag_enabled = atoi(lg) != 0;
     if (const char *nm = getenv("RCF_FIR_MFMA_MIN")) h->mfma_min = std::max(1, atoi(nm));
         if (const char *nm = getenv("RCF_FIR_MFMA_NT")) h->mfma_nt = atoi(nm);
         if (const char *nm = getenv("RCF_FIR_MFMA_PARTS")) h->mfma_parts = atoi(nm);
@@ -209,6 +217,7 @@ int rcf_close(rcf_t *h)
     if (!h) return RCF_EINVAL;
     if (h->group) { set_error("the handle belongs to a group: rcf_group_close first"); return RCF_ESTATE; }
     (void)hipSetDevice(h->device);
+    flush_lagged(h);
     (void)hipStreamSynchronize(h->stream);
     for (auto &kv : h->chans) free_channel(h, kv.second.get());
     h->chans.clear();
@@ -265,6 +274,15 @@ int rcf_set_rotator(rcf_t *h, int exact)
     return RCF_OK;
 }
 
+int rcf_set_stage2_lag(rcf_t *h, int on)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;            // (flushes a launch that is lagging now)
+    h->lag_enabled = on != 0;
+    return RCF_OK;
+}
+
 int rcf_set_decim_rule(rcf_t *h, int decim_rule)
 {
     if (!h || (decim_rule != RCF_DECIM_EXACT && decim_rule != RCF_DECIM_FLOOR)) { set_error("bad decimation rule"); return RCF_EINVAL; }
@@ -287,7 +305,7 @@ int rcf_push_iq(rcf_t *h, const float *iq, size_t n)
     if (n == 0) return RCF_OK;
     if (n > h->block_cap) { set_error("push of %zu samples exceeds block capacity %zu", n, h->block_cap); return RCF_ECAP; }
     std::lock_guard<std::mutex> g(h->mu);
-    if (set_dev(h)) return RCF_EHIP;
+    if (set_dev_ingest(h)) return RCF_EHIP;
     {
         // a real-time-sized block in pinned memory (see rcf_push_raw): copied by a kernel on the compute stream straight
         // out of host memory -- no second stream, no cross-stream waits.  In order behind every kernel that read this
@@ -327,7 +345,7 @@ int rcf_push_raw(rcf_t *h, const void *iq_raw, size_t n, int fmt, float scale, f
     if (n == 0) return RCF_OK;
     if (n > h->block_cap) { set_error("push of %zu samples exceeds block capacity %zu", n, h->block_cap); return RCF_ECAP; }
     std::lock_guard<std::mutex> g(h->mu);
-    if (set_dev(h)) return RCF_EHIP;
+    if (set_dev_ingest(h)) return RCF_EHIP;
     {
         // Pinned caller memory (rcf_host_alloc): the conversion kernel reads the wire-format block straight out of host
         // memory across PCIe -- no staging copy, no second stream, no cross-stream event waits: one event instead of
@@ -402,7 +420,7 @@ int rcf_commit(rcf_t *h, size_t n)
     if (n == 0) return RCF_OK;
     if (n > h->block_cap) { set_error("commit of %zu samples exceeds block capacity %zu", n, h->block_cap); return RCF_ECAP; }
     std::lock_guard<std::mutex> g(h->mu);
-    if (set_dev(h)) return RCF_EHIP;
+    if (set_dev_ingest(h)) return RCF_EHIP;
     return process_block(h, n);
 }
 

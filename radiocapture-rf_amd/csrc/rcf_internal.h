@@ -403,9 +403,20 @@ bool launch_pfb_group(const PfbLaunch &shape, const PfbLaunch *d_pls, const Grou
 bool pfb5_dispatch_group(const PfbLaunch &p, const PfbLaunch *d_pls, const GroupMap &gm, hipStream_t s);
 bool pfb_sees_zero_history(const PfbLaunch &p);
 int pfb_chunk_frames(int NB);
+// Stage-2 rider of a filterbank launch (pfb.hip): the small-T FIR + discriminator launch of the PREVIOUS block, run by the
+// first n_wgs workgroups of this block's filterbank kernel (its records are already in the device arena)
+struct S2Rider {
+    const ChanLaunch *chans;
+    const float *atan_tab;
+    uint64_t ring_mask;
+    int32_t n_chans, n_tiles;    // the deferred launch's grid: (channels, tiles of KB outputs)
+    int32_t D, T, KB;
+    int32_t n_wgs;               // n_chans * n_tiles rounded up to a multiple of 8; 0: no rider
+};
+bool pfb_can_carry_s2(const PfbLaunch &p);
 bool pfb_supported(int NB, int D, int P);
 int pfb_padded_p(int NB, int D, int P);   // rows the kernel instantiation reads from ptaps (zero padded)
-void launch_pfb(const PfbLaunch &p, hipStream_t s);
+void launch_pfb(const PfbLaunch &p, hipStream_t s, const S2Rider *sr = nullptr);
 // bin counts with a factor 25 (pfb5.hip): 400, 800, 1600, 3200
 bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s);
 inline bool pfb_frame_major(int NB) { return NB % 25 == 0; }

@@ -3,6 +3,14 @@
 
 namespace rcfx {
 
+void flush_lagged(rcf_t *h)
+{
+    if (!h->lag.pending) return;
+    h->lag.pending = false;
+    Timed t(h, RCF_T_FIR_DERIVED);
+    launch_fir_bank(h->lag.dev, h->lag.dims, h->stream);
+}
+
 // upload all launch parameters in one copy, then launch in dependency order
 int launch_plan(rcf_t *h, BlockPlan &bp)
 {
@@ -23,6 +31,29 @@ int launch_plan(rcf_t *h, BlockPlan &bp)
     const AudioLaunch *d_audf = bp.d_audf;
     const int symf_max_n = bp.symf_max_n, audf_max_n = bp.audf_max_n, audf_num = bp.audf_num, audf_den = bp.audf_den;
 
+    // ---- stage-2 lag.  The previous block's small-T launch, if it is still pending, rides in THIS block's filterbank launch
+    // when that launch is the kernel that can carry it and the bank's ring has room for both blocks' frames; otherwise it
+    // goes out now, ahead of everything of this block.
+    const size_t pfb_reach = bp.reach(RCF_SRC_PFB_BIN0);
+    const bool carry = run_pfb && pfb_can_carry_s2(pl);
+    if (h->lag.pending && !(carry && (size_t)(pl.n_frames + h->lag.frames) + pfb_reach <= h->out_cap)) flush_lagged(h);
+    S2Rider sr{};
+    if (h->lag.pending) {
+        const FirLaunchDims &ld = h->lag.dims;
+        sr.chans = h->lag.dev;
+        sr.atan_tab = ld.atan_tab;
+        sr.ring_mask = ld.ring_mask;
+        sr.D = ld.D; sr.T = ld.T; sr.KB = fir_small_outputs(ld.D, ld.T);
+        sr.n_chans = ld.n_chans;
+        sr.n_tiles = (ld.max_n_k + sr.KB - 1) / sr.KB;
+        sr.n_wgs = (sr.n_chans * sr.n_tiles + 7) & ~7;
+        h->lag.pending = false;
+    }
+    // ... and this block's own: ONE small-T job on the bank's bins, nothing that consumes its outputs within the block
+    FirJob *lag_job = nullptr;
+    if (h->lag_enabled && carry && fir_by_depth.size() == 2 && fir_by_depth[1].size() == 1 && fir_by_depth[1][0].dims.small &&
+        fir_by_depth[1][0].dev && fir_by_depth[1][0].bank_src && !d_symf && !d_audf && (size_t)pl.n_frames * 2 + pfb_reach <= h->out_cap)
+        lag_job = &fir_by_depth[1][0];
     {
         // the block's launch records host -> device, and -- in the same launch -- its history tail behind the OTHER input
         // buffer's block (nothing in this block reads that place, and the kernels that did read it are earlier in
@@ -67,14 +98,24 @@ int launch_plan(rcf_t *h, BlockPlan &bp)
             Timed t(h, j.dims.mfma ? RCF_T_FIR_MFMA : RCF_T_FIR);
             launch_fir_bank(j.dev, j.dims, st);
         }
-    if (run_pfb) { TimedAttached t(h, RCF_T_PFB, pl); launch_pfb(pl, st); }
+    if (run_pfb) { TimedAttached t(h, RCF_T_PFB, pl); launch_pfb(pl, st, sr.n_wgs ? &sr : nullptr); }
     if (run_pfb && pl.n_taps > 0) {
         Timed t(h, RCF_T_TAPS);
         launch_tap_finalize(d_tap_list, pl.n_taps, pl.tap_mat, pl.tap_pitch, pl.n_frames, pl.n_lo - pl.n_abs0,
                             h->ring_mask, h->d_atan, bp.d_group_bin0, pl.tap_first, pl.bins_ring, pl.NB, st);
     }
     for (size_t d = 1; d < fir_by_depth.size(); ++d)
-        for (auto &j : fir_by_depth[d]) { Timed t(h, RCF_T_FIR_DERIVED); launch_fir_bank(j.dev, j.dims, st); }
+        for (auto &j : fir_by_depth[d]) {
+            if (&j == lag_job) {                            // not queued: it rides in the next block's filterbank launch
+                h->lag.pending = true;
+                h->lag.dims = j.dims;
+                h->lag.dev = j.dev;
+                h->lag.frames = pl.n_frames;
+                continue;
+            }
+            Timed t(h, RCF_T_FIR_DERIVED);
+            launch_fir_bank(j.dev, j.dims, st);
+        }
     for (auto &dj : disc_jobs) {
         Timed t(h, RCF_T_DISC);
         launch_discriminator(dj.dev, dj.n, dj.max_n, h->ring_mask, h->d_atan, st);

@@ -61,6 +61,9 @@ int plan_arena(rcf_t *h, BlockPlan &bp)
         h->arena_need_epoch = h->chans_epoch;
     }
     if (bp.ar != &bp.own_ar) return RCF_OK;        // a group's block: the group reserved its arena for all members
+    // (a lagging stage-2 launch reads its records in the current arena: it goes out before the arenas are re-allocated or
+    // the one it lives in can come round again)
+    if (h->lag.pending && (arena_need > h->arenas.cap || h->arenas.fill + arena_need > h->arenas.cap)) flush_lagged(h);
     if (h->arenas.reserve(arena_need, h->stream) != RCF_OK) return RCF_EHIP;
     if (!h->arenas.mapped) h->copy_kernels = false;
     bp.a = h->arenas.cur;
@@ -151,6 +154,7 @@ int plan_channel(rcf_t *h, BlockPlan &bp, ClassPlan &cp, Chan *c, int D)
         return RCF_OK;
     }
     if (c->src >= 0) shared_src = false;
+    if (c->src < RCF_SRC_PFB_BIN0) cp.all_bank_src = false;
     const int64_t k_lo = std::max(ceil_div(sr.p0, D), c->k_abs0);
     const int64_t k_hi = floor_div(sr.p1 - 1, D);
     const int64_t before = c->produced;
@@ -286,6 +290,7 @@ int plan_class_jobs(rcf_t *h, BlockPlan &bp, ClassPlan &cp, int depth, std::pair
 
     if (launches.empty()) return RCF_OK;
     FirJob job{};
+    job.bank_src = cp.all_bank_src;
     job.dims.D = D; job.dims.T = T; job.dims.KT = choose_kt(D, T);
     job.dims.chans_per_wg = shared_src ? 16 : 1;
     job.dims.max_n_k = max_n;

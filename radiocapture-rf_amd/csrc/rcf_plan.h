@@ -39,6 +39,7 @@ struct FirJob {
     // return in between must not leave a key that claims a matrix nobody built)
     rcf::BankCache *bc; std::vector<std::pair<int, uint64_t>> key;
     std::vector<ChanLaunch> host;      // BlockPlan::defer: records not yet in the arena (the group merges them first)
+    bool bank_src = false;             // every channel of the job reads a bin of the filterbank (what the stage-2 lag may defer)
 };
 struct DiscJob { const DiscLaunch *dev; int n; int max_n; std::vector<DiscLaunch> host; };
 
@@ -100,6 +101,7 @@ struct ClassPlan {
     std::vector<DiscLaunch> discs;
     int max_n = 0;
     bool shared_src = true;
+    bool all_bank_src = true;          // every launched channel's source is a filterbank bin
 };
 
 // what planning a block changed in the handle, so that it can be taken back while nothing has been queued

@@ -153,6 +153,16 @@ struct rcf {
     // launch-parameter arenas (pinned host + device), double buffered
     rcfx::ArenaSet arenas;
     bool copy_kernels = true;     // RCF_COPY_KERNELS=0: hipMemcpyAsync for the launch records and the history (A/B)
+    // Stage-2 lag (rcf_launch.cpp): the small-T FIR + discriminator launch of the last block has NOT been queued -- it rides
+    // in the next block's filterbank launch (S2Rider), or goes out on its own as soon as anybody could look at its outputs
+    // (every entry point that touches the stream flushes it: set_dev).  RCF_S2_LAG=0 / rcf_set_stage2_lag(h, 0): off.
+    struct Lag {
+        bool pending = false;
+        rcfx::FirLaunchDims dims{};
+        const rcfx::ChanLaunch *dev = nullptr;
+        int64_t frames = 0;           // bank frames of the block it belongs to (ring room: the next block must not overwrite them)
+    } lag;
+    bool lag_enabled = true;
     // a handle that belongs to a group (rcf_group_open) runs on the group's stream; its own comes back at rcf_group_close
     struct rcf_group *group = nullptr;
     hipStream_t own_stream = nullptr;
@@ -222,7 +232,9 @@ struct rcf {
 namespace rcfx {
 
 // ---------------------------------------------------------------- rcf_handle.cpp
-int set_dev(rcf_t *h);
+int set_dev(rcf_t *h);               // hipSetDevice + flush_lagged: what every entry point that touches the stream calls
+int set_dev_ingest(rcf_t *h);        // hipSetDevice only: push / commit decide themselves what becomes of a lagging launch
+void flush_lagged(rcf_t *h);         // rcf_launch.cpp
 void bury(rcf_t *h, void *p, size_t slice = 0);
 void free_graveyard_idle(rcf_t *h);      // the stream is known to be idle (the caller just synchronised it)
 void drain_graveyard(rcf_t *h);

@@ -13,6 +13,7 @@ namespace {
 // with eight of them per lane it was a tenth of the matrix-core bank's time.
 __device__ __forceinline__ void sincos_fast(double a, double &sn, double &cs)
 {
+#pragma clang fp contract(off)
     const double k = rint(a * 0.63661977236758134308);
     double x = fma(-k, 1.57079632679489655800e+00, a);
     x = fma(-k, 6.12323399573676603587e-17, x);
@@ -46,6 +47,7 @@ __device__ __forceinline__ void sincos_fast(double a, double &sn, double &cs)
 template <class LT>
 __device__ __forceinline__ float2 rotate_value(const LT &L, int64_t n, float vr, float vi)
 {
+#pragma clang fp contract(off)
     float pr = 1.f, pi = 0.f;
     bool have = false;
     if constexpr (LT::kHasRotRing) {

@@ -37,7 +37,7 @@ SYMBOLS = [
     "rcf_chan_audio_close", "rcf_chan_audio_produced", "rcf_chan_read_audio",
     "rcf_host_alloc", "rcf_host_free", "rcf_comm_unique_id", "rcf_comm_init", "rcf_comm_destroy", "rcf_comm_size",
     "rcf_allgather_peaks", "rcf_allreduce_max", "rcf_pfb_tap_open", "rcf_pfb_shape_supported",
-    "rcf_pfb_tap_leakage", "rcf_set_rotator", "rcf_timing_stride",
+    "rcf_pfb_tap_leakage", "rcf_set_rotator", "rcf_timing_stride", "rcf_set_stage2_lag",
     "rcf_group_open", "rcf_group_close", "rcf_group_size", "rcf_group_push", "rcf_group_commit", "rcf_group_read_many",
     "rcf_group_sync", "rcf_pump_start", "rcf_pump_stats", "rcf_pump_written", "rcf_pump_read", "rcf_pump_stop",
 ]
@@ -107,6 +107,7 @@ def lib():
         "rcf_open_ex": (C.c_int, [C.c_int, C.c_double, C.c_double, sz, sz, sz, C.POINTER(vp)]),
         "rcf_close": (C.c_int, [vp]),
         "rcf_set_rotator": (C.c_int, [vp, C.c_int]),
+        "rcf_set_stage2_lag": (C.c_int, [vp, C.c_int]),
         "rcf_sync": (C.c_int, [vp]),
         "rcf_stream": (vp, [vp]),
         "rcf_device": (C.c_int, [vp]),
@@ -366,6 +367,10 @@ class Frontend:
     def set_rotator(self, exact=True):
         """exact: iterate GNU Radio's float32 rotator per channel (rcf_set_rotator); before the first channel"""
         _check(lib().rcf_set_rotator(self._h, 1 if exact else 0))
+
+    def set_stage2_lag(self, on=True):
+        """stage-2 channels of a power-of-two bank ride in the NEXT block's filterbank launch (rcf_set_stage2_lag; default on)"""
+        _check(lib().rcf_set_stage2_lag(self._h, 1 if on else 0))
 
     def set_decim_rule(self, rule):
         """DECIM_EXACT (default) | DECIM_FLOOR (rcf_set_decim_rule): what rcf_chan_open does with an odd int(fs/cr)"""
