@@ -22,24 +22,24 @@ __device__ __forceinline__ float fast_atan2f_gr(float y, float x, const float *t
     const float PI = 3.14159265358979323846f, PI_2 = 1.57079632679489661923f;
     const float ya = fabsf(y), xa = fabsf(x);
     if (!((ya > 0.0f) || (xa > 0.0f))) return 0.0f;
-    const float z = (ya < xa) ? __fdiv_rn(ya, xa) : __fdiv_rn(xa, ya);
+    const float z = (ya < xa) ? (ya / xa) : (xa / ya);
     float base;
     if (z < TAN_MAP_RES) {
         base = z;
     } else {
-        float alpha = __fmul_rn(z, 255.0f);
+        float alpha = z * 255.0f;
         const int index = ((int)alpha) & 0xff;
-        alpha = __fsub_rn(alpha, (float)index);
+        alpha = alpha - (float)index;
         const float t0 = tab[index], t1 = tab[index + 1];
-        base = __fadd_rn(t0, __fmul_rn(__fsub_rn(t1, t0), alpha));
+        base = t0 + ((t1 - t0) * alpha);
     }
     float angle;
     if (xa > ya) {
         if (x >= 0.0f) angle = (y >= 0.0f) ? base : -base;
-        else           angle = (y >= 0.0f) ? __fsub_rn(PI, base) : __fsub_rn(base, PI);
+        else           angle = (y >= 0.0f) ? (PI - base) : (base - PI);
     } else {
-        if (y >= 0.0f) angle = (x >= 0.0f) ? __fsub_rn(PI_2, base) : __fadd_rn(PI_2, base);
-        else           angle = (x >= 0.0f) ? __fadd_rn(-PI_2, base) : __fsub_rn(-PI_2, base);
+        if (y >= 0.0f) angle = (x >= 0.0f) ? (PI_2 - base) : (PI_2 + base);
+        else           angle = (x >= 0.0f) ? (-PI_2 + base) : (-PI_2 - base);
     }
     return angle;
 }
@@ -158,8 +158,8 @@ __device__ __forceinline__ void fir_small_tile(const ChanLaunch *__restrict__ ch
         if (j >= 1 && j <= nj) {
             const float2 b = ys[j - 1];
             // volk_32fc_x2_multiply_conjugate_32fc: a * conj(b), unfused
-            const float tr = __fadd_rn(__fmul_rn(y[o].x, b.x), __fmul_rn(y[o].y, b.y));
-            const float ti = __fsub_rn(__fmul_rn(y[o].y, b.x), __fmul_rn(y[o].x, b.y));
+            const float tr = (y[o].x * b.x) + (y[o].y * b.y);
+            const float ti = (y[o].y * b.x) - (y[o].x * b.y);
             __builtin_nontemporal_store(fast_atan2f_gr(ti, tr, tab), L.fm_ring + ((uint64_t)(k0 - 1 + j - L.k_abs0) & ring_mask));
         }
     }

@@ -285,12 +285,14 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg,
     int bid = blockIdx.x;
     if constexpr (NB == kSmallThreads && !ZH) {
         if (sr.n_wgs > 0) {
-            if (bid < sr.n_wgs) {
-                if (bid < sr.n_chans * sr.n_tiles)
-                    fir_small_tile(sr.chans, bid % sr.n_chans, bid / sr.n_chans, sr.D, sr.T, sr.KB, sr.ring_mask, sr.atan_tab, smem_raw);
+            const int n_pfb = (int)gridDim.x - sr.n_wgs;
+            const int rid = sr.at_end ? bid - n_pfb : bid;      // riders first (default) or behind the last chunk
+            if (rid >= 0 && rid < sr.n_wgs) {
+                if (rid < sr.n_chans * sr.n_tiles)
+                    fir_small_tile(sr.chans, rid % sr.n_chans, rid / sr.n_chans, sr.D, sr.T, sr.KB, sr.ring_mask, sr.atan_tab, smem_raw);
                 return;
             }
-            bid -= sr.n_wgs;                               // (a multiple of 8: the chunks keep their XCDs)
+            if (!sr.at_end) bid -= sr.n_wgs;               // (a multiple of 8: the chunks keep their XCDs)
         }
     }
     cf *buf = reinterpret_cast<cf *>(smem_raw);

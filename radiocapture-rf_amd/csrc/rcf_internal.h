@@ -412,6 +412,8 @@ struct S2Rider {
     int32_t n_chans, n_tiles;    // the deferred launch's grid: (channels, tiles of KB outputs)
     int32_t D, T, KB;
     int32_t n_wgs;               // n_chans * n_tiles rounded up to a multiple of 8; 0: no rider
+    int32_t at_end;              // the riders are the LAST workgroups of the grid instead of the first (RCF_S2_RIDER_LAST=1)
+    int32_t pad_;
 };
 bool pfb_can_carry_s2(const PfbLaunch &p);
 bool pfb_supported(int NB, int D, int P);

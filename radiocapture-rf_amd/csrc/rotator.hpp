@@ -1,6 +1,9 @@
 // rotator.hpp -- GNU Radio's rotator (phase *= incr in float32, renormalised every 512 calls) in closed form, shared
 // by the FIR bank kernels (fir.hip) and the filterbank taps (pfb5.hip).  Both files are compiled without implicit
-// FMA contraction: rotate() is an unfused float32 complex multiply in GNU Radio.
+// FMA contraction: rotate() is an unfused float32 complex multiply in GNU Radio.  The products and sums are written as plain
+// operators INSIDE bodies that switch contraction off (#pragma clang fp contract(off)): HIP's fmul_rn / fadd_rn intrinsics are
+// header functions of their own, compiled under the translation unit's default -- in a unit built with contraction (pfb.hip,
+// whose filterbank launch carries the stage-2 rider) the mul inside one and the add inside the other fuse after inlining.
 #pragma once
 #include "rcf_internal.h"
 
@@ -72,8 +75,8 @@ __device__ __forceinline__ float2 rotate_value(const LT &L, int64_t n, float vr,
     }
     // rotator::rotate(): z = in * phase, float32 complex multiply, unfused
     float2 y;
-    y.x = __fsub_rn(__fmul_rn(vr, pr), __fmul_rn(vi, pi));
-    y.y = __fadd_rn(__fmul_rn(vr, pi), __fmul_rn(vi, pr));
+    y.x = (vr * pr) - (vi * pi);
+    y.y = (vr * pi) + (vi * pr);
     return y;
 }
 
@@ -94,18 +97,20 @@ struct RotatorWalk {
     // rotate (vr, vi) by the phase at the current output
     __device__ __forceinline__ float2 rotate(const LT &L, float vr, float vi) const
     {
+#pragma clang fp contract(off)
         const int64_t dk = n - L.n_seg0;
         const int64_t r512 = n & ~(int64_t)511;
         const double lm = (r512 > L.n_seg0) ? (double)(n - r512) * L.dlogmag : L.logmag0 + (double)dk * L.dlogmag;
         const double mag = fabs(lm) < 1e-3 ? 1.0 + lm * (1.0 + lm * (0.5 + lm * (1.0 / 6.0))) : exp(lm);
         const float pr = (float)(mag * c), pi = (float)(mag * s);
         float2 y;
-        y.x = __fsub_rn(__fmul_rn(vr, pr), __fmul_rn(vi, pi));
-        y.y = __fadd_rn(__fmul_rn(vr, pi), __fmul_rn(vi, pr));
+        y.x = (vr * pr) - (vi * pi);
+        y.y = (vr * pi) + (vi * pr);
         return y;
     }
     __device__ __forceinline__ void advance()
     {
+#pragma clang fp contract(off)
         const double c2 = fma(c, cstep, -(s * sstep));
         s = fma(s, cstep, c * sstep);
         c = c2;
