@@ -285,14 +285,17 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg,
     int bid = blockIdx.x;
     if constexpr (NB == kSmallThreads && !ZH) {
         if (sr.n_wgs > 0) {
-            const int n_pfb = (int)gridDim.x - sr.n_wgs;
-            const int rid = sr.at_end ? bid - n_pfb : bid;      // riders first (default) or behind the last chunk
-            if (rid >= 0 && rid < sr.n_wgs) {
+            // the riders come in sr.n_batches batches of sr.batch_wgs workgroups, one batch at the head of every sr.period
+            // blocks of the grid (all multiples of 8: the chunks keep their XCDs): spread over the launch they run beside
+            // the bandwidth-bound chunks instead of ahead of or behind them
+            const int q = bid / sr.period, r = bid - q * sr.period;
+            if (q < sr.n_batches && r < sr.batch_wgs) {
+                const int rid = q * sr.batch_wgs + r;
                 if (rid < sr.n_chans * sr.n_tiles)
                     fir_small_tile(sr.chans, rid % sr.n_chans, rid / sr.n_chans, sr.D, sr.T, sr.KB, sr.ring_mask, sr.atan_tab, smem_raw);
                 return;
             }
-            if (!sr.at_end) bid -= sr.n_wgs;               // (a multiple of 8: the chunks keep their XCDs)
+            bid -= (q < sr.n_batches ? q + 1 : sr.n_batches) * sr.batch_wgs;
         }
     }
     cf *buf = reinterpret_cast<cf *>(smem_raw);
@@ -682,7 +685,21 @@ void launch_os(const PfbLaunch &p, hipStream_t s, const S2Rider *sr_in)
 {
     const int n_wg = (p.n_frames + F - 1) / F;
     S2Rider sr{};
-    if (sr_in) sr = *sr_in;
+    if (sr_in) {
+        sr = *sr_in;
+        // batches (RCF_S2_RIDER_BATCHES, default 16; 1 = all riders first): batch size and period are multiples of 8
+        static const int nb_env = env_int("RCF_S2_RIDER_BATCHES", 16);
+        const int work = sr.n_chans * sr.n_tiles;
+        int nbat = std::max(1, std::min(nb_env, (work + 7) / 8));
+        sr.batch_wgs = ((work + nbat - 1) / nbat + 7) & ~7;
+        sr.n_batches = (work + sr.batch_wgs - 1) / sr.batch_wgs;
+        sr.n_wgs = sr.n_batches * sr.batch_wgs;
+        const int total = n_wg + sr.n_wgs;
+        sr.period = std::max(sr.batch_wgs + 8, (total / sr.n_batches) & ~7);
+        if ((long long)sr.period * (sr.n_batches - 1) + sr.batch_wgs > total) {     // (a tiny launch: everything first)
+            sr.n_batches = 1; sr.batch_wgs = (work + 7) & ~7; sr.n_wgs = sr.batch_wgs; sr.period = n_wg + sr.n_wgs + 8;
+        }
+    }
     static const int no_remap = env_int("RCF_PFB_NOREMAP", 0);
     const int arg = no_remap ? -n_wg : n_wg;
     const size_t lds = ((size_t)F * row_stride<NB>() + NB) * sizeof(cf);

@@ -411,9 +411,8 @@ struct S2Rider {
     uint64_t ring_mask;
     int32_t n_chans, n_tiles;    // the deferred launch's grid: (channels, tiles of KB outputs)
     int32_t D, T, KB;
-    int32_t n_wgs;               // n_chans * n_tiles rounded up to a multiple of 8; 0: no rider
-    int32_t at_end;              // the riders are the LAST workgroups of the grid instead of the first (RCF_S2_RIDER_LAST=1)
-    int32_t pad_;
+    int32_t n_wgs;               // rider workgroups in the grid (n_batches * batch_wgs); 0: no rider
+    int32_t n_batches, batch_wgs, period;   // set by the launcher: batch q occupies blocks [q period, q period + batch_wgs)
 };
 bool pfb_can_carry_s2(const PfbLaunch &p);
 bool pfb_supported(int NB, int D, int P);

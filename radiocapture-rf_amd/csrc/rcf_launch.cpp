@@ -47,8 +47,7 @@ int launch_plan(rcf_t *h, BlockPlan &bp)
         sr.n_chans = ld.n_chans;
         sr.n_tiles = (ld.max_n_k + sr.KB - 1) / sr.KB;
         sr.n_wgs = (sr.n_chans * sr.n_tiles + 7) & ~7;
-        static const int at_end = [] { const char *e = getenv("RCF_S2_RIDER_LAST"); return e ? atoi(e) : 0; }();
-        sr.at_end = at_end;
+
         h->lag.pending = false;
     }
     // ... and this block's own: ONE small-T job on the bank's bins, nothing that consumes its outputs within the block
