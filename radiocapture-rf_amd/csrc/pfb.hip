@@ -687,8 +687,8 @@ void launch_os(const PfbLaunch &p, hipStream_t s, const S2Rider *sr_in)
     S2Rider sr{};
     if (sr_in) {
         sr = *sr_in;
-        // batches (RCF_S2_RIDER_BATCHES, default 16; 1 = all riders first): batch size and period are multiples of 8
-        static const int nb_env = env_int("RCF_S2_RIDER_BATCHES", 16);
+        // batches (RCF_S2_RIDER_BATCHES; 1 = all riders first): batch size and period are multiples of 8.  Fused launch on one box, filterbank alone 101.3 us: 1 batch 114.8, 4: 114.4, 16: 114.3, 64: 112.7 us (all riders LAST: the same as 64) -- the rider costs its ~50 MB of traffic wherever it sits, the trailing launch cost 18 us
+        static const int nb_env = env_int("RCF_S2_RIDER_BATCHES", 64);
         const int work = sr.n_chans * sr.n_tiles;
         int nbat = std::max(1, std::min(nb_env, (work + 7) / 8));
         sr.batch_wgs = ((work + nbat - 1) / nbat + 7) & ~7;
