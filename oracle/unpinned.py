@@ -130,3 +130,135 @@ def rotator_fma_drift(incr, n=1_000_000):
             "max_step_difference_rad": float(dstep.max()),
             "magnitude_excursion_unfused": float(np.max(np.abs(np.abs(a) - 1))),
             "magnitude_excursion_fused": float(np.max(np.abs(np.abs(b) - 1)))}
+
+
+# =========================================================================================== round 5: f-2 and the routing budget
+# The analog voice chain (logging_receiver.py:211-222) adds three details the restatement cannot pin:
+#   5. analog.fm_deemph's iir_filter_ffd: the ORDER in which one output's three products are accumulated (GNU Radio's
+#      iir_filter.h: feed-forward taps first, then feedback; double accumulator) and whether a build keeps the accumulator
+#      in double at all (iir_filter_ffd does; the restatement follows it) -- moved here to: feedback first, transposed
+#      direct form II, and a float32 accumulator (the worst a differently-typed build could do);
+#   6. gr-filter's pm_remez grid density (optfir passes 16) and its convergence: scipy's exchange at density 16 / 32 / 64;
+#   7. the rational resampler's Kaiser taps: window and sinc evaluated in float (GNU Radio) or double, +-1 float32 ulp per tap.
+# and the routing of frontend_mode = 'pfb':
+#   8. rcf_pfb_tap_leakage predicts the discriminator error of a bank bin against GNU Radio's float32-phase channel from
+#      |g|_2; the prediction must stay an upper bound (within its margin) when GNU Radio's phase arithmetic is perturbed the
+#      way a different build could compute it (fwT0 kept in double, only the product rounded to float).
+def _rms(v):
+    return float(np.sqrt(np.mean(np.asarray(v, dtype=np.float64) ** 2)))
+
+
+def deemph_forms(fm, rate, tau=75e-6):
+    """the de-emphasised stream under four evaluation orders of the same first-order section; -> {form: float32 stream}"""
+    from . import audio as A
+    b, a = A.fm_deemph_taps(rate, tau)
+    b0, b1, fb1 = float(b[0]), float(b[1]), -float(a[1])
+    x = np.asarray(fm, dtype=f32)
+    out = {"gnuradio_order_double": A.iir_filter_ffd(x, b, a)}
+    y = np.empty(len(x), dtype=f32)
+    px = py = 0.0
+    for i, v in enumerate(x):                          # feedback product first
+        acc = fb1 * py
+        acc += b1 * px
+        acc += b0 * float(v)
+        py, px = acc, float(v)
+        y[i] = f32(acc)
+    out["feedback_first_double"] = y
+    y = np.empty(len(x), dtype=f32)
+    s = 0.0
+    for i, v in enumerate(x):                          # transposed direct form II: y = b0 x + s; s = b1 x + fb1 y
+        acc = b0 * float(v) + s
+        s = b1 * float(v) + fb1 * acc
+        y[i] = f32(acc)
+    out["transposed_df2_double"] = y
+    y = np.empty(len(x), dtype=f32)
+    pxf = pyf = f32(0.0)
+    fb0, fb1_, ffb = f32(b0), f32(b1), f32(fb1)
+    for i, v in enumerate(x):                          # everything in float32 (NOT iir_filter_ffd: the worst case of a build)
+        acc = f32(fb0 * v)
+        acc = f32(acc + f32(fb1_ * pxf))
+        acc = f32(acc + f32(ffb * pyf))
+        pyf, pxf = acc, v
+        y[i] = acc
+    out["float32_accumulator"] = y
+    return out
+
+
+def audio_after_deemph(de, rate):
+    """the rest of the voice chain behind the de-emphasis (audio low-pass, 300 Hz high-pass, 8 kHz resampler)"""
+    from . import audio as A
+    lpf = A.optfir_low_pass(8, rate, rate * 0.25, rate * 0.25 + 2000, 0.1, 60)
+    hpf = A.high_pass(1, rate, 300, 30, A.WIN_HAMMING, 6.76)
+    return A.rational_resampler_fff(A.fir_filter_fff(A.fir_filter_fff(de, lpf), hpf), 8000, int(rate))
+
+
+def audio_under_deemph_forms(fm, rate):
+    forms = deemph_forms(fm, rate)
+    ref = audio_after_deemph(forms["gnuradio_order_double"], rate)
+    scale = _rms(ref)
+    return {k: _rms(audio_after_deemph(v, rate).astype(np.float64) - ref) for k, v in forms.items() if k != "gnuradio_order_double"}, scale
+
+
+def remez_density_taps(rate, densities=(16, 32, 64)):
+    """optfir.low_pass(8, rate, 0.25 rate, 0.25 rate + 2000, 0.1, 60) with the exchange run at several grid densities"""
+    from scipy.signal import remez
+    from . import audio as A
+    r = 10.0 ** (0.1 / 20.0)
+    n, fo, ao, w = A.remezord_lowpass(rate * 0.25, rate * 0.25 + 2000, (8, 0), [(r - 1.0) / (r + 1.0), 10.0 ** (-60 / 20.0)], rate)
+    return {d: np.asarray(remez(n + 3, [f / 2.0 for f in fo], [ao[0], ao[2]], weight=w, type="bandpass", grid_density=d, fs=1.0)).astype(f32)
+            for d in densities}
+
+
+def audio_under_remez_density(de, rate):
+    from . import audio as A
+    taps = remez_density_taps(rate)
+    hpf = A.high_pass(1, rate, 300, 30, A.WIN_HAMMING, 6.76)
+    outs = {d: A.rational_resampler_fff(A.fir_filter_fff(A.fir_filter_fff(de, t), hpf), 8000, int(rate)) for d, t in taps.items()}
+    ref = outs[16].astype(np.float64)
+    return ({d: _rms(o.astype(np.float64) - ref) for d, o in outs.items() if d != 16},
+            {d: float(np.max(np.abs(t.astype(np.float64) - taps[16]))) for d, t in taps.items() if d != 16}, _rms(ref))
+
+
+def audio_under_resampler_tap_rounding(hp, rate, seeds=(1, 2, 3)):
+    """the 8 kHz audio when every resampler tap moves by +-1 float32 ulp (random signs, all up, all down)"""
+    from . import audio as A
+    d = math.gcd(8000, int(rate))
+    I, Dm = 8000 // d, int(rate) // d
+    taps = A.design_resampler_taps(I, Dm)
+    ref = A.rational_resampler_fff(hp, I, Dm, taps).astype(np.float64)
+    ulp = np.spacing(np.abs(taps)).astype(f32)
+    worst = 0.0
+    pats = [np.ones(len(taps)), -np.ones(len(taps))] + [np.random.default_rng(s).choice([-1.0, 1.0], size=len(taps)) for s in seeds]
+    for pat in pats:
+        t = (taps + (pat * ulp).astype(f32)).astype(f32)
+        worst = max(worst, _rms(A.rational_resampler_fff(hp, I, Dm, t).astype(np.float64) - ref))
+    return worst, _rms(ref)
+
+
+def bin_fm_error_vs_gr(x, fs, n_bins, taps, D, k, gain, phase_mode="float_product"):
+    """rms discriminator difference between bank bin k (exact phases; the constant rotation a tap's rotator carries does
+    not reach a discriminator) and GNU Radio's channel at the same offset -- whose tap phases are float32(i * fwT0)
+    ('float_product': fwT0 = float(2 pi f0 / fs), what freq_xlating_fir_filter_ccc 3.8 computes) or float32(i * fwT0) with fwT0
+    kept in double ('double_fwT0': what a build that declares it double would compute; the product of two floats rounded once
+    in double IS the float product, so that variant is not a perturbation)"""
+    f0 = (k if k < n_bins // 2 else k - n_bins) * fs / n_bins
+    exact = G.xlating_fir_exact(x, D, taps, f0, fs).astype(np.complex64)
+    fwT0 = f32(2.0 * math.pi * f0 / fs)
+    i = np.arange(len(taps))
+    if phase_mode == "float_product":
+        ph = (i.astype(f32) * fwT0).astype(f32)
+    elif phase_mode == "double_fwT0":                     # a build that keeps fwT0 in double and rounds only the product
+        ph = (i.astype(np.float64) * (2.0 * math.pi * f0 / fs)).astype(f32)
+    else:
+        raise ValueError(phase_mode)
+    ct = (np.asarray(taps, dtype=f32) * np.exp(1j * ph.astype(np.float64))).astype(np.complex64)
+    a = f32(-fwT0 * f32(D))
+    incr = np.complex64(complex(math.cos(float(a)), math.sin(float(a))))
+    gr, _ = OC.channel_bank(x, D, ct[None, :], np.array([incr]), gains=[gain])
+    n = min(len(exact), gr.shape[1])
+    fe = G.quadrature_demod_cf(exact[:n], f32(gain))
+    fg = G.quadrature_demod_cf(gr[0][:n], f32(gain))
+    # GNU Radio's rotator turns by float32(-fwT0 D) per output instead of the exact angle: a constant in the discriminator
+    # (carried by the tap's own rotator, rcf_pfb_tap_open(gr_phase)); what is compared is what is left
+    d = fe[8:].astype(np.float64) - fg[8:]
+    return _rms(d - np.mean(d))
