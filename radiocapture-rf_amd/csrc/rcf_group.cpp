@@ -15,53 +15,14 @@
 //   gather_rings_kernel        the read: new output of any channels of any members -> pinned host memory, one launch
 // What is not concatenable (matrix-core banks with their per-handle tap slabs, voice chains, scans, banks that still see
 // zero history) follows per member on the same stream, in dependency order.  The bits are those of the members run alone.
-#include <pthread.h>
-#include <sched.h>
-
-#include <atomic>
-#include <chrono>
-#include <thread>
 #include <tuple>
 
-#include "rcf_plan.h"
+#include "rcf_group.h"
 
 using namespace rcfx;
 
-struct rcf_pump;
-
-struct rcf_group {
-    int device = 0;
-    std::vector<rcf_t *> members;
-    hipStream_t stream = nullptr;
-    ArenaSet arenas;
-    hipEvent_t ingest_ev = nullptr;            // the callers' buffers of the last push have been read
-    std::vector<void *> d_stage;               // per member: staging for pageable source buffers
-    std::vector<size_t> stage_cap;
-    // rcf_group_read_many: pinned staging the gather kernel writes (and reads its records from) across PCIe
-    unsigned char *h_many = nullptr, *h_many_dev = nullptr;
-    size_t many_cap = 0;
-    rcf_pump *pump = nullptr;
-    std::mutex mu;
-    // RCF_PUMP_DEBUG=1: the longest time one group block spent in each part of group_process (printed by rcf_pump_stop)
-    double dbg_ms[6] = {0, 0, 0, 0, 0, 0};
-};
 
 namespace {
-
-struct GroupItem {
-    int m;                 // member index
-    size_t n;              // samples
-    const void *src;       // host samples (nullptr: already resident -- commit)
-    const void *dsrc;      // the same memory as the device sees it, if the caller knows (the pump resolves its rings once)
-};
-
-size_t group_sample_bytes(int fmt) { return fmt == RCF_FMT_CF32 ? sizeof(float2) : raw_sample_bytes(fmt); }
-
-struct MemberLocks {       // every member's mutex, in index order (a group call owns all of its members)
-    std::vector<rcf_t *> &ms;
-    explicit MemberLocks(std::vector<rcf_t *> &m) : ms(m) { for (rcf_t *h : ms) h->mu.lock(); }
-    ~MemberLocks() { for (auto it = ms.rbegin(); it != ms.rend(); ++it) (*it)->mu.unlock(); }
-};
 
 struct MergedFir {
     FirLaunchDims dims{};
@@ -69,9 +30,10 @@ struct MergedFir {
     const ChanLaunch *dev = nullptr;
 };
 
-// one block of each listed member.  g->mu and the members' mutexes are held.  wait: return only once the sources have
-// been read (the caller may reuse its buffers); the pump passes false -- its rings are not overwritten for many periods.
-int group_process(rcf_group *g, const std::vector<GroupItem> &items, int fmt, float scale, float offset, bool wait)
+}  // namespace
+
+// (declared in rcf_group.h: the pump calls it)
+int rcfx::group_process(rcf_group *g, const std::vector<GroupItem> &items, int fmt, float scale, float offset, bool wait)
 {
     if (items.empty()) return RCF_OK;
     const auto dbg_t0 = std::chrono::steady_clock::now();
@@ -364,6 +326,8 @@ int group_process(rcf_group *g, const std::vector<GroupItem> &items, int fmt, fl
     return RCF_OK;
 }
 
+namespace {
+
 // ---------------------------------------------------------------- batched read over members
 struct ReadItem { rcf_t *h; Chan *c; int64_t *cur; const void *ring; int64_t n; size_t pos; };
 
@@ -415,259 +379,6 @@ int ensure_many(rcf_group *g, size_t need)
 
 }  // namespace
 
-// =================================================================== the pump
-struct rcf_pump {
-    rcf_group *g = nullptr;
-    rcf_pump_config_t cfg{};
-    std::vector<const unsigned char *> rings, rings_dev;     // host address / the same memory as the device sees it (or nullptr)
-    std::vector<size_t> ring_blocks;
-    std::vector<double> phase;
-    std::vector<const volatile uint64_t *> written;
-    std::vector<int> rd_member, rd_chan;
-    std::vector<std::vector<int>> entries_of;      // member -> indices into rd_*
-    size_t out_cap = 0;                            // host ring length per entry (items, power of two)
-    size_t elem = 4;                               // bytes per item
-    unsigned char *h_out = nullptr, *h_out_dev = nullptr;   // n_read rings of out_cap items
-    std::unique_ptr<std::atomic<int64_t>[]> out_written;    // items delivered per entry
-    // gather records of the two group blocks in flight (pinned)
-    unsigned char *h_recs = nullptr, *h_recs_dev = nullptr;
-    size_t recs_cap = 0;                           // records per slot
-    hipEvent_t slot_ev[2] = {nullptr, nullptr};
-    std::thread th;
-    std::atomic<bool> stop{false}, running{false};
-    std::atomic<int> error{0}, rt_granted{0};
-    std::mutex st_mu;                              // the statistics below
-    std::vector<float> lat_ms;
-    int64_t blocks_done = 0, judged = 0, late = 0, overruns = 0, group_blocks = 0, max_batch = 0, samples_out = 0;
-    double plan_ms = 0, wait_ms = 0;
-    double max_plan_ms = 0, max_wait_ms = 0, max_idle_gap_ms = 0;   // longest single planning / device wait / sleep overshoot
-    int64_t slow_plans = 0, slow_waits = 0, slow_sleeps = 0;        // ... and how many of them exceeded 5 / 5 / 2 ms (after the warm-up)
-    bool warm_done = false;
-    std::chrono::steady_clock::time_point t_start, t_end;
-    char err_text[256] = "";
-};
-
-namespace {
-
-using Clock = std::chrono::steady_clock;
-inline double secs(Clock::duration d) { return std::chrono::duration<double>(d).count(); }
-
-struct InFlight {
-    bool busy = false;
-    std::vector<int> members;          // member indices of the batch
-    std::vector<double> due;           // per member: when its block was complete (seconds since t0)
-    std::vector<int64_t> kidx;         // per member: which of its blocks
-    std::vector<std::pair<int, int64_t>> delivered;   // (entry, items) to publish once the gather has run
-};
-
-void pump_fail(rcf_pump *p, int code)
-{
-    p->error.store(code);
-    std::snprintf(p->err_text, sizeof p->err_text, "%s", rcf_last_error());
-}
-
-void pump_main(rcf_pump *p)
-{
-    rcf_group *g = p->g;
-    const rcf_pump_config_t &cfg = p->cfg;
-    const size_t G = g->members.size();
-    if (cfg.cpu >= 0) {
-        cpu_set_t set;
-        CPU_ZERO(&set);
-        CPU_SET(cfg.cpu, &set);
-        (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
-    }
-    if (cfg.rt_priority > 0) {
-        sched_param sp{};
-        sp.sched_priority = cfg.rt_priority;
-        p->rt_granted.store(pthread_setschedparam(pthread_self(), SCHED_FIFO, &sp) == 0 ? 1 : 0);
-    }
-    (void)hipSetDevice(g->device);
-    const double period = (double)cfg.block_samples / cfg.samp_rate;
-    const size_t blk_bytes = cfg.block_samples * group_sample_bytes(cfg.fmt);
-    const Clock::time_point t0 = Clock::now() + std::chrono::duration_cast<Clock::duration>(std::chrono::duration<double>(cfg.start_delay_s));
-    { std::lock_guard<std::mutex> l(p->st_mu); p->t_start = t0; }
-    std::vector<int64_t> next_k(G, 0);             // next block of each member
-    std::vector<double> seen_at(G, -1.0);          // counter-fed members: when the pump first saw block next_k complete
-    InFlight slots[2];
-    int head = 0, in_flight = 0;                   // slots[head] is the oldest busy one
-    std::vector<GroupItem> items;
-    std::vector<int64_t> queued(p->rd_member.size(), 0);   // items ever queued for the host ring of each subscribed channel
-    std::vector<Chan *> chan_of(p->rd_member.size(), nullptr);      // subscribed channels, resolved once per channel-set epoch
-    std::vector<uint64_t> epoch_of(G, ~0ull);
-    const uint32_t ew = (uint32_t)(p->elem / 4);
-
-    auto complete_oldest = [&](bool block) -> bool {
-        InFlight &s = slots[head];
-        if (!s.busy) return false;
-        if (!block && hipEventQuery(p->slot_ev[head]) != hipSuccess) { (void)hipGetLastError(); return false; }
-        const Clock::time_point w0 = Clock::now();
-        if (hipEventSynchronize(p->slot_ev[head]) != hipSuccess) { set_error("pump: event wait failed"); pump_fail(p, RCF_EHIP); return false; }
-        const Clock::time_point now = Clock::now();
-        const double t_done = secs(now - t0);
-        int64_t items_out = 0;
-        for (auto &d : s.delivered) { p->out_written[(size_t)d.first].fetch_add(d.second, std::memory_order_release); items_out += d.second; }
-        {
-            std::lock_guard<std::mutex> l(p->st_mu);
-            p->wait_ms += secs(now - w0) * 1e3;
-            if (p->warm_done) {
-                p->max_wait_ms = std::max(p->max_wait_ms, secs(now - w0) * 1e3);
-                if (secs(now - w0) > 5e-3) ++p->slow_waits;
-            }
-            p->samples_out += items_out;
-            for (size_t i = 0; i < s.members.size(); ++i) {
-                ++p->blocks_done;
-                if (s.kidx[i] >= cfg.warm_blocks) {
-                    const double lat = t_done - s.due[i];
-                    p->lat_ms.push_back((float)(lat * 1e3));
-                    ++p->judged;
-                    if (lat > period) ++p->late;
-                }
-            }
-        }
-        s.busy = false;
-        head ^= 1;
-        --in_flight;
-        return true;
-    };
-
-    while (!p->stop.load(std::memory_order_relaxed) && !p->error.load()) {
-        // members whose next block is complete
-        const double now_s = secs(Clock::now() - t0);
-        items.clear();
-        std::vector<double> due;
-        double next_due = 1e300;
-        bool all_finished = true;
-        for (size_t m = 0; m < G; ++m) {
-            const int64_t k = next_k[m];
-            if (cfg.n_blocks > 0 && k >= cfg.n_blocks) continue;
-            all_finished = false;
-            if (cfg.max_batch > 0 && (int)items.size() >= cfg.max_batch) { next_due = std::min(next_due, now_s); continue; }
-            double d;
-            if (p->written[m]) {
-                if (*p->written[m] <= (uint64_t)k) { next_due = std::min(next_due, now_s + 50e-6); continue; }
-                if (seen_at[m] < 0) seen_at[m] = now_s;
-                d = seen_at[m];
-            } else {
-                d = (double)(k + 1) * period + p->phase[m];
-                if (d > now_s) { next_due = std::min(next_due, d); continue; }
-            }
-            const size_t at = (size_t)(k % (int64_t)p->ring_blocks[m]) * blk_bytes;
-            items.push_back(GroupItem{(int)m, cfg.block_samples, p->rings[m] + at, p->rings_dev[m] ? p->rings_dev[m] + at : nullptr});
-            due.push_back(d);
-        }
-        if (all_finished && in_flight == 0) break;
-        // batching window: the first block that is complete waits up to batch_window_s for company -- every block that
-        // completes meanwhile rides in the same launches (at K front-ends a block completes every period / K)
-        bool hold = false;
-        if (!items.empty() && cfg.batch_window_s > 0 && !(cfg.max_batch > 0 && (int)items.size() >= cfg.max_batch)) {
-            const double oldest = *std::min_element(due.begin(), due.end());
-            if (now_s - oldest < cfg.batch_window_s) { hold = true; next_due = std::min(next_due, oldest + cfg.batch_window_s); }
-        }
-        if (!items.empty() && !hold && in_flight < 2) {
-            const Clock::time_point p0 = Clock::now();
-            const int slot = head ^ (in_flight & 1);
-            InFlight &s = slots[slot];
-            s.members.clear();
-            s.kidx.clear();
-            s.due = due;
-            s.delivered.clear();
-            int n_over = 0;
-            for (size_t i = 0; i < items.size(); ++i) {
-                s.members.push_back(items[i].m);
-                s.kidx.push_back(next_k[(size_t)items[i].m]);
-                if (now_s - due[i] > period && next_k[(size_t)items[i].m] >= cfg.warm_blocks) ++n_over;
-            }
-            int rc;
-            {
-                std::lock_guard<std::mutex> gl(g->mu);
-                MemberLocks ml(g->members);
-                rc = group_process(g, items, cfg.fmt, cfg.scale, cfg.offset, false);
-                if (rc == RCF_OK) {
-                    // the read of this batch: every subscribed channel of its members, straight into the host rings
-                    GatherRec *recs = reinterpret_cast<GatherRec *>(p->h_recs + (size_t)slot * p->recs_cap * sizeof(GatherRec));
-                    int n_recs = 0;
-                    uint32_t max_w = 0;
-                    for (const GroupItem &it : items) {
-                        rcf_t *h = g->members[(size_t)it.m];
-                        if (epoch_of[(size_t)it.m] != h->chans_epoch) {            // channels were opened / closed: look them up again
-                            for (int e : p->entries_of[(size_t)it.m]) {
-                                auto f = h->chans.find(p->rd_chan[(size_t)e]);
-                                chan_of[(size_t)e] = f == h->chans.end() ? nullptr : f->second.get();
-                            }
-                            epoch_of[(size_t)it.m] = h->chans_epoch;
-                        }
-                        for (int e : p->entries_of[(size_t)it.m]) {
-                            Chan *c = chan_of[(size_t)e];
-                            if (!c) continue;                                      // closed under the pump: starves
-                            int64_t *cur = cfg.what == RCF_READ_IQ ? &c->rd_iq : &c->rd_fm;
-                            int64_t avail = c->produced - *cur;
-                            if (avail <= 0) continue;
-                            if ((size_t)avail > h->out_cap) { *cur = c->produced - (int64_t)h->out_cap; avail = (int64_t)h->out_cap; }
-                            if ((size_t)avail > p->out_cap) { *cur += avail - (int64_t)p->out_cap; avail = (int64_t)p->out_cap; }
-                            const uint64_t dst_pos = (uint64_t)queued[(size_t)e] & (p->out_cap - 1);
-                            queued[(size_t)e] += avail;
-                            recs[n_recs++] = GatherRec{static_cast<const uint32_t *>(cfg.what == RCF_READ_IQ ? (const void *)c->d_iq : (const void *)c->d_fm),
-                                                       (uint32_t)(((uint64_t)*cur & h->ring_mask) * ew), (uint32_t)avail * ew,
-                                                       (uint32_t)(h->out_cap * ew - 1), (uint32_t)((size_t)e * p->out_cap * ew),
-                                                       (uint32_t)(dst_pos * ew), (uint32_t)(p->out_cap * ew - 1), cfg.gain,
-                                                       (cfg.what == RCF_READ_FM && cfg.gain != 1.0f) ? 1u : 0u};
-                            max_w = std::max<uint32_t>(max_w, (uint32_t)avail * ew);
-                            *cur += avail;
-                            s.delivered.push_back({e, avail});
-                        }
-                    }
-                    if (n_recs)
-                        launch_gather_rings(reinterpret_cast<const GatherRec *>(p->h_recs_dev + (size_t)slot * p->recs_cap * sizeof(GatherRec)),
-                                            n_recs, reinterpret_cast<uint32_t *>(p->h_out_dev), max_w, g->stream);
-                    if (hipEventRecord(p->slot_ev[slot], g->stream) != hipSuccess) { set_error("pump: event record failed"); rc = RCF_EHIP; }
-                }
-            }
-            if (rc != RCF_OK) { pump_fail(p, rc); break; }
-            for (const GroupItem &it : items) { ++next_k[(size_t)it.m]; seen_at[(size_t)it.m] = -1.0; }
-            s.busy = true;
-            ++in_flight;
-            {
-                std::lock_guard<std::mutex> l(p->st_mu);
-                p->plan_ms += secs(Clock::now() - p0) * 1e3;
-                if (!p->warm_done && *std::min_element(s.kidx.begin(), s.kidx.end()) >= cfg.warm_blocks) p->warm_done = true;
-                if (p->warm_done) {
-                    p->max_plan_ms = std::max(p->max_plan_ms, secs(Clock::now() - p0) * 1e3);
-                    if (secs(Clock::now() - p0) > 5e-3) ++p->slow_plans;
-                }
-                ++p->group_blocks;
-                p->max_batch = std::max<int64_t>(p->max_batch, (int64_t)items.size());
-                p->overruns += n_over;
-            }
-            (void)complete_oldest(false);          // (usually the previous batch has finished by now)
-            continue;
-        }
-        if (in_flight > 0) {
-            // nothing to queue (or both slots taken): the oldest batch's outputs are what the host waits for
-            if ((!items.empty() && !hold) || next_due - now_s > 200e-6) { (void)complete_oldest(true); continue; }
-            if (complete_oldest(false)) continue;
-        }
-        const double wait_s = next_due - secs(Clock::now() - t0);
-        if (wait_s > 0) {
-            const double want = std::min(wait_s, 1e-3);
-            const Clock::time_point s0 = Clock::now();
-            if (cfg.spin_us > 0 && want <= cfg.spin_us * 1e-6) {
-                while (secs(Clock::now() - s0) < want && !p->stop.load(std::memory_order_relaxed)) __builtin_ia32_pause();
-            } else {
-                std::this_thread::sleep_for(std::chrono::duration<double>(cfg.spin_us > 0 ? want - cfg.spin_us * 0.5e-6 : want));
-                while (secs(Clock::now() - s0) < want && cfg.spin_us > 0) __builtin_ia32_pause();
-            }
-            const double over = (secs(Clock::now() - s0) - want) * 1e3;      // how much later than asked the thread came back
-            if (p->warm_done && over > 2.0) { std::lock_guard<std::mutex> l(p->st_mu); ++p->slow_sleeps; p->max_idle_gap_ms = std::max(p->max_idle_gap_ms, over); }
-        }
-    }
-    while (in_flight > 0 && !p->error.load()) (void)complete_oldest(true);
-    (void)hipStreamSynchronize(g->stream);
-    { std::lock_guard<std::mutex> l(p->st_mu); p->t_end = Clock::now(); }
-    p->running.store(false);
-}
-
-}  // namespace
 
 // =================================================================== C ABI
 extern "C" {
@@ -832,185 +543,6 @@ int rcf_group_read_many(rcf_group_t *g, int what, const int *members, const int 
             for (int64_t k = 0; k < it.n; ++k) f[k] = gain * f[k];
         }
     }
-    return RCF_OK;
-}
-
-// ------------------------------------------------------------------ pump
-int rcf_pump_start(rcf_group_t *g, const rcf_pump_config_t *cfg, rcf_pump_t **out)
-{
-    if (!g || !cfg || !out || cfg->block_samples == 0 || !(cfg->samp_rate > 0) || !cfg->rings || !cfg->ring_blocks ||
-        cfg->n_read < 0 || (cfg->n_read && (!cfg->read_members || !cfg->read_chans)) ||
-        (cfg->what != RCF_READ_IQ && cfg->what != RCF_READ_FM) || group_sample_bytes(cfg->fmt) == 0) {
-        set_error("bad pump configuration");
-        return RCF_EINVAL;
-    }
-    std::lock_guard<std::mutex> gl(g->mu);
-    if (g->pump) { set_error("the group already has a pump"); return RCF_ESTATE; }
-    RCF_HIP(hipSetDevice(g->device));
-    const size_t G = g->members.size();
-    std::unique_ptr<rcf_pump> p(new rcf_pump);
-    p->g = g;
-    p->cfg = *cfg;
-    for (size_t m = 0; m < G; ++m) {
-        if (!cfg->rings[m] || cfg->ring_blocks[m] == 0) { set_error("member %zu has no source ring", m); return RCF_EINVAL; }
-        if (cfg->block_samples > g->members[m]->block_cap) { set_error("block of %zu samples exceeds member %zu's capacity", cfg->block_samples, m); return RCF_ECAP; }
-        p->rings.push_back(static_cast<const unsigned char *>(cfg->rings[m]));
-        void *rdv = nullptr;
-        if (hipHostGetDevicePointer(&rdv, const_cast<void *>(cfg->rings[m]), 0) != hipSuccess) { rdv = nullptr; (void)hipGetLastError(); }
-        p->rings_dev.push_back(static_cast<const unsigned char *>(rdv));
-        p->ring_blocks.push_back(cfg->ring_blocks[m]);
-        p->phase.push_back(cfg->phase_s ? cfg->phase_s[m] : 0.0);
-        p->written.push_back(cfg->written ? cfg->written[m] : nullptr);
-    }
-    p->entries_of.resize(G);
-    for (int e = 0; e < cfg->n_read; ++e) {
-        if (cfg->read_members[e] < 0 || cfg->read_members[e] >= (int)G) { set_error("subscribed channel %d: no such member", e); return RCF_EINVAL; }
-        p->rd_member.push_back(cfg->read_members[e]);
-        p->rd_chan.push_back(cfg->read_chans[e]);
-        p->entries_of[(size_t)cfg->read_members[e]].push_back(e);
-    }
-    // the configuration's arrays belong to the caller: from here on the pump's own copies are used
-    p->cfg.rings = nullptr; p->cfg.ring_blocks = nullptr; p->cfg.phase_s = nullptr; p->cfg.written = nullptr;
-    p->cfg.read_members = nullptr; p->cfg.read_chans = nullptr;
-    p->elem = cfg->what == RCF_READ_IQ ? sizeof(float2) : sizeof(float);
-    p->out_cap = pow2_at_least(cfg->out_ring_samples ? cfg->out_ring_samples : 4096);
-    const size_t out_bytes = std::max<size_t>(64, (size_t)cfg->n_read * p->out_cap * p->elem);
-    if ((uint64_t)out_bytes / 4 > 0xffffffffull) { set_error("host rings of %zu bytes exceed the 32-bit word range", out_bytes); return RCF_ECAP; }
-    void *hp = nullptr, *dv = nullptr;
-    if (hipHostMalloc(&hp, out_bytes, hipHostMallocDefault) != hipSuccess || hipHostGetDevicePointer(&dv, hp, 0) != hipSuccess) {
-        if (hp) (void)hipHostFree(hp);
-        set_error("pinned host rings of %zu bytes failed", out_bytes);
-        return RCF_ENOMEM;
-    }
-    p->h_out = static_cast<unsigned char *>(hp);
-    p->h_out_dev = static_cast<unsigned char *>(dv);
-    p->out_written.reset(new std::atomic<int64_t>[(size_t)std::max(1, cfg->n_read)]);
-    for (int e = 0; e < std::max(1, cfg->n_read); ++e) p->out_written[(size_t)e].store(0);
-    p->recs_cap = (size_t)std::max(1, cfg->n_read);
-    hp = dv = nullptr;
-    if (hipHostMalloc(&hp, 2 * p->recs_cap * sizeof(GatherRec), hipHostMallocDefault) != hipSuccess ||
-        hipHostGetDevicePointer(&dv, hp, 0) != hipSuccess) {
-        if (hp) (void)hipHostFree(hp);
-        (void)hipHostFree(p->h_out);
-        set_error("pinned gather records failed");
-        return RCF_ENOMEM;
-    }
-    p->h_recs = static_cast<unsigned char *>(hp);
-    p->h_recs_dev = static_cast<unsigned char *>(dv);
-    {
-        // RCF_PUMP_BLOCKING=1: the pump sleeps in the driver while it waits for a group block instead of spinning on the event
-        static const bool blocking = [] { const char *e = getenv("RCF_PUMP_BLOCKING"); return e && atoi(e) != 0; }();
-        for (int i = 0; i < 2; ++i)
-            RCF_HIP(hipEventCreateWithFlags(&p->slot_ev[i], hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
-    }
-    // room in the group's arena for a group block of ALL members at once (after a hiccup everything that is complete goes
-    // out together): growing the arena means a stream synchronisation and pinned allocations -- not in the middle of a run
-    {
-        MemberLocks ml(g->members);
-        size_t all = 65536;
-        for (rcf_t *h : g->members) all += arena_need_bound(h) + 1024;
-        if (!g->arenas.h[0] && g->arenas.cap < all) { size_t c_ = g->arenas.cap; while (c_ < all) c_ *= 2; g->arenas.cap = c_; }
-        if (g->arenas.reserve(all, g->stream) != RCF_OK) return RCF_EHIP;
-    }
-    // the subscribed channels' readers start at what has been produced so far
-    {
-        MemberLocks ml(g->members);
-        for (int e = 0; e < cfg->n_read; ++e) {
-            rcf_t *h = g->members[(size_t)p->rd_member[(size_t)e]];
-            auto f = h->chans.find(p->rd_chan[(size_t)e]);
-            if (f == h->chans.end()) continue;
-            (cfg->what == RCF_READ_IQ ? f->second->rd_iq : f->second->rd_fm) = f->second->produced;
-        }
-    }
-    p->running.store(true);
-    g->pump = p.get();
-    rcf_pump *raw = p.release();
-    raw->th = std::thread(pump_main, raw);
-    *out = raw;
-    return RCF_OK;
-}
-
-int rcf_pump_stats(rcf_pump_t *p, rcf_pump_stats_t *st)
-{
-    if (!p || !st) return RCF_EINVAL;
-    std::vector<float> lat;
-    {
-        std::lock_guard<std::mutex> l(p->st_mu);
-        st->blocks_done = p->blocks_done;
-        st->blocks_judged = p->judged;
-        st->late = p->late;
-        st->overruns = p->overruns;
-        st->group_blocks = p->group_blocks;
-        st->max_batch = p->max_batch;
-        st->samples_out = p->samples_out;
-        st->host_plan_ms = p->plan_ms;
-        st->host_wait_ms = p->wait_ms;
-        st->max_plan_ms = p->max_plan_ms;
-        st->max_wait_ms = p->max_wait_ms;
-        st->max_sleep_overshoot_ms = p->max_idle_gap_ms;
-        st->slow_plans = p->slow_plans;
-        st->slow_waits = p->slow_waits;
-        st->slow_sleeps = p->slow_sleeps;
-        const bool run = p->running.load();
-        st->elapsed_s = secs((run ? Clock::now() : p->t_end) - p->t_start);
-        st->running = run ? 1 : 0;
-        st->rt_priority_granted = p->rt_granted.load();
-        st->error = p->error.load();
-        lat = p->lat_ms;
-    }
-    st->latency_ms_p50 = st->latency_ms_p99 = st->latency_ms_max = 0.0;
-    if (!lat.empty()) {
-        std::sort(lat.begin(), lat.end());
-        st->latency_ms_p50 = lat[lat.size() / 2];
-        st->latency_ms_p99 = lat[std::min(lat.size() - 1, (size_t)(0.99 * (double)lat.size()))];
-        st->latency_ms_max = lat.back();
-    }
-    if (st->error) set_error("pump stopped: %s", p->err_text);
-    return RCF_OK;
-}
-
-int64_t rcf_pump_written(rcf_pump_t *p, int entry)
-{
-    if (!p || entry < 0 || entry >= (int)p->rd_member.size()) return RCF_EINVAL;
-    return p->out_written[(size_t)entry].load(std::memory_order_acquire);
-}
-
-int64_t rcf_pump_read(rcf_pump_t *p, int entry, int64_t *cursor, void *out, size_t max_items)
-{
-    if (!p || !cursor || !out || entry < 0 || entry >= (int)p->rd_member.size()) { set_error("bad pump read arguments"); return RCF_EINVAL; }
-    const int64_t w = p->out_written[(size_t)entry].load(std::memory_order_acquire);
-    int64_t avail = w - *cursor;
-    if (avail <= 0 || max_items == 0) return 0;
-    if ((size_t)avail > p->out_cap) { *cursor = w - (int64_t)p->out_cap; avail = (int64_t)p->out_cap; }
-    const int64_t n = std::min<int64_t>(avail, (int64_t)max_items);
-    const unsigned char *ring = p->h_out + (size_t)entry * p->out_cap * p->elem;
-    const size_t pos = (size_t)((uint64_t)*cursor & (p->out_cap - 1));
-    const size_t first = std::min<size_t>((size_t)n, p->out_cap - pos);
-    std::memcpy(out, ring + pos * p->elem, first * p->elem);
-    if ((size_t)n > first) std::memcpy(static_cast<unsigned char *>(out) + first * p->elem, ring, ((size_t)n - first) * p->elem);
-    *cursor += n;
-    return n;
-}
-
-int rcf_pump_stop(rcf_pump_t *p)
-{
-    if (!p) return RCF_EINVAL;
-    p->stop.store(true);
-    if (p->th.joinable()) p->th.join();
-    rcf_group *g = p->g;
-    if (getenv("RCF_PUMP_DEBUG"))
-        fprintf(stderr, "pump: longest group block by part, ms: reserve %.2f plan %.2f merge %.2f prep-launch %.2f launches %.2f\n",
-                g->dbg_ms[0], g->dbg_ms[1], g->dbg_ms[2], g->dbg_ms[3], g->dbg_ms[4]);
-    {
-        std::lock_guard<std::mutex> gl(g->mu);
-        (void)hipSetDevice(g->device);
-        (void)hipStreamSynchronize(g->stream);
-        g->pump = nullptr;
-    }
-    for (int i = 0; i < 2; ++i) if (p->slot_ev[i]) (void)hipEventDestroy(p->slot_ev[i]);
-    if (p->h_recs) (void)hipHostFree(p->h_recs);
-    if (p->h_out) (void)hipHostFree(p->h_out);
-    delete p;
     return RCF_OK;
 }
 

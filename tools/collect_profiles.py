@@ -50,16 +50,22 @@ for tag, fname, flag in (("pmc", "pfb_traffic.json", ""), ("pmc5", "pfb512_traff
         fetch = v["FETCH_SIZE"]["FETCH_SIZE"] * 1024 * 2       # KiB -> B, gfx950 x2 correction (MI355X_MICROARCH.md)
         write = v["WRITE_SIZE"]["WRITE_SIZE"] * 1024
         B = 1 << 25
+        alg = 16.0 * B
+        try:        # cfg4's launch also carries the previous block's stage-2 workgroups (round 5): the bench line states the bytes
+            bl = [l for l in open("gpurun_out/%s_bench%s.json" % (R, "_cfg5" if tag == "pmc5" else "")).read().splitlines() if l.startswith("{")]
+            alg = float(json.loads(bl[-1])["roofline"].get("algorithmic_bytes_per_launch", alg))
+        except Exception:
+            pass
         json.dump({"block": B, "kernel": short(name), "measured": "%s make_profiles run of %s" % (R, when),
                    "launches_averaged": v["FETCH_SIZE"].get("launches_averaged"),
                    "FETCH_SIZE_KiB_raw": v["FETCH_SIZE"]["FETCH_SIZE"], "WRITE_SIZE_KiB_raw": v["WRITE_SIZE"]["WRITE_SIZE"],
                    "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
-                   "algorithmic_bytes_per_launch": 16.0 * B,
+                   "algorithmic_bytes_per_launch": alg,
                    "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of `rocprofv3 --pmc X --kernel-trace -- python "
                            "bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-sustained%s`; KiB units and the "
                            "gfx950 FETCH_SIZE x2 correction per MI355X_MICROARCH.md; counters sit at the L2<->fabric "
                            "boundary, so Infinity-Cache hits are included" % flag}, open("profiles/" + fname, "w"), indent=1)
-        print("%s: fetch %.1f MB write %.1f MB (algorithmic %.1f MB)" % (fname, fetch / 1e6, write / 1e6, 16.0 * B / 1e6))
+        print("%s: fetch %.1f MB write %.1f MB (algorithmic %.1f MB)" % (fname, fetch / 1e6, write / 1e6, alg / 1e6))
     else:
         print("%s: counters missing" % fname)
 
@@ -116,7 +122,7 @@ pmc_record("%s_pfb3200b" % R, "pfb5_kernel", "profiles/%s_pfb3200_d800_pmc.json"
 pmc_record("%s_tapfin" % R, "tap_finalize", "profiles/%s_tap_finalize_pmc.json" % R, {
     "workload": "tools/pfb_probe.py NB=1600 TAPS=1600 BLOCK=2^25: tap_finalize_kernel with every bin of the 1600-bin bank open as a channel (41943 frames x 1600 taps per launch; 3 launches after idling)",
     "algorithmic_read_bytes": 8.0 * 1600 * 41943, "algorithmic_bytes": 20.0 * 1600 * 41943,
-    "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024; the kernel reads 161 rows per 128 outputs (32-aligned tiles): 1.26 x the algorithmic read"})
+    "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024; since round 5 a tile reads exactly the rows its outputs reach (r_need_lo..r_need_hi of tap_finalize_tile), not the 32-aligned 161 of round 4"})
 
 # ---- shader clock of the filterbank launches over the sustained leg (first / last 100 dispatches)
 def clock_series(d, kernel):
@@ -149,6 +155,20 @@ if len(ser) > 400:
     print("clock: first 100 %.3f GHz, last 100 %.3f GHz over %d dispatches" % (
         w([c for c, _ in ser[:100]]), w([c for c, _ in ser[-100:]]), len(ser)))
 
+for shape in ("pfb256", "grid1600"):
+    for tag in ("rt_%s_steady_state" % shape, "rt_%s_under_rocprof" % shape):
+        src = "gpurun_out/%s_%s.json" % (R, tag)
+        if os.path.exists(src) and open(src).read().strip():
+            shutil.copy(src, "profiles/%s_%s.json" % (R, tag))
+    f = newest("gpurun_out/%s_trace_rt_%s/**/*kernel_stats.csv" % (R, shape))
+    if f:
+        shutil.copy(f, "profiles/%s_rt_%s_kernel_stats.csv" % (R, shape))
+src = "gpurun_out/%s_group_capacity_under_rocprof.json" % R
+if os.path.exists(src) and open(src).read().strip():
+    shutil.copy(src, "profiles/%s_group_capacity_under_rocprof.json" % R)
+f = newest("gpurun_out/%s_trace_group/**/*kernel_stats.csv" % R)
+if f:
+    shutil.copy(f, "profiles/%s_group_capacity_kernel_stats.csv" % R)
 for tag in ("bench", "bench_cfg5", "bench_head_under_rocprof", "bench_2ranks_1gpu", "sustained_60s", "unpinned_bounds", "hbm_mix_probe"):
     src = "gpurun_out/%s_%s.json" % (R, tag)
     if os.path.exists(src):

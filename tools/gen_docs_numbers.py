@@ -65,10 +65,20 @@ def measured_block(R):
         % (b["value"], b["ms_per_step"], R))
     add("| filterbank launch, HIP events in the timed region | %.1f µs over %d timed launches ⇒ %.0f GB/s = **%s** of 8 TB/s | `%s_bench.json`: `roofline.avg_launch_ms`, `.launches`, `.achieved`, `.frac` |"
         % (ro["avg_launch_ms"] * 1e3, ro["launches"], ro["achieved"], f3(ro["frac"]), R))
+    if ro.get("stage2_rides_in_this_launch"):
+        add("| … what that launch carries | filterbank %.1f MB + the previous block's stage-2 workgroups %.1f MB = %.1f MB algorithmic per launch | `%s_bench.json`: `roofline.algorithmic_bytes_filterbank`, `.algorithmic_bytes_stage2_rider`, `.algorithmic_bytes_per_launch` |"
+            % (ro["algorithmic_bytes_filterbank"] / 1e6, ro["algorithmic_bytes_stage2_rider"] / 1e6, ro["algorithmic_bytes_per_launch"] / 1e6, R))
+    fa = ro.get("filterbank_alone")
+    if fa:
+        add("| the filterbank alone (stage-2 lag off for a pass of its own, every launch timed) | %.1f µs over %d launches ⇒ **%s** (16 B × block / launch time: the figure of rounds 1–4) | `%s_bench.json`: `roofline.filterbank_alone` |"
+            % (fa["avg_launch_ms"] * 1e3, fa["launches"], f3(fa["frac"]), R))
+    if ro.get("avg_launch_ms_every_launch_pass"):
+        add("| every launch timed (a pass of %d commits right behind the timed region, events on each launch) | %.1f µs ⇒ %s | `%s_bench.json`: `roofline.avg_launch_ms_every_launch_pass`, `.frac_every_launch_pass` |"
+            % (ro["launches_every_launch_pass"], ro["avg_launch_ms_every_launch_pass"] * 1e3, f3(ro["frac_every_launch_pass"]), R))
     st = _stats("%s_bench_kernel_stats.csv" % R, r"pfb_kernel_os<256, 1, 14, 4, false>")
     hu = _j("%s_bench_head_under_rocprof.json" % R)
     if st:
-        frac = 16.0 * b["config"]["block_samples"] / (st["avg_us"] * 1e-6) / 1e9 / 8000.0
+        frac = ro.get("algorithmic_bytes_per_launch", 16.0 * b["config"]["block_samples"]) / (st["avg_us"] * 1e-6) / 1e9 / 8000.0
         add("| the same kernel by `rocprofv3 --kernel-trace --stats` | %.1f µs over %d launches ⇒ **%s** | `%s_bench_kernel_stats.csv`, row `pfb_kernel_os<256, 1, 14, 4, false>` |"
             % (st["avg_us"], st["calls"], f3(frac), R))
     if hu:
@@ -95,8 +105,12 @@ def measured_block(R):
                tr["hbm_bytes_per_launch"] / tr["algorithmic_bytes_per_launch"], tr.get("measured", "?")))
     k = b.get("kernel_ms_per_step", {})
     if k:
-        add("| step = filterbank + stage-2 FIR with fused discriminator | %.4f + %.4f ms | `%s_bench.json`: `kernel_ms_per_step` |"
-            % (k["pfb"], k["stage2_fir_with_fused_discriminator"], R))
+        if ro.get("stage2_rides_in_this_launch"):
+            add("| step = ONE launch: filterbank with the previous block's stage-2 riding in it | %.4f ms of kernel time per step (+ %.4f ms: the one stage-2 flush the timing read forces, spread over the steps) | `%s_bench.json`: `kernel_ms_per_step` |"
+                % (k["pfb"], k.get("stage2_fir_with_fused_discriminator") or 0.0, R))
+        else:
+            add("| step = filterbank + stage-2 FIR with fused discriminator | %.4f + %.4f ms | `%s_bench.json`: `kernel_ms_per_step` |"
+                % (k["pfb"], k["stage2_fir_with_fused_discriminator"], R))
     c5 = _j("%s_bench_cfg5.json" % R)
     if c5:
         add("| cfg5 (BASELINE configs[4] per GPU: 512 bins, 25 Msps) | %.0f Msamples/s, launch %.1f µs = **%s**, sustained %s | `%s_bench_cfg5.json`: `value`, `roofline`, `sustained.frac_last_window` |"
@@ -142,6 +156,17 @@ def measured_block(R):
     if e:
         add("| PCIe-inclusive ingest (never `value`) | cf32 %.0f Msamples/s, u8 %.0f Msamples/s | `%s_bench.json`: `end_to_end` |"
             % (e["pinned_cf32_push_iq_Msps"], e["pinned_u8_push_raw_Msps"], R))
+    gc = b.get("group_capacity")
+    if gc:
+        a, o = gc["grouped"], gc["one_by_one"]
+        add("| %d front-ends (256 bins + 32 FM each, %d-sample blocks resident) committed back to back | grouped: %.3f ms per group block = %.0f Msamples/s, ONE filterbank launch %.1f µs = **%s** of 8 TB/s, one stage-2 launch %.1f µs; one by one: %.3f ms, %.1f µs per launch = %s; grouped / one by one %.2f × | `%s_bench.json`: `group_capacity` |"
+            % (gc["front_ends"], gc["block_samples"], a["wall_ms_per_group_block"], a["input_Msps"], a["filterbank_launch_us"],
+               f3(a["filterbank_frac_of_hbm_peak"]), a["stage2_launch_us"], o["wall_ms_per_group_block"], o["filterbank_launch_us"],
+               f3(o["filterbank_frac_of_hbm_peak"]), gc["grouped_over_one_by_one"], R))
+    gs = _stats("%s_group_capacity_kernel_stats.csv" % R, r"pfb_group_kernel_os<256")
+    if gs:
+        add("| the grouped filterbank launch by `rocprofv3 --kernel-trace --stats` (`tools/group_probe.py`, 80 front-ends) | %.1f µs over %d launches ⇒ **%s** (16 B × 80 × 409600 samples per launch) | `%s_group_capacity_kernel_stats.csv`, row `pfb_group_kernel_os<256, …>` |"
+            % (gs["avg_us"], gs["calls"], f3(16.0 * 80 * 409600 / (gs["avg_us"] * 1e-6) / 1e9 / 8000.0), R))
     rt = b.get("realtime")
     if rt:
         for shape, label in (("pfb256", "256-bin bank + 32 FM"), ("grid1600", "1600-bin reference-grid bank, 256 bins demodulated")):
@@ -149,10 +174,27 @@ def measured_block(R):
             if not s:
                 continue
             a = s.get("at_K_max") or {}
-            add("| **paced real time**, %s, 20 Msps u8 per front-end, %.0f ms blocks | K_max = **%d** front-ends (%d bins, %d demodulated channels, %.0f Msamples/s), first K that missed: %s; at K_max latency p50 %.2f / p99 %.2f ms, %d misses, %d overruns, PCIe in %.2f GB/s | `%s_bench.json`: `realtime.%s` |"
-                % (label, a.get("block_ms", 0), s["K_max"], s["channels_sustained"], s["fm_channels_sustained"],
-                   s["input_Msps_sustained"], s["first_K_that_missed"], a.get("latency_ms_p50") or 0, a.get("latency_ms_p99") or 0,
-                   a.get("deadline_misses", 0), a.get("ring_overruns", 0), a.get("pcie_GBps_in", 0), R, shape))
+            add("| **paced real time**, %s, 20 Msps u8 per front-end, %.0f ms blocks, %d native pump threads, ONE attempt per point | K_max_first_attempt = **%d** front-ends (%d bins, %d demodulated channels, %.0f Msamples/s), first K that missed: %s; the %.0f s confirmation run at K_max: latency p50 %.2f / p99 %.2f / max %.2f ms, %d misses, %d overruns, %.1f front-ends per group block, GPU busy %.0f %%, PCIe in %.1f GB/s | `%s_bench.json`: `realtime.%s` |"
+                % (label, a.get("block_ms", 0), rt.get("pump_threads", 0), s.get("K_max_first_attempt", s.get("K_max", 0)),
+                   s["channels_sustained"], s["fm_channels_sustained"], s["input_Msps_sustained"], s["first_K_that_missed"],
+                   rt.get("seconds_of_the_confirmation_run_at_K_max", 0), a.get("latency_ms_p50") or 0, a.get("latency_ms_p99") or 0,
+                   a.get("latency_ms_max") or 0, a.get("deadline_misses", 0), a.get("ring_overruns", 0),
+                   a.get("front_ends_per_group_block_mean") or 0, a.get("gpu_busy_percent_est") or 0, a.get("pcie_GBps_in", 0), R, shape))
+            pts = s.get("points") or []
+            if pts:
+                add("| … every point of that search (front-ends: p99 / max ms, misses) | %s | `realtime.%s.points[]` |"
+                    % ("; ".join("%d: %.2f / %.2f, %d" % (q["front_ends"], q.get("latency_ms_p99") or 0, q.get("latency_ms_max") or 0,
+                                                            q.get("deadline_misses", 0)) for q in pts), shape))
+    for shape, kern in (("pfb256", "pfb_group_kernel_os<256"), ("grid1600", "pfb5_group_kernel<20, 4, 2, 2>")):
+        ss = _j("%s_rt_%s_steady_state.json" % (R, shape))
+        if not ss:
+            continue
+        e = next((v for k, v in ss["kernels"].items() if k.startswith(kern)), None)
+        tot = sum(v["total_ms"] for v in ss["kernels"].values())
+        if e:
+            add("| kernel trace of the paced leg, %s, steady state (after %.1f s) | grouped filterbank: %d launches, mean %.1f µs (max %.0f µs), %.3f GB per launch ⇒ %.0f GB/s = **%s** of 8 TB/s; it is %.0f %% of the traced kernel time | `%s_rt_%s_steady_state.json` (`tools/rt_trace_outliers.py`), totals in `%s_rt_%s_kernel_stats.csv` |"
+                % (shape, ss["steady_state_from_s_after_first_group_block"], e["launches"], e["avg_us"], e["max_us"],
+                   e["algorithmic_GB_per_launch_mean"], e["achieved_GBps"], f3(e["frac_of_8TBps"]), 100.0 * e["total_ms"] / tot, R, shape, R, shape))
     cb = b.get("cpu_baseline")
     if cb and "all_cores" in cb:
         ac = cb["all_cores"]
@@ -186,6 +228,16 @@ def measured_block(R):
                ub["atan_table"]["max_fm_change_p25_gain"],
                max(v["largest_between_two_float32_orders"] for v in ub["summation"].values()),
                ub["rotator_fma"]["max_step_difference_rad"], ub["rotator_fma"]["max_phase_difference"], R))
+    if ub and "voice_chain" in ub:
+        vc = ub["voice_chain"]
+        add("| … voice chain (f-2) | fm_deemph evaluation order / float32 accumulator: audio moves ≤ %.1e rms; pm_remez grid density 32, 64 vs 16: ≤ %.1e; resampler taps ±1 ulp: %.1e (audio rms %.2f) | `%s_unpinned_bounds.json`: `voice_chain` |"
+            % (max(vc["fm_deemph_evaluation_order_audio_rms_change"].values()), max(vc["pm_remez_grid_density_audio_rms_change_vs_16"].values()),
+               vc["resampler_taps_pm_1ulp_audio_rms_change"], vc["audio_rms"], R))
+    if ub and "pfb_routing" in ub:
+        rows = ub["pfb_routing"]["rows"]
+        worst = max(max(r["measured_float_fwT0"], r["measured_double_fwT0"]) / r["predicted_fm_error_without_margin"] for r in rows)
+        add("| … pfb-mode routing budget | measured bin fm error / tap-leakage prediction ≤ %.2f over %d bins (float and double `fwT0` builds), against the margin of 2.5 the routing rule applies | `%s_unpinned_bounds.json`: `pfb_routing.rows` |"
+            % (worst, len(rows), R))
     mp = _j("%s_hbm_mix_probe.json" % R)
     if mp:
         best = mp["best"]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Scan-path micro-benchmark (BASELINE configs[2] shape): N-point scan FFT + log-mag + running sum over
-resident IQ, HIP-event kernel times, then the peak pick.  env: N (default 2^20), FRAMES, AVG."""
+resident IQ, HIP-event kernel times, then the peak pick.  env: N (default 2^20), FRAMES, AVG, REPS (scans; the last is
+timed), SAVE (npy of the emitted spectrum: RCF_SCAN_FUSED=0 / 1 runs are compared bit for bit)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "radiocapture-rf_amd")]
@@ -27,6 +28,12 @@ while fe.scan_frames_done() < min(F, 2 * fpb):
 fe.scan_find_peaks(cap=4096)
 if not os.environ.get("NOTIME"):
     fe.timing_enable(True)
+for _ in range(int(os.environ.get("REPS", 1)) - 1):        # untimed repeats: the last scan runs with the launch times settled
+    fe.scan_start(N, F, L)
+    while fe.scan_frames_done() < F:
+        fe.commit(B)
+    fe.sync()
+    fe.timing_read(native.T_SCAN_FFT); fe.timing_read(native.T_SCAN_MOVSUM)
 fe.scan_start(N, F, L)
 fe.sync(); t0 = time.perf_counter()
 while fe.scan_frames_done() < F:
@@ -43,3 +50,5 @@ print("N=%d frames=%d avg=%d: wall %.2f ms (%.1f Gsamples/s) | fft %.3f ms (%d l
       "movsum %.3f ms | peaks %d in %.2f ms (D2H + host)" % (
           N, F, L, (t1 - t0) * 1e3, samples / (t1 - t0) / 1e9, fft_ms, n1, 12.0 * samples / (fft_ms * 1e-3) / 1e9,
           ms_ms, len(lines), (t3 - t2) * 1e3))
+if os.environ.get("SAVE"):
+    np.save(os.environ["SAVE"], np.asarray(spec))
