@@ -70,22 +70,9 @@ constexpr int pfb5_row_stride(int NB, int R) { return NB + NB / R - 1; }
 // worth more than the third workgroup (3200 bins, D = 1600: window 8000 samples = 64 KB against 53.7 KB of rows)
 constexpr int pfb5_win(int NB, int F, int OS, int P) { return (F - 1 + OS * (P - 1)) * (NB / OS) + NB; }
 constexpr int pfb5_win_rounds(int win) { return (win + 1 + 2 * kThreads5 - 1) / (2 * kThreads5) * (2 * kThreads5); }   // DMA rounds of 640 samples
-// ... unless one TAP's share of the window -- the (F - 1) D + NB samples that tap q of every (frame, branch) reads --
-// fits the frame rows: then the window is staged tap by tap (P DMA rounds into the same LDS, the FMAs of tap q between
-// them) and the third workgroup stays (RCF_PFB5_SPLIT=0 at build time: the whole-window form)
-#ifndef RCF_PFB5_SPLIT
-#define RCF_PFB5_SPLIT 1
-#endif
-constexpr int pfb5_subwin(int NB, int F, int OS) { return (F - 1) * (NB / OS) + NB; }
-constexpr bool pfb5_split(int NB, int R, int F, int OS, int P)
-{
-    const int rows = F * pfb5_row_stride(NB, R), win = pfb5_win_rounds(pfb5_win(NB, F, OS, P));
-    return RCF_PFB5_SPLIT && P > 1 && win > rows && pfb5_win_rounds(pfb5_subwin(NB, F, OS)) <= rows;
-}
 constexpr int pfb5_buf(int NB, int R, int F, int OS, int P)
 {
     const int rows = F * pfb5_row_stride(NB, R), win = pfb5_win_rounds(pfb5_win(NB, F, OS, P));
-    if (pfb5_split(NB, R, F, OS, P)) return rows;
     if (!(win > rows && (size_t)win * 8 <= (size_t)64 * 1280)) return rows;
     // ... and behind the window as many whole rows of the prototype as the two-workgroup budget still holds
     int extra = (int)(((size_t)64 * 1280 - (size_t)win * 8) / ((size_t)NB * 4));
@@ -165,7 +152,6 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
     // FIR reads LDS (consecutive lanes = consecutive samples, conflict free).  Shapes whose window does not fit
     // (OS = 1 with 4 taps per branch) keep the direct form.
     constexpr int WIN = (F - 1 + OS * (P - 1)) * D + NB;
-    constexpr bool SPLIT = !ZH && pfb5_split(NB, R, F, OS, P);
     constexpr bool STAGE = WIN <= BUF;
     {
         const int frame = tid / BPF, j = tid % BPF;
@@ -173,43 +159,7 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
         cf vv[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) vv[t] = make_float2(0.f, 0.f);
-        if constexpr (SPLIT) {
-            // the window tap by tap: tap q of every (frame, branch) of the chunk reads the SUB samples from
-            // (n0 - OS q) D - (NB - 1) on.  Same products, same order of the sums (q ascending) as the other forms.
-            constexpr int SUB = (F - 1) * D + NB;
-            constexpr int PER = kThreads5 * 2;
-            constexpr int NLD = (SUB + 1 + PER - 1) / PER;
-            static_assert((size_t)NLD * PER <= (size_t)BUF, "a tap's window rounds fit the buffer");
-            float h[P][R];
-#pragma unroll
-            for (int q = 0; q < P; ++q)
-#pragma unroll
-                for (int t = 0; t < R; ++t) h[q][t] = p.ptaps[q * NB + j + BPF * t];
-            __builtin_amdgcn_sched_barrier(0);
-            const int64_t m_lo = n0 * D - (NB - 1);                          // first sample of tap 0's share
-            const int odd = (int)((m_lo - p.src.origin) & 1);                // (OS D = NB is even: the same for every tap)
-            const int vo0 = (int)((m_lo - odd - p.src.origin) * (int64_t)sizeof(cf)) + tid * 16;
-            unsigned char *lds_wave = reinterpret_cast<unsigned char *>(buf) + (tid >> 6) * (64 * 16);
-            const cf *sb = buf + frame * D + BPF - 1 - j + odd;              // t = R - 1
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-#pragma unroll
-                for (int r = 0; r < NLD; ++r)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (__attribute__((address_space(3))) void *)(lds_wave + r * PER * (int)sizeof(cf)),
-                                                             16, vo0 - q * OS * D * (int)sizeof(cf), r * PER * (int)sizeof(cf), 0, 0);
-                __builtin_amdgcn_s_waitcnt(0);
-                __syncthreads();
-                cf x[R];
-#pragma unroll
-                for (int t = 0; t < R; ++t) x[t] = sb[BPF * (R - 1 - t)];
-#pragma unroll
-                for (int t = 0; t < R; ++t) {
-                    vv[t].x = fmaf(h[q][t], x[t].x, vv[t].x);
-                    vv[t].y = fmaf(h[q][t], x[t].y, vv[t].y);
-                }
-                __syncthreads();                             // every thread has read this tap's share before the next lands
-            }
-        } else if constexpr (STAGE) {
+        if constexpr (STAGE) {
             const int64_t m_lo = (n0 - OS * (P - 1)) * D - (NB - 1);          // first sample of the window
             float h[P][R];
             int odd = 0;

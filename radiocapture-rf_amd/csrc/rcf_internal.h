@@ -467,11 +467,7 @@ struct ScanLaunch {
     int32_t N, R;
     int32_t f0, n_frames;    // frames f0 .. f0+n_frames-1
     float2 *scratch;         // 4-step scratch (N >= 32768), n_frames * N complex
-    // the running sum fused into the row pass (scan4_rows_sum_applicable): its state, emitted vector and parameters
-    float *fuse_sum = nullptr, *fuse_out = nullptr;
-    int32_t fuse_L = 0, fuse_emit_frame = -1;
 };
-bool scan4_rows_sum_applicable(int N, int L, int n_frames);
 bool scan_supported(int N);
 bool scan4_split(int N, int *N1, int *N2);   // four-step factorisation for N > 16384
 void launch_scan_fft(const ScanLaunch &p, hipStream_t s);

@@ -156,10 +156,8 @@ int run_scan(rcf_t *h, const BlockPlan &bp)
             sl.N = sc.N; sl.R = sc.R;
             sl.f0 = sc.frames_done; sl.n_frames = cnt;
             sl.scratch = sc.d_scratch;
-            const bool fused = scan4_rows_sum_applicable(sc.N, sc.L, cnt);
-            if (fused) { sl.fuse_sum = sc.d_sum; sl.fuse_out = sc.d_out; sl.fuse_L = sc.L; sl.fuse_emit_frame = sc.n_frames - 1; }
             { Timed t(h, RCF_T_SCAN_FFT); launch_scan_fft(sl, st); }
-            if (!fused) {
+            {
                 Timed t(h, RCF_T_SCAN_MOVSUM);
                 launch_scan_movsum(sc.d_vring, sc.N, sc.R, sc.L, sc.frames_done, cnt, sc.n_frames - 1, sc.d_sum,
                                    sc.d_out, st);

@@ -281,75 +281,6 @@ __global__ __launch_bounds__(scan_threads<N2>()) void scan4_rows_kernel(ScanLaun
     (void)N1;
 }
 
-// The row pass with the running sum fused in ("measure it instead of arguing it"; RCF_SCAN_FUSED=1).
-// One workgroup owns row k1 of the matrix for ALL frames of the launch, in order: per frame the N2-point transform in
-// LDS, the log-magnitude of its 16 bins per thread in registers, `s += v; emit; s -= oldest` on the 16 running sums the
-// thread keeps in registers across the launch (one read-modify-write of the sum state per launch), v stored to the ring
-// for the frame 99 later.  It saves the re-read of the newest frame (4 of the structure's 36 B per sample) and runs at
-// N1 = 256 workgroups of four wavefronts -- one wavefront per SIMD -- with the next frame's row and oldest values
-// requested before this frame's transform starts.  Same operations in the same order as scan4_rows_kernel + movsum_kernel.
-template <int N2>
-__global__ __launch_bounds__(scan_threads<N2>(), 1) void scan4_rows_sum_kernel(ScanLaunch p, const cf *__restrict__ tw2, int N1,
-                                                                              int L, int emit_frame, float *__restrict__ sum,
-                                                                              float *__restrict__ out)
-{
-    constexpr int NT = scan_threads<N2>();
-    static_assert(scan_fpw<N2>() == 1, "one row per workgroup");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf *buf = reinterpret_cast<cf *>(smem_raw);
-    const int tid = threadIdx.x;
-    const int k1 = blockIdx.x;
-    const size_t row = (size_t)k1 * N2;
-    float s[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s[i] = sum[row + tid + i * NT];
-    cf x[16], xn[16];
-    float vo[16], von[16];
-    auto fetch = [&](int fl, cf (&xx)[16], float (&oo)[16]) {
-        const cf *scr = p.scratch + (size_t)fl * p.N + row;
-        const int fo = p.f0 + fl - (L - 1);
-        const float *old = p.vring + (size_t)((fo >= 0 ? fo : 0) % p.R) * p.N + row;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            typedef float v2f_ __attribute__((ext_vector_type(2)));
-            const v2f_ t_ = __builtin_nontemporal_load(reinterpret_cast<const v2f_ *>(scr + tid + i * NT));
-            xx[i] = make_float2(t_.x, t_.y);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) oo[i] = fo >= 0 ? __builtin_nontemporal_load(old + tid + i * NT) : 0.f;
-    };
-    fetch(0, x, vo);
-    for (int fl = 0; fl < p.n_frames; ++fl) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) buf[lds_pad(tid + i * NT)] = x[i];
-        __syncthreads();
-        if (fl + 1 < p.n_frames) fetch(fl + 1, xn, von);
-        scan_pass<N2, NT, SPlan<N2>::r[0], 1>(buf, tw2, tid);
-        if constexpr (SPlan<N2>::n >= 2) scan_pass<N2, NT, SPlan<N2>::r[1], SPlan<N2>::r[0]>(buf, tw2, tid);
-        if constexpr (SPlan<N2>::n >= 3)
-            scan_pass<N2, NT, SPlan<N2>::r[2], SPlan<N2>::r[0] * SPlan<N2>::r[1]>(buf, tw2, tid);
-        if constexpr (SPlan<N2>::n >= 4)
-            scan_pass<N2, NT, SPlan<N2>::r[3], SPlan<N2>::r[0] * SPlan<N2>::r[1] * SPlan<N2>::r[2]>(buf, tw2, tid);
-        const int f = p.f0 + fl;
-        float *dst = p.vring + (size_t)(f % p.R) * p.N + row;
-        const bool sub = f - (L - 1) >= 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int k2 = tid + i * NT;
-            const float v = logmag_gr(buf[lds_pad(k2)]);
-            dst[k2] = v;
-            s[i] = __fadd_rn(s[i], v);
-            if (f == emit_frame) out[((k1 + N1 * k2) + p.N / 2) & (p.N - 1)] = s[i];
-            if (sub) s[i] = __fsub_rn(s[i], vo[i]);
-        }
-        __syncthreads();                      // the log-magnitude reads before the next frame's row overwrites the buffer
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { x[i] = xn[i]; vo[i] = von[i]; }
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sum[row + tid + i * NT] = s[i];
-}
-
 template <int N2>
 void launch_rows(const ScanLaunch &p, const cf *tw2, int N1, hipStream_t s)
 {
@@ -414,24 +345,6 @@ void launch_scan_movsum(float *vring, int N, int R, int L, int f0, int n_frames,
     else
         hipLaunchKernelGGL(movsum_kernel<8>, dim3((N + kMovThreads - 1) / kMovThreads), dim3(kMovThreads), 0, s, vring, N, R, L,
                            f0, n_frames, emit_frame, sum, out, n1, n2);
-}
-
-// the fused row pass + running sum: N2 = 4096 (one row per workgroup) and an averaging length that keeps the oldest frame
-// of every frame of the launch in an EARLIER launch (the one-frame-ahead prefetch must not pass a store of this launch)
-bool scan4_rows_sum_applicable(int N, int L, int n_frames)
-{
-    static const int on = [] { const char *e = getenv("RCF_SCAN_FUSED"); return e ? atoi(e) : 0; }();
-    int n1 = 0, n2 = 0;
-    return on && N > 16384 && scan4_split(N, &n1, &n2) && n2 == 4096 && L - 1 >= n_frames + 1;
-}
-
-void launch_scan4_rows_sum(const ScanLaunch &p, const cf *tw2, int N1, int L, int emit_frame, float *sum, float *out, hipStream_t s)
-{
-    constexpr int N2 = 4096;
-    const size_t lds = (size_t)scan_rs<N2>() * sizeof(cf);
-    static DynLdsAttr attr;
-    attr.ensure(reinterpret_cast<const void *>(&scan4_rows_sum_kernel<N2>), lds);
-    hipLaunchKernelGGL((scan4_rows_sum_kernel<N2>), dim3(N1), dim3(scan_threads<N2>()), lds, s, p, tw2, N1, L, emit_frame, sum, out);
 }
 
 // rows of the four-step transform (called from scan4.hip after the column kernel)

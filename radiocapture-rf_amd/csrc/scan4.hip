@@ -21,7 +21,6 @@
 namespace rcfx {
 
 void launch_scan4_rows(const ScanLaunch &p, const cf *tw2, int N1, int N2, hipStream_t s);   // scan.hip
-void launch_scan4_rows_sum(const ScanLaunch &p, const cf *tw2, int N1, int L, int emit_frame, float *sum, float *out, hipStream_t s);   // scan.hip
 
 namespace {
 
@@ -175,8 +174,7 @@ void launch_scan4_fft(const ScanLaunch &p, hipStream_t s)
     if (a.N1 == 128) launch_cols<128, 16>(a, s);
     else if (cw32)   launch_cols<256, 32>(a, s);
     else             launch_cols<256, 16>(a, s);
-    if (p.fuse_sum) launch_scan4_rows_sum(p, tw2, a.N1, p.fuse_L, p.fuse_emit_frame, p.fuse_sum, p.fuse_out, s);
-    else launch_scan4_rows(p, tw2, a.N1, a.N2, s);
+    launch_scan4_rows(p, tw2, a.N1, a.N2, s);
 }
 
 }  // namespace rcfx
