@@ -35,8 +35,21 @@ def test_bench_line_has_the_contract_keys_and_adds_up():
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
-    # achieved = algorithmic bytes per launch / the launch's average duration; 16 B per input sample of the block
-    assert r["algorithmic_bytes_per_launch"] == 16.0 * block
+    # achieved = algorithmic bytes per launch / the launch's average duration; 16 B per input sample of the block -- plus,
+    # since round 5, the bytes of the previous block's stage-2 workgroups when they ride in the launch (stated apart,
+    # with the filterbank alone timed in a pass of its own)
+    assert r.get("algorithmic_bytes_filterbank", r["algorithmic_bytes_per_launch"]) == 16.0 * block
+    assert r["algorithmic_bytes_per_launch"] == 16.0 * block + r.get("algorithmic_bytes_stage2_rider", 0.0)
+    if r.get("stage2_rides_in_this_launch"):
+        n_ch = 32                                                # BASELINE configs[1]: 32 active bins, stage-2 D = 3
+        frames = block // 256
+        assert r["algorithmic_bytes_stage2_rider"] == n_ch * (8.0 * frames + 12.0 * (frames // 3))
+        fa = r["filterbank_alone"]
+        assert fa["launches"] >= 20 and fa["frac"] == pytest.approx(16.0 * block / (fa["avg_launch_ms"] * 1e-3) / 1e9 / 8000.0, rel=1e-9)
+    if "avg_launch_ms_every_launch_pass" in r:
+        assert r["launches_every_launch_pass"] >= 20
+        assert r["frac_every_launch_pass"] == pytest.approx(
+            r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms_every_launch_pass"] * 1e-3) / 1e9 / 8000.0, rel=1e-9)
     assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-9)
     assert r["avg_launch_ms"] < d["ms_per_step"]                     # the kernel is a part of the step
     assert 0.98 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05   # PMC bytes: no wasted re-reads
