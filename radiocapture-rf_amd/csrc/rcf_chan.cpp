@@ -235,6 +235,7 @@ int rcf_pfb_tap_open(rcf_t *h, int bin, int gr_phase, int *chan_id)
     int rc = new_channel(h, RCF_SRC_PFB_BIN0 + bin, 1, &one, 1, 0.0, chan_id);
     if (rc != RCF_OK) return rc;
     h->chans[*chan_id]->is_tap = p.frame_major;     // power-of-two banks: an ordinary D = 1, T = 1 channel on the bin's ring
+    ++h->chans_epoch;                                // (the planning summary counts taps and FIR channels differently)
     if (gr_phase) {
         // What GNU Radio's freq_xlating_fir_filter_ccc(D, h, f_k, fs) would have done differently from the bank's
         // exact phases: its rotator advances by a = float32(-float32(2 pi f_k / fs) * D) per output instead of

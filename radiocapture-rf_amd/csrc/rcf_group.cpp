@@ -59,6 +59,8 @@ int rcfx::group_process(rcf_group *g, const std::vector<GroupItem> &items, int f
     if (g->arenas.reserve(need, st) != RCF_OK) return RCF_EHIP;
     if (!g->arenas.mapped) { set_error("group launches need device-mapped pinned memory for their records"); return RCF_ESTATE; }
     auto dbg_t1 = dbg_mark(0, dbg_t0);                          // set device + arena reserve
+    auto tp = dbg_t0;
+    RCF_PROF(8, "group: arena reserve", tp);
     const int a = g->arenas.cur;
     const size_t base = g->arenas.fill;
     Arena ga{g->arenas.h[a], g->arenas.d[a], base, g->arenas.cap};
@@ -99,6 +101,7 @@ int rcfx::group_process(rcf_group *g, const std::vector<GroupItem> &items, int f
         }
     }
     dbg_t1 = dbg_mark(1, dbg_t1);                               // planning
+    RCF_PROF(9, "group: planning (all)", tp);
     auto fail_all = [&](int code) {
         for (size_t j = 0; j < NI; ++j) undo_block(g->members[(size_t)items[j].m], undo[j]);
         return code;
@@ -264,10 +267,12 @@ int rcfx::group_process(rcf_group *g, const std::vector<GroupItem> &items, int f
     g->arenas.fill = (ga.used + 63) & ~size_t(63);
 
     dbg_t1 = dbg_mark(2, dbg_t1);                               // merging + records
+    RCF_PROF(10, "group: merging + records", tp);
     // ---- 6. launches, in dependency order.  From here on a failure leaves queued work behind: no roll-back.
     for (size_t at = 0, li = 0; at < prep.size(); at += kPrepMaxRecs, ++li)
         launch_group_prep(prep_mapped + at, (int)std::min<size_t>(kPrepMaxRecs, prep.size() - at), prep_tiles[li], st);
     dbg_t1 = dbg_mark(3, dbg_t1);                               // the prep launch
+    RCF_PROF(11, "group: prep launch", tp);
     if (wait) RCF_HIP(hipEventRecord(g->ingest_ev, st));
     if (d_rots) launch_rot_fill(d_rots, (int)rots.size(), h0->ring_mask, st);
     auto launch_depth = [&](size_t d, int timing_class_default) {
@@ -322,6 +327,7 @@ int rcfx::group_process(rcf_group *g, const std::vector<GroupItem> &items, int f
     }
     RCF_HIP(hipGetLastError());
     dbg_t1 = dbg_mark(4, dbg_t1);                               // the other launches
+    RCF_PROF(12, "group: other launches", tp);
     if (wait) (void)hipEventSynchronize(g->ingest_ev);
     return RCF_OK;
 }

@@ -1,65 +1,118 @@
 // rcf_plan.cpp -- the per-block schedule.  Everything one commit schedules is built on the host first (a BlockPlan:
 // launch records in the pinned arena, jobs per dependency depth), then uploaded with one copy and launched in
 // dependency order (rcf_launch.cpp).  process_block() is the sequence; the plan_*() functions each build one part.
+#include <atomic>
+#include <chrono>
+
 #include "rcf_plan.h"
 
 namespace rcfx {
 
-// an upper bound of what plan_arena() will ask for, without walking the channels (a group sizes its arena for all of its
-// members before it plans any of them)
-size_t arena_need_bound(rcf_t *h)
+namespace {
+std::atomic<uint64_t> g_prof_ns[PlanProf::N];
+std::atomic<uint64_t> g_prof_cnt[PlanProf::N];
+const char *g_prof_name[PlanProf::N];
+void prof_dump()
 {
-    if (h->arena_need_epoch == h->chans_epoch && h->arena_need_last) return h->arena_need_last;   // what plan_arena last computed
-    BlockPlan tmp;
-    Arena dummy{nullptr, nullptr, 0, 0};
-    tmp.ar = &dummy;
-    (void)plan_arena(h, tmp);
-    return tmp.arena_need;
+    for (int i = 0; i < PlanProf::N; ++i)
+        if (g_prof_cnt[i].load())
+            fprintf(stderr, "RCF_PLAN_PROF %-28s %10.3f ms  %9llu calls  %8.3f us/call\n", g_prof_name[i] ? g_prof_name[i] : "?",
+                    g_prof_ns[i].load() * 1e-6, (unsigned long long)g_prof_cnt[i].load(),
+                    g_prof_ns[i].load() * 1e-3 / (double)g_prof_cnt[i].load());
 }
+}  // namespace
+
+bool PlanProf::on()
+{
+    static const bool v = [] {
+        const char *e = getenv("RCF_PLAN_PROF");
+        const bool o = e && atoi(e) != 0;
+        if (o) atexit(prof_dump);
+        return o;
+    }();
+    return v;
+}
+
+void PlanProf::add(int slot, const char *name, std::chrono::steady_clock::time_point &from)
+{
+    const auto now = std::chrono::steady_clock::now();
+    g_prof_ns[slot] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now - from).count();
+    g_prof_cnt[slot] += 1;
+    g_prof_name[slot] = name;
+    from = now;
+}
+
+// the channel set's planning summary (see rcf_t::PlanCache), rebuilt when a channel was opened or closed or changed kind
+const rcf_t::PlanCache &plan_cache(rcf_t *h)
+{
+    rcf_t::PlanCache &pc = h->plan_cache;
+    if (pc.epoch == h->chans_epoch) return pc;
+    pc.reach_x.clear();
+    pc.max_depth = 0; pc.min_d0 = 0; pc.max_reach = 1;
+    // (one pass over the channel map for everything that needs one: at 196608 channels each pass is ~8 ms of
+    // pointer chasing)
+    size_t need = 4096, pfb_reach = 0, n_fir = 0;
+    for (auto &kv : h->chans) {
+        const Chan &c = *kv.second;
+        // (a filterbank tap has one short record; a FIR channel up to two launch records -- matrix-core launch and
+        // zero-history fix-up --, a discriminator record, an exact-rotator fill, its bank-matrix dirty flag)
+        need += c.is_tap ? sizeof(TapLaunch) + 8 : 2 * sizeof(ChanLaunch) + sizeof(DiscLaunch) + sizeof(RotFill) + 12 + 128;
+        n_fir += c.is_tap ? 0 : 1;
+        if (c.d_sym) need += sizeof(FmFirLaunch);
+        if (c.audio) need += sizeof(AudioLaunch);
+        pc.max_depth = std::max(pc.max_depth, c.depth);
+        if (c.src < 0 && (pc.min_d0 == 0 || c.D < pc.min_d0)) pc.min_d0 = c.D;
+        if (c.audio) pc.max_reach = std::max<size_t>(pc.max_reach, (size_t)std::max(std::max(c.audio->n_lpf, c.audio->n_hpf), c.audio->nt_rs));
+        if (c.d_sym) { size_t &own = pc.reach_x[c.id]; own = std::max<size_t>(own, std::max<size_t>(1, (size_t)c.sym_ntaps)); }
+        if (c.src >= RCF_SRC_PFB_BIN0) {              // (the bank's ring: one entry for all of its consumers, set after the loop)
+            pfb_reach = std::max<size_t>(pfb_reach, (size_t)(c.T - 1 + c.D));
+        } else if (c.src >= 0) {
+            size_t &r = pc.reach_x[c.src];
+            r = std::max<size_t>(r, (size_t)(c.T - 1 + c.D));
+            pc.max_reach = std::max(pc.max_reach, r);
+        }
+        if (c.d_sym) pc.max_reach = std::max<size_t>(pc.max_reach, (size_t)c.sym_ntaps);
+    }
+    if (pfb_reach) {
+        size_t &r = pc.reach_x[RCF_SRC_PFB_BIN0];
+        r = std::max(r, pfb_reach);
+        pc.max_reach = std::max(pc.max_reach, r);
+    }
+    need += 64 * (n_fir / 4 + 64);                        // per-class alignment slack
+    pc.arena_need = need;
+    // channels by depth, then by (D, T) class (a front-end has a handful of classes: linear search, then sorted -- the
+    // order classes are launched in is the key order, channels inside a class in id order, as it always was)
+    pc.by_depth.assign((size_t)pc.max_depth + 1, {});
+    for (auto &kv : h->chans) {
+        Chan *c = kv.second.get();
+        auto &lvl = pc.by_depth[(size_t)c->depth];
+        const std::pair<int, int> key{c->D, c->T};
+        size_t q = 0;
+        while (q < lvl.size() && lvl[q].first != key) ++q;
+        if (q == lvl.size()) lvl.push_back(rcf_t::PlanCache::ClassBucket{key, {}});
+        lvl[q].second.push_back(c);
+    }
+    for (auto &classes : pc.by_depth)
+        std::sort(classes.begin(), classes.end(), [](const rcf_t::PlanCache::ClassBucket &a, const rcf_t::PlanCache::ClassBucket &b) { return a.first < b.first; });
+    pc.epoch = h->chans_epoch;
+    return pc;
+}
+
+// an upper bound of what plan_arena() will ask for, without planning anything (a group sizes its arena for all of its
+// members before it plans any of them)
+size_t arena_need_bound(rcf_t *h) { return plan_cache(h).arena_need; }
 
 // arena for this commit: sized for every channel's launch records before anything is scheduled, so the schedule
 // cannot run out half way (it mutates channel state as it goes); also the consumers' reach and the deepest chain
 int plan_arena(rcf_t *h, BlockPlan &bp)
 {
-    auto &reach_x = bp.reach_x;
-    int &max_depth = bp.max_depth;
-    size_t &arena_need = bp.arena_need;
-
-    {
-        // (one pass over the channel map for everything that needs one: at 196608 channels each pass is ~8 ms of
-        // pointer chasing)
-        size_t need = 4096, pfb_reach = 0, n_fir = 0;
-        for (auto &kv : h->chans) {
-            const Chan &c = *kv.second;
-            // (a filterbank tap has one short record; a FIR channel up to two launch records -- matrix-core launch and
-            // zero-history fix-up --, a discriminator record, an exact-rotator fill, its bank-matrix dirty flag)
-            need += c.is_tap ? sizeof(TapLaunch) + 8 : 2 * sizeof(ChanLaunch) + sizeof(DiscLaunch) + sizeof(RotFill) + 12 + 128;
-            n_fir += c.is_tap ? 0 : 1;
-            if (c.d_sym) need += sizeof(FmFirLaunch);
-            if (c.audio) need += sizeof(AudioLaunch);
-            max_depth = std::max(max_depth, c.depth);
-            if (c.src < 0 && (bp.min_d0 == 0 || c.D < bp.min_d0)) bp.min_d0 = c.D;
-            if (c.audio) bp.max_reach = std::max<size_t>(bp.max_reach, (size_t)std::max(std::max(c.audio->n_lpf, c.audio->n_hpf), c.audio->nt_rs));
-            if (c.d_sym) { size_t &own = reach_x[c.id]; own = std::max<size_t>(own, std::max<size_t>(1, (size_t)c.sym_ntaps)); }
-            if (c.src >= RCF_SRC_PFB_BIN0) {              // (the bank's ring: one entry for all of its consumers, set after the loop)
-                pfb_reach = std::max<size_t>(pfb_reach, (size_t)(c.T - 1 + c.D));
-            } else if (c.src >= 0) {
-                size_t &r = reach_x[c.src];
-                r = std::max<size_t>(r, (size_t)(c.T - 1 + c.D));
-                bp.max_reach = std::max(bp.max_reach, r);
-            }
-            if (c.d_sym) bp.max_reach = std::max<size_t>(bp.max_reach, (size_t)c.sym_ntaps);
-        }
-        if (pfb_reach) {
-            size_t &r = reach_x[RCF_SRC_PFB_BIN0];
-            r = std::max(r, pfb_reach);
-            bp.max_reach = std::max(bp.max_reach, r);
-        }
-        need += 64 * (n_fir / 4 + 64);                        // per-class alignment slack
-        arena_need = need;
-        h->arena_need_last = need;
-        h->arena_need_epoch = h->chans_epoch;
-    }
+    const rcf_t::PlanCache &pc = plan_cache(h);
+    bp.reach_x = &pc.reach_x;
+    bp.max_depth = pc.max_depth;
+    bp.min_d0 = pc.min_d0;
+    bp.max_reach = pc.max_reach;
+    bp.arena_need = pc.arena_need;
+    const size_t arena_need = pc.arena_need;
     if (bp.ar != &bp.own_ar) return RCF_OK;        // a group's block: the group reserved its arena for all members
     // (a lagging stage-2 launch reads its records in the current arena: it goes out before the arenas are re-allocated or
     // the one it lives in can come round again)
@@ -77,7 +130,6 @@ int plan_pfb(rcf_t *h, BlockPlan &bp)
 {
     const int64_t S0 = bp.S0, S1 = bp.S1;
     const size_t n = bp.n;
-    auto &reach_x = bp.reach_x;
     PfbLaunch &pl = bp.pl;
     bool &run_pfb = bp.run_pfb;
 
@@ -88,9 +140,9 @@ int plan_pfb(rcf_t *h, BlockPlan &bp)
         p.produced_before = p.produced;
         if (n_hi >= n_lo) {
             const int64_t cnt = n_hi - n_lo + 1;
-            if ((size_t)cnt + (reach_x.count(RCF_SRC_PFB_BIN0) ? reach_x[RCF_SRC_PFB_BIN0] : 0) > h->out_cap) {
+            if ((size_t)cnt + (bp.reach_x && bp.reach_x->count(RCF_SRC_PFB_BIN0) ? bp.reach_x->at(RCF_SRC_PFB_BIN0) : 0) > h->out_cap) {
                 set_error("block yields %lld PFB frames (+%zu of history its stage-2 channels need) > ring capacity %zu",
-                          (long long)cnt, reach_x.count(RCF_SRC_PFB_BIN0) ? reach_x[RCF_SRC_PFB_BIN0] : (size_t)0, h->out_cap);
+                          (long long)cnt, bp.reach_x && bp.reach_x->count(RCF_SRC_PFB_BIN0) ? bp.reach_x->at(RCF_SRC_PFB_BIN0) : (size_t)0, h->out_cap);
                 return RCF_ECAP;
             }
             pl.src.base = h->d_buf[h->cur];
@@ -582,9 +634,11 @@ int plan_block(rcf_t *h, size_t n, BlockPlan &bp, BlockUndo &undo)
     bp.S0 = h->total_in;
     bp.S1 = bp.S0 + (int64_t)n;
     bp.n = n;
+    auto tp = std::chrono::steady_clock::now();
     int rc = plan_arena(h, bp);
     if (rc == RCF_OK) rc = plan_pfb(h, bp);
     if (rc != RCF_OK) return rc;
+    RCF_PROF(0, "plan_arena+pfb", tp);
     {
         // no ring can overflow when even the fastest channel's outputs of this block plus the longest reach fit
         size_t worst = bp.min_d0 ? n / (size_t)bp.min_d0 + 2 : 0;
@@ -598,45 +652,41 @@ int plan_block(rcf_t *h, size_t n, BlockPlan &bp, BlockUndo &undo)
     // bank matrix, split-K slab or tap matrix that cannot be allocated, an exhausted launch arena.  Nothing has been
     // queued at that point: put the counters back, so that they never claim outputs nobody computed (and the exact
     // rotator's device state stays in step with them).
+    // (every channel is saved right before plan_channel() touches it: one pass over the channels instead of two)
     undo.saved.clear();
     undo.saved.reserve(h->chans.size());
-    for (auto &kv : h->chans) {
-        Chan *c = kv.second.get();
-        undo.saved.push_back(BlockUndo::Saved{c, c->produced, c->n_seg0, c->blk_before, c->blk_after, c->blk_serial, c->angle0, c->logmag0});
-    }
     undo.serial_before = h->blk_serial;
     undo.armed = true;
     auto roll_back = [&](int code) { undo_block(h, undo); return code; };
-    // channels, by depth then by (D, T) class
+    // channels, by depth then by (D, T) class (the handle's PlanCache holds the buckets)
     bp.fir_by_depth.resize(bp.max_depth + 1);
     bp.serial = ++h->blk_serial;
-    // (one pass over the channel map; a front-end has a handful of (D, T) classes: linear search, then sorted -- the
-    // order classes are launched in is the key order, as it always was)
-    typedef std::pair<std::pair<int, int>, std::vector<Chan *>> ClassBucket;
-    std::vector<std::vector<ClassBucket>> by_depth((size_t)bp.max_depth + 1);
-    for (auto &kv : h->chans) {
-        Chan *c = kv.second.get();
-        auto &lvl = by_depth[(size_t)c->depth];
-        const std::pair<int, int> key{c->D, c->T};
-        size_t q = 0;
-        while (q < lvl.size() && lvl[q].first != key) ++q;
-        if (q == lvl.size()) lvl.push_back(ClassBucket{key, {}});
-        lvl[q].second.push_back(c);
-    }
+    const auto &by_depth = h->plan_cache.by_depth;
+    RCF_PROF(1, "undo + buckets", tp);
     for (int depth = 0; depth <= bp.max_depth; ++depth) {
-        auto &classes = by_depth[(size_t)depth];
-        std::sort(classes.begin(), classes.end(), [](const ClassBucket &a, const ClassBucket &b) { return a.first < b.first; });
-        for (auto &cls : classes) {
+        const auto &classes = by_depth[(size_t)depth];
+        for (const auto &cls : classes) {
             ClassPlan cp;
             cp.launches.reserve(cls.second.size());
             cp.launched.reserve(cls.second.size());
             cp.discs.reserve(cls.second.size());
-            for (Chan *c : cls.second)
+            const size_t nc = cls.second.size();
+            for (size_t ci = 0; ci < nc; ++ci) {
+                Chan *c = cls.second[ci];
+                if (ci + 6 < nc) {                    // (a thousand front-ends' channels do not fit the host's caches)
+                    const char *nx = reinterpret_cast<const char *>(cls.second[ci + 6]);
+                    __builtin_prefetch(nx); __builtin_prefetch(nx + 64); __builtin_prefetch(nx + 128); __builtin_prefetch(nx + 192);
+                }
+                undo.saved.push_back(BlockUndo::Saved{c, c->produced, c->n_seg0, c->blk_before, c->blk_after, c->blk_serial, c->angle0, c->logmag0});
                 if ((rc = plan_channel(h, bp, cp, c, cls.first.first)) != RCF_OK) return roll_back(rc);
+            }
+            RCF_PROF(3, "plan_channel (class)", tp);
             if ((rc = plan_class_jobs(h, bp, cp, depth, cls.first)) != RCF_OK) return roll_back(rc);
+            RCF_PROF(4, "plan_class_jobs", tp);
         }
     }
     if ((rc = plan_tail(h, bp)) != RCF_OK) return roll_back(rc);
+    RCF_PROF(5, "plan_tail", tp);
     {
         // RCF_FAIL_PLAN_AT=<k>: the k-th block of a handle fails here as an exhausted launch arena would (tests of the
         // roll-back above: tests/test_gpu_round4.py)

@@ -1,5 +1,7 @@
 // rcf_plan.h -- the per-block schedule: what one commit of one front-end launches, built on the host first.
 #pragma once
+#include <chrono>
+
 #include "rcf_state.h"
 
 namespace rcfx {
@@ -53,7 +55,7 @@ struct BlockPlan {
     // sources of other channels and channels with a symbol filter reach further -- the map holds just those (with
     // 131072 plain wideband channels it stays empty: a std::map entry per channel and block was a tenth of the
     // host's schedule time).
-    std::unordered_map<int, size_t> reach_x;                // source id (channel id / RCF_SRC_PFB_BIN0) -> samples
+    const std::unordered_map<int, size_t> *reach_x = nullptr;   // source id (channel id / RCF_SRC_PFB_BIN0) -> samples (the handle's PlanCache)
     int max_depth = 0;
     int min_d0 = 0;                    // smallest decimation among the channels on the wideband stream (0: none)
     size_t max_reach = 1;              // largest consumer reach of any ring (see reach_x) / voice-chain filter
@@ -88,9 +90,9 @@ struct BlockPlan {
 
     size_t reach(int id) const
     {
-        if (reach_x.empty()) return 1;
-        auto it = reach_x.find(id);
-        return it == reach_x.end() ? (size_t)1 : std::max<size_t>(1, it->second);
+        if (!reach_x || reach_x->empty()) return 1;
+        auto it = reach_x->find(id);
+        return it == reach_x->end() ? (size_t)1 : std::max<size_t>(1, it->second);
     }
 };
 
@@ -112,10 +114,19 @@ struct BlockUndo {
     bool armed = false;
 };
 
+// RCF_PLAN_PROF=1: cumulative host time per planning section, printed at exit (tools/rt_probe.py runs with it)
+struct PlanProf {
+    static constexpr int N = 16;
+    static bool on();
+    static void add(int slot, const char *name, std::chrono::steady_clock::time_point &from);
+};
+#define RCF_PROF(slot, name, tp) do { if (PlanProf::on()) PlanProf::add(slot, name, tp); } while (0)
+
 // rcf_plan.cpp
 int plan_block(rcf_t *h, size_t n, BlockPlan &bp, BlockUndo &undo);
 void undo_block(rcf_t *h, BlockUndo &undo);
 size_t arena_need_bound(rcf_t *h);
+const rcf_t::PlanCache &plan_cache(rcf_t *h);
 int plan_arena(rcf_t *h, BlockPlan &bp);
 int plan_pfb(rcf_t *h, BlockPlan &bp);
 int plan_channel(rcf_t *h, BlockPlan &bp, ClassPlan &cp, Chan *c, int D);

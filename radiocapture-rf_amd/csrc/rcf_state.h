@@ -35,28 +35,34 @@ static size_t pow2_at_least(size_t v)
 }
 
 struct Chan {
+    // ---- what planning a block reads and writes, together at the front of the object (three cache lines; plan_block
+    // prefetches them): with a thousand front-ends x 256 channels the planner's time is the cache misses of this walk
     int id = -1;
-    uint64_t many_stamp = 0;      // the rcf_chan_read_many call that last listed this channel
     int src = -1;                 // -1 wideband; RCF_SRC_PFB_BIN0 + bin; else source channel id
     int D = 0, T = 0;
-    double src_rate = 0, offset_hz = 0;
+    int depth = 0;
     bool is_tap = false;          // a bin of a frame-major filterbank open as a channel: the bank's kernel copies it
                                   // into the launch's tap matrix, tap_finalize_kernel fills the rings
-    std::vector<float> proto;     // prototype taps (host)
     float2 *d_ctaps = nullptr;
-    uint64_t taps_version = 0;    // bumped whenever d_ctaps changes (bank-matrix cache key)
     float2 *d_iq = nullptr;
     float *d_fm = nullptr;
     int64_t start_sample = 0;     // in source index space
     int64_t k_abs0 = 0;
     int64_t produced = 0;         // relative output count
+    // exact rotator (rcf_set_rotator): phase ring + {phase, counter} state, one pool slice
+    float2 *d_rot = nullptr;
+    float *d_sym = nullptr;       // optional real FIR over gain * fm (P25 symbol filter), below
+    // rotator model
+    double extra_dangle = 0, extra_dlogmag = 0;   // added to the increment's own angle / log magnitude (filterbank taps)
+    double dangle = 0, dlogmag = 0;
+    long double angle0 = 0;
+    double logmag0 = 0;
+    int64_t n_seg0 = 0;
+    // output range [blk_before, blk_after) the block with serial blk_serial gave this channel (its derived channels'
+    // input range; process_block)
+    uint64_t blk_serial = 0;
+    int64_t blk_before = 0, blk_after = 0;
     int64_t rd_iq = 0, rd_fm = 0;
-    // optional real FIR over gain * fm (P25 symbol filter)
-    float *d_sym = nullptr, *d_symtaps = nullptr;
-    int sym_ntaps = 0;
-    float sym_gain = 1.f;
-    int64_t sym_from = 0;         // first relative output index the filter is defined for
-    int64_t rd_sym = 0;
     // analog voice chain (rcf_chan_audio_open)
     struct Audio {
         AudioState *d_state = nullptr;
@@ -69,20 +75,17 @@ struct Chan {
         int64_t rd = 0;                 // audio samples handed to the reader
     };
     std::unique_ptr<Audio> audio;
-    // exact rotator (rcf_set_rotator): phase ring + {phase, counter} state, one pool slice; incr = what GNU Radio iterates
-    float2 *d_rot = nullptr;
-    float incr[2] = {1.f, 0.f};
-    // rotator model
-    double extra_dangle = 0, extra_dlogmag = 0;   // added to the increment's own angle / log magnitude (filterbank taps)
-    double dangle = 0, dlogmag = 0;
-    long double angle0 = 0;
-    double logmag0 = 0;
-    int64_t n_seg0 = 0;
-    int depth = 0;
-    // output range [blk_before, blk_after) the block with serial blk_serial gave this channel (its derived channels'
-    // input range; process_block)
-    uint64_t blk_serial = 0;
-    int64_t blk_before = 0, blk_after = 0;
+    // ---- the rest
+    float incr[2] = {1.f, 0.f};   // exact rotator: what GNU Radio iterates
+    float *d_symtaps = nullptr;
+    int sym_ntaps = 0;
+    float sym_gain = 1.f;
+    int64_t sym_from = 0;         // first relative output index the filter is defined for
+    int64_t rd_sym = 0;
+    uint64_t many_stamp = 0;      // the rcf_chan_read_many call that last listed this channel
+    double src_rate = 0, offset_hz = 0;
+    uint64_t taps_version = 0;    // bumped whenever d_ctaps changes (bank-matrix cache key)
+    std::vector<float> proto;     // prototype taps (host)
 };
 
 struct Pfb {
@@ -169,8 +172,18 @@ struct rcf {
     std::map<int, std::unique_ptr<Chan>> chans;
     uint64_t chans_epoch = 0;     // bumped whenever a channel is opened or closed or gains / loses a symbol filter or voice
                                   // chain (cached Chan pointers: the pump's; the cached arena need below)
-    size_t arena_need_last = 0;   // what plan_arena last asked for, valid while arena_need_epoch == chans_epoch
-    uint64_t arena_need_epoch = ~0ull;
+    // What planning a block needs to know about the channel SET (not their counters), valid while epoch == chans_epoch:
+    // the summary plan_arena() used to rebuild from a walk over every channel, and the (depth, D, T) classes plan_block()
+    // used to re-bucket -- three passes of pointer chasing per block (20 us of a 30 us plan for a front-end with 256
+    // tapped bins once a thousand front-ends no longer fit the host's caches, RCF_PLAN_PROF).
+    struct PlanCache {
+        uint64_t epoch = ~0ull;
+        std::unordered_map<int, size_t> reach_x;
+        int max_depth = 0, min_d0 = 0;
+        size_t max_reach = 1, arena_need = 0;
+        typedef std::pair<std::pair<int, int>, std::vector<Chan *>> ClassBucket;
+        std::vector<std::vector<ClassBucket>> by_depth;     // classes sorted by (D, T); channels in id order
+    } plan_cache;
     int next_id = 1;
     Pfb pfb;
     Scan scan;
