@@ -87,22 +87,28 @@ __device__ __forceinline__ float2 rotate_value(const LT &L, int64_t n, float vr,
 template <class LT>
 struct RotatorWalk {
     double c, s, cstep, sstep;
-    int64_t n;
-    int step;
-    __device__ __forceinline__ RotatorWalk(const LT &L, int64_t n0, int step_) : n(n0), step(step_)
+    // the magnitude model in float32: log|phase| is linear in n inside a renormalisation segment, |lm| < 512 log|incr| ~ 3e-5,
+    // so 1 + lm in float32 carries it to ~1e-12 -- the float64 series and exp() of rotate_value() bought nothing here and
+    // were a fifth of tap_finalize_kernel's vector instructions (round 5)
+    float lm, dlm_step, dlm;
+    int k512, step;              // n mod 512 (the next renormalisation resets the magnitude there)
+    __device__ __forceinline__ RotatorWalk(const LT &L, int64_t n0, int step_) : step(step_)
     {
         sincos_fast(L.angle0 + (double)(n0 - L.n_seg0) * L.dangle, s, c);
         sincos_fast((double)step_ * L.dangle, sstep, cstep);
+        dlm = (float)L.dlogmag;
+        dlm_step = dlm * (float)step_;
+        const int64_t r512 = n0 & ~(int64_t)511;
+        k512 = (int)(n0 & 511);
+        // inside the segment the host's model starts in: logmag0 + (n - n_seg0) dlogmag until n reaches the next multiple of 512
+        lm = (r512 > L.n_seg0) ? (float)k512 * dlm : (float)(L.logmag0 + (double)(n0 - L.n_seg0) * L.dlogmag);
     }
     // rotate (vr, vi) by the phase at the current output
-    __device__ __forceinline__ float2 rotate(const LT &L, float vr, float vi) const
+    __device__ __forceinline__ float2 rotate(const LT &, float vr, float vi) const
     {
 #pragma clang fp contract(off)
-        const int64_t dk = n - L.n_seg0;
-        const int64_t r512 = n & ~(int64_t)511;
-        const double lm = (r512 > L.n_seg0) ? (double)(n - r512) * L.dlogmag : L.logmag0 + (double)dk * L.dlogmag;
-        const double mag = fabs(lm) < 1e-3 ? 1.0 + lm * (1.0 + lm * (0.5 + lm * (1.0 / 6.0))) : exp(lm);
-        const float pr = (float)(mag * c), pi = (float)(mag * s);
+        const float cf_ = (float)c, sf_ = (float)s;
+        const float pr = fmaf(cf_, lm, cf_), pi = fmaf(sf_, lm, sf_);
         float2 y;
         y.x = (vr * pr) - (vi * pi);
         y.y = (vr * pi) + (vi * pr);
@@ -114,7 +120,12 @@ struct RotatorWalk {
         const double c2 = fma(c, cstep, -(s * sstep));
         s = fma(s, cstep, c * sstep);
         c = c2;
-        n += step;
+        k512 += step;
+        lm += dlm_step;
+        if (k512 >= 512) {                       // crossed a renormalisation: the magnitude restarts at that multiple of 512
+            k512 -= 512;
+            lm = (float)k512 * dlm;
+        }
     }
 };
 
