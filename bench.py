@@ -1015,6 +1015,9 @@ def main():
                     help="length of the sustained leg of the timed configuration (profiles/rNN_sustained_60s.json: 60)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run")
+    ap.add_argument("--alone-warm", type=int, default=300,
+                    help="untimed commits before the filterbank-alone pass (steady state: the chip's ramp after an idle queue is ~15 ms)")
+    ap.add_argument("--alone-launches", type=int, default=100, help="timed launches of the filterbank-alone pass")
     ap.add_argument("--time-every", type=int, default=4,
                     help="HIP events around every n-th filterbank launch of the timed region (1 = all of them)")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5,
@@ -1221,9 +1224,14 @@ def main():
     pfb_alone_ms = pfb_alone_n = None
     if s2_rides:
         fe.set_stage2_lag(False)
+        # (the read-backs and timing reads above idled the queue: the chip needs ~15 ms of work before its launch time
+        # settles -- `sustained`: first window of 100 launches 125 us, the rest 113-115 -- and up to round 5's first
+        # profiles this pass sat on that ramp: 107-108 us where tools/pfb_probe.py, 500 launches in, measures 97-100)
+        for _ in range(args.alone_warm):
+            fe.commit(B)
         fe.timing_enable(True, classes=[native.T_PFB])
         fe.timing_read(native.T_PFB)
-        for _ in range(max(args.steps, 20)):
+        for _ in range(max(args.steps, args.alone_launches)):
             fe.commit(B)
         fe.sync()
         pfb_alone_ms, pfb_alone_n = fe.timing_read(native.T_PFB)

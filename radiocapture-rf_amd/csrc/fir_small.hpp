@@ -51,6 +51,8 @@ __device__ __forceinline__ float fast_atan2f_gr(float y, float x, const float *t
 // taps come from the scalar cache, and the FM discriminator is fused in: outputs meet their predecessor in LDS,
 // thread 0 recomputes the one that belongs to the previous workgroup (the previous LAUNCH's is read back from the ring).  One launch and one pass over the channel
 // stream instead of two (the stage-2 FIR + discriminator pair was 22 % of the bench step).
+// PT: outputs per thread the tile may hold (KB <= 256 PT - 1)
+template <int PT = kSmallPerThread>
 __device__ __forceinline__ void fir_small_tile(const ChanLaunch *__restrict__ chans, const int chan_idx, const int tile_idx,
                                                const int D, const int T, const int KB, const uint64_t ring_mask,
                                                const float *__restrict__ atan_tab, unsigned char *smem_raw)
@@ -78,7 +80,7 @@ __device__ __forceinline__ void fir_small_tile(const ChanLaunch *__restrict__ ch
     // thread -- is issued before the first LDS store: table -> taps -> samples as three load -> store loops were three
     // memory latencies in a row in a kernel that is nothing but a chain of them (and a load -> store loop over the
     // samples exposes the latency once per iteration: measured, that, not arithmetic, was this kernel's time)
-    constexpr int LU = 8;     // the stage-2 shape of the timed configuration (D = 3, T = 11: 1544 samples) needs 7 per thread
+    constexpr int LU = 4 * PT;  // the stage-2 shape of the timed configuration (D = 3, T = 11: 1544 samples at 511 outputs) needs 7 per thread
     static_assert(kThreads == 256, "one table entry per thread, the 257th on thread 0");
     const float tab_a = atan_tab[tid], tab_b = atan_tab[256];
     const float2 ct_a = tid < T ? L.ctaps[tid] : make_float2(0.f, 0.f);
@@ -122,9 +124,9 @@ __device__ __forceinline__ void fir_small_tile(const ChanLaunch *__restrict__ ch
     // workgroups.  (Three per thread with the tile chosen so that the launch is exactly ONE round of resident
     // workgroups -- 32 x 64 of 683 outputs instead of 32 x 86 of 511 -- measured the same, 19.7 against 19.2 us:
     // it is the memory system's rate for 128-byte pieces, not the rounds.)
-    float2 y[kSmallPerThread];
+    float2 y[PT];
 #pragma unroll
-    for (int o = 0; o < kSmallPerThread; ++o) {
+    for (int o = 0; o < PT; ++o) {
         const int j = tid + o * kThreads;
         const int64_t n = k0 - 1 + j - L.k_abs0;               // relative output index
         y[o] = make_float2(0.f, 0.f);
@@ -153,7 +155,7 @@ __device__ __forceinline__ void fir_small_tile(const ChanLaunch *__restrict__ ch
     }
     __syncthreads();
 #pragma unroll
-    for (int o = 0; o < kSmallPerThread; ++o) {
+    for (int o = 0; o < PT; ++o) {
         const int j = tid + o * kThreads;
         if (j >= 1 && j <= nj) {
             const float2 b = ys[j - 1];

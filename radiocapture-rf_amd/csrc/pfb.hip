@@ -292,7 +292,7 @@ __global__ __launch_bounds__(NB, MINW) void pfb_kernel_os(PfbLaunch p, int n_wg,
             if (q < sr.n_batches && r < sr.batch_wgs) {
                 const int rid = q * sr.batch_wgs + r;
                 if (rid < sr.n_chans * sr.n_tiles)
-                    fir_small_tile(sr.chans, rid % sr.n_chans, rid / sr.n_chans, sr.D, sr.T, sr.KB, sr.ring_mask, sr.atan_tab, smem_raw);
+                    fir_small_tile<kSmallRiderPerThread>(sr.chans, rid % sr.n_chans, rid / sr.n_chans, sr.D, sr.T, sr.KB, sr.ring_mask, sr.atan_tab, smem_raw);
                 return;
             }
             bid -= (q < sr.n_batches ? q + 1 : sr.n_batches) * sr.batch_wgs;

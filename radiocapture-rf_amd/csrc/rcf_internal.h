@@ -124,6 +124,21 @@ inline int fir_small_outputs(int D, int T)
     if (kb > 511) kb = 511;          // 512 slots (fir.hip kSmallPerThread = 2): one is the predecessor output the discriminator needs
     return kb >= 32 ? kb : 0;
 }
+// ... and of a RIDER workgroup (the same tile run as extra workgroups of the 256-bin filterbank launch, rcf_set_stage2_lag):
+// there a tile's cost is the time it holds one of the launch's workgroup slots -- one memory round trip whatever its size --
+// so the tile is as large as the filterbank workgroup's own 37120 bytes of LDS allow (four outputs per thread): the timed
+// configuration's 32 x 86 tiles of 511 outputs become 32 x 43 of 1023, fused launch 114.5 -> 112.7 us (same box, three
+// alternating runs).  As a launch of its own the large tile is SLOWER (18.6 -> 22.4 us): fir_small_kernel keeps 511.
+constexpr int kSmallRiderPerThread = 4;
+inline int fir_small_outputs_rider(int D, int T)
+{
+    const int base = fir_small_outputs(D, T);
+    if (base == 0) return 0;
+    // (KB D + T samples, KB + 1 outputs, T taps) x 8 bytes + the 264-float table <= 37120
+    int kb = (4508 - 2 * T) / (D + 1);
+    if (kb > 256 * kSmallRiderPerThread - 1) kb = 256 * kSmallRiderPerThread - 1;
+    return kb > base ? kb : base;
+}
 
 // Matrix-core bank operand (fir_mfma_kernel, fir.hip): groups of 32 channels; the taps of a group are stored in
 // PROCESSING order -- step p = 0 .. NS-1 handles tap pairs q = 4 (NS-1-p) + kap, pair q = taps (2q, 2q-1), i.e.

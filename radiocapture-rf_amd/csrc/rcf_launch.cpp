@@ -43,7 +43,7 @@ int launch_plan(rcf_t *h, BlockPlan &bp)
         sr.chans = h->lag.dev;
         sr.atan_tab = ld.atan_tab;
         sr.ring_mask = ld.ring_mask;
-        sr.D = ld.D; sr.T = ld.T; sr.KB = fir_small_outputs(ld.D, ld.T);
+        sr.D = ld.D; sr.T = ld.T; sr.KB = fir_small_outputs_rider(ld.D, ld.T);
         sr.n_chans = ld.n_chans;
         sr.n_tiles = (ld.max_n_k + sr.KB - 1) / sr.KB;
         sr.n_wgs = (sr.n_chans * sr.n_tiles + 7) & ~7;

@@ -23,6 +23,7 @@ else:
 frames = B // D
 cap = 1
 while cap < 2 * frames: cap <<= 1
+cap *= int(os.environ.get("OUTCAP_MUL", 1))          # OUTCAP_MUL=2: bench.py's ring (two blocks + the stage-2 reach, rounded up)
 fe = native.Frontend(fs, block_capacity=B, hist_capacity=1 << 17, out_capacity=cap)
 fe.pfb_open(nb, D, taps)
 rng = np.random.default_rng(1)
