@@ -181,6 +181,9 @@ for tag in ("bench", "bench_cfg5", "bench_head_under_rocprof", "bench_2ranks_1gp
 f = newest("gpurun_out/%s_trace/**/*kernel_stats.csv" % R)
 if f:
     shutil.copy(f, "profiles/%s_bench_kernel_stats.csv" % R)
+fn = newest("gpurun_out/%s_trace_nolag/**/*kernel_stats.csv" % R)
+if fn:
+    shutil.copy(fn, "profiles/%s_bench_nolag_kernel_stats.csv" % R)
 f5 = newest("gpurun_out/%s_trace_cfg5/**/*kernel_stats.csv" % R)
 if f5:
     shutil.copy(f5, "profiles/%s_bench_cfg5_kernel_stats.csv" % R)

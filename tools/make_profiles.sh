@@ -31,6 +31,10 @@ HEAD="python $ROOT/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 
 rm -rf gpurun_out/${R}_trace gpurun_out/${R}_trace_legs gpurun_out/${R}_trace_cfg5
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace -- $HEAD > gpurun_out_head.json 2>/dev/null; cp gpurun_out_head.json $ROOT/gpurun_out/${R}_bench_head_under_rocprof.json)
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace_cfg5 -- $HEAD --config cfg5 > /dev/null 2>&1)
+# the same headline run with the stage-2 lag off (RCF_S2_LAG=0): every filterbank launch is then the filterbank ALONE (16 B x
+# 2^25 per launch, the kernel row of the rounds before the rider) and the stage-2 launches appear as fir_small_kernel rows
+rm -rf gpurun_out/${R}_trace_nolag
+(cd /tmp && timeout 600 env RCF_S2_LAG=0 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace_nolag -- $HEAD > /dev/null 2>&1)
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace_legs -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sustained --sweep-max 16384 --rt-seconds 0 > /dev/null 2>&1)
 
 mark traces done
