@@ -333,6 +333,15 @@ int rcf_pfb_chan_open(rcf_t *h, int bin, int channel_rate, double delta_hz, int 
  * freq_xlating_fir_filter_ccc started at the opening sample -- except that the bin comes with the filter's history
  * in it, where a new flowgraph starts from zeros. */
 int rcf_pfb_tap_open(rcf_t *h, int bin, int gr_phase, int *chan_id);
+/* A tap that is only ever demodulated: tap_finalize then writes its discriminator ring alone -- 4 instead of 12 bytes
+ * per output; with every bin of the 1600-bin reference grid demodulated (rc_frontend/channel.py:35 +
+ * p25_control_demod.py:120-121: every channel of the reference IS demodulated, in a process of its own) the finalize
+ * launch moves 0.8 GB instead of 1.34 per 2^25-sample block.  The channel's IQ stream is then not available:
+ * rcf_chan_read_iq / rcf_chan_read_many(RCF_READ_IQ) / rcf_chan_rings(iq) / chaining a channel or a voice chain on it
+ * fail with RCF_ESTATE, and switching it on is refused (RCF_ESTATE) while something reads that stream.  on = 0 gives the
+ * stream back from the next block on (the IQ read cursor skips what was never written).  Frame-major filterbank taps
+ * only (RCF_EINVAL otherwise).  The discriminator samples are the same bits either way. */
+int rcf_chan_set_fm_only(rcf_t *h, int chan_id, int on);
 /* How far bin `bin` of an exact-phase bank is from GNU Radio's own channel at that offset, before any sample is seen
  * (no device needed).  freq_xlating_fir_filter_ccc (rc_frontend/channel.py:35) builds its composite taps as
  * h[i] e^{j float32(i * fwT0)}; the float32 product is rounded to 2.4-9.8e-4 rad at |offset| -> fs/2,

@@ -550,6 +550,23 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
             const float2 ya = ys[tap_lds_at(lr, sl)], yb = ys[tap_lds_at(lr + 1, sl)];
             const float2 yb0 = na + 1 > 0 ? ya : make_float2(0.f, 0.f);
             const uint64_t ia = (uint64_t)na & ring_mask;
+            if (L.fm_only) {
+                // discriminator only (rcf_chan_set_fm_only): 4 of the 12 bytes per output; the launch's LAST output still goes
+                // to the IQ ring -- it is the "output before" of the next launch's first discriminator sample
+                const int64_t n_last = L.k_lo + L.n_k - 1 - L.k_abs0;
+                if (va && vb) {
+                    typedef float v2f_ __attribute__((ext_vector_type(2)));
+                    v2f_ b_; b_.x = fm_of(ya, ym); b_.y = fm_of(yb, yb0);
+                    __builtin_nontemporal_store(b_, reinterpret_cast<v2f_ *>(L.fm_ring + ia));
+                } else if (va) {
+                    L.fm_ring[ia] = fm_of(ya, ym);
+                } else {
+                    L.fm_ring[(uint64_t)(na + 1) & ring_mask] = fm_of(yb, yb0);
+                }
+                if (va && na == n_last) L.iq_ring[ia] = ya;
+                if (vb && na + 1 == n_last) L.iq_ring[(uint64_t)(na + 1) & ring_mask] = yb;
+                continue;
+            }
             if (va && vb) {                                          // na is even and the ring a power of two: no wrap inside the pair
                 // (non-temporal: 256 taps 55.4 -> 53.1 us, 1600 taps 308 -> 302 us per 2^25-sample block)
                 { typedef float v4f_ __attribute__((ext_vector_type(4))); typedef float v2f_ __attribute__((ext_vector_type(2)));

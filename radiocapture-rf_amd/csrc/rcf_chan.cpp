@@ -85,6 +85,7 @@ int new_channel(rcf_t *h, int src, int D, const float *taps, int T, double offse
     } else {
         auto it = h->chans.find(src);
         if (it == h->chans.end()) { set_error("no such source channel %d", src); return RCF_ENOCHAN; }
+        if (it->second->fm_only) { set_error("channel %d exposes its discriminator only: no IQ stream to chain on", src); return RCF_ESTATE; }
         c->src_rate = it->second->src_rate / it->second->D;
         c->start_sample = it->second->produced;
         c->depth = it->second->depth + 1;
@@ -342,6 +343,7 @@ int64_t rcf_chan_read_iq(rcf_t *h, int chan_id, float *out, size_t max_samples)
     std::lock_guard<std::mutex> g(h->mu);
     if (set_dev(h)) return RCF_EHIP;
     FIND_CHAN(h, chan_id, c);
+    if (c->fm_only) { set_error("channel %d exposes its discriminator only (rcf_chan_set_fm_only)", chan_id); return RCF_ESTATE; }
     return ring_read(h, c->d_iq, sizeof(float2), c->produced, &c->rd_iq, out, max_samples);
 }
 
@@ -382,6 +384,7 @@ int rcf_chan_read_many(rcf_t *h, int what, const int *chan_ids, int n_chans, flo
         Chan *c = f->second.get();
         if (c->many_stamp == stamp) { counts[i] = RCF_EINVAL; continue; }   // listed twice: one reader position per channel
         c->many_stamp = stamp;
+        if (what == RCF_READ_IQ && c->fm_only) { counts[i] = RCF_ESTATE; continue; }   // discriminator only
         it.c = c;
         it.cur = what == RCF_READ_IQ ? &c->rd_iq : &c->rd_fm;
         it.ring = what == RCF_READ_IQ ? (const void *)c->d_iq : (const void *)c->d_fm;
@@ -505,6 +508,7 @@ int rcf_chan_audio_open(rcf_t *h, int chan_id, const rcf_audio_params_t *p)
     std::lock_guard<std::mutex> g(h->mu);
     if (set_dev(h)) return RCF_EHIP;
     FIND_CHAN(h, chan_id, c);
+    if (c->fm_only) { set_error("channel %d exposes its discriminator only: the voice chain reads IQ", chan_id); return RCF_ESTATE; }
     const int I = p->interpolation;
     const int n_rs_pad = (p->n_rs + I - 1) / I * I;              // rational_resampler_base: pad to a multiple of I
     const size_t reach = (size_t)std::max(std::max(p->n_lpf, p->n_hpf), n_rs_pad / I);
@@ -600,11 +604,30 @@ int rcf_chan_fm_level(rcf_t *h, int chan_id, float gain, int window, float *leve
     return RCF_OK;
 }
 
+int rcf_chan_set_fm_only(rcf_t *h, int chan_id, int on)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    FIND_CHAN(h, chan_id, c);
+    if (!c->is_tap) { set_error("channel %d is not a tap of a frame-major filterbank", chan_id); return RCF_EINVAL; }
+    if (on) {
+        if (c->audio) { set_error("channel %d carries a voice chain, which reads its IQ stream", chan_id); return RCF_ESTATE; }
+        for (auto &kv : h->chans)
+            if (kv.second->src == chan_id) { set_error("channel %d reads channel %d's IQ stream", kv.first, chan_id); return RCF_ESTATE; }
+    } else if (c->fm_only) {
+        c->rd_iq = c->produced;                  // what lies behind was never written
+    }
+    c->fm_only = on != 0;
+    return RCF_OK;
+}
+
 int rcf_chan_rings(rcf_t *h, int chan_id, void **iq_ring, void **fm_ring, size_t *capacity)
 {
     if (!h) return RCF_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     FIND_CHAN(h, chan_id, c);
+    if (iq_ring && c->fm_only) { set_error("channel %d exposes its discriminator only (rcf_chan_set_fm_only)", chan_id); return RCF_ESTATE; }
     if (iq_ring) *iq_ring = c->d_iq;
     if (fm_ring) *fm_ring = c->d_fm;
     if (capacity) *capacity = h->out_cap;

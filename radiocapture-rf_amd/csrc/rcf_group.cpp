@@ -350,6 +350,7 @@ int resolve_read(rcf_group *g, int what, int member, int chan_id, size_t cap_eac
     Chan *c = f->second.get();
     if (c->many_stamp == stamps[(size_t)member]) { count = RCF_EINVAL; return 0; }     // listed twice
     c->many_stamp = stamps[(size_t)member];
+    if (what == RCF_READ_IQ && c->fm_only) { count = RCF_ESTATE; return 0; }           // discriminator only
     it.h = h;
     it.c = c;
     it.cur = what == RCF_READ_IQ ? &c->rd_iq : &c->rd_fm;

@@ -365,6 +365,8 @@ struct TapLaunch {           // one tapped bin, consumed by tap_finalize_kernel
     double logmag0, dlogmag;
     int32_t n_k;
     int32_t bin;
+    int32_t fm_only;         // 1: only the discriminator ring is written (and the launch's last IQ output, which the next launch's first discriminator sample needs)
+    int32_t pad_;
     static constexpr bool kHasRotRing = false;
 };
 // what tap_finalize needs of ONE front-end (kernel argument of the single launch, arena record of the grouped one)

@@ -225,6 +225,7 @@ int plan_channel(rcf_t *h, BlockPlan &bp, ClassPlan &cp, Chan *c, int D)
         tl.angle0 = (double)c->angle0; tl.dangle = c->dangle; tl.logmag0 = c->logmag0; tl.dlogmag = c->dlogmag;
         tl.n_k = (int32_t)cnt;
         tl.bin = c->src - RCF_SRC_PFB_BIN0;
+        tl.fm_only = c->fm_only ? 1 : 0;
         tap_list.push_back(tl);
         tap_bins.push_back(tl.bin);
     }

@@ -198,6 +198,7 @@ void pump_main(rcf_pump *p)
                         for (int e : p->entries_of[(size_t)it.m]) {
                             Chan *c = chan_of[(size_t)e];
                             if (!c) continue;                                      // closed under the pump: starves
+                            if (cfg.what == RCF_READ_IQ && c->fm_only) continue;   // discriminator only: no IQ stream to hand out
                             int64_t *cur = cfg.what == RCF_READ_IQ ? &c->rd_iq : &c->rd_fm;
                             int64_t avail = c->produced - *cur;
                             if (avail <= 0) continue;

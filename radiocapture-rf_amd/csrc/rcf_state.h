@@ -41,6 +41,8 @@ struct Chan {
     int src = -1;                 // -1 wideband; RCF_SRC_PFB_BIN0 + bin; else source channel id
     int D = 0, T = 0;
     int depth = 0;
+    bool fm_only = false;         // rcf_chan_set_fm_only: tap_finalize writes the discriminator ring only (a tap's IQ ring keeps
+                                  // just the launch's last output, for the next launch's first discriminator sample)
     bool is_tap = false;          // a bin of a frame-major filterbank open as a channel: the bank's kernel copies it
                                   // into the launch's tap matrix, tap_finalize_kernel fills the rings
     float2 *d_ctaps = nullptr;

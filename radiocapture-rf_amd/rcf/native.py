@@ -36,7 +36,7 @@ SYMBOLS = [
     "rcf_design_firdes", "rcf_design_optfir_low_pass", "rcf_design_fm_deemph", "rcf_design_resampler", "rcf_chan_audio_open",
     "rcf_chan_audio_close", "rcf_chan_audio_produced", "rcf_chan_read_audio",
     "rcf_host_alloc", "rcf_host_free", "rcf_comm_unique_id", "rcf_comm_init", "rcf_comm_destroy", "rcf_comm_size",
-    "rcf_allgather_peaks", "rcf_allreduce_max", "rcf_pfb_tap_open", "rcf_pfb_shape_supported",
+    "rcf_allgather_peaks", "rcf_allreduce_max", "rcf_pfb_tap_open", "rcf_chan_set_fm_only", "rcf_pfb_shape_supported",
     "rcf_pfb_tap_leakage", "rcf_set_rotator", "rcf_timing_stride", "rcf_set_stage2_lag",
     "rcf_group_open", "rcf_group_close", "rcf_group_size", "rcf_group_push", "rcf_group_commit", "rcf_group_read_many",
     "rcf_group_sync", "rcf_pump_start", "rcf_pump_stats", "rcf_pump_written", "rcf_pump_read", "rcf_pump_stop",
@@ -148,6 +148,7 @@ def lib():
         "rcf_pfb_rings": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
         "rcf_pfb_chan_open": (C.c_int, [vp, C.c_int, C.c_int, C.c_double, ip]),
         "rcf_pfb_tap_open": (C.c_int, [vp, C.c_int, C.c_int, ip]),
+        "rcf_chan_set_fm_only": (C.c_int, [vp, C.c_int, C.c_int]),
         "rcf_pfb_shape_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
         "rcf_pfb_tap_leakage": (C.c_int, [C.c_double, C.c_int, fp, C.c_int, C.c_int, C.POINTER(C.c_double),
                                           C.POINTER(C.c_double)]),
@@ -481,6 +482,10 @@ class Frontend:
         cid = C.c_int()
         _check(lib().rcf_pfb_tap_open(self._h, int(bin_), 1 if gr_phase else 0, C.byref(cid)))
         return cid.value
+
+    def chan_set_fm_only(self, cid, on=True):
+        """a filterbank tap that is only demodulated: its discriminator ring alone is written (rcf_chan_set_fm_only)"""
+        _check(lib().rcf_chan_set_fm_only(self._h, cid, 1 if on else 0))
 
     def chan_set_offset(self, cid, offset_hz):
         _check(lib().rcf_chan_set_offset(self._h, cid, float(offset_hz)))

@@ -1,0 +1,92 @@
+"""rcf_chan_set_fm_only: a tap of the reference-grid filterbank that is only ever demodulated (rc_frontend/channel.py:35 +
+p25_control_demod.py:120-121 -- every channel of the reference is demodulated, in a process of its own) has tap_finalize
+write its discriminator ring alone.  The discriminator samples are the SAME BITS as those of an ordinary tap, however the
+stream is cut; the IQ stream is refused while the flag is on and comes back, from the next block on, when it goes off."""
+import numpy as np
+import pytest
+
+from oracle import grspec as G
+from rcf import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_bits(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
+
+
+def _taps_fm(nat, x, cuts, bins, fm_only, fs=5e6, cr=12500):
+    D, taps = G.channel_params(fs, cr)
+    nb = 2 * D
+    with nat.Frontend(fs, 0.0, device=0, block_capacity=max(cuts), hist_capacity=1 << 14, out_capacity=1 << 12) as fe:
+        fe.pfb_open(nb, D, taps)
+        ids = [fe.pfb_tap_open(b, gr_phase=True) for b in bins]
+        for c in ids:
+            if fm_only:
+                fe.chan_set_fm_only(c, True)
+        fm = [[] for _ in ids]
+        at = 0
+        for n in cuts:
+            fe.push(x[at:at + n])
+            at += n
+            for i, c in enumerate(ids):
+                fm[i].append(fe.chan_read_fm(c, 3.0))
+        return [np.concatenate(f) for f in fm]
+
+
+def test_fm_only_taps_same_discriminator_bits_whatever_the_cuts(gpu_required):
+    nat = gpu_required
+    rng = np.random.default_rng(77)
+    fs = 5e6
+    D, _ = G.channel_params(fs, 12500)
+    x = synth.awgn(rng, D * 700 + 13)
+    t = np.arange(len(x)) / fs
+    x = (x + 8 * np.exp(2j * np.pi * (12500.0 * 21 * t + 0.3 * np.sin(2 * np.pi * 900 * t)))).astype(np.complex64)
+    # a complete aligned run of 16 bins (read from the bank's ring), scattered bins (through the tap matrix), a duplicate
+    bins = list(range(16, 32)) + [21, 3, 77, 140, 21, 399]
+    cuts_a = [len(x)]
+    cuts_b = [D * 100 + 5, D * 3, 1, D * 250 - 6, len(x) - (D * 353)]
+    assert sum(cuts_b) == len(x)
+    ref = _taps_fm(nat, x, cuts_a, bins, False)
+    for cuts in (cuts_a, cuts_b):
+        got = _taps_fm(nat, x, cuts, bins, True)
+        for r, g_ in zip(ref, got):
+            assert len(r) > 600 and _same_bits(r, g_)
+
+
+def test_fm_only_refuses_the_iq_stream_and_gives_it_back(gpu_required):
+    nat = gpu_required
+    fs = 5e6
+    D, taps = G.channel_params(fs, 12500)
+    rng = np.random.default_rng(78)
+    x = synth.awgn(rng, D * 300)
+    with nat.Frontend(fs, 0.0, device=0, block_capacity=len(x), hist_capacity=1 << 14, out_capacity=1 << 12) as fe, \
+            nat.Frontend(fs, 0.0, device=0, block_capacity=len(x), hist_capacity=1 << 14, out_capacity=1 << 12) as fr:
+        for f in (fe, fr):
+            f.pfb_open(2 * D, D, taps)
+        a, b = fe.pfb_tap_open(40, gr_phase=True), fe.pfb_tap_open(41, gr_phase=True)
+        ra = fr.pfb_tap_open(40, gr_phase=True)
+        direct = fe.chan_open(12500, 100e3)
+        with pytest.raises(nat.RcfError):
+            fe.chan_set_fm_only(direct, True)                     # not a filterbank tap
+        fe.chan_open_taps(b, 1, np.ones(3, np.float32), 0.0)
+        with pytest.raises(nat.RcfError):
+            fe.chan_set_fm_only(b, True)                          # something reads b's IQ stream
+        fe.chan_set_fm_only(a, True)
+        fe.push(x[: D * 100])
+        fr.push(x[: D * 100])
+        with pytest.raises(nat.RcfError):
+            fe.chan_read_iq(a)
+        many = fe.chan_read_many([a, b], what="iq")
+        assert many[0] is None and len(many[1]) == 100            # the batched read: refused for a, b's samples delivered
+        with pytest.raises(nat.RcfError):
+            fe.chan_open_taps(a, 1, np.ones(3, np.float32), 0.0)  # nothing chains on a discriminator-only channel
+        fe.chan_set_fm_only(a, False)                             # IQ from the next block on
+        assert len(fe.chan_read_iq(a)) == 0
+        fe.push(x[D * 100:])
+        fr.push(x[D * 100:])
+        iq = fe.chan_read_iq(a)
+        want = fr.chan_read_iq(ra)
+        assert len(iq) == 200 and _same_bits(iq, want[-200:])
+        assert _same_bits(fe.chan_read_fm(a, 1.0), fr.chan_read_fm(ra, 1.0))

@@ -81,6 +81,10 @@ def measured_block(R):
         frac = ro.get("algorithmic_bytes_per_launch", 16.0 * b["config"]["block_samples"]) / (st["avg_us"] * 1e-6) / 1e9 / 8000.0
         add("| the same kernel by `rocprofv3 --kernel-trace --stats` | %.1f µs over %d launches ⇒ **%s** | `%s_bench_kernel_stats.csv`, row `pfb_kernel_os<256, 1, 14, 4, false>` |"
             % (st["avg_us"], st["calls"], f3(frac), R))
+    sn = _stats("%s_bench_nolag_kernel_stats.csv" % R, r"pfb_kernel_os<256, 1, 14, 4, false>")
+    if sn:
+        add("| the filterbank ALONE by `rocprofv3 --kernel-trace --stats` (the same headline run with `RCF_S2_LAG=0`: no rider in the launch) | %.1f µs over %d launches ⇒ **%s** (16 B × block / launch time: the row of rounds 1–4) | `%s_bench_nolag_kernel_stats.csv`, row `pfb_kernel_os<256, 1, 14, 4, false>` |"
+            % (sn["avg_us"], sn["calls"], f3(16.0 * b["config"]["block_samples"] / (sn["avg_us"] * 1e-6) / 1e9 / 8000.0), R))
     if hu:
         add("| … and the bench line printed in that profiled run | %.1f µs (`frac` %s) | `%s_bench_head_under_rocprof.json`: `roofline.avg_launch_ms` |"
             % (hu["roofline"]["avg_launch_ms"] * 1e3, f3(hu["roofline"]["frac"]), R))
@@ -134,8 +138,9 @@ def measured_block(R):
             add("| 3200 bins, decim %d, %d taps | %.4f ms = %s | `%s_bench.json`: `…grid_6k25[]` |"
                 % (x["decim"], x["taps"], x["pfb_ms_per_block"], f3(x["frac_of_hbm_peak"]), R))
         for pt in g.get("with_taps", {}).get("points", []):
-            add("| … with %d bins tapped and demodulated | bank %.4f ms (%.2f × untapped), finalize %.4f ms | `…with_taps.points[]` |"
-                % (pt["bins_tapped"], pt["pfb_ms_per_block"], pt["pfb_over_untapped"], pt["tap_finalize_ms_per_block"]))
+            add("| … with %d bins tapped and demodulated%s | bank %.4f ms (%.2f × untapped), finalize %.4f ms | `…with_taps.points[]` |"
+                % (pt["bins_tapped"], " (discriminator only: `rcf_chan_set_fm_only`)" if pt.get("discriminator_only") else "",
+                   pt["pfb_ms_per_block"], pt["pfb_over_untapped"], pt["tap_finalize_ms_per_block"]))
     t32 = [(_j("%s_pfb3200_d1600_pmc.json" % R), 1600), (_j("%s_pfb3200_d800_pmc.json" % R), 800)]
     if all(t and "fetch_x2_over_algorithmic_read" in t for t, _ in t32):
         add("| 3200-bin banks, PMC passes of `tools/pfb_probe.py` | %s | `%s_pfb3200_d1600_pmc.json`, `%s_pfb3200_d800_pmc.json` |"

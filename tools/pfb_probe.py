@@ -36,6 +36,8 @@ ntap = int(os.environ.get("TAPS", 0))
 # TAPSEQ=1: bins 0, 1, 2, ... (complete aligned runs of 16: read from the bank's ring); default: scattered bins (tap matrix)
 seq = bool(int(os.environ.get("TAPSEQ", 0)))
 tids = [fe.pfb_tap_open(i % nb if seq else (7 + 6 * i) % nb, gr_phase=bool(int(os.environ.get("GRPHASE", 1)))) for i in range(ntap)]
+if int(os.environ.get("FMONLY", 0)):                     # FMONLY=1: the taps expose their discriminator only (rcf_chan_set_fm_only)
+    for t in tids: fe.chan_set_fm_only(t, True)
 # STAGE2=n: n stage-2 channels (xlating FIR /D2 + discriminator) on bins spread over the bank, as the timed configuration has 32
 n2 = int(os.environ.get("STAGE2", 0))
 s2 = [fe.pfb_chan_open((3 + (nb // max(n2, 1)) * i) % nb, 12500, 1000.0 + 10 * i) for i in range(n2)]
