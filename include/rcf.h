@@ -340,7 +340,10 @@ int rcf_pfb_tap_open(rcf_t *h, int bin, int gr_phase, int *chan_id);
  * rcf_chan_read_iq / rcf_chan_read_many(RCF_READ_IQ) / rcf_chan_rings(iq) / chaining a channel or a voice chain on it
  * fail with RCF_ESTATE, and switching it on is refused (RCF_ESTATE) while something reads that stream.  on = 0 gives the
  * stream back from the next block on (the IQ read cursor skips what was never written).  Frame-major filterbank taps
- * only (RCF_EINVAL otherwise).  The discriminator samples are the same bits either way. */
+ * only (RCF_EINVAL otherwise).  The discriminator path then rotates nothing either: arg(y[n] conj(y[n-1])) of the rotated
+ * stream is arg(bin[n] conj(bin[n-1]) x incr) -- equal to an ordinary tap's discriminator to float32 rounding (~1e-7 rad),
+ * bit-identical however the stream is cut, continuous across a switch in mid-stream (the call converts the one ring
+ * sample the next block's first discriminator output is taken against; it synchronises the stream for that). */
 int rcf_chan_set_fm_only(rcf_t *h, int chan_id, int on);
 /* How far bin `bin` of an exact-phase bank is from GNU Radio's own channel at that offset, before any sample is seen
  * (no device needed).  freq_xlating_fir_filter_ccc (rc_frontend/channel.py:35) builds its composite taps as

@@ -510,6 +510,18 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
                         z[it] = L.iq_ring[(uint64_t)n & ring_mask];   // produced by an earlier launch: already rotated
                 }
             }
+            if (L.fm_only) {
+                // discriminator only: no rotation at all.  The discriminator of the rotated stream, arg(y[n] conj(y[n-1])) with
+                // y = bin x phase, phase[n] = phase[n-1] x incr, is arg(bin[n] conj(bin[n-1]) x incr): the second phase turns
+                // the product by the tap's ONE angle instead of walking a float64 phasor along every row (a quarter of this
+                // kernel's vector instructions, and the kernel is vector-issue bound)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int lr = rr + 16 * it;
+                    if (lr >= kTapLdsRows) break;
+                    ys[tap_lds_at(lr, sl)] = z[it];
+                }
+            } else {
             RotatorWalk<TapLaunch> walk(L, k_first + r_lds0 + rr - L.k_abs0, 16);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -521,6 +533,7 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
                 walk.advance();
                 ys[tap_lds_at(lr, sl)] = v;
             }
+            }
         }
     }
     __syncthreads();
@@ -531,6 +544,13 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
         const TapLaunch L = taps[slot];
         const int64_t o = k_first - L.k_abs0;                       // ring index of matrix row 0
         const int a = (int)((uint64_t)(o + r0) & (kTapAlign - 1));  // this tile's outputs start at row r0 - a
+        float inc_r = 1.f, inc_i = 0.f;                              // discriminator-only taps: the rotator's increment as a phasor
+        if (L.fm_only && L.dangle != 0.0) {
+            double sn_, cs_;
+            sincos_fast(L.dangle, sn_, cs_);
+            inc_r = (float)cs_;
+            inc_i = (float)sn_;
+        }
         auto fm_of = [&](float2 y1, float2 y0) {
             // volk_32fc_x2_multiply_conjugate_32fc: y1 * conj(y0), unfused (as disc_kernel)
             const float tr = __fadd_rn(__fmul_rn(y1.x, y0.x), __fmul_rn(y1.y, y0.y));
@@ -551,17 +571,25 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
             const float2 yb0 = na + 1 > 0 ? ya : make_float2(0.f, 0.f);
             const uint64_t ia = (uint64_t)na & ring_mask;
             if (L.fm_only) {
-                // discriminator only (rcf_chan_set_fm_only): 4 of the 12 bytes per output; the launch's LAST output still goes
-                // to the IQ ring -- it is the "output before" of the next launch's first discriminator sample
+                // discriminator only (rcf_chan_set_fm_only): 4 of the 12 bytes per output; the launch's LAST bin value still goes
+                // to the IQ ring (unrotated, as every row is here) -- it is the "output before" of the next launch's first
+                // discriminator sample.  fm_c: bin[n] conj(bin[n-1]) turned by the rotator's increment (cr, ci)
                 const int64_t n_last = L.k_lo + L.n_k - 1 - L.k_abs0;
+                auto fm_c = [&](float2 y1, float2 y0) {
+                    const float tr = __fadd_rn(__fmul_rn(y1.x, y0.x), __fmul_rn(y1.y, y0.y));
+                    const float ti = __fsub_rn(__fmul_rn(y1.y, y0.x), __fmul_rn(y1.x, y0.y));
+                    const float ur = __fsub_rn(__fmul_rn(tr, inc_r), __fmul_rn(ti, inc_i));
+                    const float ui = __fadd_rn(__fmul_rn(tr, inc_i), __fmul_rn(ti, inc_r));
+                    return fast_atan2f_gr(ui, ur, tab);
+                };
                 if (va && vb) {
                     typedef float v2f_ __attribute__((ext_vector_type(2)));
-                    v2f_ b_; b_.x = fm_of(ya, ym); b_.y = fm_of(yb, yb0);
+                    v2f_ b_; b_.x = fm_c(ya, ym); b_.y = fm_c(yb, yb0);
                     __builtin_nontemporal_store(b_, reinterpret_cast<v2f_ *>(L.fm_ring + ia));
                 } else if (va) {
-                    L.fm_ring[ia] = fm_of(ya, ym);
+                    L.fm_ring[ia] = fm_c(ya, ym);
                 } else {
-                    L.fm_ring[(uint64_t)(na + 1) & ring_mask] = fm_of(yb, yb0);
+                    L.fm_ring[(uint64_t)(na + 1) & ring_mask] = fm_c(yb, yb0);
                 }
                 if (va && na == n_last) L.iq_ring[ia] = ya;
                 if (vb && na + 1 == n_last) L.iq_ring[(uint64_t)(na + 1) & ring_mask] = yb;
@@ -586,7 +614,7 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
     }
 }
 
-__global__ __launch_bounds__(kThreads) void tap_finalize_kernel(TapFinArgs A, uint64_t ring_mask,
+__global__ __launch_bounds__(kThreads, 5) void tap_finalize_kernel(TapFinArgs A, uint64_t ring_mask,
                                                                 const float *__restrict__ atan_tab)
 {
     __shared__ float tab[260];
@@ -595,7 +623,7 @@ __global__ __launch_bounds__(kThreads) void tap_finalize_kernel(TapFinArgs A, ui
 }
 
 // the taps of G front-ends in one launch: grid.z = front-end, x / y sized for the largest of them
-__global__ __launch_bounds__(kThreads) void tap_finalize_group_kernel(const TapFinArgs *__restrict__ args, uint64_t ring_mask,
+__global__ __launch_bounds__(kThreads, 5) void tap_finalize_group_kernel(const TapFinArgs *__restrict__ args, uint64_t ring_mask,
                                                                       const float *__restrict__ atan_tab)
 {
     __shared__ float tab[260];

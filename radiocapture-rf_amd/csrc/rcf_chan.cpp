@@ -618,6 +618,20 @@ int rcf_chan_set_fm_only(rcf_t *h, int chan_id, int on)
     } else if (c->fm_only) {
         c->rd_iq = c->produced;                  // what lies behind was never written
     }
+    if ((on != 0) != c->fm_only && c->produced > 0) {
+        // The newest ring sample is the "output before" of the next block's first discriminator sample, and the two modes
+        // keep it differently: rotated by the channel's rotator (ordinary tap) or as the bare bin (discriminator only: that
+        // path never rotates, it turns the conjugate product by the rotator's increment instead).  Convert the one sample,
+        // so that no discriminator sample straddles two conventions.  Only its angle matters to the discriminator.
+        RCF_HIP(hipStreamSynchronize(h->stream));
+        float2 *at = c->d_iq + ((uint64_t)(c->produced - 1) & h->ring_mask);
+        float2 v;
+        RCF_HIP(hipMemcpy(&v, at, sizeof(v), hipMemcpyDeviceToHost));
+        const long double ang = c->angle0 + (long double)(c->produced - 1 - c->n_seg0) * (long double)c->dangle;
+        const double pr = std::cos((double)ang), pi = (on ? -1.0 : 1.0) * std::sin((double)ang);
+        const float2 w = make_float2((float)(v.x * pr - v.y * pi), (float)(v.x * pi + v.y * pr));
+        RCF_HIP(hipMemcpy(at, &w, sizeof(w), hipMemcpyHostToDevice));
+    }
     c->fm_only = on != 0;
     return RCF_OK;
 }

@@ -1,7 +1,9 @@
 """rcf_chan_set_fm_only: a tap of the reference-grid filterbank that is only ever demodulated (rc_frontend/channel.py:35 +
 p25_control_demod.py:120-121 -- every channel of the reference is demodulated, in a process of its own) has tap_finalize
-write its discriminator ring alone.  The discriminator samples are the SAME BITS as those of an ordinary tap, however the
-stream is cut; the IQ stream is refused while the flag is on and comes back, from the next block on, when it goes off."""
+write its discriminator ring alone, and without rotating anything: arg(y[n] conj(y[n-1])) of the rotated stream is
+arg(bin[n] conj(bin[n-1]) x incr).  The discriminator is that of an ordinary tap to float32 rounding (a few 1e-7 rad), the
+SAME BITS however the stream is cut, continuous across a switch of the flag in mid-stream; the IQ stream is refused while
+the flag is on and comes back, from the next block on, when it goes off."""
 import numpy as np
 import pytest
 
@@ -49,10 +51,43 @@ def test_fm_only_taps_same_discriminator_bits_whatever_the_cuts(gpu_required):
     cuts_b = [D * 100 + 5, D * 3, 1, D * 250 - 6, len(x) - (D * 353)]
     assert sum(cuts_b) == len(x)
     ref = _taps_fm(nat, x, cuts_a, bins, False)
-    for cuts in (cuts_a, cuts_b):
-        got = _taps_fm(nat, x, cuts, bins, True)
-        for r, g_ in zip(ref, got):
-            assert len(r) > 600 and _same_bits(r, g_)
+    one = _taps_fm(nat, x, cuts_a, bins, True)
+    cut = _taps_fm(nat, x, cuts_b, bins, True)
+    for r, a_, b_ in zip(ref, one, cut):
+        assert len(r) > 600 and _same_bits(a_, b_)               # cut invariance, bit for bit
+        d = np.angle(np.exp(1j * (a_.astype(np.float64) - r) / 3.0))   # (gain 3; +-pi wraps of a noise bin are the same angle)
+        assert np.max(np.abs(d)) < 2e-6, float(np.max(np.abs(d)))
+
+
+def test_fm_only_switched_in_mid_stream_keeps_the_discriminator_continuous(gpu_required):
+    """the ring sample that is the next block's "output before" is kept rotated by an ordinary tap and bare by a
+    discriminator-only one: rcf_chan_set_fm_only converts it, so the sample straddling a switch is right too"""
+    nat = gpu_required
+    fs = 5e6
+    D, taps = G.channel_params(fs, 12500)
+    rng = np.random.default_rng(79)
+    x = synth.awgn(rng, D * 400)
+    t = np.arange(len(x)) / fs
+    x = (x + 8 * np.exp(2j * np.pi * (12500.0 * 40 * t + 0.4 * np.sin(2 * np.pi * 700 * t)))).astype(np.complex64)
+    cuts = [D * 100, D * 100, D * 100, D * 100]
+    out = {}
+    for mode in ("plain", "switched"):
+        with nat.Frontend(fs, 0.0, device=0, block_capacity=D * 100, hist_capacity=1 << 14, out_capacity=1 << 12) as fe:
+            fe.pfb_open(2 * D, D, taps)
+            c = fe.pfb_tap_open(40, gr_phase=True)
+            fm, at = [], 0
+            for i, n in enumerate(cuts):
+                if mode == "switched" and i in (1, 3):
+                    fe.chan_set_fm_only(c, True)
+                if mode == "switched" and i == 2:
+                    fe.chan_set_fm_only(c, False)
+                fe.push(x[at:at + n])
+                at += n
+                fm.append(fe.chan_read_fm(c, 1.0))
+            out[mode] = np.concatenate(fm)
+    assert len(out["plain"]) == 400 == len(out["switched"])
+    d = np.angle(np.exp(1j * (out["switched"].astype(np.float64) - out["plain"])))
+    assert np.max(np.abs(d)) < 2e-6, (int(np.argmax(np.abs(d))), float(np.max(np.abs(d))))
 
 
 def test_fm_only_refuses_the_iq_stream_and_gives_it_back(gpu_required):
@@ -89,4 +124,5 @@ def test_fm_only_refuses_the_iq_stream_and_gives_it_back(gpu_required):
         iq = fe.chan_read_iq(a)
         want = fr.chan_read_iq(ra)
         assert len(iq) == 200 and _same_bits(iq, want[-200:])
-        assert _same_bits(fe.chan_read_fm(a, 1.0), fr.chan_read_fm(ra, 1.0))
+        fa, fb = fe.chan_read_fm(a, 1.0), fr.chan_read_fm(ra, 1.0)
+        assert len(fa) == len(fb) == 300 and np.max(np.abs(np.angle(np.exp(1j * (fa.astype(np.float64) - fb))))) < 2e-6
