@@ -43,7 +43,11 @@ n2 = int(os.environ.get("STAGE2", 0))
 s2 = [fe.pfb_chan_open((3 + (nb // max(n2, 1)) * i) % nb, 12500, 1000.0 + 10 * i) for i in range(n2)]
 for _ in range(int(os.environ.get("WARM", 3))): fe.commit(B)
 fe.timing_enable(True, classes=None if os.environ.get('TIME_ALL') else [native.T_PFB]); fe.timing_read(native.T_PFB)
+import time
+fe.sync(); _t0 = time.perf_counter()
 for _ in range(steps): fe.commit(B)
+if os.environ.get("WALL"):
+    fe.sync(); print("wall %.4f ms per step | " % ((time.perf_counter() - _t0) / steps * 1e3), end="")
 ms, n = fe.timing_read(native.T_PFB)
 ms /= n
 extra = ""
