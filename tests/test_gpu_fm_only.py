@@ -126,3 +126,43 @@ def test_fm_only_refuses_the_iq_stream_and_gives_it_back(gpu_required):
         assert len(iq) == 200 and _same_bits(iq, want[-200:])
         fa, fb = fe.chan_read_fm(a, 1.0), fr.chan_read_fm(ra, 1.0)
         assert len(fa) == len(fb) == 300 and np.max(np.abs(np.angle(np.exp(1j * (fa.astype(np.float64) - fb))))) < 2e-6
+
+
+def test_fm_only_taps_in_a_group_same_bits_as_alone(gpu_required):
+    """discriminator-only and ordinary taps side by side on the members of a group (rcf_group_*: one tap_finalize launch over
+    the members): the same bits as the members fed one by one"""
+    nat = gpu_required
+    fs = 5e6
+    D, _ = G.channel_params(fs, 12500)
+    t = G.low_pass_2(1.0, fs, 6250.0, 6250.0, 20.0, G.WIN_HAMMING)
+    tap_sets = [list(range(32, 48)) + [3, 77, 399], list(range(0, 16)) + [200, 201]]
+    blk = D * 200
+    rng = np.random.default_rng(80)
+    xs = [synth.awgn(rng, 3 * blk) for _ in tap_sets]
+    res = []
+    for grouped in (True, False):
+        fes, ids = [], []
+        for m, ts in enumerate(tap_sets):
+            fe = nat.Frontend(fs, 0.0, device=0, block_capacity=blk, hist_capacity=1 << 13, out_capacity=1 << 11)
+            fe.pfb_open(400, D, t)
+            ids.append([fe.pfb_tap_open(b, gr_phase=True) for b in ts])
+            for i, c in enumerate(ids[-1]):
+                if i % 2 == 0 or m == 1:
+                    fe.chan_set_fm_only(c, True)
+            fes.append(fe)
+        grp = nat.Group(fes) if grouped else None
+        for r in range(3):
+            blocks = [xs[m][r * blk:(r + 1) * blk] for m in range(2)]
+            if grp is not None:
+                grp.push(blocks, nat.FMT_CF32)
+            else:
+                for m in range(2):
+                    fes[m].push(blocks[m])
+        out = [fes[m].chan_read_fm(c, 6.6315) for m in range(2) for c in ids[m]]
+        if grp is not None:
+            grp.close()
+        for fe in fes:
+            fe.close()
+        res.append(out)
+    for a_, b_ in zip(*res):
+        assert len(a_) == 600 and _same_bits(a_, b_)
