@@ -580,6 +580,74 @@ def test_random_gr_phase_taps_equal_gnuradio_channels_started_at_their_opening(g
             assert efm < 1e-4, (seed, L["segments"], L["start"], L["stop"], efm)
 
 
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_discriminator_only_taps_with_flips_equal_gnuradio_discriminators(gpu_required, seed):
+    """rcf_chan_set_fm_only on taps of the reference-grid bank, switched on and off at random block boundaries (the
+    discriminator-only path rotates nothing: it turns bin[n] conj(bin[n-1]) by the rotator's increment, and the call
+    converts the one ring sample a switch straddles): the discriminator stream must stay that of quadrature_demod_cf behind
+    a freq_xlating_fir_filter_ccc started at the tap's opening sample, through every flip; IQ is refused while the flag
+    is on"""
+    nat = gpu_required
+    rng = np.random.default_rng(8800 + seed)
+    cr, fs, nb = 12500, 5e6, 400
+    D, taps = G.channel_params(fs, cr)
+    grid = fs / nb
+    n_blocks = int(rng.integers(3, 8))
+    sizes = [int(rng.integers(1, 3 * D)) if rng.random() < 0.2 else int(rng.integers(4 * D, 120 * D)) for _ in range(n_blocks)]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    x = synth.awgn(rng, int(cuts[-1]))
+    ks = [int(v) for v in rng.integers(-(nb // 4), nb // 4 + 1, int(rng.integers(2, 9)))]
+    t = np.arange(len(x)) / fs
+    for k in ks:
+        x = x + (0.8 * np.exp(2j * np.pi * (k * grid + float(rng.uniform(-2000, 2000))) * t)).astype(np.complex64)
+    x = x.astype(np.complex64)
+    lives = []
+    with nat.Frontend(fs, block_capacity=int(max(sizes)) + 16, out_capacity=1 << 11) as fe:
+        fe.pfb_open(nb, D, taps)
+        live = {}
+        for b in range(n_blocks):
+            s0 = int(cuts[b])
+            for i, k in enumerate(ks):
+                r = rng.random()
+                if i not in live and r < (0.6 if b == 0 else 0.25):
+                    cid = fe.pfb_tap_open(k % nb, gr_phase=True)
+                    live[i] = dict(id=cid, start=s0, segments=[(s0, k * grid)], fm=[], only=False, flips=0)
+                    if rng.random() < 0.5:
+                        fe.chan_set_fm_only(cid, True)
+                        live[i]["only"] = True
+                elif i in live and r < 0.35:
+                    L = live[i]
+                    L["only"] = not L["only"]
+                    L["flips"] += 1
+                    fe.chan_set_fm_only(L["id"], L["only"])
+            fe.push(x[s0:int(cuts[b + 1])])
+            for L in live.values():
+                if L["only"] and rng.random() < 0.3:
+                    with pytest.raises(nat.RcfError):
+                        fe.chan_read_iq(L["id"])
+                if rng.random() < 0.5:
+                    L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+        for L in live.values():
+            L["fm"].append(fe.chan_read_fm(L["id"], 1.0))
+            L["stop"] = int(cuts[-1])
+            lives.append(L)
+    for L in lives:
+        fm = np.concatenate(L["fm"])
+        yo = _oracle_life(x, fs, cr, L["segments"], L["start"], L["stop"], filt=(D, taps))
+        assert len(yo) == len(fm), (seed, L["start"], L["stop"], len(yo), len(fm))
+        warm = (len(taps) - 1) // D + 1 if L["start"] else 0
+        if len(yo) < warm + 16:
+            continue
+        fo = G.quadrature_demod_cf(yo, 1.0)
+        mag = np.abs(yo)
+        ok = np.zeros(len(yo), dtype=bool)
+        ok[1:] = (mag[1:] > 0.05 * mag.mean()) & (mag[:-1] > 0.05 * mag.mean())
+        ok[:warm + 1] = False
+        if ok.sum() > 8:
+            efm = _fm_rms(fm[ok], fo[ok])
+            assert efm < 1e-4, (seed, L["segments"], L["start"], L["stop"], L["flips"], efm)
+
+
 def _hip_memcpy_h2d(dst_ptr, arr):
     """test plumbing: overwrite device memory the library handed out (hipMemcpy through the runtime librcf loaded)"""
     import ctypes as C
