@@ -464,6 +464,28 @@ constexpr int kTapOut = 128, kTapCols = 16, kTapAlign = 32, kTapLdsRows = kTapOu
 // rows 2 q + c, q = 0 .. 15, of ONE column: 16 different rotations = 16 different bank pairs.  (A pitch of 17 had the
 // second phase at stride 68 dwords: lanes q and q + 8 on the same banks, 8.9 M conflict cycles per 1600-tap launch.)
 __device__ __forceinline__ int tap_lds_at(int lr, int sl) { return lr * kTapLdsPitch + ((sl + (lr >> 1)) & (kTapCols - 1)); }
+// A tap's rows of a launch in 32 bits.  Matrix row r is the bank's frame k_first + r = the tap's output n = k - k_abs0:
+//   [lo, hi]   rows that are outputs of THIS launch (0 <= r < n_rows, k_lo <= k < k_lo + n_k, n >= 0), hi < lo: none
+//   old_lo     first row (< 0) whose output an earlier launch left in the tap's ring (n >= 0)
+//   first_ever the row of the tap's output 0 -- it has no predecessor -- clamped far below the tile when it is long past
+//   last       the row of the launch's last output of this tap (what a discriminator-only tap still stores as IQ)
+struct TapRows { int lo, hi, old_lo, first_ever, last; };
+__device__ __forceinline__ TapRows tap_rows(const TapLaunch &L, int64_t k_first, int n_rows)
+{
+    constexpr int64_t FAR = (int64_t)1 << 30;
+    auto clamp32 = [&](int64_t v) { return (int)(v < -FAR ? -FAR : (v > FAR ? FAR : v)); };
+    const int64_t first = L.k_abs0 - k_first;                  // row of output 0
+    const int64_t lo = max(max((int64_t)0, L.k_lo - k_first), first);
+    const int64_t hi = min((int64_t)n_rows, L.k_lo + L.n_k - k_first) - 1;
+    TapRows t;
+    t.lo = clamp32(lo);
+    t.hi = clamp32(hi);
+    t.old_lo = clamp32(first);
+    t.first_ever = clamp32(first);
+    t.last = clamp32(L.k_lo + L.n_k - 1 - k_first);
+    return t;
+}
+
 // one tile (16 taps x 128 outputs) of one front-end's taps; shared by the single-front-end kernel and the grouped one
 __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int bx, const int by, const uint64_t ring_mask,
                                                   const float *__restrict__ atan_tab, float *tab, float2 *ys)
@@ -497,17 +519,26 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
             // one offset for all sixteen -- the 32 alignment rows are then never fetched (they were a quarter more traffic)
             const int a_own = (int)((uint64_t)(k_first - L.k_abs0 + r0) & (kTapAlign - 1));
             const int r_need_lo = r0 - a_own - 1, r_need_hi = r0 - a_own + kTapOut - 1;
+            // The per-row index arithmetic in 32 bits (the kernel is vector-issue bound and int64 compares / masks / multiplies
+            // were a fifth of its instructions): a row r is FRESH (a frame of this launch inside the tap's range) for r in
+            // [rf_lo, rf_hi], OLD (an output of an earlier launch, read back from the tap's ring) for r in [ro_lo, -1]; ring
+            // positions wrap in uint32 (the ring is a power of two of at most 2^31 samples)
+            const TapRows tr_ = tap_rows(L, k_first, n_rows);
+            const int rf_lo = max(tr_.lo, r_need_lo), rf_hi = min(tr_.hi, r_need_hi);
+            const int ro_lo = max(tr_.old_lo, r_need_lo);
+            const uint32_t mask32 = (uint32_t)ring_mask;
+            const uint32_t kf32 = (uint32_t)((uint64_t)k_first & ring_mask);           // ring position of matrix row 0 (bank ring)
+            const uint32_t o32 = (uint32_t)((uint64_t)(k_first - L.k_abs0) & ring_mask);   // ... in the tap's own rings
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int lr = rr + 16 * it, r = r_lds0 + lr;
-                const int64_t k = k_first + r, n = k - L.k_abs0;
                 z[it] = make_float2(0.f, 0.f);
-                if (lr < kTapLdsRows && r >= r_need_lo && r <= r_need_hi) {
-                    if (r >= 0 && r < n_rows && k >= L.k_lo && k < L.k_lo + L.n_k && n >= 0)
-                        z[it] = b0 >= 0 ? bins_ring[((uint64_t)k & ring_mask) * (uint64_t)n_bins + (unsigned)(b0 + sl)]
-                                        : mat[(size_t)r * pitch + (slot - tap_first)];
-                    else if (r < 0 && n >= 0)
-                        z[it] = L.iq_ring[(uint64_t)n & ring_mask];   // produced by an earlier launch: already rotated
+                if (lr < kTapLdsRows) {
+                    if (r >= rf_lo && r <= rf_hi)
+                        z[it] = b0 >= 0 ? bins_ring[(uint64_t)((kf32 + (uint32_t)r) & mask32) * (uint32_t)n_bins + (unsigned)(b0 + sl)]
+                                        : mat[(uint64_t)(uint32_t)r * (uint32_t)pitch + (unsigned)(slot - tap_first)];
+                    else if (r < 0 && r >= ro_lo)
+                        z[it] = L.iq_ring[(o32 + (uint32_t)r) & mask32];   // produced by an earlier launch: already rotated
                 }
             }
             if (L.fm_only) {
@@ -544,6 +575,10 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
         const TapLaunch L = taps[slot];
         const int64_t o = k_first - L.k_abs0;                       // ring index of matrix row 0
         const int a = (int)((uint64_t)(o + r0) & (kTapAlign - 1));  // this tile's outputs start at row r0 - a
+        const TapRows tr_ = tap_rows(L, k_first, n_rows);           // rows [lo, hi] are outputs of this launch; 32-bit from here on
+        const uint32_t mask32 = (uint32_t)ring_mask;
+        const uint32_t o32 = (uint32_t)((uint64_t)o & ring_mask);
+        const int r_first = tr_.first_ever;                         // the row of the tap's very first output (no predecessor), or far below
         float inc_r = 1.f, inc_i = 0.f;                              // discriminator-only taps: the rotator's increment as a phasor
         if (L.fm_only && L.dangle != 0.0) {
             double sn_, cs_;
@@ -560,21 +595,18 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
 #pragma unroll
         for (int j = 0; j < kTapOut / 32; ++j) {
             const int ra = r0 - a + 2 * (q + 16 * j);               // rows ra, ra + 1 -> ring indices na (even), na + 1
-            const int64_t na = o + ra;
             const int lr = ra - r_lds0;
-            const bool va = ra >= 0 && ra < n_rows && k_first + ra >= L.k_lo && k_first + ra < L.k_lo + L.n_k && na >= 0;
-            const bool vb = ra + 1 >= 0 && ra + 1 < n_rows && k_first + ra + 1 >= L.k_lo &&
-                            k_first + ra + 1 < L.k_lo + L.n_k && na + 1 >= 0;
+            const bool va = ra >= tr_.lo && ra <= tr_.hi;
+            const bool vb = ra + 1 >= tr_.lo && ra + 1 <= tr_.hi;
             if (!va && !vb) continue;
-            const float2 ym = na > 0 ? ys[tap_lds_at(lr - 1, sl)] : make_float2(0.f, 0.f);
+            const float2 ym = ra > r_first ? ys[tap_lds_at(lr - 1, sl)] : make_float2(0.f, 0.f);   // (na > 0)
             const float2 ya = ys[tap_lds_at(lr, sl)], yb = ys[tap_lds_at(lr + 1, sl)];
-            const float2 yb0 = na + 1 > 0 ? ya : make_float2(0.f, 0.f);
-            const uint64_t ia = (uint64_t)na & ring_mask;
+            const float2 yb0 = ra + 1 > r_first ? ya : make_float2(0.f, 0.f);
+            const uint32_t ia = (o32 + (uint32_t)ra) & mask32;
             if (L.fm_only) {
                 // discriminator only (rcf_chan_set_fm_only): 4 of the 12 bytes per output; the launch's LAST bin value still goes
                 // to the IQ ring (unrotated, as every row is here) -- it is the "output before" of the next launch's first
                 // discriminator sample.  fm_c: bin[n] conj(bin[n-1]) turned by the rotator's increment (cr, ci)
-                const int64_t n_last = L.k_lo + L.n_k - 1 - L.k_abs0;
                 auto fm_c = [&](float2 y1, float2 y0) {
                     const float tr = __fadd_rn(__fmul_rn(y1.x, y0.x), __fmul_rn(y1.y, y0.y));
                     const float ti = __fsub_rn(__fmul_rn(y1.y, y0.x), __fmul_rn(y1.x, y0.y));
@@ -589,10 +621,10 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
                 } else if (va) {
                     L.fm_ring[ia] = fm_c(ya, ym);
                 } else {
-                    L.fm_ring[(uint64_t)(na + 1) & ring_mask] = fm_c(yb, yb0);
+                    L.fm_ring[(ia + 1) & mask32] = fm_c(yb, yb0);
                 }
-                if (va && na == n_last) L.iq_ring[ia] = ya;
-                if (vb && na + 1 == n_last) L.iq_ring[(uint64_t)(na + 1) & ring_mask] = yb;
+                if (va && ra == tr_.last) L.iq_ring[ia] = ya;
+                if (vb && ra + 1 == tr_.last) L.iq_ring[(ia + 1) & mask32] = yb;
                 continue;
             }
             if (va && vb) {                                          // na is even and the ring a power of two: no wrap inside the pair
@@ -606,7 +638,7 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
                 L.iq_ring[ia] = ya;
                 L.fm_ring[ia] = fm_of(ya, ym);
             } else {
-                const uint64_t ib = (uint64_t)(na + 1) & ring_mask;
+                const uint32_t ib = (ia + 1) & mask32;
                 L.iq_ring[ib] = yb;
                 L.fm_ring[ib] = fm_of(yb, yb0);
             }
