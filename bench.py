@@ -567,8 +567,21 @@ def measure_traffic_live(cfg5, block, kernel_substr, timeout_s=150):
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)
-            r = subprocess.run([rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child,
-                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            # (its own session: a pass that hangs -- it happened once in a profile run, ten minutes of nothing -- is killed
+            # WITH the child run rocprofv3 started, so that no stray copy of this script shares the GPU with the legs below)
+            pr = subprocess.Popen([rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child,
+                                  cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                pr.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.wait()
+                return None
+            r = pr
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
