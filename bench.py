@@ -902,6 +902,11 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
                 "seconds", "confirmation_run")
         out[shape] = {
             "K_max": good or 0, "K_max_first_attempt": first_attempt, "first_K_that_missed": bad,
+            # the largest K whose run(s) all held every deadline AND kept the block latency's p99 under 5 ms (near the host
+            # link's ceiling the queueing delay grows long before a deadline is missed)
+            "K_max_p99_under_5ms": max([K_ for K_ in {p["front_ends"] for p in pts}
+                                        if all(p.get("ok") and p.get("latency_ms_p99", 1e9) < 5.0
+                                               for p in pts if p["front_ends"] == K_)] or [0]),
             "bins_per_front_end": bins, "demodulated_per_front_end": demod,
             "channels_sustained": (good or 0) * bins, "fm_channels_sustained": (good or 0) * demod,
             "input_Msps_sustained": (good or 0) * FS / 1e6,
