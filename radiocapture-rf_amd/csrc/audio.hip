@@ -18,6 +18,7 @@
 // Built with -ffp-contract=off (Makefile): the unfused float / double operations below are the specified result;
 // where a fused multiply-add is meant it is written fmaf().
 #include "rcf_internal.h"
+#include "fast_atan2f_gr.hpp"
 
 namespace rcfx {
 
@@ -25,34 +26,7 @@ namespace {
 
 constexpr int kThreads = 256;
 
-// gr::fast_atan2f (same table and fix-ups as fir.hip's discriminator; the table comes in through LDS)
-__device__ __forceinline__ float fast_atan2f_gr(float y, float x, const float *tab)
-{
-    const float TAN_MAP_RES = 0.003921569f;
-    const float PI = 3.14159265358979323846f, PI_2 = 1.57079632679489661923f;
-    const float ya = fabsf(y), xa = fabsf(x);
-    if (!((ya > 0.0f) || (xa > 0.0f))) return 0.0f;
-    const float z = (ya < xa) ? __fdiv_rn(ya, xa) : __fdiv_rn(xa, ya);
-    float base;
-    if (z < TAN_MAP_RES) {
-        base = z;
-    } else {
-        float alpha = __fmul_rn(z, 255.0f);
-        const int index = ((int)alpha) & 0xff;
-        alpha = __fsub_rn(alpha, (float)index);
-        const float t0 = tab[index], t1 = tab[index + 1];
-        base = __fadd_rn(t0, __fmul_rn(__fsub_rn(t1, t0), alpha));
-    }
-    float angle;
-    if (xa > ya) {
-        if (x >= 0.0f) angle = (y >= 0.0f) ? base : -base;
-        else           angle = (y >= 0.0f) ? __fsub_rn(PI, base) : __fsub_rn(base, PI);
-    } else {
-        if (y >= 0.0f) angle = (x >= 0.0f) ? __fsub_rn(PI_2, base) : __fadd_rn(PI_2, base);
-        else           angle = (x >= 0.0f) ? __fadd_rn(-PI_2, base) : __fsub_rn(-PI_2, base);
-    }
-    return angle;
-}
+// gr::fast_atan2f: fast_atan2f_gr.hpp, the one every discriminator kernel runs (the table comes in through LDS)
 
 // Stage 1, one lane per channel: pwr_squelch_cc over the channel's new samples, in order.  Survivors are compacted
 // into c_ring; [n_prev, n_a) is published for the stages behind.

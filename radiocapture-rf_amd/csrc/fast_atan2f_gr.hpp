@@ -1,0 +1,45 @@
+// fast_atan2f_gr.hpp -- gr::fast_atan2f (gr-runtime fast_atan2f.cc: 255-interval table + linear interpolation, octant
+// fix-up) as every discriminator kernel runs it.  No HIP types in here: RCF_DEVFN is the function qualifier, so that the CPU
+// suite can compile this very source with g++ and compare it with the oracle's restatement of GNU Radio's branches over
+// millions of arguments (tests/test_device_atan_cpu.py) -- the device code is written as SELECTS, not as those branches.
+#pragma once
+#include <math.h>
+#ifndef RCF_DEVFN
+#define RCF_DEVFN __device__ __forceinline__
+#endif
+
+namespace rcfx {
+
+namespace {
+
+RCF_DEVFN float fast_atan2f_gr(float y, float x, const float *tab)
+{
+#pragma clang fp contract(off)
+    // The same values as gr::fast_atan2f's nested branches, written as selects: left as branches the compiler emits a
+    // division on EACH side of (ya < xa) and both octant arms under exec masks -- with the lanes of a wavefront spread over
+    // all octants every side runs, two 12-instruction divisions per call and ~15 scalar mask instructions around them (the
+    // discriminator was half of tap_finalize_kernel's vector issue).  a - b == -(b - a) exactly, so every arm below is the
+    // reference's own operation: base - PI = -(PI - base), -PI_2 + base = -(PI_2 - base), -PI_2 - base = -(PI_2 + base).
+    const float TAN_MAP_RES = 0.003921569f;
+    const float PI = 3.14159265358979323846f, PI_2 = 1.57079632679489661923f;
+    const float ya = fabsf(y), xa = fabsf(x);
+    const bool nonzero = (ya > 0.0f) || (xa > 0.0f);      // (0, 0) -> 0, selected at the end
+    const bool y_small = ya < xa;
+    const float num = y_small ? ya : xa, den = y_small ? xa : ya;
+    const float z = num / den;
+    float alpha = z * 255.0f;
+    const int index = ((int)alpha) & 0xff;                // (the NaN z of the (0, 0) case converts to 0: a valid table position)
+    alpha = alpha - (float)index;
+    const float t0 = tab[index], t1 = tab[index + 1];
+    const float base = (z < TAN_MAP_RES) ? z : t0 + ((t1 - t0) * alpha);
+    const bool xpos = x >= 0.0f, ypos = y >= 0.0f;
+    const float r_x = xpos ? base : (PI - base);          // |x| > |y|
+    const float r_y = PI_2 + (xpos ? -base : base);       // otherwise: PI_2 - base / PI_2 + base
+    const float r = (xa > ya) ? r_x : r_y;
+    const float angle = ypos ? r : -r;
+    return nonzero ? angle : 0.0f;
+}
+
+}  // namespace
+
+}  // namespace rcfx

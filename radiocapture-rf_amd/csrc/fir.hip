@@ -470,6 +470,18 @@ __device__ __forceinline__ int tap_lds_at(int lr, int sl) { return lr * kTapLdsP
 //   first_ever the row of the tap's output 0 -- it has no predecessor -- clamped far below the tile when it is long past
 //   last       the row of the launch's last output of this tap (what a discriminator-only tap still stores as IQ)
 struct TapRows { int lo, hi, old_lo, first_ever, last; };
+// what the second phase needs of a tap, left in LDS by the first phase's lane of that tap (rr == 0): the second phase then
+// loads no launch record, does no 64-bit row arithmetic and no sincos of its own (its preamble was ~220 of a lane's ~900
+// instructions on the discriminator-only path, and the kernel is vector-issue bound)
+struct __attribute__((aligned(16))) TapInfo {
+    float2 *iq_ring;
+    float *fm_ring;
+    int lo, hi, first_ever, last;      // TapRows of the launch
+    uint32_t o32;                      // ring position of matrix row 0 in the tap's own rings
+    int a;                             // the tile's outputs start at row r0 - a
+    float inc_r, inc_i;                // discriminator-only taps: the rotator's increment as a phasor
+    int fm_only, pad_[3];
+};
 __device__ __forceinline__ TapRows tap_rows(const TapLaunch &L, int64_t k_first, int n_rows)
 {
     constexpr int64_t FAR = (int64_t)1 << 30;
@@ -488,7 +500,7 @@ __device__ __forceinline__ TapRows tap_rows(const TapLaunch &L, int64_t k_first,
 
 // one tile (16 taps x 128 outputs) of one front-end's taps; shared by the single-front-end kernel and the grouped one
 __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int bx, const int by, const uint64_t ring_mask,
-                                                  const float *__restrict__ atan_tab, float *tab, float2 *ys)
+                                                  const float *__restrict__ atan_tab, float *tab, float2 *ys, TapInfo *info)
 {
     static_assert(kThreads == kTapCols * 16, "16 x 16 lanes");
     const TapLaunch *__restrict__ taps = A.taps;
@@ -529,6 +541,24 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
             const uint32_t mask32 = (uint32_t)ring_mask;
             const uint32_t kf32 = (uint32_t)((uint64_t)k_first & ring_mask);           // ring position of matrix row 0 (bank ring)
             const uint32_t o32 = (uint32_t)((uint64_t)(k_first - L.k_abs0) & ring_mask);   // ... in the tap's own rings
+            if (rr == 0) {
+                TapInfo ti;
+                ti.iq_ring = L.iq_ring;
+                ti.fm_ring = L.fm_ring;
+                ti.lo = tr_.lo; ti.hi = tr_.hi; ti.first_ever = tr_.first_ever; ti.last = tr_.last;
+                ti.o32 = o32;
+                ti.a = a_own;
+                ti.inc_r = 1.f; ti.inc_i = 0.f;
+                if (L.fm_only && L.dangle != 0.0) {
+                    double sn_, cs_;
+                    sincos_fast(L.dangle, sn_, cs_);
+                    ti.inc_r = (float)cs_;
+                    ti.inc_i = (float)sn_;
+                }
+                ti.fm_only = L.fm_only;
+                ti.pad_[0] = ti.pad_[1] = ti.pad_[2] = 0;
+                info[sl] = ti;
+            }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int lr = rr + 16 * it, r = r_lds0 + lr;
@@ -572,20 +602,13 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
         const int sl = tid >> 4, q = tid & 15;
         const int slot = s0 + sl;
         if (slot >= n_taps) return;
-        const TapLaunch L = taps[slot];
-        const int64_t o = k_first - L.k_abs0;                       // ring index of matrix row 0
-        const int a = (int)((uint64_t)(o + r0) & (kTapAlign - 1));  // this tile's outputs start at row r0 - a
-        const TapRows tr_ = tap_rows(L, k_first, n_rows);           // rows [lo, hi] are outputs of this launch; 32-bit from here on
+        const TapInfo L = info[sl];                                  // (the first phase's lane of this tap left it there)
+        const int a = L.a;                                           // this tile's outputs start at row r0 - a
+        struct { int lo, hi, last; } tr_ = {L.lo, L.hi, L.last};     // rows [lo, hi] are outputs of this launch
         const uint32_t mask32 = (uint32_t)ring_mask;
-        const uint32_t o32 = (uint32_t)((uint64_t)o & ring_mask);
-        const int r_first = tr_.first_ever;                         // the row of the tap's very first output (no predecessor), or far below
-        float inc_r = 1.f, inc_i = 0.f;                              // discriminator-only taps: the rotator's increment as a phasor
-        if (L.fm_only && L.dangle != 0.0) {
-            double sn_, cs_;
-            sincos_fast(L.dangle, sn_, cs_);
-            inc_r = (float)cs_;
-            inc_i = (float)sn_;
-        }
+        const uint32_t o32 = L.o32;
+        const int r_first = L.first_ever;                            // the row of the tap's very first output (no predecessor), or far below
+        const float inc_r = L.inc_r, inc_i = L.inc_i;                // discriminator-only taps: the rotator's increment as a phasor
         auto fm_of = [&](float2 y1, float2 y0) {
             // volk_32fc_x2_multiply_conjugate_32fc: y1 * conj(y0), unfused (as disc_kernel)
             const float tr = __fadd_rn(__fmul_rn(y1.x, y0.x), __fmul_rn(y1.y, y0.y));
@@ -651,7 +674,8 @@ __global__ __launch_bounds__(kThreads, 5) void tap_finalize_kernel(TapFinArgs A,
 {
     __shared__ float tab[260];
     __shared__ float2 ys[kTapLdsRows * kTapLdsPitch];
-    tap_finalize_tile(A, blockIdx.x, blockIdx.y, ring_mask, atan_tab, tab, ys);
+    __shared__ TapInfo info[kTapCols];
+    tap_finalize_tile(A, blockIdx.x, blockIdx.y, ring_mask, atan_tab, tab, ys, info);
 }
 
 // the taps of G front-ends in one launch: grid.z = front-end, x / y sized for the largest of them
@@ -660,9 +684,10 @@ __global__ __launch_bounds__(kThreads, 5) void tap_finalize_group_kernel(const T
 {
     __shared__ float tab[260];
     __shared__ float2 ys[kTapLdsRows * kTapLdsPitch];
+    __shared__ TapInfo info[kTapCols];
     const TapFinArgs A = args[blockIdx.z];
     if ((int)blockIdx.x * kTapCols >= A.n_taps || (int)blockIdx.y * kTapOut >= A.n_rows + kTapAlign - 1) return;
-    tap_finalize_tile(A, blockIdx.x, blockIdx.y, ring_mask, atan_tab, tab, ys);
+    tap_finalize_tile(A, blockIdx.x, blockIdx.y, ring_mask, atan_tab, tab, ys, info);
 }
 
 // P25 symbol filter and friends: a short real FIR over gain * fm (float32, taps in order)

@@ -6,6 +6,7 @@
 #pragma once
 #include "rcf_internal.h"
 #include "rotator.hpp"
+#include "fast_atan2f_gr.hpp"
 
 namespace rcfx {
 
@@ -14,35 +15,8 @@ namespace {
 constexpr int kSmallThreads = 256;
 constexpr int kSmallPerThread = 2;   // outputs per thread of the small-T kernel (fir_small_outputs <= 256 n - 1): 1 -> 2 took the stage-2 launch of the timed configuration from 0.030 to 0.025 ms, 3 and 4 are not faster
 
-// gr::fast_atan2f: 255-interval table + linear interpolation, octant fix-up (gr-runtime fast_atan2f.cc)
-__device__ __forceinline__ float fast_atan2f_gr(float y, float x, const float *tab)
-{
-#pragma clang fp contract(off)
-    const float TAN_MAP_RES = 0.003921569f;
-    const float PI = 3.14159265358979323846f, PI_2 = 1.57079632679489661923f;
-    const float ya = fabsf(y), xa = fabsf(x);
-    if (!((ya > 0.0f) || (xa > 0.0f))) return 0.0f;
-    const float z = (ya < xa) ? (ya / xa) : (xa / ya);
-    float base;
-    if (z < TAN_MAP_RES) {
-        base = z;
-    } else {
-        float alpha = z * 255.0f;
-        const int index = ((int)alpha) & 0xff;
-        alpha = alpha - (float)index;
-        const float t0 = tab[index], t1 = tab[index + 1];
-        base = t0 + ((t1 - t0) * alpha);
-    }
-    float angle;
-    if (xa > ya) {
-        if (x >= 0.0f) angle = (y >= 0.0f) ? base : -base;
-        else           angle = (y >= 0.0f) ? (PI - base) : (base - PI);
-    } else {
-        if (y >= 0.0f) angle = (x >= 0.0f) ? (PI_2 - base) : (PI_2 + base);
-        else           angle = (x >= 0.0f) ? (-PI_2 + base) : (-PI_2 - base);
-    }
-    return angle;
-}
+// gr::fast_atan2f: fast_atan2f_gr.hpp (a header of its own: tests/test_device_atan_cpu.py compiles it for the host and holds it
+// bit for bit to the oracle's branch form)
 
 
 // Small-T path (stage-2 FIRs on narrowband rings, e.g. D = 3, T = 11; the P25 69-tap pre-filter): one thread per
