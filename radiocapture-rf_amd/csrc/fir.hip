@@ -18,6 +18,7 @@
 // isations), so outputs do not depend on how the stream is cut into blocks.
 #include <cstdlib>
 
+#include <type_traits>
 #include "rcf_internal.h"
 #include "rotator.hpp"
 #include "fir_small.hpp"
@@ -457,6 +458,9 @@ __global__ __launch_bounds__(64) void rot_fill_kernel(const RotFill *__restrict_
 // launch come from the ring).  The 128 outputs of a tap are ALIGNED to 32 in the tap's own ring index (every tap has
 // its own k_abs0), so that every store is whole lines: a partial line costs a read-modify-write in the memory system
 // (32-byte pieces measured 4-5x slower than lines).  The price is the 32 extra rows a tile loads.
+#ifndef RCF_TAPFIN_WGS
+#define RCF_TAPFIN_WGS 5      // workgroups per CU the finalize kernels are compiled for (96 VGPRs; tools/variant_lib.sh for A/B)
+#endif
 constexpr int kTapOut = 128, kTapCols = 16, kTapAlign = 32, kTapLdsRows = kTapOut + kTapAlign + 1,
               kTapLdsPitch = kTapCols;
 // LDS position of (row lr, tap column sl): the column is rotated by half the row number, so that BOTH phases are free of
@@ -615,61 +619,79 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
             const float ti = __fsub_rn(__fmul_rn(y1.y, y0.x), __fmul_rn(y1.x, y0.y));
             return fast_atan2f_gr(ti, tr, tab);
         };
+        // one tile of one tap, four ways: INTERIOR = every one of the tile's 128 outputs is an output of this launch with a
+        // predecessor in LDS and none of them the launch's last (the steady state: 326 of a 2^25-sample launch's 328 tiles) --
+        // no per-pair range checks, no zero predecessors, whole-line stores only; FMO = discriminator-only tap.  The choice is
+        // uniform over a tap's 16 lanes (a wavefront holds four taps).
+        auto run = [&](auto interior_c, auto fmo_c) {
+            constexpr bool INTERIOR = decltype(interior_c)::value, FMO = decltype(fmo_c)::value;
 #pragma unroll
-        for (int j = 0; j < kTapOut / 32; ++j) {
-            const int ra = r0 - a + 2 * (q + 16 * j);               // rows ra, ra + 1 -> ring indices na (even), na + 1
-            const int lr = ra - r_lds0;
-            const bool va = ra >= tr_.lo && ra <= tr_.hi;
-            const bool vb = ra + 1 >= tr_.lo && ra + 1 <= tr_.hi;
-            if (!va && !vb) continue;
-            const float2 ym = ra > r_first ? ys[tap_lds_at(lr - 1, sl)] : make_float2(0.f, 0.f);   // (na > 0)
-            const float2 ya = ys[tap_lds_at(lr, sl)], yb = ys[tap_lds_at(lr + 1, sl)];
-            const float2 yb0 = ra + 1 > r_first ? ya : make_float2(0.f, 0.f);
-            const uint32_t ia = (o32 + (uint32_t)ra) & mask32;
-            if (L.fm_only) {
-                // discriminator only (rcf_chan_set_fm_only): 4 of the 12 bytes per output; the launch's LAST bin value still goes
-                // to the IQ ring (unrotated, as every row is here) -- it is the "output before" of the next launch's first
-                // discriminator sample.  fm_c: bin[n] conj(bin[n-1]) turned by the rotator's increment (cr, ci)
-                auto fm_c = [&](float2 y1, float2 y0) {
-                    const float tr = __fadd_rn(__fmul_rn(y1.x, y0.x), __fmul_rn(y1.y, y0.y));
-                    const float ti = __fsub_rn(__fmul_rn(y1.y, y0.x), __fmul_rn(y1.x, y0.y));
-                    const float ur = __fsub_rn(__fmul_rn(tr, inc_r), __fmul_rn(ti, inc_i));
-                    const float ui = __fadd_rn(__fmul_rn(tr, inc_i), __fmul_rn(ti, inc_r));
-                    return fast_atan2f_gr(ui, ur, tab);
-                };
-                if (va && vb) {
-                    typedef float v2f_ __attribute__((ext_vector_type(2)));
-                    v2f_ b_; b_.x = fm_c(ya, ym); b_.y = fm_c(yb, yb0);
-                    __builtin_nontemporal_store(b_, reinterpret_cast<v2f_ *>(L.fm_ring + ia));
-                } else if (va) {
-                    L.fm_ring[ia] = fm_c(ya, ym);
+            for (int j = 0; j < kTapOut / 32; ++j) {
+                const int ra = r0 - a + 2 * (q + 16 * j);               // rows ra, ra + 1 -> ring indices na (even), na + 1
+                const int lr = ra - r_lds0;
+                const bool va = INTERIOR || (ra >= tr_.lo && ra <= tr_.hi);
+                const bool vb = INTERIOR || (ra + 1 >= tr_.lo && ra + 1 <= tr_.hi);
+                if (!va && !vb) continue;
+                const float2 ym = (INTERIOR || ra > r_first) ? ys[tap_lds_at(lr - 1, sl)] : make_float2(0.f, 0.f);   // (na > 0)
+                const float2 ya = ys[tap_lds_at(lr, sl)], yb = ys[tap_lds_at(lr + 1, sl)];
+                const float2 yb0 = (INTERIOR || ra + 1 > r_first) ? ya : make_float2(0.f, 0.f);
+                const uint32_t ia = (o32 + (uint32_t)ra) & mask32;
+                if constexpr (FMO) {
+                    // discriminator only (rcf_chan_set_fm_only): 4 of the 12 bytes per output; the launch's LAST bin value still goes
+                    // to the IQ ring (unrotated, as every row is here) -- it is the "output before" of the next launch's first
+                    // discriminator sample.  fm_c: bin[n] conj(bin[n-1]) turned by the rotator's increment (cr, ci)
+                    auto fm_c = [&](float2 y1, float2 y0) {
+                        const float tr = __fadd_rn(__fmul_rn(y1.x, y0.x), __fmul_rn(y1.y, y0.y));
+                        const float ti = __fsub_rn(__fmul_rn(y1.y, y0.x), __fmul_rn(y1.x, y0.y));
+                        const float ur = __fsub_rn(__fmul_rn(tr, inc_r), __fmul_rn(ti, inc_i));
+                        const float ui = __fadd_rn(__fmul_rn(tr, inc_i), __fmul_rn(ti, inc_r));
+                        return fast_atan2f_gr(ui, ur, tab);
+                    };
+                    if (va && vb) {
+                        typedef float v2f_ __attribute__((ext_vector_type(2)));
+                        v2f_ b_; b_.x = fm_c(ya, ym); b_.y = fm_c(yb, yb0);
+                        __builtin_nontemporal_store(b_, reinterpret_cast<v2f_ *>(L.fm_ring + ia));
+                    } else if (va) {
+                        L.fm_ring[ia] = fm_c(ya, ym);
+                    } else {
+                        L.fm_ring[(ia + 1) & mask32] = fm_c(yb, yb0);
+                    }
+                    if constexpr (!INTERIOR) {
+                        if (va && ra == tr_.last) L.iq_ring[ia] = ya;
+                        if (vb && ra + 1 == tr_.last) L.iq_ring[(ia + 1) & mask32] = yb;
+                    }
                 } else {
-                    L.fm_ring[(ia + 1) & mask32] = fm_c(yb, yb0);
+                    if (va && vb) {                                      // na is even and the ring a power of two: no wrap inside the pair
+                        // (non-temporal: 256 taps 55.4 -> 53.1 us, 1600 taps 308 -> 302 us per 2^25-sample block)
+                        typedef float v4f_ __attribute__((ext_vector_type(4))); typedef float v2f_ __attribute__((ext_vector_type(2)));
+                        v4f_ a_; a_.x = ya.x; a_.y = ya.y; a_.z = yb.x; a_.w = yb.y;
+                        v2f_ b_; b_.x = fm_of(ya, ym); b_.y = fm_of(yb, yb0);
+                        __builtin_nontemporal_store(a_, reinterpret_cast<v4f_ *>(L.iq_ring + ia));
+                        __builtin_nontemporal_store(b_, reinterpret_cast<v2f_ *>(L.fm_ring + ia));
+                    } else if (va) {
+                        L.iq_ring[ia] = ya;
+                        L.fm_ring[ia] = fm_of(ya, ym);
+                    } else {
+                        const uint32_t ib = (ia + 1) & mask32;
+                        L.iq_ring[ib] = yb;
+                        L.fm_ring[ib] = fm_of(yb, yb0);
+                    }
                 }
-                if (va && ra == tr_.last) L.iq_ring[ia] = ya;
-                if (vb && ra + 1 == tr_.last) L.iq_ring[(ia + 1) & mask32] = yb;
-                continue;
             }
-            if (va && vb) {                                          // na is even and the ring a power of two: no wrap inside the pair
-                // (non-temporal: 256 taps 55.4 -> 53.1 us, 1600 taps 308 -> 302 us per 2^25-sample block)
-                { typedef float v4f_ __attribute__((ext_vector_type(4))); typedef float v2f_ __attribute__((ext_vector_type(2)));
-                  v4f_ a_; a_.x = ya.x; a_.y = ya.y; a_.z = yb.x; a_.w = yb.y;
-                  v2f_ b_; b_.x = fm_of(ya, ym); b_.y = fm_of(yb, yb0);
-                  __builtin_nontemporal_store(a_, reinterpret_cast<v4f_ *>(L.iq_ring + ia));
-                  __builtin_nontemporal_store(b_, reinterpret_cast<v2f_ *>(L.fm_ring + ia)); }
-            } else if (va) {
-                L.iq_ring[ia] = ya;
-                L.fm_ring[ia] = fm_of(ya, ym);
-            } else {
-                const uint32_t ib = (ia + 1) & mask32;
-                L.iq_ring[ib] = yb;
-                L.fm_ring[ib] = fm_of(yb, yb0);
-            }
+        };
+        const int t_lo = r0 - a, t_hi = r0 - a + kTapOut - 1;          // the tile's rows
+        const bool interior = t_lo > r_first && t_lo >= tr_.lo && t_hi <= tr_.hi && t_hi < tr_.last;
+        if (L.fm_only) {
+            if (interior) run(std::true_type{}, std::true_type{});
+            else          run(std::false_type{}, std::true_type{});
+        } else {
+            if (interior) run(std::true_type{}, std::false_type{});
+            else          run(std::false_type{}, std::false_type{});
         }
     }
 }
 
-__global__ __launch_bounds__(kThreads, 5) void tap_finalize_kernel(TapFinArgs A, uint64_t ring_mask,
+__global__ __launch_bounds__(kThreads, RCF_TAPFIN_WGS) void tap_finalize_kernel(TapFinArgs A, uint64_t ring_mask,
                                                                 const float *__restrict__ atan_tab)
 {
     __shared__ float tab[260];
@@ -679,7 +701,7 @@ __global__ __launch_bounds__(kThreads, 5) void tap_finalize_kernel(TapFinArgs A,
 }
 
 // the taps of G front-ends in one launch: grid.z = front-end, x / y sized for the largest of them
-__global__ __launch_bounds__(kThreads, 5) void tap_finalize_group_kernel(const TapFinArgs *__restrict__ args, uint64_t ring_mask,
+__global__ __launch_bounds__(kThreads, RCF_TAPFIN_WGS) void tap_finalize_group_kernel(const TapFinArgs *__restrict__ args, uint64_t ring_mask,
                                                                       const float *__restrict__ atan_tab)
 {
     __shared__ float tab[260];
