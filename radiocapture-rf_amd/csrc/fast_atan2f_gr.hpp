@@ -4,6 +4,9 @@
 // millions of arguments (tests/test_device_atan_cpu.py) -- the device code is written as SELECTS, not as those branches.
 #pragma once
 #include <math.h>
+#ifndef RCF_ATAN_PIN
+#define RCF_ATAN_PIN 0
+#endif
 #ifndef RCF_DEVFN
 #define RCF_DEVFN __device__ __forceinline__
 #endif
@@ -30,7 +33,10 @@ RCF_DEVFN float fast_atan2f_gr(float y, float x, const float *tab)
     float alpha = z * 255.0f;
     const int index = ((int)alpha) & 0xff;                // (the NaN z of the (0, 0) case converts to 0: a valid table position)
     alpha = alpha - (float)index;
-    const float t0 = tab[index], t1 = tab[index + 1];
+    float t0 = tab[index], t1 = tab[index + 1];
+#if defined(__HIP_DEVICE_COMPILE__) && RCF_ATAN_PIN
+    asm volatile("" : "+v"(t0), "+v"(t1));                // (keeps the two table loads out of a conditional block: tools A/B)
+#endif
     const float base = (z < TAN_MAP_RES) ? z : t0 + ((t1 - t0) * alpha);
     const bool xpos = x >= 0.0f, ypos = y >= 0.0f;
     const float r_x = xpos ? base : (PI - base);          // |x| > |y|
