@@ -28,8 +28,8 @@ def test_device_fast_atan2f_source_equals_oracle_bit_for_bit():
 
 
 def test_every_discriminator_kernel_uses_the_shared_header():
-    """No second copy of the function in the kernel sources: fir.hip / pfb.hip (through fir_small.hpp) and audio.hip all
-    include fast_atan2f_gr.hpp."""
+    """No second copy of the function in the kernel sources: fir.hip / pfb.hip (through fir_small.hpp), tapfin.hip and audio.hip
+    all include fast_atan2f_gr.hpp."""
     csrc = os.path.join(ROOT, "radiocapture-rf_amd", "csrc")
     defs = []
     for f in sorted(os.listdir(csrc)):
@@ -40,3 +40,4 @@ def test_every_discriminator_kernel_uses_the_shared_header():
     assert defs == ["fast_atan2f_gr.hpp"], defs
     assert '#include "fast_atan2f_gr.hpp"' in open(os.path.join(csrc, "fir_small.hpp")).read()
     assert '#include "fast_atan2f_gr.hpp"' in open(os.path.join(csrc, "audio.hip")).read()
+    assert '#include "fast_atan2f_gr.hpp"' in open(os.path.join(csrc, "tapfin.hip")).read()

@@ -2,7 +2,7 @@
 # kernel resource table of one .hip file:  tools/kres.sh pfb.hip [filter]   (name, VGPRs, spills, SGPRs, occupancy)
 cd "$(dirname "$0")/../radiocapture-rf_amd/csrc"
 F=${1:-pfb.hip}; PAT=${2:-.}
-EXTRA=""; case $F in pfb.hip|scan.hip) EXTRA="-fno-slp-vectorize";; pfb5.hip) EXTRA="-fno-slp-vectorize -ffp-contract=off";; fir.hip|peaks.hip|audio.hip) EXTRA="-ffp-contract=off";; esac
+EXTRA=""; case $F in pfb.hip|scan.hip) EXTRA="-fno-slp-vectorize";; pfb5.hip|tapfin.hip) EXTRA="-fno-slp-vectorize -ffp-contract=off";; fir.hip|peaks.hip|audio.hip) EXTRA="-ffp-contract=off";; esac
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form $EXTRA $KFLAGS -c $F -o /tmp/kres_$$.o \
   -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import sys,re,subprocess
