@@ -354,7 +354,7 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
     TS(3);
     // ---- taps first, copy-out last: bins that are open as channels are copied into the launch's compact tap matrix,
     // tap_mat[(frame - n_lo) tap_pitch + slot - tap_first] -- lanes = consecutive slots, so every wavefront store is 512 contiguous
-    // bytes of a row.  Rotators and the discriminator are tap_finalize_kernel's business (fir.hip).  The bin numbers
+    // bytes of a row.  Rotators and the discriminator are tap_finalize_kernel's business (tapfin.hip).  The bin numbers
     // are requested before the barrier.
     constexpr int TAP_IT = 5;                                // 5 x 320 slots cover all 1600 bins; 3200 bins loop
     // slots below tap_first are whole aligned runs of 16 bins: tap_finalize reads those from the ring this kernel

@@ -10,7 +10,7 @@
 //                              dual-written, the group's launch records host -> device        (ingest.hip)
 //   pfb_group_kernel_* / pfb5_group_kernel   the chunks of every member of one bank shape   (pfb.hip, pfb5.hip)
 //   fir_small_kernel / fir_bank_kernel       stage-2 channels of all members of one (D, T) class (records concatenated)
-//   tap_finalize_group_kernel  the tapped bins of every member                               (fir.hip)
+//   tap_finalize_group_kernel  the tapped bins of every member                               (tapfin.hip)
 //   disc / fm_fir / rot_fill   records concatenated
 //   gather_rings_kernel        the read: new output of any channels of any members -> pinned host memory, one launch
 // What is not concatenable (matrix-core banks with their per-handle tap slabs, voice chains, scans, banks that still see

@@ -299,7 +299,7 @@ struct PfbLaunch {
     // frame-major banks: bins that are open as channels (rcf_pfb_tap_open).  The kernel has every bin of the chunk in
     // LDS when it writes the frames out, so it also copies the tapped bins -- and only those -- into a compact
     // frame-major matrix of THIS launch's frames, tap_mat[(frame - n_lo) tap_pitch + slot - tap_first] (slot = position in
-    // tap_bins): whole rows of n_taps x 8 contiguous bytes, like the bins ring itself.  tap_finalize_kernel (fir.hip)
+    // tap_bins): whole rows of n_taps x 8 contiguous bytes, like the bins ring itself.  tap_finalize_kernel (tapfin.hip)
     // then transposes that matrix tile by tile through LDS into the channels' own rings, 128-byte lines, applying each
     // tap's rotator and the discriminator on the way.  (Round 2 stored a tap's F frames straight into its ring from
     // here: 32-byte pieces of lines a megabyte apart -- 0.18 -> 0.64 ms with all 1600 bins tapped; a ring TILED

@@ -1,5 +1,5 @@
 // rotator.hpp -- GNU Radio's rotator (phase *= incr in float32, renormalised every 512 calls) in closed form, shared
-// by the FIR bank kernels (fir.hip) and the filterbank taps (pfb5.hip).  Both files are compiled without implicit
+// by the FIR bank kernels (fir.hip) and the filterbank taps (tapfin.hip).  Both files are compiled without implicit
 // FMA contraction: rotate() is an unfused float32 complex multiply in GNU Radio.  The products and sums are written as plain
 // operators INSIDE bodies that switch contraction off (#pragma clang fp contract(off)): HIP's fmul_rn / fadd_rn intrinsics are
 // header functions of their own, compiled under the translation unit's default -- in a unit built with contraction (pfb.hip,
