@@ -179,8 +179,13 @@ def measured_block(R):
             if not s:
                 continue
             a = s.get("at_K_max") or {}
-            add("| **paced real time**, %s, 20 Msps u8 per front-end, %.0f ms blocks, %d native pump threads, ONE attempt per point | K_max_first_attempt = **%d** front-ends (%d bins, %d demodulated channels, %.0f Msamples/s), first K that missed: %s; the %.0f s confirmation run at K_max: latency p50 %.2f / p99 %.2f / max %.2f ms, %d misses, %d overruns, %.1f front-ends per group block, GPU busy %.0f %%, PCIe in %.1f GB/s | `%s_bench.json`: `realtime.%s` |"
+            add("| **paced real time**, %s, 20 Msps u8 per front-end, %.0f ms blocks, %d native pump threads, ONE attempt per point | K_max_first_attempt = **%d** front-ends%s (%d bins, %d demodulated channels, %.0f Msamples/s), first K that missed: %s; the %.0f s confirmation run at K_max: latency p50 %.2f / p99 %.2f / max %.2f ms, %d misses, %d overruns, %.1f front-ends per group block, GPU busy %.0f %%, PCIe in %.1f GB/s | `%s_bench.json`: `realtime.%s` |"
                 % (label, a.get("block_ms", 0), rt.get("pump_threads", 0), s.get("K_max_first_attempt", s.get("K_max", 0)),
+                   ("" if s.get("K_max_first_attempt", s.get("K_max")) == s.get("K_max") else
+                    "; its confirmation run MISSED (%s), **K_max = %d** confirmed, largest K with p99 < 5 ms in every run: %s" % (
+                        "; ".join("%d front-ends: %d misses, longest device wait %.1f ms" % (q["front_ends"], q.get("deadline_misses", 0), q.get("host_longest_device_wait_ms") or 0)
+                                  for q in (s.get("points") or []) if q.get("confirmation_run") and not q.get("ok")),
+                        s.get("K_max", 0), s.get("K_max_p99_under_5ms", "n/a"))),
                    s["channels_sustained"], s["fm_channels_sustained"], s["input_Msps_sustained"], s["first_K_that_missed"],
                    rt.get("seconds_of_the_confirmation_run_at_K_max", 0), a.get("latency_ms_p50") or 0, a.get("latency_ms_p99") or 0,
                    a.get("latency_ms_max") or 0, a.get("deadline_misses", 0), a.get("ring_overruns", 0),
