@@ -206,6 +206,22 @@ def pwr_squelch_cc(x: np.ndarray, db=-100.0, alpha=0.01, gate=True) -> np.ndarra
     return out
 
 
+def pwr_squelch_margin(x: np.ndarray, db=-100.0, alpha=0.01) -> float:
+    """min over the stream of |pwr / threshold - 1| for pwr_squelch_cc's power estimate: how well the gate's decisions are
+    conditioned.  Consecutive estimates differ by ~alpha while a carrier fades in or out, so a crossing lands within 1e-5 of
+    the threshold about once in a thousand crossings -- and then two channel streams that agree to 1e-7 (the device's and the
+    oracle's) may gate one sample apart (tests/test_gpu_fuzz.py, seed 78068)."""
+    thr = 10.0 ** (db / 10.0)
+    x = np.asarray(x, dtype=np.complex64)
+    re, im = x.real.astype(f32), x.imag.astype(f32)
+    p = (re * re + im * im).astype(f32)
+    pwr, best = 0.0, float("inf")
+    for i in range(len(x)):
+        pwr = alpha * float(p[i]) + (1.0 - alpha) * pwr
+        best = min(best, abs(pwr / thr - 1.0))
+    return best
+
+
 # ------------------------------------------------------------------ gr-filter fir_filter_fff / rational_resampler_base_fff
 def fir_filter_fff(x: np.ndarray, taps: np.ndarray) -> np.ndarray:
     """decimation 1, zero history; float64 accumulation rounded once (VOLK's summation order is unspecified)."""

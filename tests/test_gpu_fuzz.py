@@ -425,11 +425,20 @@ def test_random_voice_chain_cuts_and_silences(gpu_required, seed):
                 got.append(fe.chan_read_audio(cid))
         n_audio, n_ungated = fe.chan_audio_produced(cid)
         got.append(fe.chan_read_audio(cid))
+        y_dev = fe.chan_read_iq(cid)                        # the channel stream the device's squelch saw (the ring holds all of it)
     audio = np.concatenate(got)
     Dd, taps = G.channel_params(fs, cr)
     ct, incr = OC.xlating_composite(taps, Dd, f0, fs)
     y, _ = OC.channel_bank(x, Dd, ct[None, :], np.array([incr]), acc_double=True)
     st = A.analog_chain(y[0], 25000.0, stages=True)
+    if n_ungated != len(st["gated"]):
+        # The gate is a threshold on a power estimate: when a crossing lands within float32 accuracy of the threshold, the
+        # device's channel stream and the oracle's (equal to ~1e-7) may gate one sample apart (seed 78068: the estimate passes
+        # the threshold at 1e-6 of it).  Only then -- the oracle says how close it came -- the chain is checked on the
+        # samples the device's squelch saw; a gate that disagrees on a well-conditioned stream still fails here.
+        margin = A.pwr_squelch_margin(y[0])
+        assert margin < 1e-4 and len(y_dev) == len(y[0]), (seed, n_ungated, len(st["gated"]), margin)
+        st = A.analog_chain(y_dev, 25000.0, stages=True)
     assert n_ungated == len(st["gated"]), (seed, n_ungated, len(st["gated"]))
     assert len(audio) == n_audio == len(st["audio"]), (seed, len(audio), n_audio, len(st["audio"]))
     if len(audio):
