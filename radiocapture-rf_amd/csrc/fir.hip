@@ -18,7 +18,6 @@
 // isations), so outputs do not depend on how the stream is cut into blocks.
 #include <cstdlib>
 
-#include <type_traits>
 #include "rcf_internal.h"
 #include "rotator.hpp"
 #include "fir_small.hpp"

@@ -88,7 +88,7 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
     const float2 *__restrict__ bins_ring = A.bins_ring;
     const int tid = threadIdx.x;
     // grid: x = group of 16 taps (fastest), y = tile of rows -- workgroups dispatched together read neighbouring
-    // 128-byte pieces of the SAME matrix rows (whole rows between them), not one piece from each of 161 rows apart
+    // 128-byte pieces of the SAME matrix rows (whole rows between them), not one piece from each of 129 rows apart
     const int s0 = bx * kTapCols, r0 = by * kTapOut;
     for (int i = tid; i < 257; i += kThreads) tab[i] = atan_tab[i];
     {
@@ -99,12 +99,11 @@ __device__ __forceinline__ void tap_finalize_tile(const TapFinArgs &A, const int
             const bool idle = L.dangle == 0.0 && L.dlogmag == 0.0 && L.angle0 == 0.0 && L.logmag0 == 0.0;
             const int b0 = group_bin0[bx];                      // >= 0: this group's taps are 16 consecutive bins of the ring
             // all of a lane's rows are requested before the first is used (the loop below would otherwise pay one
-            // memory round trip per row: 11 in a row)
+            // memory round trip per row: nine in a row)
             constexpr int NIT = (kTapLdsRows + 15) / 16;
             float2 z[NIT];
             // the rows THIS tap's 128 outputs (and the output before them) come from: its tile starts a_own rows before r0
-            // (its ring index aligned to 32).  Rows outside are not requested: with the taps of a group opened together --
-            // one offset for all sixteen -- the 32 alignment rows are then never fetched (they were a quarter more traffic)
+            // (its ring index aligned to 32); the tap's LDS column starts there too, so exactly these 129 rows are staged
             const int a_own = (int)((uint64_t)(k_first - L.k_abs0 + r0) & (kTapAlign - 1));
             const int r_lds0 = r0 - a_own - 1;                  // matrix row of this tap's LDS row 0 (the output before the tile's first)
             // The per-row index arithmetic in 32 bits (the kernel is vector-issue bound and int64 compares / masks / multiplies
