@@ -1,0 +1,106 @@
+"""Untimed GPU legs: the scan path (fft_vector.py + fft_peak_detection.py) at BASELINE configs[2] and at the reference's own size."""
+import time
+
+import numpy as np
+
+from .common import HBM_PEAK_GBS, SCAN_CEILING_NOTE
+
+def scan_leg(native, synth, device):
+    """BASELINE configs[2]: 1M-point FFT, 1000 frames, 100-frame average (fft_vector.py:31-60) at 100 Msps from a
+    16-frame periodic resident buffer, then the device peak pick (fft_peak_detection.py:38-73)."""
+    N, F, L, fs = 1 << 20, 1000, 100, 100e6
+    rng = np.random.default_rng(3003)                # 12 carriers, bin centres >= 5000 bins apart
+    centres = [40000 + 80000 * i + int(rng.integers(-3000, 3000)) for i in range(12)]
+    carriers = [(c, float(rng.uniform(4000, 9000)), 45.0) for c in centres]
+    x = synth.scan_stream(fs, N, 16, carriers, seed=3003)
+    B = 16 * N
+    fe = native.Frontend(fs, 0.0, device=device, block_capacity=B, hist_capacity=N, out_capacity=1 << 10)
+    for _ in range(2):
+        fe.ingest_write(x, 0)
+        fe.commit(B)
+    fe.sync()
+    res = {}
+    for rep in range(4):                            # the last pass counts: buffers warm, launch times settled (~15 ms of work)
+        fe.timing_enable(True, classes=[native.T_SCAN_FFT, native.T_SCAN_MOVSUM])
+        fe.timing_read(native.T_SCAN_FFT)
+        fe.timing_read(native.T_SCAN_MOVSUM)
+        fe.scan_start(N, F, L)
+        t0 = time.perf_counter()
+        while fe.scan_frames_done() < F:
+            fe.commit(B)
+        fe.sync()
+        wall = time.perf_counter() - t0
+        fft_ms, _ = fe.timing_read(native.T_SCAN_FFT)
+        mov_ms, _ = fe.timing_read(native.T_SCAN_MOVSUM)
+        fe.timing_enable(False)
+        t0 = time.perf_counter()
+        idx, mean, _ = fe.scan_find_peaks(cap=1024)
+        pick_ms = (time.perf_counter() - t0) * 1e3
+        samples = float(N) * F
+        res = {
+            "workload": "BASELINE configs[2]: N=2^20, 1000 frames, 100-frame average, 100 Msps, 12 carriers",
+            "fft_logmag_ms": fft_ms, "moving_sum_ms": mov_ms, "peak_pick_ms_incl_readback": pick_ms,
+            "wall_ms": wall * 1e3, "peaks_found": int(len(idx)),
+            "input_Msamples_per_s": samples / ((fft_ms + mov_ms) * 1e-3) / 1e6,
+            "realtime_factor_at_100Msps": samples / fs / ((fft_ms + mov_ms) * 1e-3),
+            "roofline": {"bound": "hbm", "algorithmic_bytes": 12.0 * samples,
+                         "achieved": 12.0 * samples / ((fft_ms + mov_ms) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s",
+                         "frac": 12.0 * samples / ((fft_ms + mov_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "ceiling_note": SCAN_CEILING_NOTE},
+        }
+    fe.close()
+    return res
+
+
+def scan_ref_leg(native, synth, device):
+    """The scan at the size the reference runs it (fft_vector.py:31-60 as the scanner starts it): fs = 2.4 Msps,
+    N = 16384, 1000 frames, 100-frame average, then the peak pick (fft_peak_detection.py:38-73).  16384 points fit the
+    LDS: one pass (window + FFT + shift + |.|^2 + log10 -> frame-major ring), then the running sum.  125 periodic frames
+    resident (16 MB), eight commits per scan; SURVEY 8(d) cfg3's reference-sized variant (seed 3004, 5 carriers)."""
+    N, F, L, fs, U = 16384, 1000, 100, 2.4e6, 125
+    carriers = [(2000, 9000.0, 25.0), (5200, 12500.0, 30.0), (8192 + 900, 7000.0, 22.0), (11000, 20000.0, 28.0),
+                (15000, 12500.0, 26.0)]          # tests/test_gpu_parity.py: SCAN_CARRIERS_3004 -> lines 2004, 5195, 9089, 15000
+    x = synth.scan_stream(fs, N, U, carriers, seed=3004)
+    B = N * U
+    fe = native.Frontend(fs, 855.05e6, device=device, block_capacity=B, hist_capacity=1 << 16, out_capacity=1 << 10)
+    for _ in range(2):
+        fe.ingest_write(x, 0)
+        fe.commit(B)
+    fe.sync()
+    res = {}
+    for rep in range(6):                            # the last pass counts (launch times settled: ~15 ms of work)
+        fe.timing_enable(True, classes=[native.T_SCAN_FFT, native.T_SCAN_MOVSUM])
+        fe.timing_read(native.T_SCAN_FFT)
+        fe.timing_read(native.T_SCAN_MOVSUM)
+        fe.scan_start(N, F, L)
+        t0 = time.perf_counter()
+        while fe.scan_frames_done() < F:
+            fe.commit(B)
+        fe.sync()
+        wall = time.perf_counter() - t0
+        fft_ms, fft_n = fe.timing_read(native.T_SCAN_FFT)
+        mov_ms, mov_n = fe.timing_read(native.T_SCAN_MOVSUM)
+        fe.timing_enable(False)
+        t0 = time.perf_counter()
+        idx, mean, _ = fe.scan_find_peaks(cap=1024)
+        pick_ms = (time.perf_counter() - t0) * 1e3
+        samples = float(N) * F
+        k_ms = fft_ms + mov_ms
+        res = {
+            "workload": "the reference's own scan size: fs=2.4 Msps, N=16384, 1000 frames, 100-frame average, 5 carriers",
+            "fft_logmag_ms": fft_ms, "fft_launches": fft_n, "moving_sum_ms": mov_ms, "moving_sum_launches": mov_n,
+            "peak_pick_ms_incl_readback": pick_ms, "wall_ms": wall * 1e3,
+            "peak_indices": [int(i) for i in idx], "peaks_found": int(len(idx)),
+            "input_Msamples_per_s": samples / (k_ms * 1e-3) / 1e6,
+            "realtime_factor_at_2.4Msps": samples / fs / (k_ms * 1e-3),
+            "roofline": {"bound": "hbm", "kernel": "scan_fft_kernel<16384> + movsum_coop_kernel",
+                         "algorithmic_bytes": 12.0 * samples, "achieved": 12.0 * samples / (k_ms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 12.0 * samples / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_fft_pass_alone": 12.0 * samples / (fft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fft_ms > 0 else None,
+                         "note": "12 B/sample algorithmic (8 read + 4 of running sum streamed); real traffic 8 + 4 (FFT pass: "
+                                 "cf32 in, log-magnitude out) + 4 + 4 (running sum: ring in, sum out) = 20 B/sample; the 65 MB "
+                                 "of log-magnitudes of a scan stay in the 256 MB Infinity Cache between the two kernels"},
+        }
+    fe.close()
+    return res

@@ -48,6 +48,10 @@ const char *rcf_version(void);
 const char *rcf_last_error(void);
 /* number of visible HIP devices (0 when none / no driver); never fails */
 int rcf_device_count(void);
+/* PCI address of HIP device `device` ("0000:75:00.0") into out[cap]: what maps a HIP ordinal to its sysfs node
+ * (/sys/bus/pci/devices/<addr>/numa_node, local_cpulist) -- a box may show more cards in sysfs than HIP may use.
+ * RCF_EINVAL: no such device / cap too small. */
+int rcf_device_pci_bus_id(int device, char *out, size_t cap);
 
 /* ------------------------------------------------------------------ filter design (host) */
 /* gnuradio.filter.firdes.low_pass_2(gain, fs, fc, tw, att_dB, window) as called at

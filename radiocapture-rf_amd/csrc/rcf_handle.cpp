@@ -159,6 +159,14 @@ int rcf_device_count(void)
     return n;
 }
 
+int rcf_device_pci_bus_id(int device, char *out, size_t cap)
+{
+    if (!out || cap < 13 || device < 0 || device >= rcf_device_count()) { set_error("no such device / buffer too small"); return RCF_EINVAL; }
+    if (hipDeviceGetPCIBusId(out, (int)cap, device) != hipSuccess) { (void)hipGetLastError(); set_error("hipDeviceGetPCIBusId failed"); return RCF_EHIP; }
+    for (char *c = out; *c; ++c) *c = (char)tolower((unsigned char)*c);          // sysfs spells it in lower case
+    return RCF_OK;
+}
+
 int rcf_open(int device, double samp_rate, double center_freq, rcf_t **out)
 {
     return rcf_open_ex(device, samp_rate, center_freq, 0, 0, 0, out);

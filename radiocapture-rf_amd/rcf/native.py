@@ -24,7 +24,7 @@ SRC_PFB_BIN0 = 0x40000000
 
 # every symbol include/rcf.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "rcf_version", "rcf_last_error", "rcf_device_count", "rcf_design_low_pass_2", "rcf_design_window",
+    "rcf_version", "rcf_last_error", "rcf_device_count", "rcf_device_pci_bus_id", "rcf_design_low_pass_2", "rcf_design_window",
     "rcf_channel_params", "rcf_channel_params_ex", "rcf_set_decim_rule", "rcf_open", "rcf_open_ex", "rcf_close", "rcf_sync", "rcf_stream", "rcf_device",
     "rcf_push_iq", "rcf_ingest_ptr", "rcf_commit", "rcf_samples_in", "rcf_chan_open", "rcf_chan_open_taps",
     "rcf_chan_set_offset", "rcf_chan_close", "rcf_chan_info", "rcf_chan_produced", "rcf_chan_start", "rcf_chan_read_many", "rcf_chan_read_iq",
@@ -98,6 +98,7 @@ def lib():
         "rcf_version": (C.c_char_p, []),
         "rcf_last_error": (C.c_char_p, []),
         "rcf_device_count": (C.c_int, []),
+        "rcf_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
         "rcf_design_low_pass_2": (C.c_int, [C.c_double] * 5 + [C.c_int, fp, C.c_int]),
         "rcf_design_window": (C.c_int, [C.c_int, C.c_int, fp]),
         "rcf_channel_params": (C.c_int, [C.c_double, C.c_int, ip, ip]),
@@ -205,6 +206,12 @@ def _fp(a):
 
 def device_count() -> int:
     return lib().rcf_device_count()
+
+
+def device_pci_bus_id(device: int):
+    """'0000:75:00.0' of HIP device `device` (sysfs: /sys/bus/pci/devices/<that>/numa_node), None if unknown"""
+    buf = C.create_string_buffer(32)
+    return buf.value.decode() if lib().rcf_device_pci_bus_id(device, buf, 32) == 0 else None
 
 
 def design_low_pass_2(gain, fs, fc, tw, att_db, window=WIN_HAMMING) -> np.ndarray:
