@@ -61,3 +61,52 @@ def cgroup_cpu_stat():
     except Exception:
         pass
     return out.get("nr_throttled"), out.get("throttled_usec", out.get("throttled_time")), out.get("usage_usec"), quota
+
+
+def cpu_busy_sample(seconds=0.3):
+    """{cpu: busy fraction over `seconds`} of the CPUs this process may run on, from /proc/stat: EVERYONE's load on them (the
+    GPU boxes are shared; the container has a CPU quota but no CPUs of its own)"""
+    def snap():
+        out = {}
+        try:
+            for line in open("/proc/stat"):
+                if line.startswith("cpu") and line[3].isdigit():
+                    f = line.split()
+                    v = [int(x) for x in f[1:9]]
+                    out[int(f[0][3:])] = (v[3] + v[4], sum(v))
+        except Exception:
+            pass
+        return out
+    a = snap()
+    time.sleep(seconds)
+    b = snap()
+    busy = {}
+    for c in os.sched_getaffinity(0):
+        if c in a and c in b and b[c][1] > a[c][1]:
+            busy[c] = 1.0 - (b[c][0] - a[c][0]) / float(b[c][1] - a[c][1])
+    return busy
+
+
+def idlest_cpus(n, busy=None):
+    """n CPUs of the affinity mask for latency-critical threads: the least busy ones, at most one per physical core (a
+    sibling hardware thread that is busy is someone else's work on the same core).  [] when /proc/stat says nothing."""
+    busy = cpu_busy_sample() if busy is None else busy
+    if not busy:
+        return []
+    core_of = {}
+    for c in busy:
+        try:
+            core_of[c] = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+        except OSError:
+            core_of[c] = str(c)
+    load_of_core = {}
+    for c, b in busy.items():
+        load_of_core[core_of[c]] = load_of_core.get(core_of[c], 0.0) + b
+    picked, seen = [], set()
+    for c in sorted(busy, key=lambda c_: (load_of_core[core_of[c_]], busy[c_], c_)):
+        if core_of[c] not in seen:
+            seen.add(core_of[c])
+            picked.append(c)
+        if len(picked) == n:
+            break
+    return picked

@@ -55,7 +55,8 @@ def _realtime(rt):
         if isinstance(a, dict):
             e["at_K_max"] = pick(a, "seconds", "deadline_misses", "ring_overruns", "latency_ms_p50", "latency_ms_p99",
                                  "latency_ms_max", "gpu_busy_percent_est", "host_longest_device_wait_ms",
-                                 "host_longest_sleep_overshoot_ms", "pcie_GBps_in", "completion", "confirmation_run")
+                                 "host_longest_sleep_overshoot_ms", "pcie_GBps_in", "completion", "confirmation_run",
+                                 "pump_cpus", "why_late")
             cg = a.get("host_cgroup") or {}
             e["at_K_max"].update(pick(cg, "cpu_quota_cores", "throttled_ms", "cpu_cores_used_mean"))
         e["points"] = [[p.get("front_ends"), bool(p.get("ok")), p.get("deadline_misses"), p.get("latency_ms_p99")]

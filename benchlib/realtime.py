@@ -4,7 +4,7 @@ import time
 
 import numpy as np
 
-from .common import FS, NB, cgroup_cpu_stat, proto_taps
+from .common import FS, NB, cgroup_cpu_stat, cpu_busy_sample, idlest_cpus, proto_taps
 
 def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block_ms, n_pumps, stagger=True, window_ms=1.0):
     """K independent 20 Msps front-ends on ONE GPU (the reference's deployment shape: ten sources per host,
@@ -49,6 +49,12 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
     src_arr = src["array"]
     assert len(src_arr) >= 2 * blk * 2 * K
     t_classes = [native.T_PFB, native.T_FIR_DERIVED, native.T_TAPS, native.T_DISC]
+    # The pump threads FLOAT over the process's mask (the GPU's NUMA node).  Measured (profiles/r06_paced_leg_why_late.json):
+    # a pump pinned to one CPU -- even the idlest of the node -- wakes up to 12 ms late a few times per second, 99 % of that
+    # lateness run-queue delay (someone else's thread on that CPU; no SCHED_FIFO for this container), and misses deadlines
+    # at K = 384-768; floating pumps: four K = 768 runs without one wake-up > 2 ms late.  RCF_BENCH_RT_PIN=idle pins them.
+    busy = cpu_busy_sample()                               # (everyone's load on the allowed CPUs before the run: reported)
+    pump_cpus = idlest_cpus(NP, busy) if busy and os.environ.get("RCF_BENCH_RT_PIN", "none") == "idle" else []
     try:
         for j in range(NP):
             mine = list(range(j, K, NP))
@@ -68,7 +74,8 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
                                      what="fm", gain=1.0, phase_s=[(i / K) * period if stagger else 0.0 for i in mine],
                                      out_ring_samples=out_ring, n_blocks=n_blocks, warm_blocks=warm, start_delay_s=0.25,
                                      batch_window_s=window_ms * 1e-3, rt_priority=int(os.environ.get("RCF_BENCH_RT_PRIORITY", "10")),
-                                     spin_us=int(os.environ.get("RCF_BENCH_RT_SPIN_US", "0"))))   # (spinning the idle waits: measured WORSE -- 40 ms device stalls in both 10 s runs, none with sleeps)
+                                     spin_us=int(os.environ.get("RCF_BENCH_RT_SPIN_US", "0")),
+                                     cpu=pump_cpus[j] if j < len(pump_cpus) else -1))   # (spinning the idle waits: measured WORSE -- 40 ms device stalls in both 10 s runs, none with sleeps)
         t_end = time.perf_counter() + n_blocks * period + 0.25 + 10.0
         stats = []
         cg0 = cgroup_cpu_stat()
@@ -113,6 +120,18 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
         "host_longest_plan_ms": max(s_["max_plan_ms"] for s_ in stats), "host_longest_device_wait_ms": max(s_["max_wait_ms"] for s_ in stats),
         "host_longest_sleep_overshoot_ms": max(s_["max_sleep_overshoot_ms"] for s_ in stats),
         "pump_threads_sched_fifo": sum(s_["rt_priority_granted"] for s_ in stats),
+        "pump_cpus": [s_.get("cpu", -1) for s_ in stats],
+        "host_cpus": {"allowed": len(busy) or len(os.sched_getaffinity(0)),
+                      "mean_busy_before_the_run": (sum(busy.values()) / len(busy)) if busy else None,
+                      "over_50pct_busy_before_the_run": sum(1 for b_ in busy.values() if b_ > 0.5) if busy else None},
+        # why late (rcf_pump_stats_t): of the summed lateness of the slow device waits (> 5 ms) / late wake-ups (> 2 ms), how
+        # much the pump thread spent RUNNABLE WITHOUT A CPU (schedstat run_delay) -- that share is the host scheduler's
+        "why_late": {"slow_device_waits_ms": sum(s_.get("slow_wait_ms_total", 0.0) for s_ in stats),
+                     "of_it_on_a_run_queue_ms": sum(max(0.0, s_.get("runq_ms_in_slow_waits", 0.0)) for s_ in stats),
+                     "late_wakeups_ms": sum(s_.get("slow_sleep_ms_total", 0.0) for s_ in stats),
+                     "of_them_on_a_run_queue_ms": sum(max(0.0, s_.get("runq_ms_in_slow_sleeps", 0.0)) for s_ in stats),
+                     "run_queue_ms_total_worst_pump": max(s_.get("runq_ms_total", -1.0) for s_ in stats),
+                     "involuntary_switches": sum(s_.get("involuntary_switches", 0) for s_ in stats)},
         "slow_plans_waits_sleeps": [sum(s_[k_] for s_ in stats) for k_ in ("slow_plans", "slow_waits", "slow_sleeps")],
         "host_cgroup": {"cpu_quota_cores": cg1[3],
                         "throttled_periods": (cg1[0] - cg0[0]) if cg0 and cg0[0] is not None and cg1[0] is not None else None,
@@ -214,7 +233,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
         bins, demod = (NB, len(carriers)) if shape == "pfb256" else (1600, 256)
         keys = ("front_ends", "ok", "deadline_misses", "ring_overruns", "latency_ms_p50", "latency_ms_p99", "latency_ms_max",
                 "gpu_busy_percent_est", "front_ends_per_group_block_mean", "host_plan_fraction_busiest_pump", "host_longest_plan_ms",
-                "host_longest_device_wait_ms", "host_longest_sleep_overshoot_ms", "slow_plans_waits_sleeps", "host_cgroup", "pump_threads_sched_fifo", "errors",
+                "host_longest_device_wait_ms", "host_longest_sleep_overshoot_ms", "slow_plans_waits_sleeps", "host_cgroup", "pump_threads_sched_fifo", "pump_cpus", "host_cpus", "why_late", "errors",
                 "seconds", "confirmation_run")
         out[shape] = {
             "K_max": good or 0, "K_max_first_attempt": first_attempt, "first_K_that_missed": bad,

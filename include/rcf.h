@@ -293,6 +293,27 @@ int rcf_chan_rings(rcf_t *h, int chan_id, void **iq_ring, void **fm_ring, size_t
  * (rc_frontend/receiver.py:436-475); here the same Hz shift is added to every channel's offset. */
 int rcf_source_shift(rcf_t *h, double delta_hz);
 
+/* The discriminator of EVERY bin, computed by the filterbank's own kernel (frame-major banks: 400 / 800 / 1600 / 3200 bins
+ * at the reference's channel rule, rc_frontend/channel.py:31-35).  What analog.quadrature_demod_cf does behind each
+ * channel's pub_sink (p25_control_demod.py:120-121) happens before the channel ever leaves the GPU:
+ *     fm_k[n] = fast_atan2f(Im, Re of bin_k[n] conj(bin_k[n - 1]) x inc_k)          (gain 1; readers apply theirs)
+ * into a frame-major ring fm_ring[((n - n0) & (capacity - 1)) n_bins + k] -- the arithmetic (and the bits) of a tap opened
+ * with rcf_pfb_tap_open(bin, gr_phase) + rcf_chan_set_fm_only, without the tap matrix, the IQ round trip through HBM and
+ * the tap_finalize pass: 8 + 8 bytes per input sample instead of 48 at 1600 bins / decimation 800.
+ *   mode 1: beside the bins ring;  mode 2: INSTEAD of it (rcf_pfb_read_bin, rcf_pfb_chan_open and zero-copy readers of the
+ *   bins ring then see no new frames: RCF_ESTATE);  mode 0: off again.  Takes effect with the next block.
+ *   gr_phase != 0: inc_k = the float32 rotator increment GNU Radio's freq_xlating_fir_filter_ccc on bin k would carry
+ *   (what rcf_pfb_tap_open(bin, 1) models); 0: the bank's exact phases (inc_k = 1).  rcf_source_shift is followed.
+ * The first frame after enabling takes its predecessor from the input history (recomputed, not stored): the handle's
+ * history capacity must hold (chunk + taps-per-branch x oversampling + 2) x decim + n_bins samples (RCF_ECAP otherwise). */
+int rcf_pfb_fm_enable(rcf_t *h, int mode, int gr_phase);
+/* bin's discriminator samples not yet read by this call, x gain -> out; a reader more than the ring behind loses the oldest */
+int64_t rcf_pfb_read_fm(rcf_t *h, int bin, float gain, float *out, size_t max_samples);
+/* zero-copy: the device ring (floats), its capacity in frames and the relative index of its first valid frame; bin k of
+ * relative frame i sits at fm_ring[(i & (capacity - 1)) n_bins + k].  Order reads on rcf_stream(h) after rcf_sync / an event. */
+int rcf_pfb_fm_ring(rcf_t *h, void **fm_ring, size_t *capacity_frames, int64_t *first_frame);
+
+
 /* ------------------------------------------------------------------ polyphase filterbank */
 /*
  * n_bins-channel PFB with prototype `taps` and decimation `decim` (n_bins % decim == 0): bin k is
@@ -504,6 +525,15 @@ typedef struct rcf_pump_stats {
     int rt_priority_granted;             /* 1 when the SCHED_FIFO request of rt_priority went through */
     int running;                         /* 0 once the thread has finished */
     int error;                           /* RCF_E* that stopped it (0: none) */
+    /* WHY a wait or a wake-up was late (appended in round 6).  /proc/thread-self/schedstat's run_delay is the time the
+     * thread was RUNNABLE but had no CPU: lateness that is run_delay is the host scheduler (other tenants' threads on the
+     * CPUs this container may use -- it has a CFS quota, no CPUs of its own and no SCHED_FIFO), not the GPU or the link.
+     * -1: /proc not readable. */
+    int cpu;                             /* the CPU the thread is pinned to (-1: it floats over the process's mask) */
+    double runq_ms_total;                /* run_delay over the judged region */
+    double slow_wait_ms_total, runq_ms_in_slow_waits;    /* device waits > 5 ms: their summed length / the run_delay inside them */
+    double slow_sleep_ms_total, runq_ms_in_slow_sleeps;  /* wake-ups > 2 ms late: their summed lateness / the run_delay inside them */
+    int64_t involuntary_switches;        /* getrusage(RUSAGE_THREAD).ru_nivcsw over the judged region */
 } rcf_pump_stats_t;
 int rcf_pump_start(rcf_group_t *g, const rcf_pump_config_t *cfg, rcf_pump_t **out);
 int rcf_pump_stats(rcf_pump_t *p, rcf_pump_stats_t *st);

@@ -15,7 +15,10 @@ namespace rcfx {
 
 namespace {
 
-RCF_DEVFN float fast_atan2f_gr(float y, float x, const float *tab)
+// `lookup(index, t0, t1)` yields table[index] and table[index + 1], index in [0, 255]: a plain table (below) or wherever
+// a kernel keeps the pairs (pfb5.hip: the spare LDS slots of its frame rows)
+template <typename Lookup>
+RCF_DEVFN float fast_atan2f_gr_lut(float y, float x, Lookup lookup)
 {
 #pragma clang fp contract(off)
     // The same values as gr::fast_atan2f's nested branches, written as selects: left as branches the compiler emits a
@@ -33,7 +36,8 @@ RCF_DEVFN float fast_atan2f_gr(float y, float x, const float *tab)
     float alpha = z * 255.0f;
     const int index = ((int)alpha) & 0xff;                // (the NaN z of the (0, 0) case converts to 0: a valid table position)
     alpha = alpha - (float)index;
-    float t0 = tab[index], t1 = tab[index + 1];
+    float t0, t1;
+    lookup(index, t0, t1);
 #if defined(__HIP_DEVICE_COMPILE__) && RCF_ATAN_PIN
     asm volatile("" : "+v"(t0), "+v"(t1));                // (keeps the two table loads out of a conditional block: tools A/B)
 #endif
@@ -44,6 +48,11 @@ RCF_DEVFN float fast_atan2f_gr(float y, float x, const float *tab)
     const float r = (xa > ya) ? r_x : r_y;
     const float angle = ypos ? r : -r;
     return nonzero ? angle : 0.0f;
+}
+
+RCF_DEVFN float fast_atan2f_gr(float y, float x, const float *tab)
+{
+    return fast_atan2f_gr_lut(y, x, [tab](int index, float &t0, float &t1) { t0 = tab[index]; t1 = tab[index + 1]; });
 }
 
 }  // namespace

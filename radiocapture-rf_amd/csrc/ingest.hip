@@ -136,6 +136,20 @@ void launch_gather_rings(const GatherRec *d_recs, int n_recs, uint32_t *d_dst, u
     hipLaunchKernelGGL(gather_rings_kernel, dim3(std::min(items, cap)), dim3(256), 0, s, d_recs, d_dst, (uint32_t)n_recs, parts);
 }
 
+// one bin's discriminator samples out of a frame-major ring of floats (rcf_pfb_read_fm): dst[i] = gain * base[((first + i) & mask) stride]
+static __global__ void gather_f32_kernel(const float *__restrict__ base, uint64_t mask, int64_t stride, int64_t first, float gain,
+                                         float *__restrict__ dst, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = __fmul_rn(gain, base[((uint64_t)(first + (int64_t)i) & mask) * (uint64_t)stride]);
+}
+
+void launch_gather_f32(const float *base, uint64_t mask, int64_t stride, int64_t first, float gain, float *dst, size_t n, hipStream_t s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(gather_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, base, mask, stride, first, gain, dst, n);
+}
+
 void launch_gather_view(const StreamView &v, int64_t first, float2 *dst, size_t n, hipStream_t s)
 {
     if (n == 0) return;

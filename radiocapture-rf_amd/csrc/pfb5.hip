@@ -50,6 +50,8 @@
 #include "fft_core.hpp"
 #include <hip/hip_ext.h>
 #include "rcf_internal.h"
+#include "fast_atan2f_gr.hpp"
+#include "rotator.hpp"
 
 namespace rcfx {
 
@@ -89,9 +91,19 @@ __device__ __forceinline__ void wave_sync5()
     __builtin_amdgcn_wave_barrier();
 }
 
+// The discriminator fused into the bank (PfbLaunch::fm_ring): FM = 0 the bank as it always was;
+// FM_BOTH the frame-major discriminator ring fm_ring[(n & mask) NB + k] beside the bins ring; FM_ONLY the discriminator
+// ring INSTEAD of the bins ring (8 + 8 bytes per input sample at OS = 2 instead of 8 + 16, and no tap_finalize pass behind
+// it: 48 -> 16 bytes per sample for "every channel.py channel demodulated"); FM_HALO = the pass a workgroup runs on the
+// chunk BEFORE its span: nothing is stored, the chunk's last frame stays in the threads' registers (zprev) as the
+// predecessor of the span's first discriminator sample.
+enum { FM_OFF = 0, FM_BOTH = 1, FM_ONLY = 2, FM_HALO = 3 };
+constexpr int pfb5_bins_per_thread(int NB) { return (NB + kThreads5 - 1) / kThreads5; }
+
 // one chunk of one front-end's bank (shared by the single-front-end kernel and the grouped one: same instructions, same bits)
-template <int R, int R3, int OS, int P, bool ZH>
-__device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, const int tid, cf *buf)
+template <int R, int R3, int OS, int P, bool ZH, int FM = FM_OFF>
+__device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, const int tid, cf *buf, cf *zprev = nullptr,
+                                           const cf *finc = nullptr, const cf tabpair = cf{0.f, 0.f})
 {
     constexpr int NB = R * R * R3;
     constexpr int N2 = R * R;                  // W_{N2}^n = e^{+2 pi i n / (R R)} = tw[n R3]
@@ -284,6 +296,16 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
         cf *o = buf + frame * RS + j * (R + 1);              // pad5(j R + f) = j (R + 1) + f for f < R
 #pragma unroll
         for (int f = 0; f < R; ++f) o[f] = vv[Dft<R, +1>::reg_of(f)];
+        if constexpr (FM == FM_BOTH || FM == FM_ONLY) {
+            // gr::fast_atan2f's table for the copy-out's discriminator.  The LDS budget has no 1 KB left (53 728 of the 53 760
+            // bytes three workgroups per CU allow), but the frame rows have a spare complex after every R: entry e of the table,
+            // as the PAIR (tab[e], tab[e + 1]) one lookup needs, sits in spare slot e -- PADS = NB / R - 1 slots per row.  The
+            // window DMA of every chunk runs over them, so thread e (which keeps its pair in two registers for the whole
+            // span) puts it back here, once the window has been read and together with the first pass's own writes.
+            constexpr int PADS = NB / R - 1;
+            static_assert(PADS * F >= 256, "the rows' spare slots hold the 256 table pairs");
+            if (tid < 256) buf[(tid / PADS) * RS + (tid % PADS) * (R + 1) + R] = tabpair;
+        }
     }
     TS(1);
     __syncthreads();
@@ -352,6 +374,18 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
         }
     }
     TS(3);
+    if constexpr (FM == FM_HALO) {
+        // the chunk before the span: its last frame, bin tid + 320 bb in zprev[bb], is all that is wanted of it
+        __syncthreads();
+        constexpr int NBT = pfb5_bins_per_thread(NB);
+        const cf *row = buf + (F - 1) * RS;
+#pragma unroll
+        for (int bb = 0; bb < NBT; ++bb) {
+            const int bin = tid + bb * kThreads5;
+            zprev[bb] = (NB % kThreads5 == 0 || bin < NB) ? row[pad5<R>(bin)] : make_float2(0.f, 0.f);
+        }
+        return;
+    }
     // ---- taps first, copy-out last: bins that are open as channels are copied into the launch's compact tap matrix,
     // tap_mat[(frame - n_lo) tap_pitch + slot - tap_first] -- lanes = consecutive slots, so every wavefront store is 512 contiguous
     // bytes of a row.  Rotators and the discriminator are tap_finalize_kernel's business (tapfin.hip).  The bin numbers
@@ -386,6 +420,58 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
     }
 
     TS(5);
+    if constexpr (FM == FM_BOTH || FM == FM_ONLY) {
+        // ---- copy-out with the discriminator fused in: frame f of bin k leaves as fm_ring[((n0 + f) & mask) NB + k] =
+        // fast_atan2f(bin[n] conj(bin[n - 1]) x inc_k) -- tap_finalize's discriminator-only arithmetic (tapfin.hip: the
+        // discriminator of the ROTATED stream is the bare product turned by the rotator's one increment), the same bits.
+        // Lanes = consecutive bins: every wavefront store is 256 contiguous bytes of a frame row.  A thread walks ITS bins
+        // down the frames, so the predecessor is a register; across chunks it is zprev.
+        constexpr int NBT = pfb5_bins_per_thread(NB);
+        constexpr int PADS = NB / R - 1;
+        auto lookup = [&](int e, float &t0, float &t1) {
+            const cf pr = buf[(e / PADS) * RS + (e % PADS) * (R + 1) + R];
+            t0 = pr.x; t1 = pr.y;
+        };
+        __amdgpu_buffer_rsrc_t fm_rsrc[F], iq_rsrc[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int64_t slot = (int64_t)((uint64_t)(n0 + f - p.n_abs0) & p.ring_mask);
+            fm_rsrc[f] = __builtin_amdgcn_make_buffer_rsrc(p.fm_ring + slot * NB, 0, NB * (int)sizeof(float), 0x00020000);
+            if constexpr (FM == FM_BOTH)
+                iq_rsrc[f] = __builtin_amdgcn_make_buffer_rsrc(p.bins_ring + slot * NB, 0, NB * (int)sizeof(cf), 0x00020000);
+        }
+#pragma unroll
+        for (int bb = 0; bb < NBT; ++bb) {
+            const int bin = tid + bb * kThreads5;
+            if (NB % kThreads5 != 0 && bin >= NB) break;
+            cf prev = zprev[bb];
+            const cf inc = finc[bb];
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                if (f >= nf) break;
+                const cf z = buf[f * RS + pad5<R>(bin)];
+                // volk_32fc_x2_multiply_conjugate_32fc (unfused), then the turn by the rotator's increment
+                const float tr = __fadd_rn(__fmul_rn(z.x, prev.x), __fmul_rn(z.y, prev.y));
+                const float ti = __fsub_rn(__fmul_rn(z.y, prev.x), __fmul_rn(z.x, prev.y));
+                const float ur = __fsub_rn(__fmul_rn(tr, inc.x), __fmul_rn(ti, inc.y));
+                const float ui = __fadd_rn(__fmul_rn(tr, inc.y), __fmul_rn(ti, inc.x));
+                const float fm = fast_atan2f_gr_lut(ui, ur, lookup);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fm), fm_rsrc[f], bin * (int)sizeof(float), 0, RCF_P5_STORE_AUX);
+                if constexpr (FM == FM_BOTH) {
+                    u32x2 o;
+                    o.x = __float_as_uint(z.x);
+                    o.y = __float_as_uint(z.y);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, iq_rsrc[f], bin * (int)sizeof(cf), 0, RCF_P5_STORE_AUX);
+                }
+                prev = z;
+            }
+            zprev[bb] = prev;
+            // (one bin's frames at a time: left to itself the scheduler interleaves all NBT x F discriminators -- every
+            // LDS load hoisted to the top, 168 VGPRs and 40 of them spilled)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
     // ---- copy-out: whole frames, bins consecutive across lanes -- every wavefront store is 512 contiguous bytes of
     // the frame-major ring bins_ring[(n & mask) NB + k]
 #pragma unroll
@@ -439,6 +525,47 @@ __global__ __launch_bounds__(kThreads5, 3) void pfb5_kernel(PfbLaunch p, int n_w
     pfb5_chunk<R, R3, OS, P, ZH>(p, wg, threadIdx.x, buf);
 }
 
+// The bank with the discriminator fused in: a workgroup walks `span` consecutive chunks.  It first runs the chunk BEFORE its
+// span without storing anything (the halo: one chunk of arithmetic per span, 1 / span of overhead) -- the span's first
+// discriminator sample needs the frame before it, and no other workgroup's output can be waited for inside a launch.
+template <int R, int R3, int OS, int P, bool ZH, int FM>
+__device__ __forceinline__ void pfb5_fm_span(const PfbLaunch &p, const int wg, const int tid, cf *buf)
+{
+    constexpr int NB = R * R * R3, F = 16 / R3, NBT = pfb5_bins_per_thread(NB);
+    const int n_chunks = (p.n_frames + F - 1) / F;
+    const int c0 = wg * p.fm_span, c1 = min(c0 + p.fm_span, n_chunks);
+    if (c0 >= n_chunks) return;
+    cf zprev[NBT], finc[NBT];
+#pragma unroll
+    for (int bb = 0; bb < NBT; ++bb) {
+        const int bin = tid + bb * kThreads5;
+        finc[bb] = (NB % kThreads5 == 0 || bin < NB) ? p.fm_inc[bin] : make_float2(1.f, 0.f);
+    }
+    const cf tabpair = tid < 256 ? make_float2(p.atan_tab[tid], p.atan_tab[tid + 1]) : make_float2(0.f, 0.f);
+#ifndef RCF_X_NOHALO
+    pfb5_chunk<R, R3, OS, P, ZH, FM_HALO>(p, c0 - 1, tid, buf, zprev);
+#else
+    for (int bb = 0; bb < NBT; ++bb) zprev[bb] = make_float2(0.f, 0.f);
+#endif
+    for (int c = c0; c < c1; ++c) {
+        // (nothing may be carried from chunk to chunk but zprev / finc / tabpair: hoisted out of this loop, the prototype rows
+        // and twiddle seeds of a chunk -- loop invariant -- cost 60 more registers, spills and the third workgroup per CU)
+        asm volatile("" ::: "memory");
+        __syncthreads();                                   // the chunk before has been read out of LDS
+        pfb5_chunk<R, R3, OS, P, ZH, FM>(p, c, tid, buf, zprev, finc, tabpair);
+    }
+}
+
+template <int R, int R3, int OS, int P, bool ZH, int FM>
+__global__ __launch_bounds__(kThreads5, 3) __attribute__((amdgpu_waves_per_eu(4, 4))) void pfb5_fm_kernel(PfbLaunch p, int n_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+    const int b = blockIdx.x, q8 = n_wg / 8, r8 = n_wg % 8, xcd = b % 8;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    pfb5_fm_span<R, R3, OS, P, ZH, FM>(p, wg, threadIdx.x, buf);
+}
+
 // The banks of G front-ends in ONE launch (rcf_group.cpp; see pfb_group_kernel_os in pfb.hip): steady state only
 template <int R, int R3, int OS, int P>
 __global__ __launch_bounds__(kThreads5, 3) void pfb5_group_kernel(const PfbLaunch *__restrict__ pls, GroupMap gm)
@@ -459,6 +586,47 @@ void launch5_group(const PfbLaunch *d_pls, const GroupMap &gm, hipStream_t s)
     static DynLdsAttr attr;
     attr.ensure(reinterpret_cast<const void *>(pfb5_group_kernel<R, R3, OS, P>), lds);
     hipLaunchKernelGGL((pfb5_group_kernel<R, R3, OS, P>), dim3(gm.total_wg), dim3(kThreads5), lds, s, d_pls, gm);
+}
+
+// chunks per workgroup of the fused-discriminator kernel: the span that wastes least -- 1 / (span + 1) of a workgroup's
+// arithmetic is the halo chunk, and the last round of workgroups over the chip's slots (256 CUs x 3) should be full
+int pfb5_fm_span_for(int n_chunks)
+{
+    static const int forced = [] { const char *e = getenv("RCF_PFB5_FM_SPAN"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced;
+    constexpr int kSlots = 256 * 3;
+    int best = 1;
+    double best_score = 0.0;
+    for (int span = 1; span <= 16; ++span) {
+        const int n_wg = (n_chunks + span - 1) / span;
+        const int rounds = (n_wg + kSlots - 1) / kSlots;
+        const double fill = n_wg >= kSlots ? (double)n_wg / ((double)rounds * kSlots) : 1.0;   // (a launch below one round: latency)
+        const double score = fill * span / (span + 1.0) * (n_wg >= kSlots || span == 1 ? 1.0 : (double)n_wg * span / n_chunks);
+        if (score > best_score + 1e-9) { best_score = score; best = span; }
+    }
+    return best;
+}
+
+template <int R, int R3, int OS, int P>
+void launch5_fm(const PfbLaunch &p0, hipStream_t s)
+{
+    constexpr int NB = R * R * R3, F = 16 / R3;
+    PfbLaunch p = p0;
+    const int n_chunks = (p.n_frames + F - 1) / F;
+    if (p.fm_span <= 0) p.fm_span = pfb5_fm_span_for(n_chunks);
+    const int n_wg = (n_chunks + p.fm_span - 1) / p.fm_span;
+    const size_t lds = (size_t)pfb5_buf(NB, R, F, OS, P) * sizeof(cf);
+    // zero history also when the HALO chunk before the launch's first frame reaches before the stream's start
+    const bool zh = (p.n_lo - F - (int64_t)OS * (P - 1)) * (NB / OS) - (NB - 1) < p.start_sample;
+#define RCF_FM_GO(ZH_, FM_)                                                                                       \
+    do {                                                                                                           \
+        static DynLdsAttr attr;                                                                                    \
+        attr.ensure(reinterpret_cast<const void *>(pfb5_fm_kernel<R, R3, OS, P, ZH_, FM_>), lds);                  \
+        RCF_PFB_LAUNCH(p, (pfb5_fm_kernel<R, R3, OS, P, ZH_, FM_>), dim3(n_wg), dim3(kThreads5), lds, s, p, n_wg); \
+    } while (0)
+    if (p.fm_mode == FM_ONLY) { if (zh) RCF_FM_GO(true, FM_ONLY); else RCF_FM_GO(false, FM_ONLY); }
+    else                      { if (zh) RCF_FM_GO(true, FM_BOTH); else RCF_FM_GO(false, FM_BOTH); }
+#undef RCF_FM_GO
 }
 
 template <int R, int R3, int OS, int P>
@@ -490,6 +658,17 @@ bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s)
         if (!probe) launch5<R_, R3_, OS_, P_>(p, s);                 \
         return true;                                                 \
     }
+    if (p.fm_ring) {
+        // the discriminator fused in: the shapes the reference's channel rule produces (OS = 2: 12.5 kHz raster, OS = 4: 6.25 kHz)
+#define RCF_PFB5F(R_, R3_, OS_, P_)                                 \
+        if (p.NB == R_ * R_ * R3_ && OS == OS_ && PR == P_) {        \
+            if (!probe) launch5_fm<R_, R3_, OS_, P_>(p, s);          \
+            return true;                                             \
+        }
+        RCF_PFB5F(20, 4, 2, 2) RCF_PFB5F(20, 8, 4, 1) RCF_PFB5F(20, 2, 2, 2) RCF_PFB5F(20, 1, 2, 2)
+#undef RCF_PFB5F
+        return false;
+    }
     RCF_PFB5(20, 4, 2, 2) RCF_PFB5(20, 4, 2, 1) RCF_PFB5(20, 4, 1, 4) RCF_PFB5(20, 4, 4, 1)      // 1600 bins
     RCF_PFB5(20, 8, 4, 1) RCF_PFB5(20, 8, 2, 2) RCF_PFB5(20, 8, 2, 1) RCF_PFB5(20, 8, 1, 4)      // 3200 bins
     RCF_PFB5(20, 2, 2, 2) RCF_PFB5(20, 2, 2, 1) RCF_PFB5(20, 2, 1, 4) RCF_PFB5(20, 2, 4, 1)      // 800 bins
@@ -501,6 +680,7 @@ bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s)
 bool pfb5_dispatch_group(const PfbLaunch &p, const PfbLaunch *d_pls, const GroupMap &gm, hipStream_t s)
 {
     if (p.D <= 0 || p.NB % p.D) return false;
+    if (p.fm_ring) return false;                         // the fused-discriminator banks of a group run one by one
     const int OS = p.NB / p.D;
     const int PR = pfb5_padded_p(p.NB, p.D, p.P);
     if (PR == 0) return false;
@@ -513,6 +693,42 @@ bool pfb5_dispatch_group(const PfbLaunch &p, const PfbLaunch *d_pls, const Group
     RCF_PFB5G(20, 4, 2, 2) RCF_PFB5G(20, 8, 4, 1) RCF_PFB5G(20, 8, 2, 2) RCF_PFB5G(20, 2, 2, 2) RCF_PFB5G(20, 1, 2, 2)
 #undef RCF_PFB5G
     return false;
+}
+
+bool pfb5_fm_supported(int NB, int D, int P)
+{
+    PfbLaunch p{};
+    p.NB = NB; p.D = D; p.P = P;
+    p.fm_ring = reinterpret_cast<float *>(0x1);          // (never dereferenced: probe)
+    return pfb5_dispatch(p, true, nullptr);
+}
+
+// samples of input history the halo chunk of a launch's first workgroup reaches back over: F + OS (P - 1) + 1 frames and
+// the prototype's span
+size_t pfb5_fm_history(int NB, int D, int P)
+{
+    const int R3 = NB / 400, F = 16 / (R3 > 0 ? R3 : 1), OS = NB / D;
+    return (size_t)(F + OS * (pfb5_padded_p(NB, D, P) - 1) + 2) * (size_t)D + (size_t)NB;
+}
+
+namespace {
+__global__ void pfb5_fm_inc_kernel(const double *__restrict__ dangle, float2 *__restrict__ inc, int NB)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= NB) return;
+    float2 v = make_float2(1.f, 0.f);
+    if (dangle[k] != 0.0) {                                // (tapfin.hip: TapInfo::inc_r / inc_i, the same expression)
+        double sn, cs;
+        sincos_fast(dangle[k], sn, cs);
+        v = make_float2((float)cs, (float)sn);
+    }
+    inc[k] = v;
+}
+}  // namespace
+
+void launch_pfb5_fm_inc(const double *d_dangle, float2 *d_inc, int NB, hipStream_t s)
+{
+    hipLaunchKernelGGL(pfb5_fm_inc_kernel, dim3((NB + 255) / 256), dim3(256), 0, s, d_dangle, d_inc, NB);
 }
 
 // rows of the polyphase table the instantiation for (NB / D, P) reads (zero padded by rcf_pfb_open); 0: no kernel.

@@ -3,6 +3,38 @@
 
 namespace rcfx {
 
+// The rotator increment's angle a discriminator-only channel on bin k of the bank carries (Chan::dangle of a tap opened
+// with rcf_pfb_tap_open(bin, gr_phase): rcf_chan.cpp) -- for every bin at once, uploaded and turned into float32 phasors
+// on the device (launch_pfb5_fm_inc: tap_finalize's own expression)
+int pfb_fm_upload_increments(rcf_t *h)
+{
+    Pfb &p = h->pfb;
+    std::vector<double> dangle((size_t)p.NB, 0.0);
+    // what rcf_source_shift adds to every bin-fed channel's NCO (upload_composite: a D = 1, T = 1 channel at the bin rate)
+    double shift_angle = 0.0;
+    if (h->shift_hz != 0.0) {
+        const float one = 1.0f;
+        std::vector<float> ct;
+        float incr[2];
+        design_composite(&one, 1, 1, h->shift_hz, h->fs / p.D, ct, incr);
+        shift_angle = std::atan2((double)incr[1], (double)incr[0]);
+    }
+    for (int bin = 0; bin < p.NB; ++bin) {
+        double d = shift_angle;
+        if (p.fm_gr_phase) d += pfb_tap_gr_dangle(h, bin);
+        dangle[(size_t)bin] = d;
+    }
+    double *d_dangle = nullptr;
+    RCF_HIP(hipMalloc(&d_dangle, sizeof(double) * dangle.size()));
+    if (!hip_ok(hipMemcpyAsync(d_dangle, dangle.data(), sizeof(double) * dangle.size(), hipMemcpyHostToDevice, h->stream), "hipMemcpy(fm increments)")) {
+        (void)hipFree(d_dangle);
+        return RCF_EHIP;
+    }
+    launch_pfb5_fm_inc(d_dangle, p.d_fm_inc, p.NB, h->stream);
+    RCF_HIP(hipStreamSynchronize(h->stream));          // (dangle is a local vector; the stream also orders the table before the next block)
+    (void)hipFree(d_dangle);
+    return RCF_OK;
+}
 
 }  // namespace rcfx
 
@@ -73,6 +105,7 @@ int rcf_pfb_close(rcf_t *h)
         else ++it;
     }
     bury(h, p.d_ptaps); bury(h, p.d_tw); bury(h, p.d_bins); bury(h, p.d_stage);
+    bury(h, p.d_fm); bury(h, p.d_fm_inc); bury(h, p.d_fm_stage);
     p = Pfb();
     ++h->chans_epoch;
     return RCF_OK;
@@ -109,6 +142,7 @@ int64_t rcf_pfb_read_bin(rcf_t *h, int bin, float *out, size_t max_samples)
     if (set_dev(h)) return RCF_EHIP;
     Pfb &p = h->pfb;
     if (!p.open || bin < 0 || bin >= p.NB) { set_error("no such PFB bin %d", bin); return RCF_EINVAL; }
+    if (p.fm_mode == 2) { set_error("the bank writes its discriminator ring only (rcf_pfb_fm_enable mode 2): no bins to read"); return RCF_ESTATE; }
     // one bin out of the bank's ring (tiled or frame-major): gather its unread samples into a contiguous staging buffer
     int64_t avail = p.produced - p.rd[bin];
     if (avail <= 0 || max_samples == 0) return 0;
@@ -123,6 +157,68 @@ int64_t rcf_pfb_read_bin(rcf_t *h, int bin, float *out, size_t max_samples)
     free_graveyard_idle(h);
     p.rd[bin] += n;
     return n;
+}
+
+int rcf_pfb_fm_enable(rcf_t *h, int mode, int gr_phase)
+{
+    if (!h || mode < 0 || mode > 2) { set_error("bad fm mode"); return RCF_EINVAL; }
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    Pfb &p = h->pfb;
+    if (!p.open) { set_error("no filterbank open"); return RCF_ESTATE; }
+    if (mode == 0) { p.fm_mode = 0; return RCF_OK; }
+    if (!p.frame_major || !pfb5_fm_supported(p.NB, p.D, p.P)) {
+        set_error("no fused-discriminator kernel for bins=%d decim=%d taps/branch=%d", p.NB, p.D, p.P);
+        return RCF_EINVAL;
+    }
+    const size_t need = pfb5_fm_history(p.NB, p.D, p.P);
+    if (need > h->hist_cap) { set_error("history capacity %zu < %zu (the fused discriminator's halo chunk)", h->hist_cap, need); return RCF_ECAP; }
+    if (!p.d_fm) {
+        const size_t ring = (size_t)p.NB * h->out_cap;
+        RCF_HIP(hipMalloc(&p.d_fm, sizeof(float) * ring));
+        RCF_HIP(hipMemsetAsync(p.d_fm, 0, sizeof(float) * ring, h->stream));
+        RCF_HIP(hipMalloc(&p.d_fm_inc, sizeof(float2) * (size_t)p.NB));
+        p.rd_fm.assign((size_t)p.NB, p.produced);
+        p.fm_from = p.produced;
+    } else if (p.fm_mode == 0) {                       // switched on again: the frames in between were not demodulated
+        p.fm_from = p.produced;
+        for (auto &r : p.rd_fm) r = std::max(r, p.produced);
+    }
+    p.fm_gr_phase = gr_phase ? 1 : 0;
+    const int rc = pfb_fm_upload_increments(h);
+    if (rc != RCF_OK) return rc;
+    p.fm_mode = mode;
+    return RCF_OK;
+}
+
+int64_t rcf_pfb_read_fm(rcf_t *h, int bin, float gain, float *out, size_t max_samples)
+{
+    if (!h || !out) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    Pfb &p = h->pfb;
+    if (!p.open || !p.d_fm || bin < 0 || bin >= p.NB) { set_error("no discriminator ring / no such bin %d", bin); return RCF_EINVAL; }
+    int64_t &rd = p.rd_fm[(size_t)bin];
+    int64_t avail = p.produced - rd;
+    if (avail <= 0 || max_samples == 0) return 0;
+    if ((size_t)avail > h->out_cap) { rd = p.produced - (int64_t)h->out_cap; avail = (int64_t)h->out_cap; }
+    const int64_t n = std::min<int64_t>(avail, (int64_t)max_samples);
+    if (!p.d_fm_stage) RCF_HIP(hipMalloc(&p.d_fm_stage, sizeof(float) * h->out_cap));
+    launch_gather_f32(p.d_fm + bin, h->ring_mask, p.NB, rd, gain, p.d_fm_stage, (size_t)n, h->stream);
+    RCF_HIP(hipMemcpyAsync(out, p.d_fm_stage, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    RCF_HIP(hipStreamSynchronize(h->stream));
+    free_graveyard_idle(h);
+    rd += n;
+    return n;
+}
+
+int rcf_pfb_fm_ring(rcf_t *h, void **fm_ring, size_t *capacity_frames, int64_t *first_frame)
+{
+    if (!h || !h->pfb.open || !h->pfb.d_fm) return RCF_ESTATE;
+    if (fm_ring) *fm_ring = h->pfb.d_fm;
+    if (capacity_frames) *capacity_frames = h->out_cap;
+    if (first_frame) *first_frame = h->pfb.fm_from;
+    return RCF_OK;
 }
 
 int rcf_pfb_rings(rcf_t *h, void **bins_ring, size_t *capacity, size_t *pitch)

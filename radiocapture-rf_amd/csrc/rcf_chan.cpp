@@ -36,6 +36,23 @@ bool source_range(rcf_t *h, int src, int64_t S0, int64_t S1, SrcRange *out)
     return false;   // channel-sourced: resolved by the caller (needs per-commit bookkeeping)
 }
 
+// What GNU Radio's freq_xlating_fir_filter_ccc(D, h, f_k, fs) on bin k's frequency would have done differently from the
+// bank's exact phases, per output: its rotator advances by a = float32(-float32(2 pi f_k / fs) * D) instead of
+// -2 pi k D / NB.  The difference, folded into (-pi, pi]: a tap's Chan::extra_dangle.
+double pfb_tap_gr_dangle(const rcf_t *h, int bin)
+{
+    const Pfb &p = h->pfb;
+    const int ks = bin < p.NB / 2 ? bin : bin - p.NB;
+    const double f_k = (double)ks * h->fs / p.NB;
+    const float fwT0 = (float)(kTwoPi * f_k / h->fs);
+    const float a = -fwT0 * (float)p.D;
+    const long double exact = -2.0L * 3.14159265358979323846264338327950288L *
+                              (long double)(((int64_t)ks * p.D) % p.NB) / (long double)p.NB;
+    long double d = (long double)a - exact;
+    d = remainderl(d, 2.0L * 3.14159265358979323846264338327950288L);
+    return (double)d;
+}
+
 int upload_composite(rcf_t *h, Chan *c)
 {
     std::vector<float> ct;
@@ -247,11 +264,7 @@ int rcf_pfb_tap_open(rcf_t *h, int bin, int gr_phase, int *chan_id)
         const double f_k = (double)ks * h->fs / p.NB;
         const float fwT0 = (float)(kTwoPi * f_k / h->fs);
         const float a = -fwT0 * (float)p.D;
-        const long double exact = -2.0L * 3.14159265358979323846264338327950288L *
-                                  (long double)(((int64_t)ks * p.D) % p.NB) / (long double)p.NB;
-        long double d = (long double)a - exact;
-        d = remainderl(d, 2.0L * 3.14159265358979323846264338327950288L);
-        c->extra_dangle = (double)d;
+        c->extra_dangle = pfb_tap_gr_dangle(h, bin);
         c->extra_dlogmag = std::log(std::hypot((double)std::cos(a), (double)std::sin(a)));
         // ... and GNU Radio's float32 tap phases float32(i * fwT0) differ from the bank's 2 pi k i / NB by a constant
         // (their filter-weighted mean, up to ~3e-4 rad) plus rounding noise (rcf_pfb_tap_leakage): the constant is a
@@ -659,6 +672,7 @@ int rcf_source_shift(rcf_t *h, double delta_hz)
             int rc = upload_composite(h, kv.second.get());
             if (rc != RCF_OK) return rc;
         }
+    if (h->pfb.open && h->pfb.d_fm_inc) return pfb_fm_upload_increments(h);     // the bank's own discriminator follows too
     return RCF_OK;
 }
 

@@ -117,7 +117,7 @@ int rcfx::group_process(rcf_group *g, const std::vector<GroupItem> &items, int f
         BlockPlan &bp = *plans[i];
         if (!bp.run_pfb) continue;
         bp.pl.ev_start = bp.pl.ev_stop = nullptr;
-        if (pfb_sees_zero_history(bp.pl)) { bank_singles.push_back(i); continue; }
+        if (pfb_sees_zero_history(bp.pl) || bp.pl.fm_ring) { bank_singles.push_back(i); continue; }   // (fused-discriminator banks: one by one)
         banks[std::make_tuple(bp.pl.NB, bp.pl.D, pfb_padded_p(bp.pl.NB, bp.pl.D, bp.pl.P))].idx.push_back(i);
     }
     for (auto it = banks.begin(); it != banks.end();) {

@@ -319,6 +319,14 @@ struct PfbLaunch {
     unsigned long long *rider_dst[2];
     const unsigned long long *rider_src[2];
     uint32_t rider_n8[2];
+    // The discriminator fused into a frame-major bank (rcf_pfb_fm_enable; pfb5.hip): fm_ring[(i NB + k)] = fast_atan2f(bin_k[n]
+    // conj(bin_k[n - 1]) x fm_inc[k]) for every bin of every frame, written by the bank's own kernel; fm_mode 1 = beside the
+    // bins ring, 2 = INSTEAD of it.  fm_span = consecutive chunks one workgroup walks (it keeps the last frame in
+    // registers from chunk to chunk and recomputes the ONE chunk before its span).  nullptr / 0: off.
+    float *fm_ring;
+    const float2 *fm_inc;    // [NB] the rotator increment a GNU Radio channel on bin k would carry, as a phasor (1 + 0j: none)
+    const float *atan_tab;   // gr::fast_atan2f's 257-entry table
+    int32_t fm_mode, fm_span;
     // host side only (the kernels never look): events ATTACHED to the bank's dispatch (hipExtLaunchKernelGGL) instead of
     // a bracket of two event records around it (one barrier packet less inside the measured interval).  nullptr: plain launch.
     hipEvent_t ev_start, ev_stop;
@@ -437,9 +445,16 @@ int pfb_padded_p(int NB, int D, int P);   // rows the kernel instantiation reads
 void launch_pfb(const PfbLaunch &p, hipStream_t s, const S2Rider *sr = nullptr);
 // bin counts with a factor 25 (pfb5.hip): 400, 800, 1600, 3200
 bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s);
+// the fused-discriminator form of a frame-major bank (rcf_pfb_fm_enable): whether the shape has one, the input history its
+// halo chunk reaches back over, and the per-bin increment table inc[k] = (float)(cos, sin)(dangle[k]) -- computed on the
+// device with tap_finalize's own sincos_fast, so that both paths turn the discriminator's product by the same bits
+bool pfb5_fm_supported(int NB, int D, int P);
+size_t pfb5_fm_history(int NB, int D, int P);
+void launch_pfb5_fm_inc(const double *d_dangle, float2 *d_inc, int NB, hipStream_t s);
 inline bool pfb_frame_major(int NB) { return NB % 25 == 0; }
 // dst[i] = view sample (first + i), i < n (one bin's samples out of a bank ring; ingest.hip)
 void launch_gather_view(const StreamView &v, int64_t first, float2 *dst, size_t n, hipStream_t s);
+void launch_gather_f32(const float *base, uint64_t mask, int64_t stride, int64_t first, float gain, float *dst, size_t n, hipStream_t s);
 // one ring segment of a batched read (rcf_chan_read_many), in 4-byte words: dst[dst_w + w] = ring[(pos_w + w) & mask_w], w < n_w
 //   dst_mask_w = ~0u, dst_pos_w = 0: rows packed back to back; otherwise the destination is a ring of dst_mask_w + 1 words that
 //   starts at word dst_w (the real-time pump's per-channel host rings), written from dst_pos_w on

@@ -161,6 +161,13 @@ int plan_pfb(rcf_t *h, BlockPlan &bp)
             pl.src_len = (int64_t)(h->hist_cap + n);
             pl.n_frames = (int32_t)cnt;
             pl.NB = p.NB; pl.D = p.D; pl.P = p.P;
+            if (p.fm_mode) {                    // the discriminator of every bin, in the bank's own kernel (rcf_pfb_fm_enable)
+                pl.fm_ring = p.d_fm;
+                pl.fm_inc = p.d_fm_inc;
+                pl.atan_tab = h->d_atan;
+                pl.fm_mode = p.fm_mode;
+                pl.fm_span = 0;                 // chosen at the launch (pfb5_fm_span_for)
+            }
             run_pfb = true;
             p.produced = n_hi - p.n_abs0 + 1;
         }
@@ -526,7 +533,7 @@ int plan_tail(rcf_t *h, BlockPlan &bp)
         ordered.reserve(tap_list.size());
         std::vector<int32_t> group_bin0;
         group_bin0.reserve(pitch / 16);
-        for (int b0 = 0; b0 + 16 <= NB; b0 += 16) {
+        for (int b0 = 0; b0 + 16 <= NB && pl.fm_mode != 2; b0 += 16) {     // (fm_mode 2: the bank writes no bins ring to read runs from)
             bool full = true;
             for (int j = 0; j < 16 && full; ++j) full = first[b0 + j] >= 0;
             if (!full) continue;

@@ -2,8 +2,11 @@
 // complete, issues them as one group block (rcf_group.cpp), keeps two group blocks in flight and delivers every channel's
 // output into its pinned host ring.  It replaces the interpreter between "the block's last sample exists" and "its outputs
 // are in host memory" (the per-source work loop of rc_frontend/receiver.py:477-700 as GNU Radio's scheduler threads run it).
+#include <fcntl.h>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/resource.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -41,6 +44,9 @@ struct rcf_pump {
     double max_plan_ms = 0, max_wait_ms = 0, max_idle_gap_ms = 0;   // longest single planning / device wait / sleep overshoot
     int64_t slow_plans = 0, slow_waits = 0, slow_sleeps = 0;        // ... and how many of them exceeded 5 / 5 / 2 ms (after the warm-up)
     bool warm_done = false;
+    // why late: run-queue delay of the thread (schedstat), see rcf_pump_stats_t
+    double runq_total_ms = -1, slow_wait_total_ms = 0, runq_in_slow_waits_ms = 0, slow_sleep_total_ms = 0, runq_in_slow_sleeps_ms = 0;
+    int64_t nivcsw = 0;
     std::chrono::steady_clock::time_point t_start, t_end;
     char err_text[256] = "";
 };
@@ -57,6 +63,24 @@ struct InFlight {
     std::vector<int64_t> kidx;         // per member: which of its blocks
     std::vector<std::pair<int, int64_t>> delivered;   // (entry, items) to publish once the gather has run
 };
+
+// nanoseconds this thread has spent runnable without a CPU (second field of /proc/thread-self/schedstat); -1: unreadable
+long long run_delay_ns(int fd)
+{
+    if (fd < 0) return -1;
+    char b[96];
+    const ssize_t n = pread(fd, b, sizeof b - 1, 0);
+    if (n <= 0) return -1;
+    b[n] = 0;
+    long long run = 0, delay = 0;
+    return std::sscanf(b, "%lld %lld", &run, &delay) == 2 ? delay : -1;
+}
+
+long thread_nivcsw()
+{
+    rusage ru{};
+    return getrusage(RUSAGE_THREAD, &ru) == 0 ? ru.ru_nivcsw : 0;
+}
 
 void pump_fail(rcf_pump *p, int code)
 {
@@ -81,6 +105,9 @@ void pump_main(rcf_pump *p)
         p->rt_granted.store(pthread_setschedparam(pthread_self(), SCHED_FIFO, &sp) == 0 ? 1 : 0);
     }
     (void)hipSetDevice(g->device);
+    const int sfd = open("/proc/thread-self/schedstat", O_RDONLY | O_CLOEXEC);
+    long long rq_warm = -1;                        // run_delay / involuntary switches when the judged region began
+    long nv_warm = 0;
     const double period = (double)cfg.block_samples / cfg.samp_rate;
     const size_t blk_bytes = cfg.block_samples * group_sample_bytes(cfg.fmt);
     const Clock::time_point t0 = Clock::now() + std::chrono::duration_cast<Clock::duration>(std::chrono::duration<double>(cfg.start_delay_s));
@@ -99,9 +126,11 @@ void pump_main(rcf_pump *p)
         InFlight &s = slots[head];
         if (!s.busy) return false;
         if (!block && hipEventQuery(p->slot_ev[head]) != hipSuccess) { (void)hipGetLastError(); return false; }
+        const long long rq0 = run_delay_ns(sfd);
         const Clock::time_point w0 = Clock::now();
         if (hipEventSynchronize(p->slot_ev[head]) != hipSuccess) { set_error("pump: event wait failed"); pump_fail(p, RCF_EHIP); return false; }
         const Clock::time_point now = Clock::now();
+        const long long rq1 = secs(now - w0) > 5e-3 ? run_delay_ns(sfd) : -1;
         const double t_done = secs(now - t0);
         int64_t items_out = 0;
         for (auto &d : s.delivered) { p->out_written[(size_t)d.first].fetch_add(d.second, std::memory_order_release); items_out += d.second; }
@@ -110,7 +139,11 @@ void pump_main(rcf_pump *p)
             p->wait_ms += secs(now - w0) * 1e3;
             if (p->warm_done) {
                 p->max_wait_ms = std::max(p->max_wait_ms, secs(now - w0) * 1e3);
-                if (secs(now - w0) > 5e-3) ++p->slow_waits;
+                if (secs(now - w0) > 5e-3) {
+                    ++p->slow_waits;
+                    p->slow_wait_total_ms += secs(now - w0) * 1e3;
+                    if (rq0 >= 0 && rq1 >= 0) p->runq_in_slow_waits_ms += (double)(rq1 - rq0) * 1e-6;
+                }
             }
             p->samples_out += items_out;
             for (size_t i = 0; i < s.members.size(); ++i) {
@@ -229,7 +262,11 @@ void pump_main(rcf_pump *p)
             {
                 std::lock_guard<std::mutex> l(p->st_mu);
                 p->plan_ms += secs(Clock::now() - p0) * 1e3;
-                if (!p->warm_done && *std::min_element(s.kidx.begin(), s.kidx.end()) >= cfg.warm_blocks) p->warm_done = true;
+                if (!p->warm_done && *std::min_element(s.kidx.begin(), s.kidx.end()) >= cfg.warm_blocks) {
+                    p->warm_done = true;
+                    rq_warm = run_delay_ns(sfd);
+                    nv_warm = thread_nivcsw();
+                }
                 if (p->warm_done) {
                     p->max_plan_ms = std::max(p->max_plan_ms, secs(Clock::now() - p0) * 1e3);
                     if (secs(Clock::now() - p0) > 5e-3) ++p->slow_plans;
@@ -249,6 +286,7 @@ void pump_main(rcf_pump *p)
         const double wait_s = next_due - secs(Clock::now() - t0);
         if (wait_s > 0) {
             const double want = std::min(wait_s, 1e-3);
+            const long long rq0 = run_delay_ns(sfd);
             const Clock::time_point s0 = Clock::now();
             if (cfg.spin_us > 0 && want <= cfg.spin_us * 1e-6) {
                 while (secs(Clock::now() - s0) < want && !p->stop.load(std::memory_order_relaxed)) __builtin_ia32_pause();
@@ -257,12 +295,26 @@ void pump_main(rcf_pump *p)
                 while (secs(Clock::now() - s0) < want && cfg.spin_us > 0) __builtin_ia32_pause();
             }
             const double over = (secs(Clock::now() - s0) - want) * 1e3;      // how much later than asked the thread came back
-            if (p->warm_done && over > 2.0) { std::lock_guard<std::mutex> l(p->st_mu); ++p->slow_sleeps; p->max_idle_gap_ms = std::max(p->max_idle_gap_ms, over); }
+            if (p->warm_done && over > 2.0) {
+                const long long rq1 = run_delay_ns(sfd);
+                std::lock_guard<std::mutex> l(p->st_mu);
+                ++p->slow_sleeps;
+                p->max_idle_gap_ms = std::max(p->max_idle_gap_ms, over);
+                p->slow_sleep_total_ms += over;
+                if (rq0 >= 0 && rq1 >= 0) p->runq_in_slow_sleeps_ms += (double)(rq1 - rq0) * 1e-6;
+            }
         }
     }
     while (in_flight > 0 && !p->error.load()) (void)complete_oldest(true);
     (void)hipStreamSynchronize(g->stream);
-    { std::lock_guard<std::mutex> l(p->st_mu); p->t_end = Clock::now(); }
+    {
+        const long long rq_end = run_delay_ns(sfd);
+        std::lock_guard<std::mutex> l(p->st_mu);
+        p->t_end = Clock::now();
+        if (rq_warm >= 0 && rq_end >= 0) p->runq_total_ms = (double)(rq_end - rq_warm) * 1e-6;
+        p->nivcsw = thread_nivcsw() - nv_warm;
+    }
+    if (sfd >= 0) close(sfd);
     p->running.store(false);
 }
 
@@ -386,6 +438,13 @@ int rcf_pump_stats(rcf_pump_t *p, rcf_pump_stats_t *st)
         st->slow_plans = p->slow_plans;
         st->slow_waits = p->slow_waits;
         st->slow_sleeps = p->slow_sleeps;
+        st->cpu = p->cfg.cpu;
+        st->runq_ms_total = p->runq_total_ms;
+        st->slow_wait_ms_total = p->slow_wait_total_ms;
+        st->runq_ms_in_slow_waits = p->runq_in_slow_waits_ms;
+        st->slow_sleep_ms_total = p->slow_sleep_total_ms;
+        st->runq_ms_in_slow_sleeps = p->runq_in_slow_sleeps_ms;
+        st->involuntary_switches = p->nivcsw;
         const bool run = p->running.load();
         st->elapsed_s = secs((run ? Clock::now() : p->t_end) - p->t_start);
         st->running = run ? 1 : 0;

@@ -102,6 +102,14 @@ struct Pfb {
     std::vector<int64_t> rd;       // per-bin read cursors
     int64_t start_sample = 0, n_abs0 = 0, produced = 0;
     int64_t produced_before = 0;   // value of `produced` before the current commit (for derived channels)
+    // the discriminator fused into a frame-major bank (rcf_pfb_fm_enable): d_fm[(i & ring_mask) NB + k], i = frame - n_abs0
+    int fm_mode = 0;               // 0 off, 1 beside the bins ring, 2 instead of it
+    int fm_gr_phase = 0;
+    float *d_fm = nullptr;
+    float2 *d_fm_inc = nullptr;    // [NB] per-bin rotator increment as a phasor
+    float *d_fm_stage = nullptr;   // contiguous staging for rcf_pfb_read_fm
+    int64_t fm_from = 0;           // first relative frame the discriminator ring holds
+    std::vector<int64_t> rd_fm;    // per-bin read cursors
 };
 
 struct Scan {
@@ -311,6 +319,8 @@ struct SrcRange {
 };
 bool source_range(rcf_t *h, int src, int64_t S0, int64_t S1, SrcRange *out);
 int upload_composite(rcf_t *h, Chan *c);
+double pfb_tap_gr_dangle(const rcf_t *h, int bin);
+int pfb_fm_upload_increments(rcf_t *h);
 int new_channel(rcf_t *h, int src, int D, const float *taps, int T, double offset_hz, int *chan_id);
 void free_channel(rcf_t *h, Chan *c);
 int64_t ring_read_enqueue(rcf_t *h, const void *ring, size_t elem, int64_t produced, int64_t *cursor, void *out,
