@@ -122,6 +122,29 @@ def reference_grid_leg(native, tile, device, B=1 << 25, n_taps=256):
         tap_points.append({"bins_tapped": n_t, "discriminator_only": fm_only, "pfb_ms_per_block": tap_ms, "tap_finalize_ms_per_block": fin_ms,
                            "wall_ms_per_block": tap_wall, "realtime_factor_at_20Msps": B / FS / (tap_wall * 1e-3),
                            "pfb_over_untapped": tap_ms / bank_ms})
+    # every bin demodulated INSIDE the bank's kernel (rcf_pfb_fm_enable): no tap matrix, no IQ round trip
+    # through HBM, no tap_finalize pass -- mode 2 writes the frame-major discriminator ring instead of the bins ring
+    # (8 + 8 bytes per input sample), mode 1 beside it (8 + 16 + 8)
+    fused = []
+    for i in ids:
+        fe.chan_close(i)
+    ids = []
+    if hasattr(fe, "pfb_fm_enable"):
+        for mode, alg_b in ((2, 16.0), (1, 32.0)):
+            try:
+                fe.pfb_fm_enable(mode, gr_phase=True)
+                for _ in range(60):
+                    fe.commit(B)
+                f_ms, fin_ms, f_wall = timed(50)
+                fused.append({"mode": mode, "what": "discriminator ring only" if mode == 2 else "bins ring + discriminator ring",
+                              "pfb_ms_per_block": f_ms, "tap_finalize_ms_per_block": fin_ms, "wall_ms_per_block": f_wall,
+                              "algorithmic_bytes_per_launch": alg_b * B,
+                              "frac_of_hbm_peak": alg_b * B / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "over_untapped_bank": f_ms / bank_ms,
+                              "realtime_factor_at_20Msps": B / FS / (f_wall * 1e-3)})
+            except Exception as e:  # noqa: BLE001 -- an untimed leg reports its own failure
+                fused.append({"mode": mode, "error": "%s: %s" % (type(e).__name__, e)})
+        fe.pfb_fm_enable(0)
     fe.close()
     # the 6.25 kHz grid: 3200 bins, rings of 3.4 GB -- (a) the reference's own 6.25 kHz channel,
     # channel.py:31-35 at cr = 6250: D = 1600, T = 5819; (b) its 12.5 kHz channel filter on the finer raster, D = 800
@@ -163,4 +186,8 @@ def reference_grid_leg(native, tile, device, B=1 << 25, n_taps=256):
                               "tap and the discriminator fused in (pfb_ms = the bank incl. the matrix, tap_finalize_ms = "
                               "that kernel).  Points: 256 scattered bins (matrix), all 1600 bins (ring)",
                       "points": tap_points},
+        "fused_discriminator": {"kernel": "pfb5_fm_kernel<20,4,2,2>", "points": fused,
+                                "note": "every one of the 1600 bins demodulated in the bank's own launch: a workgroup walks "
+                                        "a span of chunks and keeps each bin's last frame in registers; one extra chunk per "
+                                        "span (the halo) is computed and not stored"},
     }

@@ -103,7 +103,7 @@ constexpr int pfb5_bins_per_thread(int NB) { return (NB + kThreads5 - 1) / kThre
 // one chunk of one front-end's bank (shared by the single-front-end kernel and the grouped one: same instructions, same bits)
 template <int R, int R3, int OS, int P, bool ZH, int FM = FM_OFF>
 __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, const int tid, cf *buf, cf *zprev = nullptr,
-                                           const cf *finc = nullptr, const cf tabpair = cf{0.f, 0.f})
+                                           const cf tabpair = cf{0.f, 0.f})
 {
     constexpr int NB = R * R * R3;
     constexpr int N2 = R * R;                  // W_{N2}^n = e^{+2 pi i n / (R R)} = tw[n R3]
@@ -400,6 +400,16 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
         const int sl = tid + it * kThreads5;
         tap_bin[it] = sl < n_mat ? p.tap_bins[p.tap_first + sl] : -1;
     }
+    // (fused discriminator: the bins' rotator increments, requested before the barrier like the tap numbers -- carried across
+    // the chunks of a span they would be 2 NBT registers held through the FIR and both FFT passes)
+    cf finc[FM == FM_BOTH || FM == FM_ONLY ? pfb5_bins_per_thread(NB) : 1];
+    if constexpr (FM == FM_BOTH || FM == FM_ONLY) {
+#pragma unroll
+        for (int bb = 0; bb < pfb5_bins_per_thread(NB); ++bb) {
+            const int bin = tid + bb * kThreads5;
+            finc[bb] = (NB % kThreads5 == 0 || bin < NB) ? p.fm_inc[bin] : make_float2(1.f, 0.f);
+        }
+    }
     __syncthreads();
     TS(4);
     if (n_mat > 0) {
@@ -432,14 +442,6 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
             const cf pr = buf[(e / PADS) * RS + (e % PADS) * (R + 1) + R];
             t0 = pr.x; t1 = pr.y;
         };
-        __amdgpu_buffer_rsrc_t fm_rsrc[F], iq_rsrc[F];
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-            const int64_t slot = (int64_t)((uint64_t)(n0 + f - p.n_abs0) & p.ring_mask);
-            fm_rsrc[f] = __builtin_amdgcn_make_buffer_rsrc(p.fm_ring + slot * NB, 0, NB * (int)sizeof(float), 0x00020000);
-            if constexpr (FM == FM_BOTH)
-                iq_rsrc[f] = __builtin_amdgcn_make_buffer_rsrc(p.bins_ring + slot * NB, 0, NB * (int)sizeof(cf), 0x00020000);
-        }
 #pragma unroll
         for (int bb = 0; bb < NBT; ++bb) {
             const int bin = tid + bb * kThreads5;
@@ -455,13 +457,26 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
                 const float ti = __fsub_rn(__fmul_rn(z.y, prev.x), __fmul_rn(z.x, prev.y));
                 const float ur = __fsub_rn(__fmul_rn(tr, inc.x), __fmul_rn(ti, inc.y));
                 const float ui = __fadd_rn(__fmul_rn(tr, inc.y), __fmul_rn(ti, inc.x));
+#ifdef RCF_X_NOATAN
+                const float fm = ui + ur;
+#elif defined(RCF_X_NODISC)
+                const float fm = z.x;
+#else
                 const float fm = fast_atan2f_gr_lut(ui, ur, lookup);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fm), fm_rsrc[f], bin * (int)sizeof(float), 0, RCF_P5_STORE_AUX);
+#endif
+                // one descriptor per frame row (scalar arithmetic, redone per bin column: a table of F of them is 64
+                // SGPRs at 400 bins and went to scratch)
+                const int64_t slot = (int64_t)((uint64_t)(n0 + f - p.n_abs0) & p.ring_mask);
+                const __amdgpu_buffer_rsrc_t fm_rsrc =
+                    __builtin_amdgcn_make_buffer_rsrc(p.fm_ring + slot * NB, 0, NB * (int)sizeof(float), 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fm), fm_rsrc, bin * (int)sizeof(float), 0, RCF_P5_STORE_AUX);
                 if constexpr (FM == FM_BOTH) {
+                    const __amdgpu_buffer_rsrc_t iq_rsrc =
+                        __builtin_amdgcn_make_buffer_rsrc(p.bins_ring + slot * NB, 0, NB * (int)sizeof(cf), 0x00020000);
                     u32x2 o;
                     o.x = __float_as_uint(z.x);
                     o.y = __float_as_uint(z.y);
-                    __builtin_amdgcn_raw_buffer_store_b64(o, iq_rsrc[f], bin * (int)sizeof(cf), 0, RCF_P5_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, iq_rsrc, bin * (int)sizeof(cf), 0, RCF_P5_STORE_AUX);
                 }
                 prev = z;
             }
@@ -535,12 +550,7 @@ __device__ __forceinline__ void pfb5_fm_span(const PfbLaunch &p, const int wg, c
     const int n_chunks = (p.n_frames + F - 1) / F;
     const int c0 = wg * p.fm_span, c1 = min(c0 + p.fm_span, n_chunks);
     if (c0 >= n_chunks) return;
-    cf zprev[NBT], finc[NBT];
-#pragma unroll
-    for (int bb = 0; bb < NBT; ++bb) {
-        const int bin = tid + bb * kThreads5;
-        finc[bb] = (NB % kThreads5 == 0 || bin < NB) ? p.fm_inc[bin] : make_float2(1.f, 0.f);
-    }
+    cf zprev[NBT];
     const cf tabpair = tid < 256 ? make_float2(p.atan_tab[tid], p.atan_tab[tid + 1]) : make_float2(0.f, 0.f);
 #ifndef RCF_X_NOHALO
     pfb5_chunk<R, R3, OS, P, ZH, FM_HALO>(p, c0 - 1, tid, buf, zprev);
@@ -548,16 +558,26 @@ __device__ __forceinline__ void pfb5_fm_span(const PfbLaunch &p, const int wg, c
     for (int bb = 0; bb < NBT; ++bb) zprev[bb] = make_float2(0.f, 0.f);
 #endif
     for (int c = c0; c < c1; ++c) {
-        // (nothing may be carried from chunk to chunk but zprev / finc / tabpair: hoisted out of this loop, the prototype rows
-        // and twiddle seeds of a chunk -- loop invariant -- cost 60 more registers, spills and the third workgroup per CU)
-        asm volatile("" ::: "memory");
+        // Nothing may be carried from chunk to chunk but zprev / tabpair.  Everything a chunk derives from the thread index
+        // (twenty 64-bit prototype-row addresses, the LDS addresses of three phases) is loop invariant, and hoisted out of
+        // this loop it cost 168 VGPRs + 34 spilled: the thread index is made opaque per chunk, the chunk recomputes them
+        // as the one-chunk kernel does (121 VGPRs, none spilled, three workgroups per CU).
+        int tid_c = tid;
+        asm volatile("" : "+v"(tid_c) :: "memory");
         __syncthreads();                                   // the chunk before has been read out of LDS
-        pfb5_chunk<R, R3, OS, P, ZH, FM>(p, c, tid, buf, zprev, finc, tabpair);
+        pfb5_chunk<R, R3, OS, P, ZH, FM>(p, c, tid_c, buf, zprev, tabpair);
     }
 }
 
+// (HIP's second launch bound is waves per SIMD, not workgroups per CU: three workgroups of five waves need FOUR per SIMD,
+// i.e. <= 128 VGPRs; the shapes whose LDS allows two workgroups only get the 168 of three)
+constexpr int pfb5_fm_waves(int R, int R3, int OS, int P)
+{
+    return (size_t)pfb5_buf(R * R * R3, R, 16 / R3, OS, P) * sizeof(cf) <= (size_t)42 * 1280 ? 4 : 3;
+}
+
 template <int R, int R3, int OS, int P, bool ZH, int FM>
-__global__ __launch_bounds__(kThreads5, 3) __attribute__((amdgpu_waves_per_eu(4, 4))) void pfb5_fm_kernel(PfbLaunch p, int n_wg)
+__global__ __launch_bounds__(kThreads5, pfb5_fm_waves(R, R3, OS, P)) void pfb5_fm_kernel(PfbLaunch p, int n_wg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf *buf = reinterpret_cast<cf *>(smem_raw);

@@ -166,7 +166,11 @@ int rcf_pfb_fm_enable(rcf_t *h, int mode, int gr_phase)
     if (set_dev(h)) return RCF_EHIP;
     Pfb &p = h->pfb;
     if (!p.open) { set_error("no filterbank open"); return RCF_ESTATE; }
-    if (mode == 0) { p.fm_mode = 0; return RCF_OK; }
+    if (mode == 0) {
+        if (p.fm_mode) p.fm_until = p.produced;          // frames from here on are not demodulated: readers stop here
+        p.fm_mode = 0;
+        return RCF_OK;
+    }
     if (!p.frame_major || !pfb5_fm_supported(p.NB, p.D, p.P)) {
         set_error("no fused-discriminator kernel for bins=%d decim=%d taps/branch=%d", p.NB, p.D, p.P);
         return RCF_EINVAL;
@@ -199,9 +203,14 @@ int64_t rcf_pfb_read_fm(rcf_t *h, int bin, float gain, float *out, size_t max_sa
     Pfb &p = h->pfb;
     if (!p.open || !p.d_fm || bin < 0 || bin >= p.NB) { set_error("no discriminator ring / no such bin %d", bin); return RCF_EINVAL; }
     int64_t &rd = p.rd_fm[(size_t)bin];
-    int64_t avail = p.produced - rd;
+    const int64_t end = p.fm_mode ? p.produced : p.fm_until;
+    int64_t avail = end - rd;
     if (avail <= 0 || max_samples == 0) return 0;
-    if ((size_t)avail > h->out_cap) { rd = p.produced - (int64_t)h->out_cap; avail = (int64_t)h->out_cap; }
+    if (p.produced - rd > (int64_t)h->out_cap) {        // overwritten since: skip to the oldest frame the ring still holds
+        rd = p.produced - (int64_t)h->out_cap;
+        avail = end - rd;
+        if (avail <= 0) return 0;
+    }
     const int64_t n = std::min<int64_t>(avail, (int64_t)max_samples);
     if (!p.d_fm_stage) RCF_HIP(hipMalloc(&p.d_fm_stage, sizeof(float) * h->out_cap));
     launch_gather_f32(p.d_fm + bin, h->ring_mask, p.NB, rd, gain, p.d_fm_stage, (size_t)n, h->stream);

@@ -109,6 +109,7 @@ struct Pfb {
     float2 *d_fm_inc = nullptr;    // [NB] per-bin rotator increment as a phasor
     float *d_fm_stage = nullptr;   // contiguous staging for rcf_pfb_read_fm
     int64_t fm_from = 0;           // first relative frame the discriminator ring holds
+    int64_t fm_until = 0;          // (fm_mode == 0) the frame the discriminator was switched off at
     std::vector<int64_t> rd_fm;    // per-bin read cursors
 };
 

@@ -41,6 +41,10 @@ if int(os.environ.get("FMONLY", 0)):                     # FMONLY=1: the taps ex
 # STAGE2=n: n stage-2 channels (xlating FIR /D2 + discriminator) on bins spread over the bank, as the timed configuration has 32
 n2 = int(os.environ.get("STAGE2", 0))
 s2 = [fe.pfb_chan_open((3 + (nb // max(n2, 1)) * i) % nb, 12500, 1000.0 + 10 * i) for i in range(n2)]
+# FMFUSED=1|2: the discriminator of every bin in the bank's own kernel (rcf_pfb_fm_enable: 1 beside the bins ring, 2 instead
+# of it); RCF_PFB5_FM_SPAN=n forces the chunks one workgroup walks
+fmf = int(os.environ.get("FMFUSED", 0))
+if fmf: fe.pfb_fm_enable(fmf, gr_phase=True)
 for _ in range(int(os.environ.get("WARM", 3))): fe.commit(B)
 fe.timing_enable(True, classes=None if os.environ.get('TIME_ALL') else [native.T_PFB]); fe.timing_read(native.T_PFB)
 import time
