@@ -509,6 +509,7 @@ typedef struct rcf_pump_config {
     double batch_window_s;               /* a complete block waits up to this long for others to share its launches (0: none) */
     int rt_priority;                     /* > 0: the thread asks for SCHED_FIFO at this priority (needs CAP_SYS_NICE; refused: it runs as it is) */
     int spin_us;                         /* idle waits up to this long are spun instead of slept (a late wake-up is a late block) */
+    int max_read;                        /* subscription slots (>= n_read; 0: n_read): room for rcf_pump_subscribe while it runs */
 } rcf_pump_config_t;
 typedef struct rcf_pump_stats {
     int64_t blocks_done;                 /* member blocks whose outputs are in host memory */
@@ -542,6 +543,18 @@ int64_t rcf_pump_written(rcf_pump_t *p, int entry);
 /* copies up to max_items new items (cf32 pairs or floats) from *cursor on; a reader that fell more than the ring behind
  * loses the oldest (as a PUB socket at its HWM does) */
 int64_t rcf_pump_read(rcf_pump_t *p, int entry, int64_t *cursor, void *out, size_t max_items);
+/* rcf_pump_read for n slots at once: slot entries[i] from cursors[i] on into out + i * cap_each * 8 bytes (cf32 pairs, or
+ * floats in the first half of the row), counts[i] items (-1: no such slot) */
+int rcf_pump_read_many(rcf_pump_t *p, const int *entries, int64_t *cursors, int n, void *out, size_t cap_each, int64_t *counts);
+/* Channels come and go while a channelizer runs (rc_frontend/receiver.py:296-342 connect_channel builds and starts a
+ * channel flowgraph under the running top block, :424-435 / :635-648 release and destroy it): a running pump takes a new
+ * subscription -- channel chan_id of member `member`, delivered as `what` (RCF_READ_IQ / RCF_READ_FM x gain) from where
+ * the channel's own reader stands (a channel nobody has read: its first output, as far as its device ring still holds
+ * it) -- into a free slot.  Returns the slot (>= 0; use it as `entry` above) and in *cursor where in
+ * the slot's item count the new stream begins; RCF_ECAP when all max_read slots are taken. */
+int rcf_pump_subscribe(rcf_pump_t *p, int member, int chan_id, int what, float gain, int64_t *cursor);
+/* frees the slot (its channel may already be closed) */
+int rcf_pump_unsubscribe(rcf_pump_t *p, int entry);
 /* stops the thread (if still running), waits for it, releases the pump */
 int rcf_pump_stop(rcf_pump_t *p);
 

@@ -406,15 +406,29 @@ int rcf_group_open(rcf_t *const *handles, int n, rcf_group_t **out)
     std::unique_ptr<rcf_group> g(new rcf_group);
     g->device = handles[0]->device;
     RCF_HIP(hipSetDevice(g->device));
-    RCF_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-    RCF_HIP(hipEventCreateWithFlags(&g->ingest_ev, hipEventDisableTiming));
     g->members.assign(handles, handles + n);
     g->d_stage.assign((size_t)n, nullptr);
     g->stage_cap.assign((size_t)n, 0);
+    // everything that can fail comes first and touches no member's state: a failure below leaves the handles as they were
+    // (no dangling group / stream pointers on them, rcf_close still works), the stream and the event are destroyed
+    MemberLocks ml(g->members);
+    for (rcf_t *h : g->members)
+        if (h->group) { set_error("a group member already belongs to a group"); return RCF_ESTATE; }   // (checked again under its lock)
+    int rc = RCF_OK;
+    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) rc = RCF_EHIP;
+    if (rc == RCF_OK && hipEventCreateWithFlags(&g->ingest_ev, hipEventDisableTiming) != hipSuccess) rc = RCF_EHIP;
     for (rcf_t *h : g->members) {
-        std::lock_guard<std::mutex> l(h->mu);
+        if (rc != RCF_OK) break;
         flush_lagged(h);
-        RCF_HIP(hipStreamSynchronize(h->stream));          // whatever it queued on its own stream comes first
+        if (hipStreamSynchronize(h->stream) != hipSuccess) rc = RCF_EHIP;   // whatever it queued on its own stream comes first
+    }
+    if (rc != RCF_OK) {
+        set_error("group open: %s", hipGetErrorString(hipGetLastError()));
+        if (g->ingest_ev) (void)hipEventDestroy(g->ingest_ev);
+        if (g->stream) (void)hipStreamDestroy(g->stream);
+        return rc;
+    }
+    for (rcf_t *h : g->members) {                          // (cannot fail)
         time_collect(h);
         h->own_stream = h->stream;
         h->stream = g->stream;

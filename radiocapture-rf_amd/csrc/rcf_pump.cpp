@@ -24,12 +24,20 @@ struct rcf_pump {
     std::vector<size_t> ring_blocks;
     std::vector<double> phase;
     std::vector<const volatile uint64_t *> written;
-    std::vector<int> rd_member, rd_chan;
+    // subscription slots (guarded by g->mu): slot e delivers channel rd_chan[e] of member rd_member[e] (-1: free) as
+    // rd_what[e] (RCF_READ_IQ / RCF_READ_FM x rd_gain[e]).  Slots are fixed at start (cfg.n_read of them subscribed, room
+    // for max_read): rcf_pump_subscribe / rcf_pump_unsubscribe move channels in and out while the thread runs
+    std::vector<int> rd_member, rd_chan, rd_what;
+    std::vector<float> rd_gain;
     std::vector<std::vector<int>> entries_of;      // member -> indices into rd_*
-    size_t out_cap = 0;                            // host ring length per entry (items, power of two)
-    size_t elem = 4;                               // bytes per item
-    unsigned char *h_out = nullptr, *h_out_dev = nullptr;   // n_read rings of out_cap items
-    std::unique_ptr<std::atomic<int64_t>[]> out_written;    // items delivered per entry
+    std::vector<int64_t> queued;                   // items ever queued for the host ring of each slot
+    std::vector<Chan *> chan_of;                   // subscribed channels, resolved once per channel-set epoch
+    std::vector<uint64_t> epoch_of;                // per member: the epoch chan_of was resolved at (~0: resolve again)
+    size_t out_cap = 0;                            // host ring length per slot (items, power of two)
+    static constexpr size_t kSlotItemBytes = 8;    // every slot is out_cap x 8 bytes (a discriminator slot uses half)
+    unsigned char *h_out = nullptr, *h_out_dev = nullptr;   // the slots' rings
+    std::unique_ptr<std::atomic<int64_t>[]> out_written;    // items delivered per slot
+    std::unique_ptr<std::atomic<int64_t>[]> out_queued;     // items whose gather has been (or is about to be) launched
     // gather records of the two group blocks in flight (pinned)
     unsigned char *h_recs = nullptr, *h_recs_dev = nullptr;
     size_t recs_cap = 0;                           // records per slot
@@ -49,6 +57,14 @@ struct rcf_pump {
     int64_t nivcsw = 0;
     std::chrono::steady_clock::time_point t_start, t_end;
     char err_text[256] = "";
+    size_t item_bytes(int e) const { return rd_what[(size_t)e] == RCF_READ_IQ ? sizeof(float2) : sizeof(float); }
+    ~rcf_pump()
+    {
+        // (also what an rcf_pump_start that fails half-way leaves through: pinned rings, records, events)
+        for (int i = 0; i < 2; ++i) if (slot_ev[i]) (void)hipEventDestroy(slot_ev[i]);
+        if (h_recs) (void)hipHostFree(h_recs);
+        if (h_out) (void)hipHostFree(h_out);
+    }
 };
 
 namespace {
@@ -117,10 +133,10 @@ void pump_main(rcf_pump *p)
     InFlight slots[2];
     int head = 0, in_flight = 0;                   // slots[head] is the oldest busy one
     std::vector<GroupItem> items;
-    std::vector<int64_t> queued(p->rd_member.size(), 0);   // items ever queued for the host ring of each subscribed channel
-    std::vector<Chan *> chan_of(p->rd_member.size(), nullptr);      // subscribed channels, resolved once per channel-set epoch
-    std::vector<uint64_t> epoch_of(G, ~0ull);
-    const uint32_t ew = (uint32_t)(p->elem / 4);
+    auto &queued = p->queued;
+    auto &chan_of = p->chan_of;
+    auto &epoch_of = p->epoch_of;
+    constexpr uint32_t slot_w = (uint32_t)(rcf_pump::kSlotItemBytes / 4);   // words per item a slot is laid out for
 
     auto complete_oldest = [&](bool block) -> bool {
         InFlight &s = slots[head];
@@ -231,19 +247,25 @@ void pump_main(rcf_pump *p)
                         for (int e : p->entries_of[(size_t)it.m]) {
                             Chan *c = chan_of[(size_t)e];
                             if (!c) continue;                                      // closed under the pump: starves
-                            if (cfg.what == RCF_READ_IQ && c->fm_only) continue;   // discriminator only: no IQ stream to hand out
-                            int64_t *cur = cfg.what == RCF_READ_IQ ? &c->rd_iq : &c->rd_fm;
+                            const int what = p->rd_what[(size_t)e];
+                            const float gain = p->rd_gain[(size_t)e];
+                            const uint32_t ew = what == RCF_READ_IQ ? 2u : 1u;     // words per item of this slot's stream
+                            if (what == RCF_READ_IQ && c->fm_only) continue;       // discriminator only: no IQ stream to hand out
+                            if (what == RCF_READ_FM && !c->d_fm) continue;
+                            int64_t *cur = what == RCF_READ_IQ ? &c->rd_iq : &c->rd_fm;
                             int64_t avail = c->produced - *cur;
                             if (avail <= 0) continue;
                             if ((size_t)avail > h->out_cap) { *cur = c->produced - (int64_t)h->out_cap; avail = (int64_t)h->out_cap; }
                             if ((size_t)avail > p->out_cap) { *cur += avail - (int64_t)p->out_cap; avail = (int64_t)p->out_cap; }
                             const uint64_t dst_pos = (uint64_t)queued[(size_t)e] & (p->out_cap - 1);
                             queued[(size_t)e] += avail;
-                            recs[n_recs++] = GatherRec{static_cast<const uint32_t *>(cfg.what == RCF_READ_IQ ? (const void *)c->d_iq : (const void *)c->d_fm),
+                            // (published BEFORE the launch: a reader that copied positions this gather overwrites finds out)
+                            p->out_queued[(size_t)e].store(queued[(size_t)e], std::memory_order_release);
+                            recs[n_recs++] = GatherRec{static_cast<const uint32_t *>(what == RCF_READ_IQ ? (const void *)c->d_iq : (const void *)c->d_fm),
                                                        (uint32_t)(((uint64_t)*cur & h->ring_mask) * ew), (uint32_t)avail * ew,
-                                                       (uint32_t)(h->out_cap * ew - 1), (uint32_t)((size_t)e * p->out_cap * ew),
-                                                       (uint32_t)(dst_pos * ew), (uint32_t)(p->out_cap * ew - 1), cfg.gain,
-                                                       (cfg.what == RCF_READ_FM && cfg.gain != 1.0f) ? 1u : 0u};
+                                                       (uint32_t)(h->out_cap * ew - 1), (uint32_t)((size_t)e * p->out_cap * slot_w),
+                                                       (uint32_t)(dst_pos * ew), (uint32_t)(p->out_cap * ew - 1), gain,
+                                                       (what == RCF_READ_FM && gain != 1.0f) ? 1u : 0u};
                             max_w = std::max<uint32_t>(max_w, (uint32_t)avail * ew);
                             *cur += avail;
                             s.delivered.push_back({e, avail});
@@ -349,38 +371,47 @@ int rcf_pump_start(rcf_group_t *g, const rcf_pump_config_t *cfg, rcf_pump_t **ou
         p->phase.push_back(cfg->phase_s ? cfg->phase_s[m] : 0.0);
         p->written.push_back(cfg->written ? cfg->written[m] : nullptr);
     }
+    const int n_slots = std::max(std::max(cfg->n_read, cfg->max_read), 1);
     p->entries_of.resize(G);
+    p->rd_member.assign((size_t)n_slots, -1);
+    p->rd_chan.assign((size_t)n_slots, -1);
+    p->rd_what.assign((size_t)n_slots, cfg->what);
+    p->rd_gain.assign((size_t)n_slots, cfg->gain);
+    p->queued.assign((size_t)n_slots, 0);
+    p->chan_of.assign((size_t)n_slots, nullptr);
+    p->epoch_of.assign(G, ~0ull);
     for (int e = 0; e < cfg->n_read; ++e) {
         if (cfg->read_members[e] < 0 || cfg->read_members[e] >= (int)G) { set_error("subscribed channel %d: no such member", e); return RCF_EINVAL; }
-        p->rd_member.push_back(cfg->read_members[e]);
-        p->rd_chan.push_back(cfg->read_chans[e]);
+        p->rd_member[(size_t)e] = cfg->read_members[e];
+        p->rd_chan[(size_t)e] = cfg->read_chans[e];
         p->entries_of[(size_t)cfg->read_members[e]].push_back(e);
     }
     // the configuration's arrays belong to the caller: from here on the pump's own copies are used
     p->cfg.rings = nullptr; p->cfg.ring_blocks = nullptr; p->cfg.phase_s = nullptr; p->cfg.written = nullptr;
     p->cfg.read_members = nullptr; p->cfg.read_chans = nullptr;
-    p->elem = cfg->what == RCF_READ_IQ ? sizeof(float2) : sizeof(float);
     p->out_cap = pow2_at_least(cfg->out_ring_samples ? cfg->out_ring_samples : 4096);
-    const size_t out_bytes = std::max<size_t>(64, (size_t)cfg->n_read * p->out_cap * p->elem);
+    const size_t out_bytes = std::max<size_t>(64, (size_t)n_slots * p->out_cap * rcf_pump::kSlotItemBytes);
     if ((uint64_t)out_bytes / 4 > 0xffffffffull) { set_error("host rings of %zu bytes exceed the 32-bit word range", out_bytes); return RCF_ECAP; }
     void *hp = nullptr, *dv = nullptr;
     if (hipHostMalloc(&hp, out_bytes, hipHostMallocDefault) != hipSuccess || hipHostGetDevicePointer(&dv, hp, 0) != hipSuccess) {
         if (hp) (void)hipHostFree(hp);
+        (void)hipGetLastError();
         set_error("pinned host rings of %zu bytes failed", out_bytes);
         return RCF_ENOMEM;
     }
     p->h_out = static_cast<unsigned char *>(hp);
     p->h_out_dev = static_cast<unsigned char *>(dv);
-    p->out_written.reset(new std::atomic<int64_t>[(size_t)std::max(1, cfg->n_read)]);
-    for (int e = 0; e < std::max(1, cfg->n_read); ++e) p->out_written[(size_t)e].store(0);
-    p->recs_cap = (size_t)std::max(1, cfg->n_read);
+    p->out_written.reset(new std::atomic<int64_t>[(size_t)n_slots]);
+    p->out_queued.reset(new std::atomic<int64_t>[(size_t)n_slots]);
+    for (int e = 0; e < n_slots; ++e) { p->out_written[(size_t)e].store(0); p->out_queued[(size_t)e].store(0); }
+    p->recs_cap = (size_t)n_slots;
     hp = dv = nullptr;
     if (hipHostMalloc(&hp, 2 * p->recs_cap * sizeof(GatherRec), hipHostMallocDefault) != hipSuccess ||
         hipHostGetDevicePointer(&dv, hp, 0) != hipSuccess) {
         if (hp) (void)hipHostFree(hp);
-        (void)hipHostFree(p->h_out);
+        (void)hipGetLastError();
         set_error("pinned gather records failed");
-        return RCF_ENOMEM;
+        return RCF_ENOMEM;                            // (~rcf_pump releases the rings)
     }
     p->h_recs = static_cast<unsigned char *>(hp);
     p->h_recs_dev = static_cast<unsigned char *>(dv);
@@ -469,21 +500,92 @@ int64_t rcf_pump_written(rcf_pump_t *p, int entry)
     return p->out_written[(size_t)entry].load(std::memory_order_acquire);
 }
 
-int64_t rcf_pump_read(rcf_pump_t *p, int entry, int64_t *cursor, void *out, size_t max_items)
+// one slot's new items from *cursor on -> out; the items the pump has meanwhile queued over (up to two gathers are in flight and
+// write [written, queued) of the ring -- the oldest out_cap region a lagging reader may be copying) are dropped from the
+// front AFTER the copy, so that what is returned was whole when it was read
+static int64_t pump_read_slot(rcf_pump *p, int entry, int64_t *cursor, unsigned char *out, size_t max_items)
 {
-    if (!p || !cursor || !out || entry < 0 || entry >= (int)p->rd_member.size()) { set_error("bad pump read arguments"); return RCF_EINVAL; }
+    const size_t elem = p->item_bytes(entry);
     const int64_t w = p->out_written[(size_t)entry].load(std::memory_order_acquire);
     int64_t avail = w - *cursor;
     if (avail <= 0 || max_items == 0) return 0;
-    if ((size_t)avail > p->out_cap) { *cursor = w - (int64_t)p->out_cap; avail = (int64_t)p->out_cap; }
-    const int64_t n = std::min<int64_t>(avail, (int64_t)max_items);
-    const unsigned char *ring = p->h_out + (size_t)entry * p->out_cap * p->elem;
+    const int64_t q0 = p->out_queued[(size_t)entry].load(std::memory_order_acquire);
+    if (*cursor < q0 - (int64_t)p->out_cap) { *cursor = q0 - (int64_t)p->out_cap; avail = w - *cursor; if (avail <= 0) return 0; }
+    int64_t n = std::min<int64_t>(avail, (int64_t)max_items);
+    const unsigned char *ring = p->h_out + (size_t)entry * p->out_cap * rcf_pump::kSlotItemBytes;
     const size_t pos = (size_t)((uint64_t)*cursor & (p->out_cap - 1));
     const size_t first = std::min<size_t>((size_t)n, p->out_cap - pos);
-    std::memcpy(out, ring + pos * p->elem, first * p->elem);
-    if ((size_t)n > first) std::memcpy(static_cast<unsigned char *>(out) + first * p->elem, ring, ((size_t)n - first) * p->elem);
+    std::memcpy(out, ring + pos * elem, first * elem);
+    if ((size_t)n > first) std::memcpy(out + first * elem, ring, ((size_t)n - first) * elem);
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const int64_t lo = p->out_queued[(size_t)entry].load(std::memory_order_acquire) - (int64_t)p->out_cap;
+    if (lo > *cursor) {                               // overwritten while it was copied: what is left starts at lo
+        const int64_t drop = std::min<int64_t>(n, lo - *cursor);
+        if (drop < n) std::memmove(out, out + (size_t)drop * elem, (size_t)(n - drop) * elem);
+        *cursor += drop;
+        n -= drop;
+    }
     *cursor += n;
     return n;
+}
+
+int64_t rcf_pump_read(rcf_pump_t *p, int entry, int64_t *cursor, void *out, size_t max_items)
+{
+    if (!p || !cursor || !out || entry < 0 || entry >= (int)p->rd_member.size()) { set_error("bad pump read arguments"); return RCF_EINVAL; }
+    return pump_read_slot(p, entry, cursor, static_cast<unsigned char *>(out), max_items);
+}
+
+int rcf_pump_read_many(rcf_pump_t *p, const int *entries, int64_t *cursors, int n, void *out, size_t cap_each, int64_t *counts)
+{
+    if (!p || n < 0 || (n && (!entries || !cursors || !out || !counts))) { set_error("bad pump read arguments"); return RCF_EINVAL; }
+    for (int i = 0; i < n; ++i) {
+        if (entries[i] < 0 || entries[i] >= (int)p->rd_member.size()) { counts[i] = -1; continue; }
+        counts[i] = pump_read_slot(p, entries[i], &cursors[i], static_cast<unsigned char *>(out) + (size_t)i * cap_each * rcf_pump::kSlotItemBytes, cap_each);
+    }
+    return RCF_OK;
+}
+
+int rcf_pump_subscribe(rcf_pump_t *p, int member, int chan_id, int what, float gain, int64_t *cursor)
+{
+    if (!p || (what != RCF_READ_IQ && what != RCF_READ_FM)) { set_error("bad subscription"); return RCF_EINVAL; }
+    rcf_group *g = p->g;
+    std::lock_guard<std::mutex> gl(g->mu);
+    if (member < 0 || member >= (int)g->members.size()) { set_error("no such member %d", member); return RCF_EINVAL; }
+    int e = -1;
+    for (size_t i = 0; i < p->rd_member.size(); ++i) if (p->rd_member[i] < 0) { e = (int)i; break; }
+    if (e < 0) { set_error("all %zu subscription slots of the pump are taken (rcf_pump_config_t.max_read)", p->rd_member.size()); return RCF_ECAP; }
+    rcf_t *h = g->members[(size_t)member];
+    {
+        // (the channel's own reader position is left where it is: a channel nobody has read yet is delivered from its
+        // first output on -- what rcf_chan_read_iq would have handed out -- as far as its device ring still holds it)
+        std::lock_guard<std::mutex> l(h->mu);
+        if (h->chans.find(chan_id) == h->chans.end()) { set_error("no such channel %d on member %d", chan_id, member); return RCF_EINVAL; }
+    }
+    p->rd_member[(size_t)e] = member;
+    p->rd_chan[(size_t)e] = chan_id;
+    p->rd_what[(size_t)e] = what;
+    p->rd_gain[(size_t)e] = gain;
+    p->chan_of[(size_t)e] = nullptr;
+    p->entries_of[(size_t)member].push_back(e);
+    p->epoch_of[(size_t)member] = ~0ull;               // resolved at the member's next block
+    // the slot's counters go on from where its previous tenant left them: the new stream starts at `queued`, which the
+    // reader's cursor is set to (the gathers still in flight for the previous tenant end below it)
+    if (cursor) *cursor = p->queued[(size_t)e];
+    return e;
+}
+
+int rcf_pump_unsubscribe(rcf_pump_t *p, int entry)
+{
+    if (!p) return RCF_EINVAL;
+    rcf_group *g = p->g;
+    std::lock_guard<std::mutex> gl(g->mu);
+    if (entry < 0 || entry >= (int)p->rd_member.size() || p->rd_member[(size_t)entry] < 0) { set_error("no such subscription %d", entry); return RCF_EINVAL; }
+    auto &v = p->entries_of[(size_t)p->rd_member[(size_t)entry]];
+    v.erase(std::remove(v.begin(), v.end(), entry), v.end());
+    p->rd_member[(size_t)entry] = -1;
+    p->rd_chan[(size_t)entry] = -1;
+    p->chan_of[(size_t)entry] = nullptr;
+    return RCF_OK;
 }
 
 int rcf_pump_stop(rcf_pump_t *p)
@@ -501,10 +603,7 @@ int rcf_pump_stop(rcf_pump_t *p)
         (void)hipStreamSynchronize(g->stream);
         g->pump = nullptr;
     }
-    for (int i = 0; i < 2; ++i) if (p->slot_ev[i]) (void)hipEventDestroy(p->slot_ev[i]);
-    if (p->h_recs) (void)hipHostFree(p->h_recs);
-    if (p->h_out) (void)hipHostFree(p->h_out);
-    delete p;
+    delete p;                                          // (~rcf_pump: events, records, rings)
     return RCF_OK;
 }
 

@@ -104,32 +104,7 @@ class EgressPump:
                 except Exception as e:
                     self._fail(block_id, e)
             for fe, items in groups.values():
-                iqs = fms = None
-                if len(items) > 1 and hasattr(fe, "chan_read_many"):
-                    # all channels of one front-end behind ONE device synchronisation (rcf_chan_read_many).  The two
-                    # streams have independent reader positions: a batch that succeeded has ADVANCED its positions and
-                    # its samples are kept whatever happens to the other one -- only the stream whose batch failed is
-                    # read again channel by channel
-                    ids = tuple(ch.chan_id for _, ch in items)
-                    try:
-                        iqs = self._read_many(fe, ids, "iq", 1.0)
-                    except Exception as e:
-                        log.error("batched IQ egress read failed (%s): reading channel by channel" % e)
-                    if self.fm_gain is not None:
-                        try:
-                            fms = self._read_many(fe, ids, "fm", self.fm_gain)
-                        except Exception as e:
-                            log.error("batched discriminator egress read failed (%s): reading channel by channel" % e)
-                for i, (block_id, ch) in enumerate(items):
-                    try:
-                        iq = iqs[i] if iqs is not None and iqs[i] is not None else ch.read_iq()
-                        if fms is not None and fms[i] is not None:
-                            fm = fms[i]
-                        else:
-                            fm = ch.read_fm(self.fm_gain) if block_id in self.fm_socks else None
-                        ready.append((block_id, iq, fm))
-                    except Exception as e:
-                        self._fail(block_id, e)
+                ready.extend(self.read_group(fe, items))
         for block_id, iq, fm in ready:
             try:
                 if len(iq):
@@ -142,6 +117,37 @@ class EgressPump:
                 self._fail(block_id, e)
         for block_id in [b for b in self.socks if b not in chans]:   # destroyed channels
             self._drop(block_id)
+
+    def read_group(self, fe, items):
+        """items: [(block_id, channel)] of one front-end -> [(block_id, iq, fm or None)] (called under tb.access_lock)"""
+        ready = []
+        iqs = fms = None
+        if len(items) > 1 and hasattr(fe, "chan_read_many"):
+            # all channels of one front-end behind ONE device synchronisation (rcf_chan_read_many).  The two
+            # streams have independent reader positions: a batch that succeeded has ADVANCED its positions and
+            # its samples are kept whatever happens to the other one -- only the stream whose batch failed is
+            # read again channel by channel
+            ids = tuple(ch.chan_id for _, ch in items)
+            try:
+                iqs = self._read_many(fe, ids, "iq", 1.0)
+            except Exception as e:
+                log.error("batched IQ egress read failed (%s): reading channel by channel" % e)
+            if self.fm_gain is not None:
+                try:
+                    fms = self._read_many(fe, ids, "fm", self.fm_gain)
+                except Exception as e:
+                    log.error("batched discriminator egress read failed (%s): reading channel by channel" % e)
+        for i, (block_id, ch) in enumerate(items):
+            try:
+                iq = iqs[i] if iqs is not None and iqs[i] is not None else ch.read_iq()
+                if fms is not None and fms[i] is not None:
+                    fm = fms[i]
+                else:
+                    fm = ch.read_fm(self.fm_gain) if block_id in self.fm_socks else None
+                ready.append((block_id, iq, fm))
+            except Exception as e:
+                self._fail(block_id, e)
+        return ready
 
     def _read_many(self, fe, ids, what, gain):
         """all channels of one front-end behind one device synchronisation; the call's arguments are kept while the

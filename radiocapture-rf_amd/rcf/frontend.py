@@ -7,8 +7,13 @@ systemd/radiocapture-channelizer@.service:11).  It assembles the parts the same 
   receiver.py:497       tb = receiver(index)                                        -> rcf.receiver.receiver(config, index, device)
   receiver.py:44-46     REP socket on tcp://0.0.0.0:0                               -> FrontendServer over ZeroMQ (serve_zmq) or TCP frames
   receiver.py:268       redis_channel_publisher(sources, channels, zmq_socket, index) -> rcf.registry.redis_channel_publisher(..., extra=metrics, health=healthy)
-  channel.py:36         one zeromq.pub_sink per channel                             -> rcf.egress.EgressPump (PUB sockets fed from the GPU's channel rings)
-  receiver.py:74-204    SDR source blocks                                           -> rcf.sources.PacedSource for type 'synthetic' | 'file'
+  receiver.py:271       tb.start(): GNU Radio's scheduler threads move the samples  -> rcf.dataplane.NativeDataPlane: one native pump thread
+                                                                                       (rcf_pump_t) per class of sources, no interpreter in it
+  channel.py:36         one zeromq.pub_sink per channel                             -> PUB sockets fed from the pump's per-channel host rings
+  receiver.py:74-204    SDR source blocks                                           -> pinned source rings: 'synthetic' (the pump's clock replays
+                                                                                       the tile) | 'file' (a feeder thread) | receiver.feed
+  (`--dataplane python`: the earlier arrangement -- rcf.sources.PacedSource threads call receiver.feed, rcf.egress.EgressPump
+   reads the channel rings behind a device synchronisation; what receiver_split2 configurations and stub front-ends run on)
   receiver.py:616-699   the main loop (status, idle sweep, heartbeat expiry, recv/handle/send) -> FrontendServer.tick + handle
 
 One process drives one GPU (`--device`, default: index modulo the visible devices).  ZeroMQ and Redis are used when
@@ -68,7 +73,7 @@ class Daemon:
 
     def __init__(self, config, index=None, device=None, transport=None, registry=None, bind="0.0.0.0", port=0,
                  egress_period=0.01, fm_gain=None, block_ms=20.0, frontend_factory=None, start_sources=True,
-                 kernel_metrics=32):
+                 kernel_metrics=32, dataplane=None, max_channels=1024, pump_cpu=-1):
         from . import egress, protocol, receiver, registry as registry_mod, sources, transport as tr
         self.log = logging.getLogger("frontend" if index is None else "frontend-%s" % index)
         transport = transport or ("zmq" if have("zmq") else "tcp")
@@ -83,13 +88,30 @@ class Daemon:
                 device = (int(index) if index is not None else 0) % n
         self.transport, self.device, self.index = transport, device, index
         self.tb = receiver.receiver(config, index=index, frontend_factory=frontend_factory, device=device)
-        self.pump = egress.EgressPump(self.tb, socket_factory=egress.zmq_pub_factory() if transport == "zmq"
-                                      else tr.tcp_pub_factory(), period=egress_period, fm_gain=fm_gain)
+        make_socket = egress.zmq_pub_factory() if transport == "zmq" else tr.tcp_pub_factory()
+        # who moves the samples: the native pump wherever the front-ends are native ones and the sources whole (default);
+        # the Python threads for receiver_split2 halves and injected stub front-ends
+        pumpable = frontend_factory is None and not getattr(config, "receiver_split2", False)
+        if dataplane is None:
+            dataplane = "pump" if pumpable else "python"
+        if dataplane == "pump" and not pumpable:
+            raise ValueError("--dataplane pump needs native front-ends and whole sources (no receiver_split2)")
+        self.dataplane = dataplane
+        if dataplane == "pump":
+            from . import dataplane as dp
+            self.pump = dp.NativeDataPlane(self.tb, socket_factory=make_socket, period=egress_period, fm_gain=fm_gain,
+                                           block_ms=block_ms, max_channels=max_channels, cpu=pump_cpu)
+        elif dataplane == "python":
+            self.pump = egress.EgressPump(self.tb, socket_factory=make_socket, period=egress_period, fm_gain=fm_gain)
+        else:
+            raise ValueError("dataplane %r" % dataplane)
         self.server = protocol.FrontendServer(self.tb)
         self.last_metrics = {}
         self.server.status_extra = lambda: {k: v for k, v in self.last_metrics.items() if k != "rcf_channel_starts"}
         if kernel_metrics and frontend_factory is None:
             self.tb.enable_kernel_metrics(kernel_metrics)
+        from . import hostinfo
+        self.cpu_meter = hostinfo.CpuMeter()
         self.stop_flag = threading.Event()
         self.rep = None
         self._zmq_thread = None
@@ -118,16 +140,26 @@ class Daemon:
                 address="127.0.0.1" if bind in ("127.0.0.1", "localhost") else None,
                 extra=self.metrics, health=self.tb.healthy)
         self.pump.start()
-        self.sources = sources.start_paced_sources(self.tb, block_ms=block_ms) if start_sources else []
-        self.log.info("channelizer up: index %s device %s control port %s (%s) sources %s" % (
-            index, device, self.port, transport, {k: (v["center_freq"], v["samp_rate"]) for k, v in self.tb.sources.items()}))
+        self.sources = []
+        if start_sources and dataplane == "python":
+            self.sources = sources.start_paced_sources(self.tb, block_ms=block_ms)
+        self.log.info("channelizer up: index %s device %s control port %s (%s) data plane %s sources %s" % (
+            index, device, self.port, transport, dataplane,
+            {k: (v["center_freq"], v["samp_rate"]) for k, v in self.tb.sources.items()}))
 
     def metrics(self):
+        pump_stats = self.pump.stats() if self.dataplane == "pump" else {}     # (also refreshes the samples-in count)
         m = self.tb.metrics()
+        m.update(pump_stats)
+        m.update(self.cpu_meter.sample())            # what the host gave the process: cores used, quota, throttled time
+        if pump_stats.get("rcf_pump_error") and self.tb.fault is None:
+            self.tb.fault = "pump: %s" % pump_stats["rcf_pump_error"]          # healthy() -> False: the heartbeat stops
         m["rcf_egress_bytes"] = self.pump.bytes_out
         m["rcf_egress_errors"] = self.pump.errors
         if self.sources:
             m["rcf_source_late_blocks"] = sum(s.late for s in self.sources)
+        elif pump_stats:
+            m["rcf_source_late_blocks"] = pump_stats.get("rcf_pump_late", 0) + pump_stats.get("rcf_pump_overruns", 0)
         # the data wire has no timestamps: where each channel's stream starts, for consumers that care
         with self.tb.access_lock:
             m["rcf_channel_starts"] = {b: [c.start_sample, c.decim] for b, c in self.tb.channels.items()
@@ -180,6 +212,10 @@ def main(argv=None):
     ap.add_argument("--fm-gain", type=float, default=None, help="also publish quadrature_demod_cf(gain) of every channel on port + 1")
     ap.add_argument("--kernel-metrics", type=int, default=32,
                     help="time every n-th kernel launch for the status line / registry record (0 = off)")
+    ap.add_argument("--dataplane", choices=["pump", "python"], default=None,
+                    help="who moves the samples: the native pump thread (default) or Python source / egress threads")
+    ap.add_argument("--max-channels", type=int, default=1024, help="subscription slots of the native pump (channels delivered at once)")
+    ap.add_argument("--pump-cpu", type=int, default=-1, help="pin the pump thread to this CPU (default: leave it to the scheduler)")
     ap.add_argument("--ready-file", default=None, help="write {'port':..,'pid':..} here once the control port is bound")
     args = ap.parse_args(argv)
 
@@ -196,7 +232,8 @@ def main(argv=None):
 
     config = load_config(args.config)
     d = Daemon(config, index=args.index, device=args.device, transport=args.transport, registry=args.registry,
-               bind=args.bind, port=args.port, fm_gain=args.fm_gain, block_ms=args.block_ms, kernel_metrics=args.kernel_metrics)
+               bind=args.bind, port=args.port, fm_gain=args.fm_gain, block_ms=args.block_ms, kernel_metrics=args.kernel_metrics,
+               dataplane=args.dataplane, max_channels=args.max_channels, pump_cpu=args.pump_cpu)
     signal.signal(signal.SIGTERM, d.stop)
     signal.signal(signal.SIGINT, d.stop)
     if args.ready_file:

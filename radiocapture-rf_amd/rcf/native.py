@@ -39,7 +39,7 @@ SYMBOLS = [
     "rcf_allgather_peaks", "rcf_allreduce_max", "rcf_pfb_tap_open", "rcf_chan_set_fm_only", "rcf_pfb_shape_supported",
     "rcf_pfb_tap_leakage", "rcf_set_rotator", "rcf_timing_stride", "rcf_set_stage2_lag",
     "rcf_group_open", "rcf_group_close", "rcf_group_size", "rcf_group_push", "rcf_group_commit", "rcf_group_read_many",
-    "rcf_group_sync", "rcf_pump_start", "rcf_pump_stats", "rcf_pump_written", "rcf_pump_read", "rcf_pump_stop",
+    "rcf_group_sync", "rcf_pump_start", "rcf_pump_stats", "rcf_pump_written", "rcf_pump_read", "rcf_pump_read_many", "rcf_pump_subscribe", "rcf_pump_unsubscribe", "rcf_pump_stop",
 ]
 FMT_CF32, FMT_U8, FMT_S8, FMT_S16 = 0, 1, 2, 3
 READ_IQ, READ_FM = 0, 1
@@ -63,7 +63,7 @@ class PumpConfig(C.Structure):
                 ("gain", C.c_float), ("read_members", C.POINTER(C.c_int)), ("read_chans", C.POINTER(C.c_int)),
                 ("n_read", C.c_int), ("out_ring_samples", C.c_size_t), ("n_blocks", C.c_int64),
                 ("warm_blocks", C.c_int64), ("max_batch", C.c_int), ("cpu", C.c_int), ("start_delay_s", C.c_double),
-                ("batch_window_s", C.c_double), ("rt_priority", C.c_int), ("spin_us", C.c_int)]
+                ("batch_window_s", C.c_double), ("rt_priority", C.c_int), ("spin_us", C.c_int), ("max_read", C.c_int)]
 
 
 class PumpStats(C.Structure):
@@ -190,6 +190,9 @@ def lib():
         "rcf_pump_stats": (C.c_int, [vp, C.POINTER(PumpStats)]),
         "rcf_pump_written": (i64, [vp, C.c_int]),
         "rcf_pump_read": (i64, [vp, C.c_int, C.POINTER(i64), vp, sz]),
+        "rcf_pump_read_many": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(i64), C.c_int, vp, sz, C.POINTER(i64)]),
+        "rcf_pump_subscribe": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(i64)]),
+        "rcf_pump_unsubscribe": (C.c_int, [vp, C.c_int]),
         "rcf_pump_stop": (C.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
@@ -743,12 +746,15 @@ class Group:
 class Pump:
     """The native real-time loop of a group (rcf_pump_t): one C++ thread takes whichever members' blocks are complete,
     pushes them as one group block, gathers the subscribed channels' new output into pinned host rings.  `rings[i]`: a
-    PinnedArray (or any pinned uint8 / int8 / int16 / complex64 array) holding whole blocks of member i, replayed
-    cyclically at `samp_rate` of wall-clock time, block boundaries shifted by phase_s[i]."""
+    PinnedArray (or any pinned uint8 / int8 / int16 / complex64 array) holding whole blocks of member i -- replayed
+    cyclically at `samp_rate` of wall-clock time, block boundaries shifted by phase_s[i], or, where `written[i]` is a
+    one-element uint64 array, taken block by block as its producer counts them complete.  Subscriptions may be given at
+    start ((member, channel id) pairs delivered as `what` x `gain`) and change while it runs (subscribe / unsubscribe, up to
+    `max_read` at a time)."""
 
-    def __init__(self, group, rings, block_samples, samp_rate, subscriptions, fmt=FMT_U8, scale=1.0, offset=0.0,
+    def __init__(self, group, rings, block_samples, samp_rate, subscriptions=(), fmt=FMT_U8, scale=1.0, offset=0.0,
                  what="fm", gain=1.0, phase_s=None, out_ring_samples=4096, n_blocks=0, warm_blocks=0, max_batch=0,
-                 cpu=-1, start_delay_s=0.05, batch_window_s=0.0, rt_priority=0, spin_us=0):
+                 cpu=-1, start_delay_s=0.05, batch_window_s=0.0, rt_priority=0, spin_us=0, written=None, max_read=0):
         self.group = group
         n = len(group)
         if len(rings) != n:
@@ -764,13 +770,24 @@ class Pump:
             if rb[i] < 1:
                 raise ValueError("source ring %d is shorter than one block" % i)
         ph = (C.c_double * n)(*([0.0] * n if phase_s is None else [float(x) for x in phase_s]))
+        wr = None
+        if written is not None and any(w is not None for w in written):
+            wr = (C.c_void_p * n)()
+            for i, w in enumerate(written):
+                if w is None:
+                    wr[i] = None
+                    continue
+                if w.dtype != np.uint64 or w.size < 1:
+                    raise ValueError("written[%d] must be a uint64 array" % i)
+                self._keep.append(w)
+                wr[i] = w.ctypes.data
         ne = len(subscriptions)
         ms = (C.c_int * max(ne, 1))(*[int(m) for m, _ in subscriptions])
         cs = (C.c_int * max(ne, 1))(*[int(c) for _, c in subscriptions])
         cfg = PumpConfig()
         cfg.block_samples, cfg.fmt, cfg.scale, cfg.offset = int(block_samples), int(fmt), float(scale), float(offset)
         cfg.samp_rate = float(samp_rate)
-        cfg.rings, cfg.ring_blocks, cfg.phase_s, cfg.written = rp, rb, ph, None
+        cfg.rings, cfg.ring_blocks, cfg.phase_s, cfg.written = rp, rb, ph, wr
         cfg.what, cfg.gain = (READ_IQ if what == "iq" else READ_FM), float(gain)
         cfg.read_members, cfg.read_chans, cfg.n_read = ms, cs, ne
         cfg.out_ring_samples, cfg.n_blocks, cfg.warm_blocks = int(out_ring_samples), int(n_blocks), int(warm_blocks)
@@ -778,9 +795,12 @@ class Pump:
         cfg.batch_window_s = float(batch_window_s)
         cfg.rt_priority = int(rt_priority)
         cfg.spin_us = int(spin_us)
+        cfg.max_read = int(max_read)
         self.what = what
         self.n_entries = ne
-        self._cursors = [C.c_int64(0) for _ in range(ne)]
+        self.n_slots = max(ne, int(max_read), 1)
+        self._cursors = [C.c_int64(0) for _ in range(self.n_slots)]
+        self._what = [what] * self.n_slots
         self._p = C.c_void_p()
         _check(lib().rcf_pump_start(group._g, C.byref(cfg), C.byref(self._p)))
 
@@ -806,15 +826,49 @@ class Pump:
             time.sleep(poll_s)
         return self.stats()
 
+    def subscribe(self, member, chan_id, what="iq", gain=1.0):
+        """channel `chan_id` of member `member` from its next output on -> the slot (rcf_pump_subscribe)"""
+        cur = C.c_int64(0)
+        e = _check(lib().rcf_pump_subscribe(self._p, int(member), int(chan_id), READ_IQ if what == "iq" else READ_FM,
+                                            float(gain), C.byref(cur)))
+        self._cursors[e] = cur
+        self._what[e] = what
+        return e
+
+    def unsubscribe(self, entry):
+        _check(lib().rcf_pump_unsubscribe(self._p, int(entry)))
+
     def written(self, entry):
         return _check(lib().rcf_pump_written(self._p, int(entry)))
 
     def read(self, entry, max_items=1 << 16):
-        dt = np.complex64 if self.what == "iq" else np.float32
+        dt = np.complex64 if self._what[entry] == "iq" else np.float32
         out = np.empty(max_items, dtype=dt)
         n = _check(lib().rcf_pump_read(self._p, int(entry), C.byref(self._cursors[entry]),
                                        out.ctypes.data_as(C.c_void_p), int(max_items)))
         return out[:n].copy()
+
+    def read_many_plan(self, entries, cap_each=1 << 13):
+        """-> call() -> list of arrays (views into one buffer that the next call overwrites; None: no such slot): the new
+        items of every listed slot with ONE native call (rcf_pump_read_many).  The call's arguments are built once."""
+        n = len(entries)
+        ents = (C.c_int * max(n, 1))(*[int(e) for e in entries])
+        curs = (C.c_int64 * max(n, 1))(*[self._cursors[e].value for e in entries])
+        counts = (C.c_int64 * max(n, 1))()
+        out = np.empty((max(n, 1), cap_each), dtype=np.complex64)
+        outf = out.view(np.float32)
+        is_iq = [self._what[e] == "iq" for e in entries]
+        fn, pp, op = lib().rcf_pump_read_many, self._p, out.ctypes.data_as(C.c_void_p)
+
+        def call():
+            _check(fn(pp, ents, curs, n, op, int(cap_each), counts))
+            res = []
+            for i in range(n):
+                c = counts[i]
+                self._cursors[entries[i]].value = curs[i]
+                res.append(None if c < 0 else (out[i, :c] if is_iq[i] else outf[i, :c]))
+            return res
+        return call
 
     def stop(self):
         if self._p:

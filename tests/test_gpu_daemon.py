@@ -83,6 +83,9 @@ def test_channelizer_process_serves_a_backend(gpu_required, tmp_path, wire):
             scale, off = sources.WIRE_SCALE[wire]
             raw = sources.to_wire(tile, wire).astype(np.float32)
             tile = ((raw - np.float32(off)) * np.float32(scale)).view(np.complex64)   # rcf_push_raw's conversion
+        # (the channel's outputs sit on the absolute decimation grid: output k ends at sample k D of the source's stream, the
+        # first one at the first multiple of D at or after the channel's start)
+        start = -(-start // D) * D
         need = (n + 100000) * D
         reps = (start % len(tile) + need) // len(tile) + 2
         x = np.tile(tile, reps)[start % len(tile):][:need]
@@ -93,7 +96,11 @@ def test_channelizer_process_serves_a_backend(gpu_required, tmp_path, wire):
         win = np.lib.stride_tricks.sliding_window_view(want[: len(want) - n + probe], probe)
         k0 = int(np.argmin(np.abs(win - got[:probe]).sum(axis=1)))
         ref = want[k0:k0 + n]
-        err = float(np.sqrt(np.mean(np.abs(got - ref) ** 2) / np.mean(np.abs(ref) ** 2)))
+        # (on the native pump a subscriber that connects at once sees the channel's very first outputs: their filter
+        # history reaches before the channel's start, where the device has zeros and this oracle run -- started on the
+        # decimation grid, up to D - 1 samples later -- has not: the first ntaps / D outputs are left out)
+        lead = len(taps) // D + 2
+        err = float(np.sqrt(np.mean(np.abs(got[lead:] - ref[lead:]) ** 2) / np.mean(np.abs(ref[lead:]) ** 2)))
         assert err < 1e-5, (wire, k0, err)
         # a second subscriber joins the same stream later and sees the same samples further on
         # heartbeats: the connector's own thread has been sending them; the daemon kept the channel
@@ -187,7 +194,7 @@ def test_channelizer_process_in_pfb_mode_replaying_a_capture_file(gpu_required, 
         for name, (chan, f_off) in chans.items():
             start, decim = rec["rcf_channel_starts"][chan]
             # a bank tap's start counts the bank's FRAMES (decim 200 samples each); the direct channel's, samples
-            s0 = start * D if name == "bank" else start
+            s0 = start * D if name == "bank" else -(-start // D) * D      # (a direct channel's outputs: the absolute decimation grid)
             need = (n_out + 60000) * D
             reps = (s0 % n + need) // n + 2
             if name == "bank":
@@ -305,3 +312,187 @@ def test_channelizer_process_keeps_up_with_one_20_msps_source_and_64_subscribed_
         if proc.poll() is None:
             proc.kill()
         log.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The product process on the native pump: what the reference's channelizer holds in ONE top block
+# (rc_frontend/receiver.py:67-70,170-204) moved by one native thread, no interpreter between a source's ring and a
+# channel's host ring.
+
+CONFIG_TEN = '''
+class rc_config:
+    def __init__(self):
+        self.receiver_split2 = False
+        self.frontend_mode = 'xlat'
+        self.sources = {}
+        for i in range(10):
+            self.sources[i] = {'type': 'synthetic', 'center_freq': 851000000 + 3000000 * i, 'samp_rate': 2400000,
+                               'seed': 2000 + i, 'tile_samples': 1 << 20, 'wire': 'u8' if i % 2 else 'cf32', 'block_ms': 20.0,
+                               'carriers': [{'f_off': 12500.0 * (3 * i - 14), 'f_mod': 700.0 + 50 * i, 'dev': 2500.0, 'snr_db': 30.0}]}
+'''
+
+
+def _tile_of(src):
+    tile = sources.synthetic_tile(src)
+    if src.get("wire", "cf32") != "cf32":
+        scale, off = sources.WIRE_SCALE[src["wire"]]
+        raw = sources.to_wire(tile, src["wire"]).astype(np.float32)
+        tile = ((raw - np.float32(off)) * np.float32(scale)).view(np.complex64)   # rcf_push_raw's conversion
+    return tile
+
+
+def _stream_error(got, tile, start, f_off, fs):
+    n = len(got)
+    D, taps = G.channel_params(fs, CR)
+    start = -(-start // D) * D                         # (outputs sit on the absolute decimation grid)
+    need = (n + 100000) * D
+    reps = (start % len(tile) + need) // len(tile) + 2
+    x = np.tile(tile, reps)[start % len(tile):][:need]
+    ct, incr = OC.xlating_composite(taps, D, float(f_off), float(fs))
+    want, _ = OC.channel_bank(x, D, ct[None, :], np.array([incr]), gains=[1.0])
+    want = want[0]
+    probe = 64
+    win = np.lib.stride_tricks.sliding_window_view(want[: len(want) - n + probe], probe)
+    k0 = int(np.argmin(np.abs(win - got[:probe]).sum(axis=1)))
+    ref = want[k0:k0 + n]
+    lead = len(taps) // D + 2                          # (outputs whose filter history reaches before the channel's start)
+    return float(np.sqrt(np.mean(np.abs(got[lead:] - ref[lead:]) ** 2) / np.mean(np.abs(ref[lead:]) ** 2))), k0
+
+
+def test_channelizer_process_with_ten_sources_on_the_native_pump(gpu_required, tmp_path):
+    """the reference's shipped shape (configs/config_denver_dev_den817.py:25-118: ten 2.4 Msps RTL-SDRs behind one
+    channelizer host) as ONE process without -i: ten sources in two wire formats (two pump classes), every source's
+    control channel requested over the control wire and subscribed to; the bytes off each data socket are the oracle's
+    channel of that source's stream, the status record carries the pump's own statistics, nothing was late."""
+    fs = 2400000
+    cfg = tmp_path / "config.py"
+    cfg.write_text(CONFIG_TEN)
+    ready = tmp_path / "ready.json"
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "radiocapture-rf_amd"), ROOT]))
+    log = open(tmp_path / "daemon.log", "w")
+    proc = subprocess.Popen([sys.executable, "-m", "rcf.frontend", "--config", str(cfg), "--transport", "tcp",
+                             "--registry", "dir:%s" % (tmp_path / "reg"), "--bind", "127.0.0.1", "--ready-file", str(ready)],
+                            env=env, cwd=str(tmp_path), stdout=log, stderr=subprocess.STDOUT)
+    try:
+        _wait(lambda: ready.exists() or proc.poll() is not None, 180, "daemon did not come up")
+        assert proc.poll() is None, open(tmp_path / "daemon.log").read()
+        reg = transport.DirRegistryClient(str(tmp_path / "reg"))
+        mgr = registry.redis_channelizer_manager(clients=[reg], start_thread=False)
+        _wait(lambda: (mgr.poll_once(), mgr.channelizers)[1], 10, "no registry record")
+        rec = next(iter(mgr.channelizers.values()))
+        assert rec["source_count"] == 10
+        clients, subs, chans = [], [], []
+        for i in range(10):
+            f_off = 12500 * (3 * i - 14)                           # (the control wire carries integers: receiver.py:520)
+            fc_ = FC.frontend_connector("ten-%d" % i, mgr, transport_factory=transport.tcp_req_factory)
+            chan, port = fc_.create_channel(CR, 851000000 + 3000000 * i + f_off)
+            assert chan, (i, open(tmp_path / "daemon.log").read()[-3000:])
+            subs.append(transport.TcpSubSocket(fc_.host, port))
+            clients.append(fc_)
+            chans.append((chan, f_off))
+        n = 16000
+        got = [np.frombuffer(s_.recv_exact(8 * n), dtype=np.complex64) for s_ in subs]
+
+        def record_with_starts():
+            mgr.poll_once()
+            r = next(iter(mgr.channelizers.values()))
+            return r if all(c in r.get("rcf_channel_starts", {}) for c, _ in chans) else None
+        mgr.poll_once()
+        rec0 = next(iter(mgr.channelizers.values()))
+        time.sleep(3.0)
+        mgr.poll_once()
+        rec = next(iter(mgr.channelizers.values()))
+        assert rec["rcf_channels_in_use"] == 10 and rec["rcf_healthy"]
+        assert rec["rcf_pump_classes"] == 2 and rec["rcf_pump_subscriptions"] == 10
+        assert rec["rcf_pump_blocks_done"] > 10 * 20 and rec["rcf_pump_group_blocks"] > 0
+        assert "rcf_pump_error" not in rec
+        # steady state (ten channels open, ten subscribers reading): ~2200 blocks of 13.7 ms in the window, none late
+        late = rec["rcf_pump_late"] + rec["rcf_pump_overruns"] - rec0["rcf_pump_late"] - rec0["rcf_pump_overruns"]
+        assert abs(rec["rcf_msps_in"] - 24.0) < 1.5, rec["rcf_msps_in"]
+        # a late block is the library's only when the pump thread had a CPU: the record says how long its late wake-ups
+        # were and how much of that the thread spent on a run queue (this container has a CFS quota and no CPUs of its own)
+        on_rq = rec["rcf_pump_late_wakeups_on_run_queue_ms"] - rec0["rcf_pump_late_wakeups_on_run_queue_ms"]
+        slow = rec["rcf_pump_late_wakeups_ms"] - rec0["rcf_pump_late_wakeups_ms"]
+        host = {k: (rec0.get(k), rec.get(k)) for k in rec if k.startswith("rcf_host_")}
+        print("ten sources: %d late blocks in 3 s; late wake-ups %.1f ms, %.1f ms of them on a run queue; host %s" % (late, slow, on_rq, host))
+        assert late <= 2 or on_rq > 0.9 * slow > 0, (late, slow, on_rq, host)
+        # (the oracle runs of this process come AFTER the steady-state window: they take every core of the container's quota)
+        rec = _wait(record_with_starts, 6, "channel starts never reached the registry")
+        for i, (chan, f_off) in enumerate(chans):
+            src = dict(type="synthetic", samp_rate=fs, seed=2000 + i, tile_samples=1 << 20, wire="u8" if i % 2 else "cf32",
+                       carriers=[dict(f_off=float(f_off), f_mod=700.0 + 50 * i, dev=2500.0, snr_db=30.0)])
+            start, decim = rec["rcf_channel_starts"][chan]
+            err, k0 = _stream_error(got[i], _tile_of(src), start, f_off, fs)
+            assert err < 1e-5, (i, k0, err)
+        for s_ in subs:
+            s_.close()
+        for c in clients:
+            c.release_channel()
+            c.exit()
+        proc.send_signal(signal.SIGTERM)
+        proc.wait(timeout=30)
+        assert proc.returncode == 0
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+        log.close()
+
+
+class _CountingSocket:
+    """a PUB socket nobody listens to: counts what the egress thread hands it"""
+    made = []
+
+    def __init__(self, port):
+        self.port, self.n = port, 0
+        _CountingSocket.made.append(self)
+
+    def send(self, payload):
+        self.n += len(payload)
+
+    def close(self):
+        pass
+
+
+def test_data_plane_32_front_ends_at_20_msps_with_256_subscribed_channels_each(gpu_required):
+    """32 x 20 Msps u8 sources in one receiver, 256 reference-shaped 12.5 kHz channels on each (8192 channel flowgraphs in
+    the reference: rc_frontend/channel.py:29-38 each), all of them subscribed -- ten seconds on the native pump: no block
+    late, every channel delivers its 25 kS/s to its socket."""
+    from rcf import dataplane, receiver as receiver_mod
+
+    class Cfg:
+        receiver_split2 = False
+        frontend_mode = "xlat"
+        sources = {i: {"type": "synthetic", "center_freq": 400000000 + 25000000 * i, "samp_rate": 20000000, "seed": 50 + i,
+                       "tile_samples": 1 << 21, "wire": "u8", "block_ms": 20.0, "carriers": []} for i in range(32)}
+
+    _CountingSocket.made = []
+    tb = receiver_mod.receiver(Cfg(), device=0)
+    plane = dataplane.NativeDataPlane(tb, socket_factory=_CountingSocket, period=0.02, max_channels=8192, out_ring_samples=1 << 13)
+    try:
+        for i in range(32):
+            for k in range(256):
+                tb.connect_channel(CR, 400000000 + 25000000 * i + (k - 128) * 62500 + 12500)
+        assert len(tb.channels) == 8192
+        cl, = plane.classes.values()
+        period = cl.block / cl.fs
+        plane.start()
+        t_sub = time.time()
+        _wait(lambda: plane.stats()["rcf_pump_subscriptions"] == 8192, 60, "the channels were never all subscribed")
+        t_sub = time.time() - t_sub
+        time.sleep(1.0)
+        s0, b0, t0 = plane.stats(), [k.n for k in _CountingSocket.made], time.time()
+        time.sleep(10.0)
+        s1, b1, wall = plane.stats(), [k.n for k in _CountingSocket.made], time.time() - t0
+        assert "rcf_pump_error" not in s1, s1
+        blocks = s1["rcf_pump_blocks_done"] - s0["rcf_pump_blocks_done"]
+        assert blocks > 0.97 * 32 * wall / period, (blocks, wall, period)
+        assert s1["rcf_pump_late"] == s0["rcf_pump_late"] and s1["rcf_pump_overruns"] == s0["rcf_pump_overruns"], (s0, s1)
+        # (random ports collide now and then: a socket bound for a port that another channel then took stays unused)
+        rates = [(b - a) / 8.0 / wall for a, b in zip(b0, b1) if b > 0]
+        assert len(rates) == 8192 and min(rates) > 0.95 * 25000 and max(rates) < 1.05 * 25000, (min(rates), max(rates))
+        assert plane.errors == 0 and tb.healthy()
+        print("32 x 20 Msps, 8192 channels: %d blocks of %.1f ms in %.1f s, latency p99 %.2f ms max %.2f ms, subscribing took %.1f s" % (
+            blocks, period * 1e3, wall, s1["rcf_pump_latency_ms_p99"], s1["rcf_pump_latency_ms_max"], t_sub))
+    finally:
+        plane.stop()
+        tb.close()
