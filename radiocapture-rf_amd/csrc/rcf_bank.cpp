@@ -223,7 +223,10 @@ int64_t rcf_pfb_read_fm(rcf_t *h, int bin, float gain, float *out, size_t max_sa
 
 int rcf_pfb_fm_ring(rcf_t *h, void **fm_ring, size_t *capacity_frames, int64_t *first_frame)
 {
-    if (!h || !h->pfb.open || !h->pfb.d_fm) return RCF_ESTATE;
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    if (!h->pfb.open || !h->pfb.d_fm) return RCF_ESTATE;
     if (fm_ring) *fm_ring = h->pfb.d_fm;
     if (capacity_frames) *capacity_frames = h->out_cap;
     if (first_frame) *first_frame = h->pfb.fm_from;
@@ -232,7 +235,10 @@ int rcf_pfb_fm_ring(rcf_t *h, void **fm_ring, size_t *capacity_frames, int64_t *
 
 int rcf_pfb_rings(rcf_t *h, void **bins_ring, size_t *capacity, size_t *pitch)
 {
-    if (!h || !h->pfb.open) return RCF_ESTATE;
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;                  // (queues the deferred stage-2 launch: see rcf_chan_rings)
+    if (!h->pfb.open) return RCF_ESTATE;
     if (bins_ring) *bins_ring = h->pfb.d_bins;
     if (capacity) *capacity = h->out_cap;
     if (pitch) *pitch = h->pfb.frame_major ? 0 : (size_t(1) << kPfbTileLog2);   // frames per tile (0: frame-major)

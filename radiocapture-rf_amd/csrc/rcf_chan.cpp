@@ -338,6 +338,7 @@ int64_t rcf_chan_produced(rcf_t *h, int chan_id)
 {
     if (!h) return RCF_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;                  // (the count includes the deferred stage-2 block: it is queued first)
     FIND_CHAN(h, chan_id, c);
     return c->produced;
 }
@@ -653,6 +654,7 @@ int rcf_chan_rings(rcf_t *h, int chan_id, void **iq_ring, void **fm_ring, size_t
 {
     if (!h) return RCF_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;                  // (zero-copy readers order themselves on rcf_stream: nothing stays deferred)
     FIND_CHAN(h, chan_id, c);
     if (iq_ring && c->fm_only) { set_error("channel %d exposes its discriminator only (rcf_chan_set_fm_only)", chan_id); return RCF_ESTATE; }
     if (iq_ring) *iq_ring = c->d_iq;

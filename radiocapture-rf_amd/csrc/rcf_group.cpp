@@ -273,7 +273,11 @@ int rcfx::group_process(rcf_group *g, const std::vector<GroupItem> &items, int f
         launch_group_prep(prep_mapped + at, (int)std::min<size_t>(kPrepMaxRecs, prep.size() - at), prep_tiles[li], st);
     dbg_t1 = dbg_mark(3, dbg_t1);                               // the prep launch
     RCF_PROF(11, "group: prep launch", tp);
-    if (wait) RCF_HIP(hipEventRecord(g->ingest_ev, st));
+    // (past this point every listed member's channel counters have been advanced by the planning and the prep kernel has
+    // written its buffers: a failure no longer returns at once -- the bookkeeping of every member is finished, the members
+    // are marked faulted, and the error is returned at the end)
+    int rc_late = RCF_OK;
+    if (wait && hipEventRecord(g->ingest_ev, st) != hipSuccess) { set_error("group: event record failed"); rc_late = RCF_EHIP; }
     if (d_rots) launch_rot_fill(d_rots, (int)rots.size(), h0->ring_mask, st);
     auto launch_depth = [&](size_t d, int timing_class_default) {
         for (size_t i = 0; i < NI; ++i) {
@@ -319,13 +323,24 @@ int rcfx::group_process(rcf_group *g, const std::vector<GroupItem> &items, int f
             Timed t(h, RCF_T_AUDIO);
             launch_audio(bp.d_audf, (int)bp.audf.size(), bp.audf_max_n, bp.audf_num, bp.audf_den, h->ring_mask, h->d_atan, st);
         }
-        int rc = run_scan(h, bp);
-        if (rc != RCF_OK) return rc;
+        const int rc = run_scan(h, bp);
+        if (rc != RCF_OK && rc_late == RCF_OK) rc_late = rc;
         h->buf_dirty[h->cur] = true;                           // (rcf_push_iq on this member later orders its copy behind these reads)
         h->cur ^= 1;
         h->total_in = bp.S1;
     }
-    RCF_HIP(hipGetLastError());
+    if (rc_late == RCF_OK) {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_error("group launch failed: %s", hipGetErrorString(e)); rc_late = RCF_EHIP; }
+    }
+    if (rc_late != RCF_OK) {
+        for (size_t i = 0; i < NI; ++i) {
+            rcf_t *h = g->members[(size_t)items[i].m];
+            h->fault = rc_late;
+            std::snprintf(h->fault_text, sizeof h->fault_text, "group block failed: %s", rcf_last_error());
+        }
+        return rc_late;
+    }
     dbg_t1 = dbg_mark(4, dbg_t1);                               // the other launches
     RCF_PROF(12, "group: other launches", tp);
     if (wait) (void)hipEventSynchronize(g->ingest_ev);

@@ -29,14 +29,25 @@ bool hip_ok(hipError_t e, const char *what)
     return false;
 }
 
+// a front-end whose group block failed AFTER launches had been queued (rcf_group.cpp) has channel counters ahead of what the
+// device holds: every later call that would push, commit or read says so instead of going on with that state
+static int faulted(rcf_t *h)
+{
+    if (!h->fault) return RCF_OK;
+    set_error("the front-end is faulted (%s): close it and open a new one", h->fault_text);
+    return RCF_ESTATE;
+}
+
 int set_dev_ingest(rcf_t *h)
 {
+    if (faulted(h)) return RCF_ESTATE;
     RCF_HIP(hipSetDevice(h->device));
     return RCF_OK;
 }
 
 int set_dev(rcf_t *h)
 {
+    if (faulted(h)) return RCF_ESTATE;
     RCF_HIP(hipSetDevice(h->device));
     flush_lagged(h);
     return RCF_OK;
@@ -231,6 +242,7 @@ int rcf_close(rcf_t *h)
     h->chans.clear();
     Pfb &p = h->pfb;
     bury(h, p.d_ptaps); bury(h, p.d_tw); bury(h, p.d_bins); bury(h, p.d_stage);
+    bury(h, p.d_fm); bury(h, p.d_fm_inc); bury(h, p.d_fm_stage);
     Scan &s = h->scan;
     bury(h, s.d_window); bury(h, s.d_vring); bury(h, s.d_sum); bury(h, s.d_out); bury(h, s.d_tw);
     bury(h, s.d_scratch); bury(h, s.d_peaks); bury(h, s.d_peak_ws);
@@ -299,7 +311,15 @@ int rcf_set_decim_rule(rcf_t *h, int decim_rule)
     return RCF_OK;
 }
 
-void *rcf_stream(rcf_t *h) { return h ? (void *)h->stream : nullptr; }
+void *rcf_stream(rcf_t *h)
+{
+    if (!h) return nullptr;
+    // (a consumer that orders itself on this stream must find every launch it could observe queued on it: the deferred
+    // stage-2 launch of the previous block goes out first)
+    std::lock_guard<std::mutex> g(h->mu);
+    (void)set_dev(h);
+    return (void *)h->stream;
+}
 int rcf_device(rcf_t *h) { return h ? h->device : RCF_EINVAL; }
 int64_t rcf_samples_in(rcf_t *h) { return h ? h->total_in : RCF_EINVAL; }
 

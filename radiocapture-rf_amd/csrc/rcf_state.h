@@ -152,6 +152,8 @@ using rcfx::Scan;
 
 struct rcf {
     int device = 0;
+    int fault = 0;                 // sticky: a group block failed after its launches had been queued (set_dev refuses from then on)
+    char fault_text[160] = "";
     double fs = 0, fc = 0;
     size_t block_cap = 0, hist_cap = 0, out_cap = 0;
     uint64_t blk_serial = 0;       // process_block count (Chan::blk_serial)

@@ -6,8 +6,8 @@ collective.  The only exchange is the all-gather of detected-peak lists after a 
   * on GPUs it is ONE ncclAllGather over xGMI through the C ABI (`rcf_allgather_peaks`, librccl loaded by
     librcf on first use); the 128-byte communicator id travels over `HostGroup`, a plain TCP rendezvous
     (rank 0 listens next to MASTER_PORT) -- no PyTorch anywhere on this path;
-  * `allgather_peaks_host` is the same exchange over the HostGroup alone (no GPU-to-GPU link, CPU-only tests);
-  * `allgather_peaks_torch` keeps the torch.distributed form (gloo in the CPU tests).
+  * `allgather_peaks_host` is the same exchange over the HostGroup alone (no GPU-to-GPU link, CPU-only tests).
+(The world-size-2 gloo test carries the same records over torch.distributed with helpers of its own: tests/test_dist_gloo.py.)
 """
 from __future__ import annotations
 
@@ -192,7 +192,7 @@ def init_comm(frontend, group: HostGroup):
     frontend.comm_init(group.rank, group.world, uid)
 
 
-# --------------------------------------------------------------------------- the exchange, three transports
+# --------------------------------------------------------------------------- the exchange, two transports
 def allgather_peaks(frontend, freqs_hz, cap=PEAK_CAP):
     """Every rank ends with the global sorted list of detected peak frequencies: ncclAllGather over xGMI via
     the C ABI (rcf_allgather_peaks) on the front-end's device."""
@@ -204,18 +204,3 @@ def allgather_peaks_host(group: HostGroup, freqs_hz, cap=PEAK_CAP):
     """The same exchange over the host rendezvous (no GPU-to-GPU path / CPU-only runs)."""
     recs = group.all_gather(pack_peaks(freqs_hz, cap).tobytes())
     return unpack_peaks([np.frombuffer(r, dtype=np.int64) for r in recs])
-
-
-def allgather_peaks_torch(dist, torch, freqs_hz, device, cap=PEAK_CAP):
-    """torch.distributed form ("nccl" == RCCL on ROCm, "gloo" in the CPU tests)."""
-    mine = torch.from_numpy(pack_peaks(freqs_hz, cap)).to(device)
-    world = dist.get_world_size()
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine)
-    return unpack_peaks([g.cpu().numpy() for g in gathered])
-
-
-def max_over_ranks(dist, torch, seconds, device):
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())

@@ -20,6 +20,23 @@ def _free_port():
     return p
 
 
+def _allgather_peaks_torch(dist, torch, multigpu, freqs_hz, device, cap=None):
+    """the product's record format (multigpu.pack_peaks / unpack_peaks) over torch.distributed -- "gloo" here, as "nccl"
+    (== RCCL) would carry it on a node; the product itself exchanges through the C ABI (rcf_allgather_peaks) or the host
+    rendezvous and has no torch in it"""
+    cap = multigpu.PEAK_CAP if cap is None else cap
+    mine = torch.from_numpy(multigpu.pack_peaks(freqs_hz, cap)).to(device)
+    gathered = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(gathered, mine)
+    return multigpu.unpack_peaks([g.cpu().numpy() for g in gathered])
+
+
+def _max_over_ranks(dist, torch, seconds, device):
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def _worker(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "radiocapture-rf_amd")):
         if p not in sys.path:
@@ -44,8 +61,8 @@ def _worker(rank, world, port, q):
         lines, freqs = scan.peak_detect(x, fs, fc)              # product host picker (librcf, no GPU needed)
         l_ref, f_ref = P.peak_detect_scipy(x, fs, fc)
         assert list(lines) == list(l_ref) and freqs == f_ref and len(freqs) == 2
-        everyone = multigpu.allgather_peaks_torch(dist, torch, freqs, "cpu")
-        tmax = multigpu.max_over_ranks(dist, torch, 1.0 + rank, "cpu")
+        everyone = _allgather_peaks_torch(dist, torch, multigpu, freqs, "cpu")
+        tmax = _max_over_ranks(dist, torch, 1.0 + rank, "cpu")
         q.put((rank, mine, freqs, everyone, tmax))
     finally:
         dist.destroy_process_group()
