@@ -29,6 +29,7 @@ The legs (benchlib/, one module each; all but the first outside the timed region
                 bank whose bins are the reference's channels (+ taps, + the discriminator fused into the bank)
   scan.py       scan: BASELINE configs[2] (1M-point FFT x 1000 frames / 100-frame average + peak pick);  scan_ref: the
                 reference's own size (fs = 2.4 Msps, N = 16384, 1000 / 100), each with its roofline
+  daemon.py     daemon (the product's own data plane: receiver + native pump + egress thread, 32 x 20 Msps x 64 channels)
   ingest.py     end_to_end (PCIe-inclusive ingest: never `value`), control_plane (100 x create / release)
   group.py      group_capacity: one grouped launch per stage over 80 front-ends, resident
   realtime.py   the paced leg: K independent 20 Msps u8 front-ends fed at WALL-CLOCK rate by native pump threads
@@ -66,6 +67,7 @@ from benchlib.scan import scan_leg, scan_ref_leg  # noqa: E402,F401
 from benchlib.ingest import end_to_end_leg, control_plane_leg  # noqa: E402,F401
 from benchlib.group import group_capacity_leg  # noqa: E402,F401
 from benchlib.realtime import realtime_point, realtime_leg  # noqa: E402,F401
+from benchlib.daemon import daemon_leg  # noqa: E402,F401
 from benchlib.cpu import cpu_baseline  # noqa: E402,F401
 from benchlib import compact, headline  # noqa: E402
 
@@ -129,6 +131,8 @@ def untimed_legs(args, out, ctx, native, synth, device):
         out["realtime"] = leg(realtime_leg, native, tile, carriers, device, seconds=args.rt_seconds, block_ms=args.rt_block_ms,
                               k_first=args.rt_k_first, k_cap=args.rt_k_cap, stagger=not args.rt_burst, n_pumps=args.rt_pumps,
                               window_ms=args.rt_window_ms, shapes=tuple(x for x in args.rt_shapes.split(",") if x))
+    if args.rt_seconds > 0:
+        out["daemon"] = leg(daemon_leg, device)
     out["control_plane"] = leg(control_plane_leg, device)
     counts = [c for c in (256, 1024, 4096, 16384, 65536, 131072, 196608) if c <= args.sweep_max]
     out["channels"]["direct_bank"] = leg(direct_bank_sweep, native, tile, device, counts)

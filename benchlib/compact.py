@@ -7,7 +7,7 @@ import os
 
 from .common import ROOT
 
-LIMIT = 7600          # bytes of the line incl. newline; the driver's stdout tail is 8 018
+LIMIT = 7900          # bytes of the line incl. newline; the driver's stdout tail is 8 018
 
 
 def sig(x, n=5):
@@ -55,13 +55,16 @@ def _realtime(rt):
         if isinstance(a, dict):
             e["at_K_max"] = pick(a, "seconds", "deadline_misses", "ring_overruns", "latency_ms_p50", "latency_ms_p99",
                                  "latency_ms_max", "gpu_busy_percent_est", "host_longest_device_wait_ms",
-                                 "host_longest_sleep_overshoot_ms", "pcie_GBps_in", "completion", "confirmation_run",
-                                 "pump_cpus", "why_late")
+                                 "host_longest_sleep_overshoot_ms", "pcie_GBps_in", "completion", "confirmation_run")
+            wl = a.get("why_late") or {}
+            if wl:
+                e["at_K_max"]["late_wakeups_ms"] = wl.get("late_wakeups_ms")
+                e["at_K_max"]["of_them_on_a_run_queue_ms"] = wl.get("of_them_on_a_run_queue_ms")
             cg = a.get("host_cgroup") or {}
             e["at_K_max"].update(pick(cg, "cpu_quota_cores", "throttled_ms", "cpu_cores_used_mean"))
         e["points"] = [[p.get("front_ends"), bool(p.get("ok")), p.get("deadline_misses"), p.get("latency_ms_p99")]
                        for p in s.get("points", [])]
-        e["points_are"] = "[K, ok, deadline misses, latency p99 ms] in the order run"
+        out["points_are"] = "[K, ok, deadline misses, latency p99 ms] in the order run"
         out[shape] = e
     return out
 
@@ -88,9 +91,13 @@ def _channels(ch):
             e = pick(rg, "kernel", "pfb_ms_per_block", "reference_channels_per_frontend")
             e["frac"] = (rg.get("roofline") or {}).get("frac")
             e["sustained_frac_last_window"] = (rg.get("sustained") or {}).get("frac_last_window")
-            e["with_taps"] = [pick(p, "bins_tapped", "discriminator_only", "fused_in_bank", "pfb_ms_per_block",
-                                   "tap_finalize_ms_per_block", "total_ms_per_block", "wall_ms_per_block")
-                              for p in (rg.get("with_taps") or {}).get("points", [])]
+            e["with_taps"] = [[p.get("bins_tapped"), bool(p.get("discriminator_only")), p.get("pfb_ms_per_block"),
+                               p.get("tap_finalize_ms_per_block")] for p in (rg.get("with_taps") or {}).get("points", [])]
+            e["with_taps_are"] = "[bins tapped, discriminator only, bank ms, tap_finalize ms] per 2^25-sample block"
+            e["fused_discriminator"] = [[p.get("mode"), p.get("pfb_ms_per_block"), p.get("frac_of_hbm_peak")] if "error" not in p
+                                        else [p.get("mode"), str(p["error"])[:80]]
+                                        for p in (rg.get("fused_discriminator") or {}).get("points", [])]
+            e["fused_discriminator_are"] = "[mode (2: discriminator ring only, 1: beside the bins ring), ms per block, frac of HBM peak on its own bytes]"
             e["grid_6k25"] = [pick(p, "bins", "decim", "pfb_ms_per_block", frac="frac_of_hbm_peak") for p in rg.get("grid_6k25", [])]
             out["reference_grid_filterbank"] = e
     return out
@@ -181,7 +188,9 @@ def compact(full, full_path=None):
         rest["realtime"] = _realtime(full["realtime"])
     dm = full.get("daemon")
     if isinstance(dm, dict):
-        rest["daemon"] = _err(dm) or {k: v for k, v in dm.items() if not isinstance(v, (dict, list)) or k == "pump_stats"}
+        rest["daemon"] = _err(dm) or pick(dm, "sources", "channels", "block_ms", "seconds", "input_Msps", "blocks", "late_blocks",
+                                         "overruns", "latency_ms_p99", "latency_ms_max", "channels_delivering",
+                                         "channel_rate_min_sps", "channel_rate_max_sps", "egress_MBps", "egress_errors")
     cp = full.get("control_plane")
     if isinstance(cp, dict):
         rest["control_plane"] = _err(cp) or pick(cp, "n", "create_ms_median", "release_ms_median", "connect_channel_new_ms_mean")
@@ -189,8 +198,8 @@ def compact(full, full_path=None):
     out.update(sig(rest))
     out["full_record"] = full_path or "bench_full.json"
     # the guard: whatever a leg grows into, the line stays under LIMIT -- least important summaries go first
-    for k in ("control_plane", "group_capacity", "end_to_end", "numa", "numa_node_by_rank", "rccl_proof", "daemon", "scan",
-              "scan_ref", "realtime", "channels", "sustained", "realtime_per_gpu", "peaks_allgather"):
+    for k in ("control_plane", "group_capacity", "end_to_end", "numa", "numa_node_by_rank", "rccl_proof", "scan",
+              "scan_ref", "daemon", "realtime", "channels", "sustained", "realtime_per_gpu", "peaks_allgather"):
         if len(json.dumps(out)) + 1 <= LIMIT:
             break
         if k in out:
