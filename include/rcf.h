@@ -309,6 +309,9 @@ int rcf_source_shift(rcf_t *h, double delta_hz);
 int rcf_pfb_fm_enable(rcf_t *h, int mode, int gr_phase);
 /* bin's discriminator samples not yet read by this call, x gain -> out; a reader more than the ring behind loses the oldest */
 int64_t rcf_pfb_read_fm(rcf_t *h, int bin, float gain, float *out, size_t max_samples);
+/* how many chunk hand-overs inside the bank's kernel never arrived (a bounded wait gave up: those frames were demodulated
+ * against a zero predecessor).  0 on a healthy device: a check for tests and health probes, not a data path. */
+int64_t rcf_pfb_fm_lost(rcf_t *h);
 /* zero-copy: the device ring (floats), its capacity in frames and the relative index of its first valid frame; bin k of
  * relative frame i sits at fm_ring[(i & (capacity - 1)) n_bins + k].  Order reads on rcf_stream(h) after rcf_sync / an event. */
 int rcf_pfb_fm_ring(rcf_t *h, void **fm_ring, size_t *capacity_frames, int64_t *first_frame);

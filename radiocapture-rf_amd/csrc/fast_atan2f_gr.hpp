@@ -17,7 +17,11 @@ namespace {
 
 // `lookup(index, t0, t1)` yields table[index] and table[index + 1], index in [0, 255]: a plain table (below) or wherever
 // a kernel keeps the pairs (pfb5.hip: the spare LDS slots of its frame rows)
-template <typename Lookup>
+// RCP: the quotient as num * rcp(den) (v_rcp_f32: 1 ulp) instead of the correctly rounded division (eleven instructions with
+// its scaling and fix-up): the argument of the table moves by <= 2 ulp, the angle by <= 2e-7 rad -- for the kernel that is
+// bound by its vector instruction count (pfb5.hip: the discriminator fused into the bank).  Magnitudes below 1e-38 (denormal
+// products: |bin| < 1e-19) are not handled -- v_rcp_f32 flushes them -- and come out as arbitrary angles; (0, 0) stays 0.
+template <typename Lookup, bool RCP = false>
 RCF_DEVFN float fast_atan2f_gr_lut(float y, float x, Lookup lookup)
 {
 #pragma clang fp contract(off)
@@ -32,7 +36,11 @@ RCF_DEVFN float fast_atan2f_gr_lut(float y, float x, Lookup lookup)
     const bool nonzero = (ya > 0.0f) || (xa > 0.0f);      // (0, 0) -> 0, selected at the end
     const bool y_small = ya < xa;
     const float num = y_small ? ya : xa, den = y_small ? xa : ya;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float z = RCP ? num * __builtin_amdgcn_rcpf(den) : num / den;
+#else
     const float z = num / den;
+#endif
     float alpha = z * 255.0f;
     const int index = ((int)alpha) & 0xff;                // (the NaN z of the (0, 0) case converts to 0: a valid table position)
     alpha = alpha - (float)index;

@@ -101,9 +101,24 @@ enum { FM_OFF = 0, FM_BOTH = 1, FM_ONLY = 2, FM_HALO = 3 };
 constexpr int pfb5_bins_per_thread(int NB) { return (NB + kThreads5 - 1) / kThreads5; }
 
 // one chunk of one front-end's bank (shared by the single-front-end kernel and the grouped one: same instructions, same bits)
-template <int R, int R3, int OS, int P, bool ZH, int FM = FM_OFF>
+#ifndef RCF_FM_RCP
+#define RCF_FM_RCP 1                // the fused discriminator's quotient as num * v_rcp_f32(den) (fast_atan2f_gr.hpp)
+#endif
+
+// where entry e of gr::fast_atan2f's table sits in the chunk's LDS, as the PAIR (tab[e], tab[e + 1]) one lookup needs: the
+// frame rows have a spare complex after every R -- 256 / F of them are used per row
+template <int R, int R3>
+__device__ __forceinline__ int pfb5_tab_slot(int e)
+{
+    constexpr int NB = R * R * R3, F = 16 / R3, PER = 256 / F, RS = pfb5_row_stride(NB, R);
+    static_assert(PER <= NB / R - 1 && (PER & (PER - 1)) == 0, "the rows' spare slots hold the 256 table pairs");
+    return (e / PER) * RS + (e % PER) * (R + 1) + R;
+}
+
+template <int R, int R3, int OS, int P, bool ZH, int FM = FM_OFF, bool LB = false>
 __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, const int tid, cf *buf, cf *zprev = nullptr,
-                                           const cf tabpair = cf{0.f, 0.f})
+                                           const cf tabpair = cf{0.f, 0.f}, unsigned long long *halo_row = nullptr,
+                                           const bool own_halo = false)
 {
     constexpr int NB = R * R * R3;
     constexpr int N2 = R * R;                  // W_{N2}^n = e^{+2 pi i n / (R R)} = tw[n R3]
@@ -302,9 +317,7 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
             // as the PAIR (tab[e], tab[e + 1]) one lookup needs, sits in spare slot e -- PADS = NB / R - 1 slots per row.  The
             // window DMA of every chunk runs over them, so thread e (which keeps its pair in two registers for the whole
             // span) puts it back here, once the window has been read and together with the first pass's own writes.
-            constexpr int PADS = NB / R - 1;
-            static_assert(PADS * F >= 256, "the rows' spare slots hold the 256 table pairs");
-            if (tid < 256) buf[(tid / PADS) * RS + (tid % PADS) * (R + 1) + R] = tabpair;
+            if (tid < 256) buf[pfb5_tab_slot<R, R3>(tid)] = tabpair;
         }
     }
     TS(1);
@@ -382,7 +395,15 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
 #pragma unroll
         for (int bb = 0; bb < NBT; ++bb) {
             const int bin = tid + bb * kThreads5;
-            zprev[bb] = (NB % kThreads5 == 0 || bin < NB) ? row[pad5<R>(bin)] : make_float2(0.f, 0.f);
+            const cf z = (NB % kThreads5 == 0 || bin < NB) ? row[pad5<R>(bin)] : make_float2(0.f, 0.f);
+            if constexpr (LB) {
+                // (a global row instead of registers: the thread reads its own words back after the chunk proper)
+                if (NB % kThreads5 == 0 || bin < NB)
+                    __hip_atomic_store(halo_row + bin, ((unsigned long long)__float_as_uint(z.y) << 32) | __float_as_uint(z.x),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                zprev[bb] = z;
+            }
         }
         return;
     }
@@ -433,15 +454,115 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
     if constexpr (FM == FM_BOTH || FM == FM_ONLY) {
         // ---- copy-out with the discriminator fused in: frame f of bin k leaves as fm_ring[((n0 + f) & mask) NB + k] =
         // fast_atan2f(bin[n] conj(bin[n - 1]) x inc_k) -- tap_finalize's discriminator-only arithmetic (tapfin.hip: the
-        // discriminator of the ROTATED stream is the bare product turned by the rotator's one increment), the same bits.
+        // discriminator of the ROTATED stream is the bare product turned by the rotator's one increment).
         // Lanes = consecutive bins: every wavefront store is 256 contiguous bytes of a frame row.  A thread walks ITS bins
-        // down the frames, so the predecessor is a register; across chunks it is zprev.
+        // down the frames, so the predecessor is a register; across chunks it is zprev (span form) or the row the
+        // workgroup before this one published (look-back form).
         constexpr int NBT = pfb5_bins_per_thread(NB);
-        constexpr int PADS = NB / R - 1;
         auto lookup = [&](int e, float &t0, float &t1) {
-            const cf pr = buf[(e / PADS) * RS + (e % PADS) * (R + 1) + R];
+            const cf pr = buf[pfb5_tab_slot<R, R3>(e)];
             t0 = pr.x; t1 = pr.y;
         };
+        auto emit = [&](const int f, const int bin, const cf z, const cf prev, const cf inc) {
+            // volk_32fc_x2_multiply_conjugate_32fc (unfused), then the turn by the rotator's increment
+            const float tr = __fadd_rn(__fmul_rn(z.x, prev.x), __fmul_rn(z.y, prev.y));
+            const float ti = __fsub_rn(__fmul_rn(z.y, prev.x), __fmul_rn(z.x, prev.y));
+            const float ur = __fsub_rn(__fmul_rn(tr, inc.x), __fmul_rn(ti, inc.y));
+            const float ui = __fadd_rn(__fmul_rn(tr, inc.y), __fmul_rn(ti, inc.x));
+#ifdef RCF_X_NOATAN
+            const float fm = ui + ur;
+#elif defined(RCF_X_NODISC)
+            const float fm = z.x;
+#else
+            const float fm = fast_atan2f_gr_lut<decltype(lookup), (RCF_FM_RCP != 0)>(ui, ur, lookup);
+#endif
+            // one descriptor per frame row (scalar arithmetic, redone per bin column: a table of F of them is 64
+            // SGPRs at 400 bins and went to scratch)
+            const int64_t slot = (int64_t)((uint64_t)(n0 + f - p.n_abs0) & p.ring_mask);
+            const __amdgpu_buffer_rsrc_t fm_rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(p.fm_ring + slot * NB, 0, NB * (int)sizeof(float), 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fm), fm_rsrc, bin * (int)sizeof(float), 0, RCF_P5_STORE_AUX);
+            if constexpr (FM == FM_BOTH) {
+                const __amdgpu_buffer_rsrc_t iq_rsrc =
+                    __builtin_amdgcn_make_buffer_rsrc(p.bins_ring + slot * NB, 0, NB * (int)sizeof(cf), 0x00020000);
+                u32x2 o;
+                o.x = __float_as_uint(z.x);
+                o.y = __float_as_uint(z.y);
+                __builtin_amdgcn_raw_buffer_store_b64(o, iq_rsrc, bin * (int)sizeof(cf), 0, RCF_P5_STORE_AUX);
+            }
+        };
+        if constexpr (LB) {
+            // ---- look-back form: one chunk per workgroup, no arithmetic done twice.
+            // (1) the chunk's LAST frame goes to this chunk's edge row, then its flag: the workgroup of the next chunk needs
+            //     it for that chunk's first discriminator sample -- published FIRST, a whole copy-out before it is asked for
+            const int my_slot = wg % p.fm_slots;
+            unsigned long long *edge = p.fm_edge + (size_t)my_slot * NB;
+            {
+                const cf *last = buf + (nf - 1) * RS;
+#pragma unroll
+                for (int bb = 0; bb < NBT; ++bb) {
+                    const int bin = tid + bb * kThreads5;
+                    if (NB % kThreads5 != 0 && bin >= NB) break;
+                    const cf z = last[pad5<R>(bin)];
+                    __hip_atomic_store(edge + bin, ((unsigned long long)__float_as_uint(z.y) << 32) | __float_as_uint(z.x),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // Every word that is handed over is itself an agent-scope atomic access (coherent in L2 whichever CU asks:
+                // the stores write through, the loads bypass the vector cache), so no cache maintenance is wanted here -- an
+                // agent-scope release / acquire FENCE writes back and invalidates the whole L2 on this chip and made the
+                // kernel 7x slower.  What the order needs is that the row's stores have been acknowledged before the flag's
+                // store is issued: a workgroup-scope fence (s_waitcnt vmcnt(0)) and the barrier.
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();
+                if (tid == 0)
+                    __hip_atomic_store(p.fm_flag + my_slot, p.fm_tag + (unsigned long long)(unsigned)wg, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // (2) frames 1 .. nf - 1: the predecessor is in LDS
+#pragma unroll
+            for (int bb = 0; bb < NBT; ++bb) {
+                const int bin = tid + bb * kThreads5;
+                if (NB % kThreads5 != 0 && bin >= NB) break;
+                cf prev = buf[pad5<R>(bin)];
+                const cf inc = finc[bb];
+#pragma unroll
+                for (int f = 1; f < F; ++f) {
+                    if (f >= nf) break;
+                    const cf z = buf[f * RS + pad5<R>(bin)];
+                    emit(f, bin, z, prev, inc);
+                    prev = z;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // (3) frame 0: its predecessor is the last frame of the chunk before -- the row that chunk's workgroup published
+            //     (same XCD, dispatched eight blocks earlier: long there), or, for the first workgroup of an XCD's range, the
+            //     row this workgroup computed for itself before its own chunk.  The wait is bounded: a predecessor that never
+            //     arrives is counted (fm_err) and the frame's samples are computed against zeros.
+            const unsigned long long *src = halo_row;
+            if (!own_halo) {
+                const int ps = (wg - 1) % p.fm_slots;
+                src = p.fm_edge + (size_t)ps * NB;
+                if (tid == 0) {
+                    const unsigned long long want = p.fm_tag + (unsigned long long)(unsigned)(wg - 1);
+                    int tries = 0;
+                    while (__hip_atomic_load(p.fm_flag + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++tries > (1 << 21)) { atomicAdd(p.fm_err, 1); break; }
+                    }
+                }
+                __syncthreads();
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (the row's loads are issued after the flag was seen)
+#pragma unroll
+            for (int bb = 0; bb < NBT; ++bb) {
+                const int bin = tid + bb * kThreads5;
+                if (NB % kThreads5 != 0 && bin >= NB) break;
+                const unsigned long long w = __hip_atomic_load(src + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const cf prev = make_float2(__uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
+                emit(0, bin, buf[pad5<R>(bin)], prev, finc[bb]);
+            }
+            return;
+        }
 #pragma unroll
         for (int bb = 0; bb < NBT; ++bb) {
             const int bin = tid + bb * kThreads5;
@@ -452,32 +573,7 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
             for (int f = 0; f < F; ++f) {
                 if (f >= nf) break;
                 const cf z = buf[f * RS + pad5<R>(bin)];
-                // volk_32fc_x2_multiply_conjugate_32fc (unfused), then the turn by the rotator's increment
-                const float tr = __fadd_rn(__fmul_rn(z.x, prev.x), __fmul_rn(z.y, prev.y));
-                const float ti = __fsub_rn(__fmul_rn(z.y, prev.x), __fmul_rn(z.x, prev.y));
-                const float ur = __fsub_rn(__fmul_rn(tr, inc.x), __fmul_rn(ti, inc.y));
-                const float ui = __fadd_rn(__fmul_rn(tr, inc.y), __fmul_rn(ti, inc.x));
-#ifdef RCF_X_NOATAN
-                const float fm = ui + ur;
-#elif defined(RCF_X_NODISC)
-                const float fm = z.x;
-#else
-                const float fm = fast_atan2f_gr_lut(ui, ur, lookup);
-#endif
-                // one descriptor per frame row (scalar arithmetic, redone per bin column: a table of F of them is 64
-                // SGPRs at 400 bins and went to scratch)
-                const int64_t slot = (int64_t)((uint64_t)(n0 + f - p.n_abs0) & p.ring_mask);
-                const __amdgpu_buffer_rsrc_t fm_rsrc =
-                    __builtin_amdgcn_make_buffer_rsrc(p.fm_ring + slot * NB, 0, NB * (int)sizeof(float), 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fm), fm_rsrc, bin * (int)sizeof(float), 0, RCF_P5_STORE_AUX);
-                if constexpr (FM == FM_BOTH) {
-                    const __amdgpu_buffer_rsrc_t iq_rsrc =
-                        __builtin_amdgcn_make_buffer_rsrc(p.bins_ring + slot * NB, 0, NB * (int)sizeof(cf), 0x00020000);
-                    u32x2 o;
-                    o.x = __float_as_uint(z.x);
-                    o.y = __float_as_uint(z.y);
-                    __builtin_amdgcn_raw_buffer_store_b64(o, iq_rsrc, bin * (int)sizeof(cf), 0, RCF_P5_STORE_AUX);
-                }
+                emit(f, bin, z, prev, inc);
                 prev = z;
             }
             zprev[bb] = prev;
@@ -586,6 +682,32 @@ __global__ __launch_bounds__(kThreads5, pfb5_fm_waves(R, R3, OS, P)) void pfb5_f
     pfb5_fm_span<R, R3, OS, P, ZH, FM>(p, wg, threadIdx.x, buf);
 }
 
+// The look-back form of the same: ONE chunk per workgroup, as pfb5_kernel has it, and the frame before a chunk's first one
+// handed over by the workgroup of the chunk before (pfb5_chunk: LB).  Neighbouring chunks run on one XCD, eight blocks
+// apart in dispatch order: the wait at the end of the copy-out practically never waits.  Only the first workgroup of each
+// XCD's range (its predecessor chunk belongs to the END of another XCD's range, dispatched much later) computes the frame
+// before its chunk itself: eight halo chunks per launch instead of one per span.
+template <int R, int R3, int OS, int P, bool ZH, int FM>
+__global__ __launch_bounds__(kThreads5, pfb5_fm_waves(R, R3, OS, P)) void pfb5_fmlb_kernel(PfbLaunch p, int n_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+    constexpr int NB = R * R * R3;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x, q8 = n_wg / 8, r8 = n_wg % 8, xcd = b % 8;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    const bool own_halo = b / 8 == 0;
+    const cf tabpair = tid < 256 ? make_float2(p.atan_tab[tid], p.atan_tab[tid + 1]) : make_float2(0.f, 0.f);
+    unsigned long long *halo_row = p.fm_edge + (size_t)(p.fm_slots + xcd) * NB;
+    if (own_halo) {
+        int tid_h = tid;
+        asm volatile("" : "+v"(tid_h) :: "memory");        // (nothing of the halo chunk's addressing survives into the chunk proper)
+        pfb5_chunk<R, R3, OS, P, ZH, FM_HALO, true>(p, wg - 1, tid_h, buf, nullptr, tabpair, halo_row);
+        __syncthreads();
+    }
+    pfb5_chunk<R, R3, OS, P, ZH, FM, true>(p, wg, tid, buf, nullptr, tabpair, halo_row, own_halo);
+}
+
 // The banks of G front-ends in ONE launch (rcf_group.cpp; see pfb_group_kernel_os in pfb.hip): steady state only
 template <int R, int R3, int OS, int P>
 __global__ __launch_bounds__(kThreads5, 3) void pfb5_group_kernel(const PfbLaunch *__restrict__ pls, GroupMap gm)
@@ -644,9 +766,21 @@ void launch5_fm(const PfbLaunch &p0, hipStream_t s)
         attr.ensure(reinterpret_cast<const void *>(pfb5_fm_kernel<R, R3, OS, P, ZH_, FM_>), lds);                  \
         RCF_PFB_LAUNCH(p, (pfb5_fm_kernel<R, R3, OS, P, ZH_, FM_>), dim3(n_wg), dim3(kThreads5), lds, s, p, n_wg); \
     } while (0)
+#define RCF_FMLB_GO(ZH_, FM_)                                                                                         \
+    do {                                                                                                             \
+        static DynLdsAttr attr;                                                                                      \
+        attr.ensure(reinterpret_cast<const void *>(pfb5_fmlb_kernel<R, R3, OS, P, ZH_, FM_>), lds);                  \
+        RCF_PFB_LAUNCH(p, (pfb5_fmlb_kernel<R, R3, OS, P, ZH_, FM_>), dim3(n_chunks), dim3(kThreads5), lds, s, p, n_chunks); \
+    } while (0)
+    if (p.fm_edge) {                                     // look-back form: one chunk per workgroup
+        if (p.fm_mode == FM_ONLY) { if (zh) RCF_FMLB_GO(true, FM_ONLY); else RCF_FMLB_GO(false, FM_ONLY); }
+        else                      { if (zh) RCF_FMLB_GO(true, FM_BOTH); else RCF_FMLB_GO(false, FM_BOTH); }
+        return;
+    }
     if (p.fm_mode == FM_ONLY) { if (zh) RCF_FM_GO(true, FM_ONLY); else RCF_FM_GO(false, FM_ONLY); }
     else                      { if (zh) RCF_FM_GO(true, FM_BOTH); else RCF_FM_GO(false, FM_BOTH); }
 #undef RCF_FM_GO
+#undef RCF_FMLB_GO
 }
 
 template <int R, int R3, int OS, int P>

@@ -105,7 +105,7 @@ int rcf_pfb_close(rcf_t *h)
         else ++it;
     }
     bury(h, p.d_ptaps); bury(h, p.d_tw); bury(h, p.d_bins); bury(h, p.d_stage);
-    bury(h, p.d_fm); bury(h, p.d_fm_inc); bury(h, p.d_fm_stage);
+    bury(h, p.d_fm); bury(h, p.d_fm_inc); bury(h, p.d_fm_stage); bury(h, p.d_fm_edge); bury(h, p.d_fm_flag); bury(h, p.d_fm_err);
     p = Pfb();
     ++h->chans_epoch;
     return RCF_OK;
@@ -182,6 +182,17 @@ int rcf_pfb_fm_enable(rcf_t *h, int mode, int gr_phase)
         RCF_HIP(hipMalloc(&p.d_fm, sizeof(float) * ring));
         RCF_HIP(hipMemsetAsync(p.d_fm, 0, sizeof(float) * ring, h->stream));
         RCF_HIP(hipMalloc(&p.d_fm_inc, sizeof(float2) * (size_t)p.NB));
+        // the look-back form's hand-over rows (RCF_PFB5_FM_LOOKBACK=0: the span form, which needs none): more slots than
+        // workgroups can be resident at once, so a row is never rewritten while the chunk behind it still wants it
+        static const bool lookback = [] { const char *e = getenv("RCF_PFB5_FM_LOOKBACK"); return !e || atoi(e) != 0; }();
+        if (lookback) {
+            p.fm_slots = 4096;
+            RCF_HIP(hipMalloc(&p.d_fm_edge, sizeof(unsigned long long) * (size_t)(p.fm_slots + 8) * (size_t)p.NB));
+            RCF_HIP(hipMalloc(&p.d_fm_flag, sizeof(unsigned long long) * (size_t)p.fm_slots));
+            RCF_HIP(hipMalloc(&p.d_fm_err, sizeof(int)));
+            RCF_HIP(hipMemsetAsync(p.d_fm_flag, 0, sizeof(unsigned long long) * (size_t)p.fm_slots, h->stream));
+            RCF_HIP(hipMemsetAsync(p.d_fm_err, 0, sizeof(int), h->stream));
+        }
         p.rd_fm.assign((size_t)p.NB, p.produced);
         p.fm_from = p.produced;
     } else if (p.fm_mode == 0) {                       // switched on again: the frames in between were not demodulated
@@ -219,6 +230,20 @@ int64_t rcf_pfb_read_fm(rcf_t *h, int bin, float gain, float *out, size_t max_sa
     free_graveyard_idle(h);
     rd += n;
     return n;
+}
+
+int64_t rcf_pfb_fm_lost(rcf_t *h)
+{
+    if (!h) return RCF_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (set_dev(h)) return RCF_EHIP;
+    Pfb &p = h->pfb;
+    if (!p.open || !p.d_fm) { set_error("no discriminator ring"); return RCF_ESTATE; }
+    if (!p.d_fm_err) return 0;
+    int v = 0;
+    RCF_HIP(hipMemcpyAsync(&v, p.d_fm_err, sizeof v, hipMemcpyDeviceToHost, h->stream));
+    RCF_HIP(hipStreamSynchronize(h->stream));
+    return v;
 }
 
 int rcf_pfb_fm_ring(rcf_t *h, void **fm_ring, size_t *capacity_frames, int64_t *first_frame)

@@ -242,7 +242,7 @@ int rcf_close(rcf_t *h)
     h->chans.clear();
     Pfb &p = h->pfb;
     bury(h, p.d_ptaps); bury(h, p.d_tw); bury(h, p.d_bins); bury(h, p.d_stage);
-    bury(h, p.d_fm); bury(h, p.d_fm_inc); bury(h, p.d_fm_stage);
+    bury(h, p.d_fm); bury(h, p.d_fm_inc); bury(h, p.d_fm_stage); bury(h, p.d_fm_edge); bury(h, p.d_fm_flag); bury(h, p.d_fm_err);
     Scan &s = h->scan;
     bury(h, s.d_window); bury(h, s.d_vring); bury(h, s.d_sum); bury(h, s.d_out); bury(h, s.d_tw);
     bury(h, s.d_scratch); bury(h, s.d_peaks); bury(h, s.d_peak_ws);

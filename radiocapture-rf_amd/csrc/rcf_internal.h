@@ -327,6 +327,16 @@ struct PfbLaunch {
     const float2 *fm_inc;    // [NB] the rotator increment a GNU Radio channel on bin k would carry, as a phasor (1 + 0j: none)
     const float *atan_tab;   // gr::fast_atan2f's 257-entry table
     int32_t fm_mode, fm_span;
+    // ... or, instead of spans, ONE chunk per workgroup and the predecessor frame handed from workgroup to workgroup
+    // through global memory (pfb5_fmlb_kernel): fm_edge[slot][NB] holds the last frame of chunk `slot mod fm_slots` (complex
+    // bits as 64-bit words), fm_flag[slot] = fm_tag + chunk once it is there; rows fm_slots .. fm_slots + 7 are the
+    // predecessor frames the first workgroup of each XCD's range computes for itself.  fm_err counts predecessors that
+    // never arrived (a bounded wait).  nullptr: the span form above.
+    unsigned long long *fm_edge;
+    unsigned long long *fm_flag;
+    unsigned long long fm_tag;       // launch serial << 32
+    int32_t fm_slots;
+    int32_t *fm_err;
     // host side only (the kernels never look): events ATTACHED to the bank's dispatch (hipExtLaunchKernelGGL) instead of
     // a bracket of two event records around it (one barrier packet less inside the measured interval).  nullptr: plain launch.
     hipEvent_t ev_start, ev_stop;

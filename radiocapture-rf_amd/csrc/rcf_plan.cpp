@@ -167,6 +167,17 @@ int plan_pfb(rcf_t *h, BlockPlan &bp)
                 pl.atan_tab = h->d_atan;
                 pl.fm_mode = p.fm_mode;
                 pl.fm_span = 0;                 // chosen at the launch (pfb5_fm_span_for)
+                if (p.d_fm_edge) {              // look-back form: the chunks' workgroups hand their last frames over
+                    pl.fm_edge = p.d_fm_edge;
+                    pl.fm_flag = p.d_fm_flag;
+                    pl.fm_err = p.d_fm_err;
+                    pl.fm_slots = p.fm_slots;
+                    pl.fm_tag = (unsigned long long)(++p.fm_serial) << 32;
+                }
+            } else {
+                pl.fm_ring = nullptr;
+                pl.fm_edge = nullptr;
+                pl.fm_mode = 0;
             }
             run_pfb = true;
             p.produced = n_hi - p.n_abs0 + 1;

@@ -110,6 +110,11 @@ struct Pfb {
     float *d_fm_stage = nullptr;   // contiguous staging for rcf_pfb_read_fm
     int64_t fm_from = 0;           // first relative frame the discriminator ring holds
     int64_t fm_until = 0;          // (fm_mode == 0) the frame the discriminator was switched off at
+    // look-back form (pfb5_fmlb_kernel): edge rows + flags the chunks' workgroups hand their last frames over through
+    unsigned long long *d_fm_edge = nullptr, *d_fm_flag = nullptr;
+    int *d_fm_err = nullptr;
+    int fm_slots = 0;
+    uint64_t fm_serial = 0;        // launches so far (the flags' tags)
     std::vector<int64_t> rd_fm;    // per-bin read cursors
 };
 

@@ -29,7 +29,7 @@ SYMBOLS = [
     "rcf_push_iq", "rcf_ingest_ptr", "rcf_commit", "rcf_samples_in", "rcf_chan_open", "rcf_chan_open_taps",
     "rcf_chan_set_offset", "rcf_chan_close", "rcf_chan_info", "rcf_chan_produced", "rcf_chan_start", "rcf_chan_read_many", "rcf_chan_read_iq",
     "rcf_chan_read_fm", "rcf_chan_rings", "rcf_source_shift", "rcf_pfb_open", "rcf_pfb_close",
-    "rcf_pfb_produced", "rcf_pfb_read_bin", "rcf_pfb_rings", "rcf_pfb_fm_enable", "rcf_pfb_read_fm", "rcf_pfb_fm_ring", "rcf_pfb_chan_open", "rcf_scan_start",
+    "rcf_pfb_produced", "rcf_pfb_read_bin", "rcf_pfb_rings", "rcf_pfb_fm_enable", "rcf_pfb_read_fm", "rcf_pfb_fm_ring", "rcf_pfb_fm_lost", "rcf_pfb_chan_open", "rcf_scan_start",
     "rcf_scan_result", "rcf_scan_frames_done", "rcf_scan_result_device", "rcf_find_peaks",
     "rcf_peak_frequency", "rcf_scan_find_peaks", "rcf_timing_enable", "rcf_timing_read",
     "rcf_ingest_write", "rcf_push_raw", "rcf_chan_fm_filter", "rcf_chan_read_sym", "rcf_chan_fm_level",
@@ -152,6 +152,7 @@ def lib():
         "rcf_pfb_fm_enable": (C.c_int, [vp, C.c_int, C.c_int]),
         "rcf_pfb_read_fm": (i64, [vp, C.c_int, C.c_float, fp, sz]),
         "rcf_pfb_fm_ring": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(i64)]),
+        "rcf_pfb_fm_lost": (i64, [vp]),
         "rcf_pfb_rings": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
         "rcf_pfb_chan_open": (C.c_int, [vp, C.c_int, C.c_int, C.c_double, ip]),
         "rcf_pfb_tap_open": (C.c_int, [vp, C.c_int, C.c_int, ip]),
@@ -635,6 +636,9 @@ class Frontend:
         """the discriminator of EVERY bin in the bank's own kernel (rcf_pfb_fm_enable): mode 1 beside the bins ring, 2
         instead of it, 0 off"""
         _check(lib().rcf_pfb_fm_enable(self._h, int(mode), 1 if gr_phase else 0))
+
+    def pfb_fm_lost(self):
+        return _check(lib().rcf_pfb_fm_lost(self._h))
 
     def pfb_read_fm(self, bin_, gain=1.0, max_samples=1 << 20) -> np.ndarray:
         out = np.empty(max_samples, dtype=np.float32)
