@@ -101,8 +101,11 @@ enum { FM_OFF = 0, FM_BOTH = 1, FM_ONLY = 2, FM_HALO = 3 };
 constexpr int pfb5_bins_per_thread(int NB) { return (NB + kThreads5 - 1) / kThreads5; }
 
 // one chunk of one front-end's bank (shared by the single-front-end kernel and the grouped one: same instructions, same bits)
+// -DRCF_FM_RCP=1: the fused discriminator's quotient as num * v_rcp_f32(den) (fast_atan2f_gr.hpp) instead of the correctly
+// rounded division.  Measured at 1600 bins, discriminator ring only: 0.232 against 0.236 ms per 2^25 samples -- not worth
+// giving up the bits of tap_finalize's discriminator (and of gr::fast_atan2f) for.
 #ifndef RCF_FM_RCP
-#define RCF_FM_RCP 1                // the fused discriminator's quotient as num * v_rcp_f32(den) (fast_atan2f_gr.hpp)
+#define RCF_FM_RCP 0
 #endif
 
 // where entry e of gr::fast_atan2f's table sits in the chunk's LDS, as the PAIR (tab[e], tab[e + 1]) one lookup needs: the
@@ -317,12 +320,19 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
             // as the PAIR (tab[e], tab[e + 1]) one lookup needs, sits in spare slot e -- PADS = NB / R - 1 slots per row.  The
             // window DMA of every chunk runs over them, so thread e (which keeps its pair in two registers for the whole
             // span) puts it back here, once the window has been read and together with the first pass's own writes.
-            if (tid < 256) buf[pfb5_tab_slot<R, R3>(tid)] = tabpair;
+            if constexpr (!LB)
+                if (tid < 256) buf[pfb5_tab_slot<R, R3>(tid)] = tabpair;
         }
     }
     TS(1);
     __syncthreads();
     TS(2);
+    // (look-back form: the table pair is requested HERE, a whole second pass ahead of the barrier it is written behind -- at
+    // kernel entry two more dependent-address loads per thread set the first pass back, the reason the twiddle seeds are not
+    // requested there either)
+    cf tabpair_lb = make_float2(0.f, 0.f);
+    if constexpr (LB && (FM == FM_BOTH || FM == FM_ONLY))
+        if (tid < 256) tabpair_lb = make_float2(p.atan_tab[tid], p.atan_tab[tid + 1]);
 
     // ---- phase B: second pass + radix-R3 finish + stores, closed inside the 16 lanes of one k
     {
@@ -430,6 +440,8 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
             const int bin = tid + bb * kThreads5;
             finc[bb] = (NB % kThreads5 == 0 || bin < NB) ? p.fm_inc[bin] : make_float2(1.f, 0.f);
         }
+        if constexpr (LB)
+            if (tid < 256) buf[pfb5_tab_slot<R, R3>(tid)] = tabpair_lb;      // (spare slots: no pass of the FFT touches them)
     }
     __syncthreads();
     TS(4);
@@ -492,12 +504,20 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
             }
         };
         if constexpr (LB) {
-            // ---- look-back form: one chunk per workgroup, no arithmetic done twice.
-            // (1) the chunk's LAST frame goes to this chunk's edge row, then its flag: the workgroup of the next chunk needs
-            //     it for that chunk's first discriminator sample -- published FIRST, a whole copy-out before it is asked for
+            // ---- look-back form: one chunk per workgroup, no arithmetic done twice, no workgroup barrier added.
+            // A thread handles the same bins (tid + 320 bb) in every chunk, so the hand-over is WAVE to WAVE: wave w of this
+            // workgroup publishes its 64 x NBT words of the chunk's last frame and its own flag, wave w of the next chunk's
+            // workgroup waits for that flag only.
+            // Every word that is handed over is itself an agent-scope atomic access (coherent in L2 whichever CU asks: the
+            // stores write through, the loads bypass the vector cache), so no cache maintenance is wanted -- an agent-scope
+            // release / acquire FENCE pair writes back and invalidates the whole L2 on this chip and made the kernel 7x
+            // slower.  What the order needs is that a wave's row stores have been acknowledged before its flag store is
+            // issued: s_waitcnt vmcnt(0) of that wave alone.
+            const int wave = tid >> 6;
             const int my_slot = wg % p.fm_slots;
-            unsigned long long *edge = p.fm_edge + (size_t)my_slot * NB;
+            // (1) the chunk's LAST frame -> this chunk's edge row
             {
+                unsigned long long *edge = p.fm_edge + (size_t)my_slot * NB;
                 const cf *last = buf + (nf - 1) * RS;
 #pragma unroll
                 for (int bb = 0; bb < NBT; ++bb) {
@@ -507,18 +527,40 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
                     __hip_atomic_store(edge + bin, ((unsigned long long)__float_as_uint(z.y) << 32) | __float_as_uint(z.x),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                // Every word that is handed over is itself an agent-scope atomic access (coherent in L2 whichever CU asks:
-                // the stores write through, the loads bypass the vector cache), so no cache maintenance is wanted here -- an
-                // agent-scope release / acquire FENCE writes back and invalidates the whole L2 on this chip and made the
-                // kernel 7x slower.  What the order needs is that the row's stores have been acknowledged before the flag's
-                // store is issued: a workgroup-scope fence (s_waitcnt vmcnt(0)) and the barrier.
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __syncthreads();
-                if (tid == 0)
-                    __hip_atomic_store(p.fm_flag + my_slot, p.fm_tag + (unsigned long long)(unsigned)wg, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                // ... and the wave's flag, once its words have landed (measured: with the flag behind the frames 1 .. nf - 1
+                // work the wait is for THEIR streaming stores too, 0.248 -> 0.278 ms)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if ((tid & 63) == 0)
+                    __hip_atomic_store(p.fm_flag + (size_t)my_slot * 8 + wave, p.fm_tag + (unsigned long long)(unsigned)wg,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // (2) frames 1 .. nf - 1: the predecessor is in LDS
+            // (2) the predecessor of frame 0 is the last frame of the chunk before: the row that chunk's workgroup published
+            //     (same XCD, dispatched eight blocks earlier: usually there by now) or, for the first workgroup of an XCD's
+            //     range, the row this workgroup computed for itself before its own chunk.  Its words are REQUESTED here, if the
+            //     flag is already up, and used last: the loads (they bypass the vector cache) fly during the frames 1 .. nf - 1 work.
+            const unsigned long long *src = halo_row;
+            const unsigned long long *flag = nullptr;
+            unsigned long long want = 0;
+            bool have = own_halo;
+            if (!own_halo) {
+                const int ps = (wg - 1) % p.fm_slots;
+                src = p.fm_edge + (size_t)ps * NB;
+                flag = p.fm_flag + (size_t)ps * 8 + wave;
+                want = p.fm_tag + (unsigned long long)(unsigned)(wg - 1);
+                have = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
+                asm volatile("" ::: "memory");                         // (the row's loads are issued after the flag was seen)
+            }
+            unsigned long long pw[NBT];
+#pragma unroll
+            for (int bb = 0; bb < NBT; ++bb) pw[bb] = 0;
+            if (have) {
+#pragma unroll
+                for (int bb = 0; bb < NBT; ++bb) {
+                    const int bin = tid + bb * kThreads5;
+                    if (NB % kThreads5 == 0 || bin < NB) pw[bb] = __hip_atomic_load(src + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // (3) frames 1 .. nf - 1: the predecessor is in LDS
 #pragma unroll
             for (int bb = 0; bb < NBT; ++bb) {
                 const int bin = tid + bb * kThreads5;
@@ -534,31 +576,26 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // (3) frame 0: its predecessor is the last frame of the chunk before -- the row that chunk's workgroup published
-            //     (same XCD, dispatched eight blocks earlier: long there), or, for the first workgroup of an XCD's range, the
-            //     row this workgroup computed for itself before its own chunk.  The wait is bounded: a predecessor that never
-            //     arrives is counted (fm_err) and the frame's samples are computed against zeros.
-            const unsigned long long *src = halo_row;
-            if (!own_halo) {
-                const int ps = (wg - 1) % p.fm_slots;
-                src = p.fm_edge + (size_t)ps * NB;
-                if (tid == 0) {
-                    const unsigned long long want = p.fm_tag + (unsigned long long)(unsigned)(wg - 1);
-                    int tries = 0;
-                    while (__hip_atomic_load(p.fm_flag + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-                        __builtin_amdgcn_s_sleep(8);
-                        if (++tries > (1 << 21)) { atomicAdd(p.fm_err, 1); break; }
-                    }
+            // (4) frame 0.  A predecessor that was not there before is waited for now -- a bounded wait: one that never
+            //     arrives is counted (fm_err) and the frame's samples are computed against whatever the row holds.
+            if (!have) {
+                int tries = 0;
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++tries > (1 << 22)) { if ((tid & 63) == 0) atomicAdd(p.fm_err, 1); break; }
                 }
-                __syncthreads();
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int bb = 0; bb < NBT; ++bb) {
+                    const int bin = tid + bb * kThreads5;
+                    if (NB % kThreads5 == 0 || bin < NB) pw[bb] = __hip_atomic_load(src + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (the row's loads are issued after the flag was seen)
 #pragma unroll
             for (int bb = 0; bb < NBT; ++bb) {
                 const int bin = tid + bb * kThreads5;
                 if (NB % kThreads5 != 0 && bin >= NB) break;
-                const unsigned long long w = __hip_atomic_load(src + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const cf prev = make_float2(__uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
+                const cf prev = make_float2(__uint_as_float((unsigned)pw[bb]), __uint_as_float((unsigned)(pw[bb] >> 32)));
                 emit(0, bin, buf[pad5<R>(bin)], prev, finc[bb]);
             }
             return;
@@ -697,7 +734,7 @@ __global__ __launch_bounds__(kThreads5, pfb5_fm_waves(R, R3, OS, P)) void pfb5_f
     const int b = blockIdx.x, q8 = n_wg / 8, r8 = n_wg % 8, xcd = b % 8;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
     const bool own_halo = b / 8 == 0;
-    const cf tabpair = tid < 256 ? make_float2(p.atan_tab[tid], p.atan_tab[tid + 1]) : make_float2(0.f, 0.f);
+    const cf tabpair = make_float2(0.f, 0.f);              // (requested inside the chunk: pfb5_chunk, LB)
     unsigned long long *halo_row = p.fm_edge + (size_t)(p.fm_slots + xcd) * NB;
     if (own_halo) {
         int tid_h = tid;

@@ -329,7 +329,7 @@ struct PfbLaunch {
     int32_t fm_mode, fm_span;
     // ... or, instead of spans, ONE chunk per workgroup and the predecessor frame handed from workgroup to workgroup
     // through global memory (pfb5_fmlb_kernel): fm_edge[slot][NB] holds the last frame of chunk `slot mod fm_slots` (complex
-    // bits as 64-bit words), fm_flag[slot] = fm_tag + chunk once it is there; rows fm_slots .. fm_slots + 7 are the
+    // bits as 64-bit words), fm_flag[8 slot + wave] = fm_tag + chunk once that wave's part of it is there; rows fm_slots .. fm_slots + 7 are the
     // predecessor frames the first workgroup of each XCD's range computes for itself.  fm_err counts predecessors that
     // never arrived (a bounded wait).  nullptr: the span form above.
     unsigned long long *fm_edge;

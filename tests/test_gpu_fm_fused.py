@@ -77,7 +77,7 @@ SHAPES = [
 
 
 @pytest.mark.parametrize("fs,cr,os_", SHAPES)
-def test_fused_discriminator_is_the_discriminator_only_tap_and_cut_invariant(gpu_required, fs, cr, os_):
+def test_fused_discriminator_has_the_bits_of_a_discriminator_only_tap(gpu_required, fs, cr, os_):
     nat = gpu_required
     D, taps = G.channel_params(fs, cr)
     nb = os_ * D
@@ -95,12 +95,9 @@ def test_fused_discriminator_is_the_discriminator_only_tap_and_cut_invariant(gpu
     only, _ = _fused(nat, fs, nb, D, taps, x, cuts_b, bins, 2)
     for b, r, a_, o_ in zip(bins, ref, both, only):
         assert len(r) >= frames - 1 and len(a_) == len(r) == len(o_), (b, len(r), len(a_), len(o_))
-        # the same bits whichever mode and however the stream is cut ...
-        assert _same_bits(a_, o_), (b, float(np.max(np.abs(a_ - o_))), int(np.argmax(np.abs(a_ - o_))))
-        # ... and the discriminator-only tap's arithmetic up to the quotient's last bits (the fused kernel takes it as
-        # num * v_rcp_f32(den): fast_atan2f_gr.hpp) -- a few 1e-7 rad, +-pi wraps of a noise bin being the same angle
-        d = np.angle(np.exp(1j * (a_.astype(np.float64) - r)))
-        assert np.max(np.abs(d)) < 1e-6, (b, float(np.max(np.abs(d))), int(np.argmax(np.abs(d))))
+        # the bits of the discriminator-only tap (tap_finalize's arithmetic), whichever mode and however the stream is cut
+        assert _same_bits(a_, r), (b, float(np.max(np.abs(a_ - r))), int(np.argmax(np.abs(a_ - r))))
+        assert _same_bits(o_, r), (b, float(np.max(np.abs(o_ - r))), int(np.argmax(np.abs(o_ - r))))
 
 
 def test_fused_discriminator_within_budget_of_the_gr_faithful_oracle(gpu_required):
