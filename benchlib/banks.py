@@ -186,8 +186,11 @@ def reference_grid_leg(native, tile, device, B=1 << 25, n_taps=256):
                               "tap and the discriminator fused in (pfb_ms = the bank incl. the matrix, tap_finalize_ms = "
                               "that kernel).  Points: 256 scattered bins (matrix), all 1600 bins (ring)",
                       "points": tap_points},
-        "fused_discriminator": {"kernel": "pfb5_fm_kernel<20,4,2,2>", "points": fused,
-                                "note": "every one of the 1600 bins demodulated in the bank's own launch: a workgroup walks "
-                                        "a span of chunks and keeps each bin's last frame in registers; one extra chunk per "
-                                        "span (the halo) is computed and not stored"},
+        "fused_discriminator": {"kernel": "pfb5_fmlb_kernel<20,4,2,2>", "points": fused,
+                                "two_kernel_path_ms_per_block": next((p["pfb_ms_per_block"] + p["tap_finalize_ms_per_block"]
+                                                                      for p in tap_points if p.get("discriminator_only")), None),
+                                "note": "every one of the 1600 bins demodulated in the bank's own launch (one chunk per "
+                                        "workgroup, the frame before a chunk handed over wave to wave through L2): 8 + 8 bytes "
+                                        "per input sample in mode 2 against the 8 + 16 of the bank plus the 16 + 8 of a "
+                                        "tap_finalize pass behind it (two_kernel_path_ms_per_block)"},
     }

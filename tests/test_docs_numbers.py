@@ -16,7 +16,7 @@ def test_documents_quote_what_the_tracked_profiles_say():
     assert g.apply(R, check=True) == [], "run: python tools/gen_docs_numbers.py %s" % R
     for doc in g.DOCS:
         text = open(os.path.join(ROOT, doc)).read()
-        m = re.search(r"<!-- numbers:measured (r\d+) -->", text)
+        m = re.search(r"<!-- numbers:(?:measured|summary) (r\d+) -->", text)
         assert m and m.group(1) == R, (doc, "block is not of the newest round with a bench line")
 
 

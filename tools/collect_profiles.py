@@ -119,6 +119,10 @@ pmc_record("%s_pfb3200b" % R, "pfb5_kernel", "profiles/%s_pfb3200_d800_pmc.json"
     "workload": "tools/pfb_probe.py NB=3200 CR=12500 BLOCK=2^25: 3200-bin bank, D = 800, 2909 taps (3 launches after idling); algorithmic 40 B/sample = 1342.2 MB",
     "algorithmic_read_bytes": 8.0 * (1 << 25), "algorithmic_bytes": 40.0 * (1 << 25),
     "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024"})
+pmc_record("%s_pfb1600fm" % R, "pfb5_fmlb_kernel", "profiles/%s_pfb1600_fused_pmc.json" % R, {
+    "workload": "tools/pfb_probe.py NB=1600 FMFUSED=2 BLOCK=2^25: the 1600-bin bank with the discriminator of every bin fused in, discriminator ring only (pfb5_fmlb_kernel); algorithmic 8 + 8 B/sample = 536.9 MB",
+    "algorithmic_read_bytes": 8.0 * (1 << 25), "algorithmic_bytes": 16.0 * (1 << 25),
+    "how_to_read": "HBM bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024; the hand-over rows (one frame per chunk, written through L2 and read back by the next chunk's workgroup) are part of the traffic: 4 + 4 B per input sample at most"})
 pmc_record("%s_tapfin" % R, "tap_finalize", "profiles/%s_tap_finalize_pmc.json" % R, {
     "workload": "tools/pfb_probe.py NB=1600 TAPS=1600 BLOCK=2^25: tap_finalize_kernel with every bin of the 1600-bin bank open as a channel (41943 frames x 1600 taps per launch; 3 launches after idling)",
     "algorithmic_read_bytes": 8.0 * 1600 * 41943, "algorithmic_bytes": 20.0 * 1600 * 41943,
@@ -169,7 +173,11 @@ if os.path.exists(src) and open(src).read().strip():
 f = newest("gpurun_out/%s_trace_group/**/*kernel_stats.csv" % R)
 if f:
     shutil.copy(f, "profiles/%s_group_capacity_kernel_stats.csv" % R)
-for tag in ("bench", "bench_cfg5", "bench_head_under_rocprof", "bench_2ranks_1gpu", "sustained_60s", "unpinned_bounds", "hbm_mix_probe"):
+for tag in ("pfb1600_limiter_pmc", "pfb1600_fused_limiter_pmc", "fused_discriminator_timings"):
+    src = "gpurun_out/%s_%s.txt" % (R, tag)
+    if os.path.exists(src) and open(src).read().strip():
+        shutil.copy(src, "profiles/%s_%s.txt" % (R, tag))
+for tag in ("bench", "bench_line", "bench_cfg5", "bench_head_under_rocprof", "bench_2ranks_1gpu", "sustained_60s", "unpinned_bounds", "hbm_mix_probe"):
     src = "gpurun_out/%s_%s.json" % (R, tag)
     if os.path.exists(src):
         text = open(src).read()

@@ -141,6 +141,15 @@ def measured_block(R):
             add("| … with %d bins tapped and demodulated%s | bank %.4f ms (%.2f × untapped), finalize %.4f ms | `…with_taps.points[]` |"
                 % (pt["bins_tapped"], " (discriminator only: `rcf_chan_set_fm_only`)" if pt.get("discriminator_only") else "",
                    pt["pfb_ms_per_block"], pt["pfb_over_untapped"], pt["tap_finalize_ms_per_block"]))
+    fd = (g or {}).get("fused_discriminator")
+    if fd:
+        for pt in fd.get("points", []):
+            if "error" in pt:
+                continue
+            add("| … every bin demodulated INSIDE the bank's launch (`rcf_pfb_fm_enable(%d)`: %s) | %.4f ms per 2^25 block (%.2f × the untapped bank%s); %.0f MB algorithmic ⇒ %s of 8 TB/s | `…fused_discriminator.points[]` |"
+                % (pt["mode"], pt["what"], pt["pfb_ms_per_block"], pt["over_untapped_bank"],
+                   "; the bank + `tap_finalize` path: %.4f ms" % fd["two_kernel_path_ms_per_block"] if fd.get("two_kernel_path_ms_per_block") and pt["mode"] == 2 else "",
+                   pt["algorithmic_bytes_per_launch"] / 1e6, f3(pt["frac_of_hbm_peak"])))
     t32 = [(_j("%s_pfb3200_d1600_pmc.json" % R), 1600), (_j("%s_pfb3200_d800_pmc.json" % R), 800)]
     if all(t and "fetch_x2_over_algorithmic_read" in t for t, _ in t32):
         add("| 3200-bin banks, PMC passes of `tools/pfb_probe.py` | %s | `%s_pfb3200_d1600_pmc.json`, `%s_pfb3200_d800_pmc.json` |"
@@ -157,6 +166,18 @@ def measured_block(R):
         add("| scan (BASELINE configs[2]: N = 2^20 × 1000 frames, 100-frame sum) | FFT+log %.2f ms, running sum %.2f ms, pick %.2f ms; %.0f Msamples/s; **%s** of the HBM peak; %d peaks | `%s_bench.json`: `scan` |"
             % (sc["fft_logmag_ms"], sc["moving_sum_ms"], sc["peak_pick_ms_incl_readback"], sc["input_Msamples_per_s"],
                f3(sc["roofline"]["frac"]), sc["peaks_found"], R))
+    sr = b.get("scan_ref")
+    if sr and "roofline" in sr:
+        add("| scan at the reference's own size (`fft_vector.py:31-60`: fs = 2.4 Msps, N = 16384, 1000 frames / 100-frame average) | FFT+log %.3f ms, running sum %.3f ms, pick %.3f ms; %.0f Msamples/s = %.0f × real time; %s of the HBM peak on 12 B/sample (FFT pass alone %s); %d peaks | `%s_bench.json`: `scan_ref` |"
+            % (sr["fft_logmag_ms"], sr["moving_sum_ms"], sr["peak_pick_ms_incl_readback"], sr["input_Msamples_per_s"],
+               sr.get("realtime_factor_at_2.4Msps", 0.0), f3(sr["roofline"]["frac"]), f3(sr["roofline"].get("frac_fft_pass_alone", 0.0)),
+               sr["peaks_found"], R))
+    dm = b.get("daemon")
+    if dm and "error" not in dm:
+        add("| **the product's data plane** (`rcf.receiver` + `rcf.dataplane.NativeDataPlane`: source rings → native pump → per-channel host rings → `socket.send`), %d × 20 Msps u8 sources, %d channels, %.1f s | %.0f Msamples/s in, %d blocks of %.1f ms: %d late, %d overruns, latency p99 %.2f / max %.2f ms; every channel delivered %.0f–%.0f samples/s (%d of %d), %.0f MB/s to the sockets | `%s_bench.json`: `daemon` |"
+            % (dm["sources"], dm["channels"], dm["seconds"], dm["input_Msps"], dm["blocks"], dm["block_ms"], dm["late_blocks"],
+               dm["overruns"], dm["latency_ms_p99"], dm["latency_ms_max"], dm["channel_rate_min_sps"], dm["channel_rate_max_sps"],
+               dm["channels_delivering"], dm["channels"], dm["egress_MBps"], R))
     e = b.get("end_to_end")
     if e:
         add("| PCIe-inclusive ingest (never `value`) | cf32 %.0f Msamples/s, u8 %.0f Msamples/s | `%s_bench.json`: `end_to_end` |"
@@ -208,10 +229,14 @@ def measured_block(R):
     cb = b.get("cpu_baseline")
     if cb and "all_cores" in cb:
         ac = cb["all_cores"]
-        add("| CPU baseline (oracle C port, %d physical cores) | one channel on one core %.1f × real time; all cores, reference structure %.0f real-time channels (%.0f GB/s of stream reads, host read bandwidth %.0f GB/s); SURVEY formula cores × single-core %.0f; time-tiled best CPU %.0f | `%s_bench.json`: `cpu_baseline` |"
-            % (cb["cores"], cb["single_channel_one_core"]["realtime_channels_per_core_at_20Msps"],
-               ac["reference_structure_measured"]["realtime_channels"], ac["reference_structure_measured"]["stream_read_GBps"],
-               ac["host_read_bandwidth_GBps"], ac["survey_formula_cores_x_single_core"]["realtime_channels"],
+        hc = cb.get("host_cgroup") or {}
+        add("| CPU baseline (oracle C port; %d threads under a CPU quota of %s cores, box: %d physical cores; throttled %.0f ms during the leg) | one channel on one core %.1f × real time; reference structure on those threads %.0f real-time channels; threads × single-core %.0f; SURVEY formula (every physical core × single-core, an upper bound under the quota) %.0f; time-tiled best CPU %.0f | `%s_bench.json`: `cpu_baseline` |"
+            % (cb["cores"], hc.get("cpu_quota_cores", "?"), cb.get("box_physical_cores", 0), hc.get("throttled_ms", 0.0),
+               cb["single_channel_one_core"]["realtime_channels_per_core_at_20Msps"],
+               ac["reference_structure_measured"]["realtime_channels"],
+               (ac.get("formula_threads_x_single_core") or {}).get("realtime_channels", 0.0),
+               ac["survey_formula_box_cores_x_single_core"]["realtime_channels"] if "survey_formula_box_cores_x_single_core" in ac
+               else ac["survey_formula_cores_x_single_core"]["realtime_channels"],
                ac["best_cpu_time_tiled_measured"]["realtime_channels"], R))
         if "gpu_channels_run_in_real_time_over_cpu_realtime_channels" in cb:
             add("| GPU / CPU concurrent channels at 20 Msps | %.1f × (against the largest CPU figure, %.0f) | `cpu_baseline.gpu_channels_run_in_real_time_over_cpu_realtime_channels` |"
@@ -269,6 +294,67 @@ def measured_block(R):
     return "\n".join(L)
 
 
+def summary_block(R):
+    """a dozen lines for DESIGN.md 5 and README.md; the full table is profiles/README.md"""
+    b = _j("%s_bench.json" % R)
+    if b is None:
+        return "(no %s_bench.json under profiles/)" % R
+    ro = b["roofline"]
+    L = ["Measured on one MI355X, round %s (`profiles/%s_bench.json`; every row of the full table in `profiles/README.md` names its file and key):" % (R[1:].lstrip("0"), R), ""]
+    add = L.append
+    add("* headline: **%.0f Msamples/s** of input IQ (256 bins + 32 FM channels per front-end, block 2^25), step %.4f ms; the filterbank launch %.1f µs ⇒ %.0f GB/s = **%s of the 8 TB/s HBM peak** (HIP events in the timed region), PMC traffic %.3f × algorithmic"
+        % (b["value"], b["ms_per_step"], ro["avg_launch_ms"] * 1e3, ro["achieved"], f3(ro["frac"]),
+           (ro.get("traffic") or 0) / ro["algorithmic_bytes_per_launch"] if ro.get("traffic") else float("nan")))
+    st = _stats("%s_bench_kernel_stats.csv" % R, r"pfb_kernel_os<256, 1, 14, 4, false>")
+    if st:
+        add("* the same kernel by `rocprofv3 --kernel-trace --stats`: %.1f µs over %d launches ⇒ %s (`%s_bench_kernel_stats.csv`)"
+            % (st["avg_us"], st["calls"], f3(ro["algorithmic_bytes_per_launch"] / (st["avg_us"] * 1e-6) / 1e9 / 8000.0), R))
+    fa = ro.get("filterbank_alone")
+    su = b.get("sustained")
+    if fa and su:
+        add("* the filterbank alone %s; sustained (%.1f s of back-to-back commits) last window %s" % (f3(fa["frac"]), su["seconds"], f3(su["frac_last_window"])))
+    db = (b.get("channels") or {}).get("direct_bank")
+    cb = b.get("cpu_baseline") or {}
+    if db and "channels_run_in_real_time" in db:
+        add("* reference-shaped direct bank (2909-tap xlating FIR /800 + discriminator per channel, FP32 matrix cores): **%d channels** opened and run in real time at 20 Msps%s"
+            % (db["channels_run_in_real_time"],
+               " = %.1f × the largest CPU figure (%.0f channels: every physical core of the box × the measured single-core rate)" % (
+                   cb["gpu_channels_run_in_real_time_over_cpu_realtime_channels"], cb["largest_cpu_realtime_channels"])
+               if "gpu_channels_run_in_real_time_over_cpu_realtime_channels" in cb else ""))
+    g = (b.get("channels") or {}).get("reference_grid_filterbank")
+    if g and "roofline" in g:
+        line = "* 1600-bin reference-grid bank (every bin one `channel.py` channel): %.4f ms per 2^25 block = %s" % (g["pfb_ms_per_block"], f3(g["roofline"]["frac"]))
+        fd = g.get("fused_discriminator") or {}
+        p2 = next((p for p in fd.get("points", []) if p.get("mode") == 2 and "error" not in p), None)
+        if p2:
+            line += "; all 1600 bins demodulated inside the bank's launch: **%.4f ms**" % p2["pfb_ms_per_block"]
+            if fd.get("two_kernel_path_ms_per_block"):
+                line += " (bank + `tap_finalize`: %.4f ms)" % fd["two_kernel_path_ms_per_block"]
+        add(line)
+    sc, sr = b.get("scan"), b.get("scan_ref")
+    if sc and "roofline" in sc:
+        add("* scan: N = 2^20 × 1000 frames %s of the HBM peak on 12 B/sample%s" % (
+            f3(sc["roofline"]["frac"]), "; the reference's own size (N = 16384) %.0f × real time" % sr["realtime_factor_at_2.4Msps"] if sr and "realtime_factor_at_2.4Msps" in sr else ""))
+    rt = b.get("realtime") or {}
+    cells = []
+    for shape, label in (("pfb256", "256-bin bank + 32 FM"), ("grid1600", "1600-bin bank, 256 bins demodulated")):
+        s_ = rt.get(shape)
+        if s_ and "K_max" in s_:
+            a = s_.get("at_K_max") or {}
+            cells.append("%s: K_max **%d** front-ends (p99 %.1f ms, %d misses in the confirmation run)" % (label, s_["K_max"], a.get("latency_ms_p99") or 0, a.get("deadline_misses", 0)))
+    if cells:
+        add("* paced real time (20 Msps u8 per front-end at wall-clock rate, native pumps): " + "; ".join(cells))
+    dm = b.get("daemon")
+    if dm and "error" not in dm:
+        add("* the product's own data plane (`rcf.dataplane`): %d × 20 Msps sources, %d channels all delivered, %d late blocks of %d, latency p99 %.2f ms"
+            % (dm["sources"], dm["channels"], dm["late_blocks"] + dm["overruns"], dm["blocks"], dm["latency_ms_p99"]))
+    if "value" in cb:
+        add("* CPU baseline (C restatement of the GNU Radio path, %d threads under the container's quota): %.1f real-time channels per core" % (
+            cb.get("cores", 0), (cb.get("single_channel_one_core") or {}).get("realtime_channels_per_core_at_20Msps", 0.0)))
+    add("* multi-GPU scaling: unmeasured (no 8-GPU node has run it yet)")
+    return "\n".join(L)
+
+
 def files_block(R):
     """what is tracked for the round (profiles/README.md)"""
     L = ["| file | present |", "|---|---|"]
@@ -278,7 +364,7 @@ def files_block(R):
     return "\n".join(L)
 
 
-BLOCKS = {"measured": measured_block, "files": files_block}
+BLOCKS = {"measured": measured_block, "summary": summary_block, "files": files_block}
 DOCS = ["DESIGN.md", "README.md", os.path.join("profiles", "README.md")]
 
 

@@ -15,7 +15,7 @@
 # gpurun merges only gpurun_out/ back: run `python tools/collect_profiles.py <R>` locally afterwards.
 # Counter passes never share a run with trace domains other than --kernel-trace.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 cd "$(dirname "$0")/.."
 ROOT=$PWD
 mkdir -p profiles gpurun_out
@@ -23,11 +23,15 @@ export TMPDIR=/tmp
 date -u +%Y-%m-%dT%H:%MZ > gpurun_out/${R}_when.txt
 mark() { echo "[$(date +%T)] $*"; }
 
-python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
-python bench.py --steps 20 --warmup 5 --config cfg5 > gpurun_out/${R}_bench_cfg5.json 2> gpurun_out/${R}_bench_cfg5.err
+# (round 6: the LAST stdout line is the compact object the driver parses -> <R>_bench_line.json; the full record, which the
+# generated tables read, is what bench.py leaves in gpurun_out/bench_full.json -> <R>_bench.json.  Every auxiliary run below
+# prints its full record on stdout.)
+python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench.err
+cp gpurun_out/bench_full.json gpurun_out/${R}_bench.json
+python bench.py --steps 20 --warmup 5 --config cfg5 --full-on-stdout > gpurun_out/${R}_bench_cfg5.json 2> gpurun_out/${R}_bench_cfg5.err
 
 mark benches done
-HEAD="python $ROOT/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-sustained"
+HEAD="python $ROOT/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-sustained --full-on-stdout"
 rm -rf gpurun_out/${R}_trace gpurun_out/${R}_trace_legs gpurun_out/${R}_trace_cfg5
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace -- $HEAD > gpurun_out_head.json 2>/dev/null; cp gpurun_out_head.json $ROOT/gpurun_out/${R}_bench_head_under_rocprof.json)
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace_cfg5 -- $HEAD --config cfg5 > /dev/null 2>&1)
@@ -50,7 +54,7 @@ rm -rf gpurun_out/${R}_pmc_clock
 (cd /tmp && timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $ROOT/gpurun_out/${R}_pmc_clock -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > /dev/null 2>&1)
 
 # the N > 1 code on this 1-GPU box: bench.py starts its own two ranks, both on device 0 (host transport: RCCL cannot span one device twice)
-RCF_BENCH_DEVICE=0 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_2ranks_1gpu.json 2> gpurun_out/${R}_bench_2ranks_1gpu.err
+RCF_BENCH_DEVICE=0 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-extras --no-cpu-baseline --full-on-stdout > gpurun_out/${R}_bench_2ranks_1gpu.json 2> gpurun_out/${R}_bench_2ranks_1gpu.err
 
 mark clock + 2 ranks done
 tools/fir_pmc.sh ${R}_fir4096 C=4096 > /dev/null 2>&1
@@ -60,6 +64,13 @@ PROBE=tools/pfb_probe.py KERNEL=pfb5_kernel tools/fir_pmc.sh ${R}_pfb1600 NB=160
 PROBE=tools/pfb_probe.py KERNEL=tap_finalize tools/fir_pmc.sh ${R}_tapfin NB=1600 BLOCK=33554432 TAPS=1600 TIME_ALL=1 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb5_kernel tools/fir_pmc.sh ${R}_pfb3200a NB=3200 CR=6250 BLOCK=33554432 > /dev/null 2>&1
 PROBE=tools/pfb_probe.py KERNEL=pfb5_kernel tools/fir_pmc.sh ${R}_pfb3200b NB=3200 CR=12500 BLOCK=33554432 > /dev/null 2>&1
+PROBE=tools/pfb_probe.py KERNEL=pfb5_fmlb_kernel tools/fir_pmc.sh ${R}_pfb1600fm NB=1600 BLOCK=33554432 FMFUSED=2 > /dev/null 2>&1
+# what bounds the 1600-bin bank, and the bank with the discriminator fused in: issue / wait counters in small sets
+LIM=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM")
+PROBE=tools/pfb_probe.py KERNEL=pfb5_kernel tools/pmc_sets.sh ${R}_pfb1600_limiter "${LIM[@]}" -- NB=1600 BLOCK=33554432 WARM=20 > /dev/null 2>&1
+PROBE=tools/pfb_probe.py KERNEL=pfb5_fmlb_kernel tools/pmc_sets.sh ${R}_pfb1600_fused_limiter "${LIM[@]}" -- NB=1600 BLOCK=33554432 WARM=20 FMFUSED=2 > /dev/null 2>&1
+# the fused-discriminator timings next to the bank's and the two-kernel path's (un-profiled, HIP events from librcf)
+( for rep in 1 2 3; do echo -n "bank: "; NB=1600 WARM=200 STEPS=100 python tools/pfb_probe.py; echo -n "fused, discriminator ring only (look-back): "; NB=1600 WARM=200 STEPS=100 FMFUSED=2 python tools/pfb_probe.py; echo -n "fused, beside the bins ring: "; NB=1600 WARM=200 STEPS=100 FMFUSED=1 python tools/pfb_probe.py; echo -n "fused, span form: "; RCF_PFB5_FM_LOOKBACK=0 NB=1600 WARM=200 STEPS=100 FMFUSED=2 python tools/pfb_probe.py; echo -n "bank + tap_finalize, 1600 discriminator-only taps: "; NB=1600 WARM=100 STEPS=50 TAPS=1600 TAPSEQ=1 FMONLY=1 TIME_ALL=1 python tools/pfb_probe.py; done ) 2>&1 | grep -v "^ROCm\|^Hostname\|^Librccl\|^RCCL\|^HIP version" > gpurun_out/${R}_fused_discriminator_timings.txt
 mark probe pmc passes done
 # the real-time leg under the kernel trace: one fixed point per shape (no search), and the busy-GPU counterpart
 for spec in "pfb256 1024" "grid1600 768"; do
@@ -73,7 +84,7 @@ rm -rf gpurun_out/${R}_trace_group
 (cd /tmp && timeout 600 env G=80 SECONDS=3 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace_group -- python $ROOT/tools/group_probe.py > $ROOT/gpurun_out/${R}_group_capacity_under_rocprof.json 2>/dev/null)
 mark rt + group traces done
 # one minute of back-to-back commits of the timed configuration (the "sustained" of the metric, at length)
-python bench.py --no-extras --no-cpu-baseline --no-live-traffic --rt-seconds 0 --sustained-seconds 60 > gpurun_out/${R}_sustained_60s.json 2> /dev/null
+python bench.py --no-extras --no-cpu-baseline --no-live-traffic --rt-seconds 0 --sustained-seconds 60 --full-on-stdout > gpurun_out/${R}_sustained_60s.json 2> /dev/null
 # what the memory system sustains for the kernels' read : write mixes with no arithmetic at all
 [ -x tools/hbm_mix_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/hbm_mix_probe tools/hbm_mix_probe.hip
 timeout 300 tools/hbm_mix_probe json > gpurun_out/${R}_hbm_mix_probe.json 2> /dev/null
