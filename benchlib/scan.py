@@ -56,12 +56,15 @@ def scan_leg(native, synth, device):
 def scan_ref_leg(native, synth, device):
     """The scan at the size the reference runs it (fft_vector.py:31-60 as the scanner starts it): fs = 2.4 Msps,
     N = 16384, 1000 frames, 100-frame average, then the peak pick (fft_peak_detection.py:38-73).  16384 points fit the
-    LDS: one pass (window + FFT + shift + |.|^2 + log10 -> frame-major ring), then the running sum.  125 periodic frames
-    resident (16 MB), eight commits per scan; SURVEY 8(d) cfg3's reference-sized variant (seed 3004, 5 carriers)."""
-    N, F, L, fs, U = 16384, 1000, 100, 2.4e6, 125
+    LDS: one pass (window + FFT + shift + |.|^2 + log10 -> frame-major ring), then the running sum.  All 1000 frames of
+    the scan are resident (131 MB: 125 periodic frames x 8) and go out as ONE commit -- a transform of this size is one
+    workgroup per CU (139 KB of LDS), so a launch wants many more than 256 frames; with 125 frames per commit (round 6's
+    first form of this leg) half the chip idled and a launch lasted 20 us.  SURVEY 8(d) cfg3's reference-sized variant
+    (seed 3004, 5 carriers)."""
+    N, F, L, fs, U = 16384, 1000, 100, 2.4e6, 1000
     carriers = [(2000, 9000.0, 25.0), (5200, 12500.0, 30.0), (8192 + 900, 7000.0, 22.0), (11000, 20000.0, 28.0),
                 (15000, 12500.0, 26.0)]          # tests/test_gpu_parity.py: SCAN_CARRIERS_3004 -> lines 2004, 5195, 9089, 15000
-    x = synth.scan_stream(fs, N, U, carriers, seed=3004)
+    x = np.tile(synth.scan_stream(fs, N, 125, carriers, seed=3004), U // 125)
     B = N * U
     fe = native.Frontend(fs, 855.05e6, device=device, block_capacity=B, hist_capacity=1 << 16, out_capacity=1 << 10)
     for _ in range(2):

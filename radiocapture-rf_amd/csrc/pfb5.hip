@@ -745,6 +745,48 @@ __global__ __launch_bounds__(kThreads5, pfb5_fm_waves(R, R3, OS, P)) void pfb5_f
     pfb5_chunk<R, R3, OS, P, ZH, FM, true>(p, wg, tid, buf, nullptr, tabpair, halo_row, own_halo);
 }
 
+// ... and the banks of G front-ends with the discriminator fused in, in ONE launch (rcf_group.cpp): the same hand-over inside
+// every front-end's run of chunks; the first chunk of a front-end (its predecessor frame is the previous BLOCK's last one)
+// computes the chunk before it itself, like the first workgroup of an XCD's range.  Steady state only.
+template <int R, int R3, int OS, int P, int FM>
+__global__ __launch_bounds__(kThreads5, pfb5_fm_waves(R, R3, OS, P)) void pfb5_fmlb_group_kernel(const PfbLaunch *__restrict__ pls, GroupMap gm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *buf = reinterpret_cast<cf *>(smem_raw);
+    constexpr int NB = R * R * R3;
+    const int tid = threadIdx.x;
+    int fe, wg;
+    group_resolve(gm, blockIdx.x, fe, wg);
+    const PfbLaunch p = pls[fe];
+    const bool own_halo = blockIdx.x / 8 == 0 || wg == 0;
+    const cf tabpair = make_float2(0.f, 0.f);
+    // (rows fm_slots .. fm_slots + 7: the XCD ranges' first workgroups; row fm_slots + 8: the front-end's first chunk)
+    unsigned long long *halo_row = p.fm_edge + (size_t)(p.fm_slots + (wg == 0 ? 8 : (int)(blockIdx.x % 8))) * NB;
+    if (own_halo) {
+        int tid_h = tid;
+        asm volatile("" : "+v"(tid_h) :: "memory");
+        pfb5_chunk<R, R3, OS, P, false, FM_HALO, true>(p, wg - 1, tid_h, buf, nullptr, tabpair, halo_row);
+        __syncthreads();
+    }
+    pfb5_chunk<R, R3, OS, P, false, FM, true>(p, wg, tid, buf, nullptr, tabpair, halo_row, own_halo);
+}
+
+template <int R, int R3, int OS, int P>
+void launch5_fmlb_group(const PfbLaunch &shape, const PfbLaunch *d_pls, const GroupMap &gm, hipStream_t s)
+{
+    constexpr int NB = R * R * R3, F = 16 / R3;
+    const size_t lds = (size_t)pfb5_buf(NB, R, F, OS, P) * sizeof(cf);
+    if (shape.fm_mode == FM_ONLY) {
+        static DynLdsAttr attr;
+        attr.ensure(reinterpret_cast<const void *>(pfb5_fmlb_group_kernel<R, R3, OS, P, FM_ONLY>), lds);
+        hipLaunchKernelGGL((pfb5_fmlb_group_kernel<R, R3, OS, P, FM_ONLY>), dim3(gm.total_wg), dim3(kThreads5), lds, s, d_pls, gm);
+    } else {
+        static DynLdsAttr attr;
+        attr.ensure(reinterpret_cast<const void *>(pfb5_fmlb_group_kernel<R, R3, OS, P, FM_BOTH>), lds);
+        hipLaunchKernelGGL((pfb5_fmlb_group_kernel<R, R3, OS, P, FM_BOTH>), dim3(gm.total_wg), dim3(kThreads5), lds, s, d_pls, gm);
+    }
+}
+
 // The banks of G front-ends in ONE launch (rcf_group.cpp; see pfb_group_kernel_os in pfb.hip): steady state only
 template <int R, int R3, int OS, int P>
 __global__ __launch_bounds__(kThreads5, 3) void pfb5_group_kernel(const PfbLaunch *__restrict__ pls, GroupMap gm)
@@ -871,10 +913,20 @@ bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s)
 bool pfb5_dispatch_group(const PfbLaunch &p, const PfbLaunch *d_pls, const GroupMap &gm, hipStream_t s)
 {
     if (p.D <= 0 || p.NB % p.D) return false;
-    if (p.fm_ring) return false;                         // the fused-discriminator banks of a group run one by one
     const int OS = p.NB / p.D;
     const int PR = pfb5_padded_p(p.NB, p.D, p.P);
     if (PR == 0) return false;
+    if (p.fm_ring) {
+        if (!p.fm_edge) return false;                    // (the span form has no grouped kernel: one by one)
+#define RCF_PFB5FG(R_, R3_, OS_, P_)                                \
+        if (p.NB == R_ * R_ * R3_ && OS == OS_ && PR == P_) {        \
+            launch5_fmlb_group<R_, R3_, OS_, P_>(p, d_pls, gm, s);   \
+            return true;                                             \
+        }
+        RCF_PFB5FG(20, 4, 2, 2) RCF_PFB5FG(20, 8, 4, 1) RCF_PFB5FG(20, 2, 2, 2) RCF_PFB5FG(20, 1, 2, 2)
+#undef RCF_PFB5FG
+        return false;
+    }
 #define RCF_PFB5G(R_, R3_, OS_, P_)                                 \
     if (p.NB == R_ * R_ * R3_ && OS == OS_ && PR == P_) {            \
         launch5_group<R_, R3_, OS_, P_>(d_pls, gm, s);               \
@@ -884,6 +936,16 @@ bool pfb5_dispatch_group(const PfbLaunch &p, const PfbLaunch *d_pls, const Group
     RCF_PFB5G(20, 4, 2, 2) RCF_PFB5G(20, 8, 4, 1) RCF_PFB5G(20, 8, 2, 2) RCF_PFB5G(20, 2, 2, 2) RCF_PFB5G(20, 1, 2, 2)
 #undef RCF_PFB5G
     return false;
+}
+
+// whether the launch's halo chunks (the chunk before its first frame, recomputed by the workgroups that have no predecessor
+// inside the launch) reach before the stream's start: such a launch takes the zero-history kernel, alone
+bool pfb5_fm_sees_zero_history(const PfbLaunch &p)
+{
+    if (p.D <= 0 || p.NB % p.D || p.NB % 400) return true;
+    const int R3 = p.NB / 400, F = 16 / R3, OS = p.NB / p.D;
+    const int PR = pfb5_padded_p(p.NB, p.D, p.P);
+    return (p.n_lo - F - (int64_t)OS * (PR - 1)) * (int64_t)p.D - (p.NB - 1) < p.start_sample;
 }
 
 bool pfb5_fm_supported(int NB, int D, int P)

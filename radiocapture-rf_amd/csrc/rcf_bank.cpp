@@ -187,7 +187,7 @@ int rcf_pfb_fm_enable(rcf_t *h, int mode, int gr_phase)
         static const bool lookback = [] { const char *e = getenv("RCF_PFB5_FM_LOOKBACK"); return !e || atoi(e) != 0; }();
         if (lookback) {
             p.fm_slots = 4096;
-            RCF_HIP(hipMalloc(&p.d_fm_edge, sizeof(unsigned long long) * (size_t)(p.fm_slots + 8) * (size_t)p.NB));
+            RCF_HIP(hipMalloc(&p.d_fm_edge, sizeof(unsigned long long) * (size_t)(p.fm_slots + 9) * (size_t)p.NB));
             RCF_HIP(hipMalloc(&p.d_fm_flag, sizeof(unsigned long long) * (size_t)p.fm_slots * 8));      // one flag per wave of a chunk's workgroup
             RCF_HIP(hipMalloc(&p.d_fm_err, sizeof(int)));
             RCF_HIP(hipMemsetAsync(p.d_fm_flag, 0, sizeof(unsigned long long) * (size_t)p.fm_slots * 8, h->stream));

@@ -111,14 +111,19 @@ int rcfx::group_process(rcf_group *g, const std::vector<GroupItem> &items, int f
     // ---- 4. what goes out together
     // filterbanks: members of one shape in steady state share a launch
     struct BankGroup { std::vector<size_t> idx; const PfbLaunch *d_pls = nullptr; GroupMap gm{}; };
-    std::map<std::tuple<int, int, int>, BankGroup> banks;
+    std::map<std::tuple<int, int, int, int>, BankGroup> banks;       // (bins, decimation, taps per branch, fused-discriminator mode)
     std::vector<size_t> bank_singles;
     for (size_t i = 0; i < NI; ++i) {
         BlockPlan &bp = *plans[i];
         if (!bp.run_pfb) continue;
         bp.pl.ev_start = bp.pl.ev_stop = nullptr;
-        if (pfb_sees_zero_history(bp.pl) || bp.pl.fm_ring) { bank_singles.push_back(i); continue; }   // (fused-discriminator banks: one by one)
-        banks[std::make_tuple(bp.pl.NB, bp.pl.D, pfb_padded_p(bp.pl.NB, bp.pl.D, bp.pl.P))].idx.push_back(i);
+        // (a fused-discriminator bank joins a grouped launch in its look-back form only, and not while the chunk before
+        // its first frame -- which its first workgroup recomputes -- reaches before the stream's start)
+        if (pfb_sees_zero_history(bp.pl) || (bp.pl.fm_ring && (!bp.pl.fm_edge || pfb5_fm_sees_zero_history(bp.pl)))) {
+            bank_singles.push_back(i);
+            continue;
+        }
+        banks[std::make_tuple(bp.pl.NB, bp.pl.D, pfb_padded_p(bp.pl.NB, bp.pl.D, bp.pl.P), bp.pl.fm_ring ? bp.pl.fm_mode : 0)].idx.push_back(i);
     }
     for (auto it = banks.begin(); it != banks.end();) {
         BankGroup &bg = it->second;

@@ -330,7 +330,8 @@ struct PfbLaunch {
     // ... or, instead of spans, ONE chunk per workgroup and the predecessor frame handed from workgroup to workgroup
     // through global memory (pfb5_fmlb_kernel): fm_edge[slot][NB] holds the last frame of chunk `slot mod fm_slots` (complex
     // bits as 64-bit words), fm_flag[8 slot + wave] = fm_tag + chunk once that wave's part of it is there; rows fm_slots .. fm_slots + 7 are the
-    // predecessor frames the first workgroup of each XCD's range computes for itself.  fm_err counts predecessors that
+    // predecessor frames the first workgroup of each XCD's range computes for itself, row fm_slots + 8 the one a front-end's
+    // first chunk in a GROUPED launch computes.  fm_err counts predecessors that
     // never arrived (a bounded wait).  nullptr: the span form above.
     unsigned long long *fm_edge;
     unsigned long long *fm_flag;
@@ -459,6 +460,7 @@ bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s);
 // halo chunk reaches back over, and the per-bin increment table inc[k] = (float)(cos, sin)(dangle[k]) -- computed on the
 // device with tap_finalize's own sincos_fast, so that both paths turn the discriminator's product by the same bits
 bool pfb5_fm_supported(int NB, int D, int P);
+bool pfb5_fm_sees_zero_history(const PfbLaunch &p);
 size_t pfb5_fm_history(int NB, int D, int P);
 void launch_pfb5_fm_inc(const double *d_dangle, float2 *d_inc, int NB, hipStream_t s);
 inline bool pfb_frame_major(int NB) { return NB % 25 == 0; }

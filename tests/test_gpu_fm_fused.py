@@ -193,3 +193,54 @@ def test_fused_discriminator_beside_taps_and_switching(gpu_required):
             assert np.max(np.abs(d)) < 2e-6, (i, float(np.max(np.abs(d))))
         # mode 1 keeps the bins ring: the bin read back is the tap's bare stream
         assert len(fb.pfb_read_bin(21)) > 0
+
+
+def test_fused_discriminator_in_a_grouped_launch_has_the_bits_of_one_by_one(gpu_required):
+    """G front-ends whose banks demodulate every bin, pushed as group blocks (rcf_group_push: ONE bank launch for all of
+    them, pfb5_fmlb_group_kernel) -- ragged rounds, a member skipped in one of them: the discriminator rings hold the
+    bits of the same front-ends run one by one."""
+    nat = gpu_required
+    fs = 5e6
+    D, taps = G.channel_params(fs, 12500)
+    nb = 2 * D
+    G_ = 3
+    rng = np.random.default_rng(313)
+    xs = [_signal(rng, fs, D * 900 + 50, nb, [11 + 40 * m, nb - 7 - m]) for m in range(G_)]
+    rounds = [[D * 100 + 3, D * 80, D * 120], [D * 200, D * 150 + 1, 0], [D * 300 - 3, D * 250, D * 260 + 9], [D * 90, 0, D * 100]]
+    bins = [0, 11, 51, 91, nb - 7, nb - 8, nb - 9, nb // 2, 333]
+    out = {}
+    for which in ("grouped", "one by one"):
+        fes = []
+        for m in range(G_):
+            fe = nat.Frontend(fs, 0.0, device=0, block_capacity=D * 300, hist_capacity=1 << 15, out_capacity=1 << 12)
+            fe.pfb_open(nb, D, taps)
+            fe.pfb_fm_enable(2, gr_phase=True)
+            fes.append(fe)
+        grp = nat.Group(fes) if which == "grouped" else None
+        at = [0] * G_
+        got = [[[] for _ in bins] for _ in range(G_)]
+        for r in rounds:
+            blocks = [xs[m][at[m]:at[m] + r[m]] if r[m] else None for m in range(G_)]
+            for m in range(G_):
+                at[m] += r[m]
+            if grp is not None:
+                grp.push(blocks, nat.FMT_CF32)
+            else:
+                for m in range(G_):
+                    if blocks[m] is not None:
+                        fes[m].push(blocks[m])
+            for m in range(G_):
+                for i, b in enumerate(bins):
+                    got[m][i].append(fes[m].pfb_read_fm(b, 1.0))
+        for fe in fes:
+            assert fe.pfb_fm_lost() == 0
+        if grp is not None:
+            grp.close()
+        for fe in fes:
+            fe.close()
+        out[which] = [[np.concatenate(g_) for g_ in gm] for gm in got]
+    for m in range(G_):
+        for i, b in enumerate(bins):
+            a_, o_ = out["grouped"][m][i], out["one by one"][m][i]
+            assert len(a_) == len(o_) > 400, (m, b, len(a_), len(o_))
+            assert _same_bits(a_, o_), (m, b, float(np.max(np.abs(a_ - o_))), int(np.argmax(np.abs(a_ - o_))))

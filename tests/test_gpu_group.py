@@ -328,3 +328,114 @@ def test_receiver_feed_all_is_the_sources_fed_one_by_one(gpu_required):
             tb.close()
     for (gi, gf), (si, sf) in zip(*res):
         assert len(gi) > 2000 and _same_bits(gi, si) and _same_bits(gf, sf)
+
+
+def test_pump_subscriptions_come_and_go_and_a_counter_fed_member(gpu_required):
+    """channels are subscribed and unsubscribed under the RUNNING pump (rcf_pump_subscribe / rcf_pump_unsubscribe: the
+    reference creates and destroys channel flowgraphs under its running top block, rc_frontend/receiver.py:296-342,
+    :635-648): an IQ slot and a discriminator slot of the same channel side by side, a slot reused by another channel
+    (its new tenant's stream starts at the returned cursor), a slot whose channel is closed under the pump (it starves,
+    nothing else does); member 1 is fed by a producer that counts its blocks complete (rcf_pump_config_t.written)
+    instead of the pump's clock.  Everything delivered equals the same blocks pushed one front-end at a time."""
+    nat = gpu_required
+    fs, blk, n_blocks = 3.2e6, 64000, 14
+    srcs = []
+    for m in range(2):
+        rng = np.random.default_rng(2001 + m)
+        xm = synth.awgn(rng, n_blocks * blk).astype(np.complex128)
+        xm += synth.nbfm_carrier(len(xm), fs, -2 * fs / 64, 650.0 + 100 * m, 2500.0, synth.snr_amp(30.0, 12500.0, fs))
+        srcs.append(_u8(xm.astype(np.complex64)))
+
+    def open_all():
+        fes, ids = [], []
+        for m in range(2):
+            fe = nat.Frontend(fs, 0.0, device=0, block_capacity=blk, hist_capacity=1 << 13, out_capacity=1 << 13)
+            fe.pfb_open(64, 64, G.low_pass_2(1.0, fs, fs / 64 * 0.4, fs / 64 * 0.2, 60.0, G.WIN_BLACKMAN_HARRIS))
+            ids.append([fe.pfb_chan_open((b - 2) % 64, 12500, 0.0) for b in range(3)])
+            fes.append(fe)
+        return fes, ids
+
+    fes, ids = open_all()
+    ring0 = nat.PinnedArray(len(srcs[0]), np.uint8)
+    ring0.array[:] = srcs[0]                                  # member 0: the whole stream, replayed by the pump's clock
+    ring1 = nat.PinnedArray(4 * blk * 2, np.uint8)            # member 1: a ring of four blocks, filled by a producer
+    ring1.array[:] = 0
+    counter = np.zeros(1, dtype=np.uint64)
+    grp = nat.Group(fes)
+    pump = nat.Pump(grp, [ring0, ring1], blk, fs, (), fmt=nat.FMT_U8, scale=1.0 / 32, offset=127.4, what="iq",
+                    out_ring_samples=1 << 14, n_blocks=n_blocks, max_read=4, written=[None, counter], start_delay_s=0.05)
+    period = blk / fs
+    got = {}
+
+    def drain(name, slot):
+        got.setdefault(name, []).append(pump.read(slot))
+
+    # before the first block: member 0's channel 0 as IQ AND as discriminator x 5, member 1's channel 1 as IQ
+    s_iq = pump.subscribe(0, ids[0][0], "iq")
+    s_fm = pump.subscribe(0, ids[0][0], "fm", 5.0)
+    s_b = pump.subscribe(1, ids[1][1], "iq")
+    assert len({s_iq, s_fm, s_b}) == 3
+    s_c = pump.subscribe(0, ids[0][2], "iq")
+    with pytest.raises(nat.RcfError):
+        pump.subscribe(1, ids[1][0], "iq")                    # max_read = 4 slots, all taken
+    with pytest.raises(nat.RcfError):
+        pump.unsubscribe(17)
+    t0 = time.perf_counter() + 0.05
+    fed = 0
+    swapped = closed = False
+    while pump.running():
+        now = time.perf_counter() - t0
+        while fed < n_blocks and now >= (fed + 1) * period:   # the producer of member 1: block `fed` is complete
+            at = (fed % 4) * blk * 2
+            ring1.array[at:at + 2 * blk] = srcs[1][2 * fed * blk: 2 * (fed + 1) * blk]
+            fed += 1
+            counter[0] = fed
+        if not swapped and now > 5.2 * period:
+            # the slot of member 0's channel 2 goes to member 1's channel 2: what it delivered so far is the old tenant's
+            drain("c", s_c)
+            pump.unsubscribe(s_c)
+            s_d = pump.subscribe(1, ids[1][2], "iq")
+            assert s_d == s_c                                  # the freed slot is the one handed out
+            swapped = True
+        if not closed and now > 9.2 * period:
+            fes[1].chan_close(ids[1][1])                       # closed under the pump: its slot starves, nobody else
+            closed = True
+        drain("iq", s_iq), drain("fm", s_fm), drain("b", s_b)
+        if swapped:
+            drain("d", s_d)
+        time.sleep(0.002)
+    st = pump.stats()
+    assert st["error"] == 0 and st["blocks_done"] == 2 * n_blocks, st
+    drain("iq", s_iq), drain("fm", s_fm), drain("b", s_b), drain("d", s_d)
+    pump.stop()
+    grp.close()
+    produced_b = None
+    for fe in fes:
+        fe.close()
+    g = {k: np.concatenate(v) for k, v in got.items()}
+    # the same blocks one front-end at a time
+    fes, ids2 = open_all()
+    want = {}
+    for b in range(n_blocks):
+        for m in range(2):
+            fes[m].push_raw(srcs[m][2 * b * blk: 2 * (b + 1) * blk], nat.FMT_U8, 1.0 / 32, 127.4)
+        want.setdefault("iq", []).append(fes[0].chan_read_iq(ids2[0][0]))
+        want.setdefault("fm", []).append(fes[0].chan_read_fm(ids2[0][0], 5.0))
+        want.setdefault("b", []).append(fes[1].chan_read_iq(ids2[1][1]))
+        want.setdefault("c", []).append(fes[0].chan_read_iq(ids2[0][2]))
+        want.setdefault("d", []).append(fes[1].chan_read_iq(ids2[1][2]))
+    w = {k: np.concatenate(v) for k, v in want.items()}
+    for fe in fes:
+        fe.close()
+    ring0.free()
+    ring1.free()
+    assert len(g["iq"]) == len(w["iq"]) > 3000 and _same_bits(g["iq"], w["iq"])
+    assert len(g["fm"]) == len(w["fm"]) and _same_bits(g["fm"], w["fm"])
+    # the channel that was closed under the pump delivered a whole number of blocks' worth of its stream, then nothing
+    nb_ = len(g["b"])
+    assert 0 < nb_ < len(w["b"]) and _same_bits(g["b"], w["b"][:nb_])
+    # the slot's first tenant up to the hand-over, its second from the hand-over on: the channel existed all along, so its
+    # reader stood at its first output and the pump delivers it from there as far as the device ring reaches (all of it here)
+    nc = len(g["c"])
+    assert 0 < nc < len(w["c"]) and _same_bits(g["c"], w["c"][:nc])
+    assert len(g["d"]) == len(w["d"]) and _same_bits(g["d"], w["d"])

@@ -355,6 +355,62 @@ def summary_block(R):
     return "\n".join(L)
 
 
+def _pmc_txt(name):
+    """{counter: average per dispatch} of a tools/pmc_sets.sh summary"""
+    f = os.path.join(P, name)
+    if not os.path.exists(f):
+        return None
+    out = {}
+    for line in open(f):
+        m = re.match(r"(\w+)\s+([0-9.]+)\s+\(n=", line)
+        if m:
+            out[m.group(1)] = float(m.group(2))
+    return out or None
+
+
+def limiter_block(R):
+    """what bounds the 1600-bin bank and the bank with the discriminator fused in, from the counter passes"""
+    L, seen = [], []
+    for fname, label in (("%s_pfb1600_limiter_pmc.txt" % R, "`pfb5_kernel<20,4,2,2>` (1600 bins, D = 800, block 2^25)"),
+                         ("%s_pfb1600_fused_limiter_pmc.txt" % R, "`pfb5_fmlb_kernel<20,4,2,2>` (the same bank, every bin demodulated, discriminator ring only)")):
+        c = _pmc_txt(fname)
+        if not c or "GRBM_GUI_ACTIVE" not in c:
+            continue
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0                      # per XCD = the dispatch's duration in shader clocks
+        simds, cus = 1024.0, 256.0
+        seen.append((c, cyc))
+        parts = ["%s, `%s`: %.0f k shader cycles per dispatch under the counters" % (label, fname, cyc / 1e3)]
+        if "SQ_WAVE_CYCLES" in c:
+            parts.append("%.1f waves resident per SIMD on average (`SQ_WAVE_CYCLES` × 4 / 1024 SIMDs / cycles; 3.75 = three workgroups of five waves per CU, the LDS limit)" % (c["SQ_WAVE_CYCLES"] * 4 / simds / cyc))
+        if "SQ_ACTIVE_INST_VALU" in c:
+            parts.append("the vector ALU issues in **%.0f %%** of the cycles (`SQ_ACTIVE_INST_VALU` × 4 / 1024 / cycles; %.1f M wave-instructions, `SQ_INSTS_VALU`)" % (
+                100 * c["SQ_ACTIVE_INST_VALU"] * 4 / simds / cyc, c.get("SQ_INSTS_VALU", 0) / 1e6))
+        if "SQ_INSTS_LDS" in c and "SQ_LDS_BANK_CONFLICT" in c:
+            parts.append("LDS: %.1f M instructions, %.2f bank-conflict cycles per instruction, the LDS pipe busy in %.0f %% of a CU's cycles (`SQ_ACTIVE_INST_LDS` × 4 / 256 CUs / cycles)" % (
+                c["SQ_INSTS_LDS"] / 1e6, c["SQ_LDS_BANK_CONFLICT"] / c["SQ_INSTS_LDS"], 100 * c.get("SQ_ACTIVE_INST_LDS", 0) * 4 / cus / cyc))
+        if "SQ_WAIT_INST_ANY" in c and "SQ_WAVE_CYCLES" in c:
+            parts.append("a resident wave waits on an outstanding instruction %.0f %% of its time (`SQ_WAIT_INST_ANY` / `SQ_WAVE_CYCLES`), %.0f %% on LDS alone (`SQ_WAIT_INST_LDS`)" % (
+                100 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 100 * c.get("SQ_WAIT_INST_LDS", 0) / c["SQ_WAVE_CYCLES"]))
+        if "SQ_INSTS_VMEM_RD" in c:
+            parts.append("%.2f M vector-memory reads and %.2f M writes" % (c["SQ_INSTS_VMEM_RD"] / 1e6, c.get("SQ_INSTS_VMEM_WR", 0) / 1e6))
+        L.append("* " + "; ".join(parts) + ".")
+    if not L:
+        return "(no limiter counter files for %s)" % R
+    L.append("")
+    text = ("Reading: no unit is saturated — not HBM (the fractions of the table above), not the vector ALU, not the LDS pipe.  "
+            "A chunk is 53.7 KB of LDS, which allows three workgroups of five waves per CU and no fourth: with fewer than four "
+            "waves per SIMD there is not enough independent work to cover one phase's latencies (the window's DMA, two barrier-"
+            "separated FFT passes, the copy-out) with another's.")
+    if len(seen) == 2 and all("SQ_INSTS_VALU" in c for c, _ in seen):
+        (c0, y0), (c1, y1) = seen
+        text += ("  With the discriminator fused in the kernel issues %.2f × the vector instructions of the bank and lasts %.2f × as "
+                 "long under the counters, at about the same VALU utilisation: its time follows the vector instruction count, not "
+                 "the bytes (it moves a third of the bytes of the bank + `tap_finalize` path) — the discriminator of a frame is as "
+                 "many VALU instructions as the bank's own arithmetic for it." % (c1["SQ_INSTS_VALU"] / c0["SQ_INSTS_VALU"], y1 / y0))
+    L.append(text)
+    return "\n".join(L)
+
+
 def files_block(R):
     """what is tracked for the round (profiles/README.md)"""
     L = ["| file | present |", "|---|---|"]
@@ -364,7 +420,7 @@ def files_block(R):
     return "\n".join(L)
 
 
-BLOCKS = {"measured": measured_block, "summary": summary_block, "files": files_block}
+BLOCKS = {"measured": measured_block, "summary": summary_block, "limiter": limiter_block, "files": files_block}
 DOCS = ["DESIGN.md", "README.md", os.path.join("profiles", "README.md")]
 
 
