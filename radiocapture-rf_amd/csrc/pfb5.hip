@@ -45,6 +45,9 @@
 // out (RCF_EXPLICIT_FMA).  Tried and dropped (git history): one frame per wavefront, 1600 = 25 x 64 with the 64-point
 // part done across the lanes by shuffles -- no barriers at all, but 1.7x the arithmetic: 0.118 ms against 0.111.
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #define RCF_EXPLICIT_FMA 1
 #include "fft_core.hpp"
@@ -107,6 +110,30 @@ constexpr int pfb5_bins_per_thread(int NB) { return (NB + kThreads5 - 1) / kThre
 #ifndef RCF_FM_RCP
 #define RCF_FM_RCP 0
 #endif
+
+// The words one workgroup hands to the next (look-back form).  Two ways, chosen per launch (PfbLaunch::fm_local):
+//   agent scope   atomic stores that write through and atomic loads that miss the vector cache: right wherever the two
+//                 workgroups run;
+//   one XCD's L2  plain stores (the vector cache writes through to L2, the write-back L2 keeps the line) and the same loads
+//                 (they miss the vector cache and are served by L2): right when producer and consumer share an L2 -- which the
+//                 chunk map arranges (neighbouring chunks are eight blocks apart, block b runs on XCD b mod 8) and which the
+//                 host VERIFIES on the device before it asks for this mode (pfb5_xcd_map_ok: a probe launch reads every
+//                 block's XCC_ID).  Measured at 1600 bins: 0.245 -> 0.229 ms per 2^25 samples.  Either way the rows are HBM
+//                 traffic in the counters (+ 4 + 4 B per input sample: the ring of rows, 52 MB, does not stay in 4 MB of L2 per
+//                 XCD next to the streamed input), and a hand-over that does not arrive is counted (fm_err).
+__device__ __forceinline__ void ho_store(const bool local, unsigned long long *row, const int i, const unsigned long long v)
+{
+    if (local) row[i] = v;
+    else       __hip_atomic_store(row + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ho_load(const bool local, const __amdgpu_buffer_rsrc_t rsrc, const unsigned long long *base,
+                                                      const size_t word)
+{
+    // (the load is the agent-scope one either way -- it has to miss the vector cache, and sc0 alone does not: measured, a
+    // poll with sc0 never sees the flag; what the local mode changes is the STORE: plain, so that the line stays in L2)
+    (void)local; (void)rsrc;
+    return __hip_atomic_load(base + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // where entry e of gr::fast_atan2f's table sits in the chunk's LDS, as the PAIR (tab[e], tab[e + 1]) one lookup needs: the
 // frame rows have a spare complex after every R -- 256 / F of them are used per row
@@ -409,8 +436,7 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
             if constexpr (LB) {
                 // (a global row instead of registers: the thread reads its own words back after the chunk proper)
                 if (NB % kThreads5 == 0 || bin < NB)
-                    __hip_atomic_store(halo_row + bin, ((unsigned long long)__float_as_uint(z.y) << 32) | __float_as_uint(z.x),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ho_store(p.fm_local != 0, halo_row, bin, ((unsigned long long)__float_as_uint(z.y) << 32) | __float_as_uint(z.x));
             } else {
                 zprev[bb] = z;
             }
@@ -515,6 +541,11 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
             // issued: s_waitcnt vmcnt(0) of that wave alone.
             const int wave = tid >> 6;
             const int my_slot = wg % p.fm_slots;
+            const bool local = p.fm_local != 0;
+            const __amdgpu_buffer_rsrc_t edge_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                p.fm_edge, 0, (int)((size_t)(p.fm_slots + 9) * NB * sizeof(unsigned long long)), 0x00020000);
+            const __amdgpu_buffer_rsrc_t flag_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                p.fm_flag, 0, (int)((size_t)p.fm_slots * 8 * sizeof(unsigned long long)), 0x00020000);
             // (1) the chunk's LAST frame -> this chunk's edge row
             {
                 unsigned long long *edge = p.fm_edge + (size_t)my_slot * NB;
@@ -524,30 +555,28 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
                     const int bin = tid + bb * kThreads5;
                     if (NB % kThreads5 != 0 && bin >= NB) break;
                     const cf z = last[pad5<R>(bin)];
-                    __hip_atomic_store(edge + bin, ((unsigned long long)__float_as_uint(z.y) << 32) | __float_as_uint(z.x),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ho_store(local, edge, bin, ((unsigned long long)__float_as_uint(z.y) << 32) | __float_as_uint(z.x));
                 }
                 // ... and the wave's flag, once its words have landed (measured: with the flag behind the frames 1 .. nf - 1
                 // work the wait is for THEIR streaming stores too, 0.248 -> 0.278 ms)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if ((tid & 63) == 0)
-                    __hip_atomic_store(p.fm_flag + (size_t)my_slot * 8 + wave, p.fm_tag + (unsigned long long)(unsigned)wg,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ho_store(local, p.fm_flag, my_slot * 8 + wave, p.fm_tag + (unsigned long long)(unsigned)wg);
             }
             // (2) the predecessor of frame 0 is the last frame of the chunk before: the row that chunk's workgroup published
             //     (same XCD, dispatched eight blocks earlier: usually there by now) or, for the first workgroup of an XCD's
             //     range, the row this workgroup computed for itself before its own chunk.  Its words are REQUESTED here, if the
             //     flag is already up, and used last: the loads (they bypass the vector cache) fly during the frames 1 .. nf - 1 work.
-            const unsigned long long *src = halo_row;
-            const unsigned long long *flag = nullptr;
+            size_t src_w = (size_t)(halo_row - p.fm_edge);             // the predecessor row's first word in the edge buffer
+            size_t flag_w = 0;
             unsigned long long want = 0;
             bool have = own_halo;
             if (!own_halo) {
                 const int ps = (wg - 1) % p.fm_slots;
-                src = p.fm_edge + (size_t)ps * NB;
-                flag = p.fm_flag + (size_t)ps * 8 + wave;
+                src_w = (size_t)ps * NB;
+                flag_w = (size_t)ps * 8 + wave;
                 want = p.fm_tag + (unsigned long long)(unsigned)(wg - 1);
-                have = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
+                have = ho_load(local, flag_rsrc, p.fm_flag, flag_w) == want;
                 asm volatile("" ::: "memory");                         // (the row's loads are issued after the flag was seen)
             }
             unsigned long long pw[NBT];
@@ -557,7 +586,7 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
 #pragma unroll
                 for (int bb = 0; bb < NBT; ++bb) {
                     const int bin = tid + bb * kThreads5;
-                    if (NB % kThreads5 == 0 || bin < NB) pw[bb] = __hip_atomic_load(src + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (NB % kThreads5 == 0 || bin < NB) pw[bb] = ho_load(local, edge_rsrc, p.fm_edge, src_w + bin);
                 }
             }
             // (3) frames 1 .. nf - 1: the predecessor is in LDS
@@ -580,15 +609,16 @@ __device__ __forceinline__ void pfb5_chunk(const PfbLaunch &p, const int wg, con
             //     arrives is counted (fm_err) and the frame's samples are computed against whatever the row holds.
             if (!have) {
                 int tries = 0;
-                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+                while (ho_load(local, flag_rsrc, p.fm_flag, flag_w) != want) {
                     __builtin_amdgcn_s_sleep(4);
+                    asm volatile("" ::: "memory");                     // (every poll is a load)
                     if (++tries > (1 << 22)) { if ((tid & 63) == 0) atomicAdd(p.fm_err, 1); break; }
                 }
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int bb = 0; bb < NBT; ++bb) {
                     const int bin = tid + bb * kThreads5;
-                    if (NB % kThreads5 == 0 || bin < NB) pw[bb] = __hip_atomic_load(src + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (NB % kThreads5 == 0 || bin < NB) pw[bb] = ho_load(local, edge_rsrc, p.fm_edge, src_w + bin);
                 }
             }
 #pragma unroll
@@ -946,6 +976,50 @@ bool pfb5_fm_sees_zero_history(const PfbLaunch &p)
     const int R3 = p.NB / 400, F = 16 / R3, OS = p.NB / p.D;
     const int PR = pfb5_padded_p(p.NB, p.D, p.P);
     return (p.n_lo - F - (int64_t)OS * (PR - 1)) * (int64_t)p.D - (p.NB - 1) < p.start_sample;
+}
+
+namespace {
+__global__ void pfb5_xcc_probe_kernel(int *out)
+{
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(x & 0xf);
+}
+}  // namespace
+
+// whether block b of a one-dimensional grid runs on XCD b mod 8 on this device -- what the chunk maps of the filterbank
+// kernels assume for LOCALITY, and what the look-back hand-over through one XCD's L2 needs for CORRECTNESS: asked of the
+// device itself, once per device and process (a 4096-block probe launch with the banks' LDS footprint; every block
+// reports the XCC_ID register).  Anything unexpected (fewer XCDs, another dispatch order, a failed launch): false.
+bool pfb5_xcd_map_ok(int device, hipStream_t s)
+{
+    static std::mutex mu;
+    static std::map<int, bool> known;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = known.find(device);
+    if (it != known.end()) return it->second;
+    bool ok = false;
+    constexpr int n = 4096;
+    int *d = nullptr;
+    std::vector<int> h((size_t)n, -1);
+    if (hipMalloc(&d, n * sizeof(int)) == hipSuccess) {
+        static DynLdsAttr attr;
+        attr.ensure(reinterpret_cast<const void *>(pfb5_xcc_probe_kernel), 53 * 1024);
+        hipLaunchKernelGGL(pfb5_xcc_probe_kernel, dim3(n), dim3(kThreads5), 53 * 1024, s, d);
+        if (hipMemcpyAsync(h.data(), d, n * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess &&
+            hipStreamSynchronize(s) == hipSuccess) {
+            ok = true;
+            for (int b = 0; b < 8 && ok; ++b)
+                for (int c = 0; c < b; ++c)
+                    if (h[(size_t)b] == h[(size_t)c]) ok = false;          // eight different XCDs
+            for (int b = 0; b < n && ok; ++b)
+                if (h[(size_t)b] != h[(size_t)(b % 8)]) ok = false;
+        }
+        (void)hipFree(d);
+    }
+    (void)hipGetLastError();
+    known[device] = ok;
+    return ok;
 }
 
 bool pfb5_fm_supported(int NB, int D, int P)

@@ -192,6 +192,8 @@ int rcf_pfb_fm_enable(rcf_t *h, int mode, int gr_phase)
             RCF_HIP(hipMalloc(&p.d_fm_err, sizeof(int)));
             RCF_HIP(hipMemsetAsync(p.d_fm_flag, 0, sizeof(unsigned long long) * (size_t)p.fm_slots * 8, h->stream));
             RCF_HIP(hipMemsetAsync(p.d_fm_err, 0, sizeof(int), h->stream));
+            static const bool want_local = [] { const char *e = getenv("RCF_PFB5_FM_LOCAL"); return !e || atoi(e) != 0; }();
+            p.fm_local = want_local && pfb5_xcd_map_ok(h->device, h->stream) ? 1 : 0;
         }
         p.rd_fm.assign((size_t)p.NB, p.produced);
         p.fm_from = p.produced;

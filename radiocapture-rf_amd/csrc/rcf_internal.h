@@ -337,6 +337,7 @@ struct PfbLaunch {
     unsigned long long *fm_flag;
     unsigned long long fm_tag;       // launch serial << 32
     int32_t fm_slots;
+    int32_t fm_local;                // 1: the hand-over goes through ONE XCD's L2 (host-verified block -> XCD map), 0: agent scope
     int32_t *fm_err;
     // host side only (the kernels never look): events ATTACHED to the bank's dispatch (hipExtLaunchKernelGGL) instead of
     // a bracket of two event records around it (one barrier packet less inside the measured interval).  nullptr: plain launch.
@@ -461,6 +462,7 @@ bool pfb5_dispatch(const PfbLaunch &p, bool probe, hipStream_t s);
 // device with tap_finalize's own sincos_fast, so that both paths turn the discriminator's product by the same bits
 bool pfb5_fm_supported(int NB, int D, int P);
 bool pfb5_fm_sees_zero_history(const PfbLaunch &p);
+bool pfb5_xcd_map_ok(int device, hipStream_t s);
 size_t pfb5_fm_history(int NB, int D, int P);
 void launch_pfb5_fm_inc(const double *d_dangle, float2 *d_inc, int NB, hipStream_t s);
 inline bool pfb_frame_major(int NB) { return NB % 25 == 0; }

@@ -172,6 +172,7 @@ int plan_pfb(rcf_t *h, BlockPlan &bp)
                     pl.fm_flag = p.d_fm_flag;
                     pl.fm_err = p.d_fm_err;
                     pl.fm_slots = p.fm_slots;
+                    pl.fm_local = p.fm_local;
                     pl.fm_tag = (unsigned long long)(++p.fm_serial) << 32;
                 }
             } else {

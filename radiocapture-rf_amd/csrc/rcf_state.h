@@ -114,6 +114,7 @@ struct Pfb {
     unsigned long long *d_fm_edge = nullptr, *d_fm_flag = nullptr;
     int *d_fm_err = nullptr;
     int fm_slots = 0;
+    int fm_local = 0;              // the hand-over stays in one XCD's L2 (pfb5_xcd_map_ok said so; RCF_PFB5_FM_LOCAL=0: never)
     uint64_t fm_serial = 0;        // launches so far (the flags' tags)
     std::vector<int64_t> rd_fm;    // per-bin read cursors
 };
