@@ -87,6 +87,8 @@ def _channels(ch):
     if isinstance(rg, dict):
         if "error" in rg:
             out["reference_grid_filterbank"] = _err(rg)
+        elif isinstance(rg.get("with_taps"), list):              # (already a compact line's summary: as it is)
+            out["reference_grid_filterbank"] = rg
         else:
             e = pick(rg, "kernel", "pfb_ms_per_block", "reference_channels_per_frontend")
             e["frac"] = (rg.get("roofline") or {}).get("frac")
