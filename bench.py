@@ -103,7 +103,7 @@ def parse_args(argv=None):
                     help="N > 1: front-ends of the one paced point every rank runs (capped by CPU quota x 32 / ranks)")
     ap.add_argument("--rt-pumps", type=int, default=0, help="native pump threads (groups) of the real-time leg (0: four)")
     ap.add_argument("--rt-window-ms", type=float, default=1.0, help="batching window of the pumps")
-    ap.add_argument("--rt-shapes", default="pfb256,grid1600", help="shapes of the real-time leg")
+    ap.add_argument("--rt-shapes", default="pfb256,grid1600,grid1600fm", help="shapes of the real-time leg")
     ap.add_argument("--rt-burst", action="store_true",
                     help="real-time leg: every front-end's block completes at the same instant (default: spread over the period)")
     ap.add_argument("--full-on-stdout", action="store_true", help="print the FULL record as the one line (pre-round-6 behaviour)")

@@ -45,7 +45,7 @@ def _realtime(rt):
         return _err(rt)
     out = pick(rt, "pump_threads", "staggered", block_ms="block_ms")
     out["confirm_seconds"] = rt.get("seconds_of_the_confirmation_run_at_K_max")
-    for shape in ("pfb256", "grid1600"):
+    for shape in ("pfb256", "grid1600", "grid1600fm"):
         s = rt.get(shape)
         if not isinstance(s, dict):
             continue

@@ -28,6 +28,15 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
             fe = native.Frontend(FS, 0.0, device=device, block_capacity=blk, hist_capacity=1 << 14, out_capacity=1 << 12)
             fe.pfb_open(NB, NB, proto_taps(native))
             ids = [fe.pfb_chan_open(c["bin"] % NB, 12500, c["delta"]) for c in carriers]
+        elif shape == "grid1600fm":
+            # the same bank with the discriminator of EVERY bin fused into its launch (rcf_pfb_fm_enable, discriminator ring
+            # only): all 1600 reference channels of the front-end are demodulated on the device, 256 of them are subscribed
+            # (bins of the fused ring: rcf_pump_subscribe with RCF_SRC_PFB_BIN0 + bin) and land in host rings
+            D, T = native.channel_params(FS, 12500)
+            fe = native.Frontend(FS, 0.0, device=device, block_capacity=blk, hist_capacity=1 << 14, out_capacity=1 << 11)
+            fe.pfb_open(1600, D, native.design_low_pass_2(1.0, FS, 6250.0, 6250.0, 20.0))
+            fe.pfb_fm_enable(2, gr_phase=True)
+            ids = [native.SRC_PFB_BIN0 + (7 + 6 * j) % 1600 for j in range(256)]
         else:                                            # the bank whose bins ARE the reference's channels + 256 of them tapped
             D, T = native.channel_params(FS, 12500)
             fe = native.Frontend(FS, 0.0, device=device, block_capacity=blk, hist_capacity=1 << 14, out_capacity=1 << 11)
@@ -36,7 +45,11 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
         fes.append(fe)
         chans.append(ids)
     fes, chans = fes[:K], chans[:K]
-    produced0 = sum(fes[i].chan_produced(c) for i in range(K) for c in chans[i])
+    def produced_total():
+        if shape == "grid1600fm":                         # (every subscribed bin gets one sample per frame of its bank)
+            return sum(fes[i].pfb_produced() * len(chans[i]) for i in range(K))
+        return sum(fes[i].chan_produced(c) for i in range(K) for c in chans[i])
+    produced0 = produced_total()
     n_ch = len(chans[0]) if chans else 0
     out_rate = FS / NB / 3 if shape == "pfb256" else 25000.0
     out_ring = 1 << max(10, int(np.ceil(np.log2(4 * out_rate * period))))   # four blocks of output per channel
@@ -98,7 +111,7 @@ def realtime_point(native, pool, K, shape, src, carriers, device, seconds, block
     for g_ in groups:
         g_.close()
     errors = [s_.get("error_text", "error %d" % s_["error"]) for s_ in stats if s_["error"]] + (["pump still running at the deadline"] if hung else [])
-    produced = sum(fes[i].chan_produced(c) for i in range(K) for c in chans[i]) - produced0
+    produced = produced_total() - produced0
     read = sum(s_["samples_out"] for s_ in stats)
     wall = max(s_["elapsed_s"] for s_ in stats)
     miss = sum(s_["late"] for s_ in stats)
@@ -155,7 +168,8 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
     misses is a miss (`K_max_first_attempt` = the largest K whose FIRST run was clean, which is what `K_max` is too unless
     the confirmation run disagrees).  Per shape: pfb256 = BASELINE configs[1] per front-end (256-bin bank + 32 FM
     channels); grid1600 = the 1600-bin reference-grid bank (every bin one of channel.py's 25 kS/s channels) with 256
-    bins tapped and demodulated."""
+    bins tapped and demodulated; grid1600fm = the same bank with the discriminator of EVERY bin fused into its launch
+    (all 1600 channels demodulated on the device, 256 of them delivered to host rings)."""
     blk = int(round(FS * block_ms * 1e-3))
     raw = native.PinnedArray(2 * blk * 2 * k_cap, np.uint8)   # two blocks of its own per front-end
     t8 = np.clip(np.round(tile.view(np.float32) * 32 + 127.4), 0, 255).astype(np.uint8)
@@ -180,7 +194,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
            "attempts_per_point": 1, "batch_window_ms": window_ms,
            "batch_window_note": "a complete block waits up to this long for the blocks that complete meanwhile: they share its launches"}
     for shape in shapes:
-        if shape == "grid1600":
+        if shape in ("grid1600", "grid1600fm"):
             k_cap = min(k_cap, 1024)                     # (256 tapped bins per front-end: a point above this does not pay for its setup time)
         pts, good, bad = [], None, None
         pool = {"fes": [], "chans": []}
@@ -230,7 +244,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
                 good = 0
         for fe in pool["fes"]:
             fe.close()
-        bins, demod = (NB, len(carriers)) if shape == "pfb256" else (1600, 256)
+        bins, demod = (NB, len(carriers)) if shape == "pfb256" else ((1600, 256) if shape == "grid1600" else (1600, 1600))
         keys = ("front_ends", "ok", "deadline_misses", "ring_overruns", "latency_ms_p50", "latency_ms_p99", "latency_ms_max",
                 "gpu_busy_percent_est", "front_ends_per_group_block_mean", "host_plan_fraction_busiest_pump", "host_longest_plan_ms",
                 "host_longest_device_wait_ms", "host_longest_sleep_overshoot_ms", "slow_plans_waits_sleeps", "host_cgroup", "pump_threads_sched_fifo", "pump_cpus", "host_cpus", "why_late", "errors",
@@ -242,7 +256,7 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
             "K_max_p99_under_5ms": max([K_ for K_ in {p["front_ends"] for p in pts}
                                         if all(p.get("ok") and p.get("latency_ms_p99", 1e9) < 5.0
                                                for p in pts if p["front_ends"] == K_)] or [0]),
-            "bins_per_front_end": bins, "demodulated_per_front_end": demod,
+            "bins_per_front_end": bins, "demodulated_per_front_end": demod, "delivered_to_host_per_front_end": len(carriers) if shape == "pfb256" else 256,
             "channels_sustained": (good or 0) * bins, "fm_channels_sustained": (good or 0) * demod,
             "input_Msps_sustained": (good or 0) * FS / 1e6,
             "at_K_max": best, "points": [{k: p[k] for k in keys if k in p} for p in pts],

@@ -556,6 +556,10 @@ int rcf_pump_read_many(rcf_pump_t *p, const int *entries, int64_t *cursors, int 
  * it) -- into a free slot.  Returns the slot (>= 0; use it as `entry` above) and in *cursor where in
  * the slot's item count the new stream begins; RCF_ECAP when all max_read slots are taken. */
 int rcf_pump_subscribe(rcf_pump_t *p, int member, int chan_id, int what, float gain, int64_t *cursor);
+/* chan_id = RCF_SRC_PFB_BIN0 + bin (here and in rcf_pump_config_t.read_chans) with what = RCF_READ_FM subscribes ONE BIN of the
+ * member's fused discriminator ring (rcf_pfb_fm_enable: every bin of the bank demodulated inside its launch) instead of a
+ * channel: delivered from the bank's next frame on, x gain -- quadrature_demod_cf behind the reference's channel at that
+ * bin's frequency (p25_control_demod.py:120-121) without a tap, a tap matrix or a tap_finalize pass. */
 /* frees the slot (its channel may already be closed) */
 int rcf_pump_unsubscribe(rcf_pump_t *p, int entry);
 /* stops the thread (if still running), waits for it, releases the pump */

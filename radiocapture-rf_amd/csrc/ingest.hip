@@ -120,7 +120,8 @@ static __global__ __launch_bounds__(256) void gather_rings_kernel(const GatherRe
         // the destination is either linear (dst_mask_w = ~0: rows packed back to back, rcf_chan_read_many) or a ring of its
         // own (the real-time pump's per-channel host rings: dst_w = the ring's first word, dst_pos_w where this segment starts)
         for (uint32_t w = (item % parts) * 256 + threadIdx.x; w < r.n_w; w += stride) {
-            uint32_t v = r.ring[(r.pos_w + w) & r.mask_w];
+            const uint32_t i = (r.pos_w + w) & r.mask_w;
+            uint32_t v = r.ring[r.stride_w > 1 ? (size_t)i * r.stride_w : (size_t)i];
             if (r.flags & 1u) v = __float_as_uint(__fmul_rn(r.gain, __uint_as_float(v)));
             dst[r.dst_w + ((r.dst_pos_w + w) & r.dst_mask_w)] = v;
         }

@@ -478,6 +478,8 @@ struct GatherRec {
     uint32_t dst_pos_w, dst_mask_w;
     float gain;              // flags & 1: the words are float32 and leave multiplied by gain (quadrature_demod_cf's gain, one
     uint32_t flags;          // float32 multiply -- what rcf_chan_read_fm does on the host)
+    uint32_t stride_w;       // words between consecutive source items (0 / 1: contiguous); > 1: one bin of a frame-major ring of
+                             // floats (the bank's fused discriminator ring: ring = its bin, stride = bins)
 };
 void launch_gather_rings(const GatherRec *d_recs, int n_recs, uint32_t *d_dst, uint32_t max_words, hipStream_t s);
 // one record of the grouped ingest launch (group_prep_kernel, ingest.hip): a block of one front-end, or a plain copy

@@ -30,6 +30,7 @@ struct rcf_pump {
     std::vector<int> rd_member, rd_chan, rd_what;
     std::vector<float> rd_gain;
     std::vector<std::vector<int>> entries_of;      // member -> indices into rd_*
+    std::vector<int64_t> bin_rd;                   // slots on a BIN of a member's fused discriminator ring (rd_chan >= RCF_SRC_PFB_BIN0): frames delivered
     std::vector<int64_t> queued;                   // items ever queued for the host ring of each slot
     std::vector<Chan *> chan_of;                   // subscribed channels, resolved once per channel-set epoch
     std::vector<uint64_t> epoch_of;                // per member: the epoch chan_of was resolved at (~0: resolve again)
@@ -239,12 +240,39 @@ void pump_main(rcf_pump *p)
                         rcf_t *h = g->members[(size_t)it.m];
                         if (epoch_of[(size_t)it.m] != h->chans_epoch) {            // channels were opened / closed: look them up again
                             for (int e : p->entries_of[(size_t)it.m]) {
+                                if (p->rd_chan[(size_t)e] >= RCF_SRC_PFB_BIN0) continue;
                                 auto f = h->chans.find(p->rd_chan[(size_t)e]);
                                 chan_of[(size_t)e] = f == h->chans.end() ? nullptr : f->second.get();
                             }
                             epoch_of[(size_t)it.m] = h->chans_epoch;
                         }
                         for (int e : p->entries_of[(size_t)it.m]) {
+                            if (p->rd_chan[(size_t)e] >= RCF_SRC_PFB_BIN0) {
+                                // one bin of the bank's fused discriminator ring (rcf_pfb_fm_enable): frame-major floats,
+                                // read with a stride of n_bins words
+                                Pfb &pf = h->pfb;
+                                const int bin = p->rd_chan[(size_t)e] - RCF_SRC_PFB_BIN0;
+                                if (!pf.open || !pf.d_fm || bin >= pf.NB) continue;
+                                const int64_t end = pf.fm_mode ? pf.produced : pf.fm_until;
+                                int64_t &cur = p->bin_rd[(size_t)e];
+                                int64_t avail = end - cur;
+                                if (avail <= 0) continue;
+                                if ((size_t)avail > h->out_cap) { cur = end - (int64_t)h->out_cap; avail = (int64_t)h->out_cap; }
+                                if ((size_t)avail > p->out_cap) { cur += avail - (int64_t)p->out_cap; avail = (int64_t)p->out_cap; }
+                                const float gain = p->rd_gain[(size_t)e];
+                                const uint64_t dst_pos = (uint64_t)queued[(size_t)e] & (p->out_cap - 1);
+                                queued[(size_t)e] += avail;
+                                p->out_queued[(size_t)e].store(queued[(size_t)e], std::memory_order_release);
+                                recs[n_recs++] = GatherRec{reinterpret_cast<const uint32_t *>(pf.d_fm + bin),
+                                                           (uint32_t)((uint64_t)cur & h->ring_mask), (uint32_t)avail,
+                                                           (uint32_t)(h->out_cap - 1), (uint32_t)((size_t)e * p->out_cap * slot_w),
+                                                           (uint32_t)dst_pos, (uint32_t)(p->out_cap - 1), gain, gain != 1.0f ? 1u : 0u,
+                                                           (uint32_t)pf.NB};
+                                max_w = std::max<uint32_t>(max_w, (uint32_t)avail);
+                                cur += avail;
+                                s.delivered.push_back({e, avail});
+                                continue;
+                            }
                             Chan *c = chan_of[(size_t)e];
                             if (!c) continue;                                      // closed under the pump: starves
                             const int what = p->rd_what[(size_t)e];
@@ -378,6 +406,7 @@ int rcf_pump_start(rcf_group_t *g, const rcf_pump_config_t *cfg, rcf_pump_t **ou
     p->rd_what.assign((size_t)n_slots, cfg->what);
     p->rd_gain.assign((size_t)n_slots, cfg->gain);
     p->queued.assign((size_t)n_slots, 0);
+    p->bin_rd.assign((size_t)n_slots, 0);
     p->chan_of.assign((size_t)n_slots, nullptr);
     p->epoch_of.assign(G, ~0ull);
     for (int e = 0; e < cfg->n_read; ++e) {
@@ -435,6 +464,11 @@ int rcf_pump_start(rcf_group_t *g, const rcf_pump_config_t *cfg, rcf_pump_t **ou
         MemberLocks ml(g->members);
         for (int e = 0; e < cfg->n_read; ++e) {
             rcf_t *h = g->members[(size_t)p->rd_member[(size_t)e]];
+            if (p->rd_chan[(size_t)e] >= RCF_SRC_PFB_BIN0) {              // a bin of the fused discriminator ring
+                p->rd_what[(size_t)e] = RCF_READ_FM;
+                p->bin_rd[(size_t)e] = h->pfb.produced;
+                continue;
+            }
             auto f = h->chans.find(p->rd_chan[(size_t)e]);
             if (f == h->chans.end()) continue;
             (cfg->what == RCF_READ_IQ ? f->second->rd_iq : f->second->rd_fm) = f->second->produced;
@@ -559,7 +593,18 @@ int rcf_pump_subscribe(rcf_pump_t *p, int member, int chan_id, int what, float g
         // (the channel's own reader position is left where it is: a channel nobody has read yet is delivered from its
         // first output on -- what rcf_chan_read_iq would have handed out -- as far as its device ring still holds it)
         std::lock_guard<std::mutex> l(h->mu);
-        if (h->chans.find(chan_id) == h->chans.end()) { set_error("no such channel %d on member %d", chan_id, member); return RCF_EINVAL; }
+        if (chan_id >= RCF_SRC_PFB_BIN0) {
+            // a bin of the member's fused discriminator ring (rcf_pfb_fm_enable): delivered from the bank's next frame on
+            const int bin = chan_id - RCF_SRC_PFB_BIN0;
+            if (what != RCF_READ_FM || !h->pfb.open || !h->pfb.d_fm || bin >= h->pfb.NB) {
+                set_error("member %d has no fused discriminator ring with a bin %d (rcf_pfb_fm_enable; what = RCF_READ_FM)", member, bin);
+                return RCF_EINVAL;
+            }
+            p->bin_rd[(size_t)e] = h->pfb.fm_mode ? h->pfb.produced : h->pfb.fm_until;
+        } else if (h->chans.find(chan_id) == h->chans.end()) {
+            set_error("no such channel %d on member %d", chan_id, member);
+            return RCF_EINVAL;
+        }
     }
     p->rd_member[(size_t)e] = member;
     p->rd_chan[(size_t)e] = chan_id;

@@ -805,6 +805,9 @@ class Pump:
         self.n_slots = max(ne, int(max_read), 1)
         self._cursors = [C.c_int64(0) for _ in range(self.n_slots)]
         self._what = [what] * self.n_slots
+        for i, (_, c) in enumerate(subscriptions):
+            if int(c) >= SRC_PFB_BIN0:                 # a bin of the member's fused discriminator ring: floats whatever `what` says
+                self._what[i] = "fm"
         self._p = C.c_void_p()
         _check(lib().rcf_pump_start(group._g, C.byref(cfg), C.byref(self._p)))
 
@@ -838,6 +841,10 @@ class Pump:
         self._cursors[e] = cur
         self._what[e] = what
         return e
+
+    def subscribe_bin(self, member, bin_, gain=1.0):
+        """bin `bin_` of member `member`'s fused discriminator ring (Frontend.pfb_fm_enable) from the bank's next frame on"""
+        return self.subscribe(member, SRC_PFB_BIN0 + int(bin_), "fm", gain)
 
     def unsubscribe(self, entry):
         _check(lib().rcf_pump_unsubscribe(self._p, int(entry)))

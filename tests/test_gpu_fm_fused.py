@@ -244,3 +244,77 @@ def test_fused_discriminator_in_a_grouped_launch_has_the_bits_of_one_by_one(gpu_
             a_, o_ = out["grouped"][m][i], out["one by one"][m][i]
             assert len(a_) == len(o_) > 400, (m, b, len(a_), len(o_))
             assert _same_bits(a_, o_), (m, b, float(np.max(np.abs(a_ - o_))), int(np.argmax(np.abs(a_ - o_))))
+
+
+def test_pump_delivers_bins_of_the_fused_discriminator_ring(gpu_required):
+    """rcf_pump_subscribe(member, RCF_SRC_PFB_BIN0 + bin, RCF_READ_FM): bins of the bank's own discriminator ring delivered
+    into host rings by the native pump (no tap, no tap matrix, no tap_finalize) -- two front-ends in one group, some bins
+    subscribed at the start, one while it runs; what arrives is, bit for bit, gain x what rcf_pfb_read_fm hands out for
+    the same blocks pushed one front-end at a time."""
+    import time
+    nat = gpu_required
+    fs = 5e6
+    D, taps = G.channel_params(fs, 12500)
+    nb = 2 * D
+    blk, n_blocks = 100000, 12
+    rng = np.random.default_rng(515)
+    xs = [_signal(rng, fs, blk * n_blocks, nb, [21 + 9 * m, nb - 30 - m]) for m in range(2)]
+    u8 = [np.clip(np.round(x.view(np.float32) * 32.0 + 127.4), 0, 255).astype(np.uint8) for x in xs]
+    gain = 3.5
+
+    def open_all():
+        fes = []
+        for m in range(2):
+            fe = nat.Frontend(fs, 0.0, device=0, block_capacity=blk, hist_capacity=1 << 15, out_capacity=1 << 13)
+            fe.pfb_open(nb, D, taps)
+            fe.pfb_fm_enable(2, gr_phase=True)
+            fes.append(fe)
+        return fes
+
+    fes = open_all()
+    rings = []
+    for m in range(2):
+        r = nat.PinnedArray(len(u8[m]), np.uint8)
+        r.array[:] = u8[m]
+        rings.append(r)
+    subs = [(0, nat.SRC_PFB_BIN0 + 21), (0, nat.SRC_PFB_BIN0 + nb - 30), (1, nat.SRC_PFB_BIN0 + 30)]
+    grp = nat.Group(fes)
+    pump = nat.Pump(grp, rings, blk, fs, subs, fmt=nat.FMT_U8, scale=1.0 / 32, offset=127.4, what="fm", gain=gain,
+                    phase_s=[0.0, 0.009], out_ring_samples=1 << 14, n_blocks=n_blocks, max_read=6, start_delay_s=0.05)
+    with pytest.raises(nat.RcfError):
+        pump.subscribe(0, nat.SRC_PFB_BIN0 + 5, "iq")             # the fused ring holds discriminator samples only
+    with pytest.raises(nat.RcfError):
+        pump.subscribe_bin(1, nb)                                  # no such bin
+    late = None
+    t0 = time.perf_counter()
+    while pump.running():
+        if late is None and time.perf_counter() - t0 > 0.05 + 4.3 * blk / fs:
+            late = pump.subscribe_bin(1, nb - 31, gain)
+        time.sleep(0.003)
+    st = pump.stats()
+    assert st["error"] == 0 and st["blocks_done"] == 2 * n_blocks, st
+    got = [pump.read(e) for e in range(3)] + [pump.read(late)]
+    pump.stop()
+    grp.close()
+    for fe in fes:
+        assert fe.pfb_fm_lost() == 0
+        fe.close()
+    fes = open_all()
+    want = {k: [] for k in range(4)}
+    for b in range(n_blocks):
+        for m in range(2):
+            fes[m].push_raw(u8[m][2 * b * blk: 2 * (b + 1) * blk], nat.FMT_U8, 1.0 / 32, 127.4)
+        want[0].append(fes[0].pfb_read_fm(21, gain))
+        want[1].append(fes[0].pfb_read_fm(nb - 30, gain))
+        want[2].append(fes[1].pfb_read_fm(30, gain))
+        want[3].append(fes[1].pfb_read_fm(nb - 31, gain))
+    for fe in fes:
+        fe.close()
+    for r in rings:
+        r.free()
+    for k in range(3):
+        w = np.concatenate(want[k])
+        assert len(w) == len(got[k]) > 5000 and _same_bits(got[k], w), (k, len(w), len(got[k]))
+    w = np.concatenate(want[3])
+    n = len(got[3])
+    assert 0 < n < len(w) and n % (blk // D) == 0 and _same_bits(got[3], w[len(w) - n:]), (n, len(w))   # from the block it was subscribed in on

@@ -12,7 +12,9 @@ mkdir -p gpurun_out
   echo "# ASan runtime: $RT"
   RCF_LIBRCF=$PWD/radiocapture-rf_amd/rcf/librcf_asan.so LD_PRELOAD=$RT \
   ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 \
-  timeout 2000 python -m pytest tests -m gpu -x -q -k "not rccl_world1" 2>&1 | tail -25     # (librccl's own dlopen()s do not survive the preloaded ASan runtime)
+  timeout 2000 python -m pytest tests -m gpu -x -q -k "not rccl_world1 and not 32_front_ends_at_20_msps" 2>&1 | tail -25
+  # (librccl's own dlopen()s do not survive the preloaded ASan runtime; the 32 x 20 Msps real-time test asserts that no block
+  # is late, which the instrumented host layer -- several times slower at planning a group block -- cannot promise)
   echo "# exit: $?"
 } > $OUT 2>&1
 cat $OUT

@@ -195,7 +195,8 @@ def measured_block(R):
             % (gs["avg_us"], gs["calls"], f3(16.0 * 80 * 409600 / (gs["avg_us"] * 1e-6) / 1e9 / 8000.0), R))
     rt = b.get("realtime")
     if rt:
-        for shape, label in (("pfb256", "256-bin bank + 32 FM"), ("grid1600", "1600-bin reference-grid bank, 256 bins demodulated")):
+        for shape, label in (("pfb256", "256-bin bank + 32 FM"), ("grid1600", "1600-bin reference-grid bank, 256 bins demodulated"),
+                             ("grid1600fm", "1600-bin reference-grid bank with the discriminator of ALL 1600 bins fused into its launch, 256 bins delivered to host rings")):
             s = rt.get(shape)
             if not s:
                 continue
@@ -337,11 +338,13 @@ def summary_block(R):
             f3(sc["roofline"]["frac"]), "; the reference's own size (N = 16384) %.0f × real time" % sr["realtime_factor_at_2.4Msps"] if sr and "realtime_factor_at_2.4Msps" in sr else ""))
     rt = b.get("realtime") or {}
     cells = []
-    for shape, label in (("pfb256", "256-bin bank + 32 FM"), ("grid1600", "1600-bin bank, 256 bins demodulated")):
+    for shape, label in (("pfb256", "256-bin bank + 32 FM"), ("grid1600", "1600-bin bank, 256 bins demodulated"),
+                         ("grid1600fm", "1600-bin bank, ALL bins demodulated in its launch")):
         s_ = rt.get(shape)
         if s_ and "K_max" in s_:
             a = s_.get("at_K_max") or {}
-            cells.append("%s: K_max **%d** front-ends (p99 %.1f ms, %d misses in the confirmation run)" % (label, s_["K_max"], a.get("latency_ms_p99") or 0, a.get("deadline_misses", 0)))
+            cells.append("%s: K_max **%d** front-ends = %d FM channels (p99 %.1f ms, %d misses in the confirmation run)" % (
+                label, s_["K_max"], s_.get("fm_channels_sustained", 0), a.get("latency_ms_p99") or 0, a.get("deadline_misses", 0)))
     if cells:
         add("* paced real time (20 Msps u8 per front-end at wall-clock rate, native pumps): " + "; ".join(cells))
     dm = b.get("daemon")
