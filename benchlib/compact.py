@@ -50,21 +50,22 @@ def _realtime(rt):
         if not isinstance(s, dict):
             continue
         e = pick(s, "K_max", "K_max_first_attempt", "first_K_that_missed", "K_max_p99_under_5ms", "bins_per_front_end",
-                 "demodulated_per_front_end", "channels_sustained", "fm_channels_sustained", "input_Msps_sustained")
+                 "demodulated_per_front_end", "fm_channels_sustained", "input_Msps_sustained")
         a = s.get("at_K_max")
         if isinstance(a, dict):
             e["at_K_max"] = pick(a, "seconds", "deadline_misses", "ring_overruns", "latency_ms_p50", "latency_ms_p99",
-                                 "latency_ms_max", "gpu_busy_percent_est", "host_longest_device_wait_ms",
-                                 "host_longest_sleep_overshoot_ms", "pcie_GBps_in", "completion", "confirmation_run")
+                                 "latency_ms_max", "gpu_busy_percent_est", "pcie_GBps_in", "confirmation_run")
             wl = a.get("why_late") or {}
             if wl:
                 e["at_K_max"]["late_wakeups_ms"] = wl.get("late_wakeups_ms")
                 e["at_K_max"]["of_them_on_a_run_queue_ms"] = wl.get("of_them_on_a_run_queue_ms")
             cg = a.get("host_cgroup") or {}
-            e["at_K_max"].update(pick(cg, "cpu_quota_cores", "throttled_ms", "cpu_cores_used_mean"))
+            e["at_K_max"].update(pick(cg, "throttled_ms", "cpu_cores_used_mean"))
+            if cg.get("cpu_quota_cores") is not None:
+                out["cpu_quota_cores"] = cg["cpu_quota_cores"]
         e["points"] = [[p.get("front_ends"), bool(p.get("ok")), p.get("deadline_misses"), p.get("latency_ms_p99")]
                        for p in s.get("points", [])]
-        out["points_are"] = "[K, ok, deadline misses, latency p99 ms] in the order run"
+        out["points_are"] = "[K, ok, misses, p99 ms] in run order"
         out[shape] = e
     return out
 
@@ -95,11 +96,11 @@ def _channels(ch):
             e["sustained_frac_last_window"] = (rg.get("sustained") or {}).get("frac_last_window")
             e["with_taps"] = [[p.get("bins_tapped"), bool(p.get("discriminator_only")), p.get("pfb_ms_per_block"),
                                p.get("tap_finalize_ms_per_block")] for p in (rg.get("with_taps") or {}).get("points", [])]
-            e["with_taps_are"] = "[bins tapped, discriminator only, bank ms, tap_finalize ms] per 2^25-sample block"
+            e["with_taps_are"] = "[bins tapped, fm only, bank ms, tap_finalize ms] per block"
             e["fused_discriminator"] = [[p.get("mode"), p.get("pfb_ms_per_block"), p.get("frac_of_hbm_peak")] if "error" not in p
                                         else [p.get("mode"), str(p["error"])[:80]]
                                         for p in (rg.get("fused_discriminator") or {}).get("points", [])]
-            e["fused_discriminator_are"] = "[mode (2: discriminator ring only, 1: beside the bins ring), ms per block, frac of HBM peak on its own bytes]"
+            e["fused_discriminator_are"] = "[mode (2: fm ring only, 1: + bins ring), ms per block, frac of HBM peak]"
             e["grid_6k25"] = [pick(p, "bins", "decim", "pfb_ms_per_block", frac="frac_of_hbm_peak") for p in rg.get("grid_6k25", [])]
             out["reference_grid_filterbank"] = e
     return out
@@ -153,6 +154,8 @@ def compact(full, full_path=None):
         if isinstance(c.get("gpu_fm_parity_vs_oracle"), dict):
             cb["gpu_fm_parity_vs_oracle"] = pick(c["gpu_fm_parity_vs_oracle"], "ok", "worst_fm_rms_error", "tolerance",
                                                  "channels_checked")
+        if isinstance(cb.get("sample"), str) and len(cb["sample"]) > 200:      # (the whole sentence is in the full record)
+            cb["sample"] = cb["sample"][:197] + "..."
         rest["cpu_baseline"] = cb
     else:
         rest["cpu_baseline"] = None
