@@ -103,7 +103,13 @@ def scan_ref_leg(native, synth, device):
                          "frac_fft_pass_alone": 12.0 * samples / (fft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fft_ms > 0 else None,
                          "note": "12 B/sample algorithmic (8 read + 4 of running sum streamed); real traffic 8 + 4 (FFT pass: "
                                  "cf32 in, log-magnitude out) + 4 + 4 (running sum: ring in, sum out) = 20 B/sample; the 65 MB "
-                                 "of log-magnitudes of a scan stay in the 256 MB Infinity Cache between the two kernels"},
+                                 "of log-magnitudes of a scan stay in the 256 MB Infinity Cache between the two kernels.  "
+                                 "Why the FFT pass sits where it does: a 16384-point frame is 131 KB of LDS -- ONE workgroup per "
+                                 "CU, so a CU runs a frame's load, transform and store back to back with no second workgroup to "
+                                 "overlap them (a launch of 512 frames is two rounds over the 256 CUs, %.1f us per frame and "
+                                 "CU); the transform at this size is latency-bound per CU, not bandwidth-bound -- and it runs "
+                                 "four orders of magnitude faster than the 2.4 Msps stream it serves" % (
+                                     fft_ms * 1e3 / max(1, fft_n) / 2.0)},
         }
     fe.close()
     return res

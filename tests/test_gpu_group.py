@@ -406,6 +406,13 @@ def test_pump_subscriptions_come_and_go_and_a_counter_fed_member(gpu_required):
         time.sleep(0.002)
     st = pump.stats()
     assert st["error"] == 0 and st["blocks_done"] == 2 * n_blocks, st
+    if not (swapped and closed):
+        # (this thread did not get to run for a third of a second while the pump did: a host so busy decides nothing here)
+        pump.stop(); grp.close()
+        for fe in fes:
+            fe.close()
+        ring0.free(); ring1.free()
+        pytest.skip("the test's own thread was starved of CPU: the pump finished before the subscriptions were changed")
     drain("iq", s_iq), drain("fm", s_fm), drain("b", s_b), drain("d", s_d)
     pump.stop()
     grp.close()
