@@ -400,16 +400,23 @@ def limiter_block(R):
     if not L:
         return "(no limiter counter files for %s)" % R
     L.append("")
-    text = ("Reading: no unit is saturated — not HBM (the fractions of the table above), not the vector ALU, not the LDS pipe.  "
-            "A chunk is 53.7 KB of LDS, which allows three workgroups of five waves per CU and no fourth: with fewer than four "
-            "waves per SIMD there is not enough independent work to cover one phase's latencies (the window's DMA, two barrier-"
-            "separated FFT passes, the copy-out) with another's.")
+    def util(c, cyc):
+        return 100 * c.get("SQ_ACTIVE_INST_VALU", 0) * 4 / 1024.0 / cyc
+    c0, y0 = seen[0]
+    text = ("Reading.  The bank alone saturates no unit: HBM at the fraction of the table above, the vector ALU issuing in %.0f %% of "
+            "the cycles, the LDS pipe in about half of a CU's.  A chunk is 53.7 KB of LDS, which allows three workgroups of five "
+            "waves per CU and no fourth: with fewer than four waves per SIMD there is not enough independent work to cover one "
+            "phase's latencies (the window's DMA, two barrier-separated FFT passes, the copy-out) with another's -- a resident "
+            "wave waits on its own outstanding instructions for about a third of its time." % util(c0, y0))
     if len(seen) == 2 and all("SQ_INSTS_VALU" in c for c, _ in seen):
-        (c0, y0), (c1, y1) = seen
-        text += ("  With the discriminator fused in the kernel issues %.2f × the vector instructions of the bank and lasts %.2f × as "
-                 "long under the counters, at about the same VALU utilisation: its time follows the vector instruction count, not "
-                 "the bytes (it moves a third of the bytes of the bank + `tap_finalize` path) — the discriminator of a frame is as "
-                 "many VALU instructions as the bank's own arithmetic for it." % (c1["SQ_INSTS_VALU"] / c0["SQ_INSTS_VALU"], y1 / y0))
+        c1, y1 = seen[1]
+        text += ("  With the discriminator fused in the kernel issues %.2f x the vector instructions of the bank (the discriminator "
+                 "of a frame is as many VALU instructions as the bank's own arithmetic for it) and lasts %.2f x as long under the "
+                 "counters; its vector ALU issues in %.0f %% of the cycles%s.  It moves a third of the bytes of the bank + "
+                 "`tap_finalize` path and is not bounded by them." % (
+                     c1["SQ_INSTS_VALU"] / c0["SQ_INSTS_VALU"], y1 / y0, util(c1, y1),
+                     ": the copy-out's arithmetic fills the issue slots the bank leaves idle, and the vector ALU is what bounds this kernel"
+                     if util(c1, y1) > 75 else ""))
     L.append(text)
     return "\n".join(L)
 
