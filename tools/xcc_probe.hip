@@ -1,3 +1,8 @@
+// xcc_probe.hip -- which XCD does block b of a one-dimensional grid run on?  Every block reports the XCC_ID register.
+//   hipcc -O2 --offload-arch=gfx950 -o tools/xcc_probe tools/xcc_probe.hip && gpurun -- tools/xcc_probe
+// Measured on MI355X (SPX): block b runs on XCD b mod 8, exactly, also with the banks' 53 KB of LDS per workgroup -- what the
+// filterbanks' chunk maps assume for locality and what pfb5_xcd_map_ok (pfb5.hip) verifies before the look-back hand-over
+// is allowed to go through one XCD's L2.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void probe(int *out) {
