@@ -52,6 +52,9 @@ class RingWriter:
     the sources' clock (an SDR, a paced file feeder): one that got more than ring_blocks - 1 blocks ahead of the pump would
     overwrite blocks not yet taken, as an SDR driver's own ring overruns when its reader stalls."""
 
+    # (how many blocks a counter-fed ring holds is NativeDataPlane's ring_blocks, 64 = 1.3 s of 20 ms blocks: the first
+    # blocks of a process take hundreds of milliseconds -- code objects load, buffers are touched for the first time -- and
+    # the producer does not wait)
     def __init__(self, ring, block_items, ring_blocks):
         self.ring, self.block_items, self.ring_blocks = ring, int(block_items), int(ring_blocks)
         self.counter = np.zeros(1, dtype=np.uint64)
@@ -89,7 +92,7 @@ class NativeDataPlane(egress.EgressPump):
     (the pump's host rings instead of rcf_chan_read_many + a device synchronisation)."""
 
     def __init__(self, tb, socket_factory=None, period=0.01, fm_gain=None, block_ms=20.0, max_channels=1024,
-                 out_ring_samples=1 << 13, ring_blocks=8, cpu=-1, spin_us=0, batch_window_s=0.0):
+                 out_ring_samples=1 << 13, ring_blocks=64, cpu=-1, spin_us=0, batch_window_s=0.0):
         super().__init__(tb, socket_factory=socket_factory, period=period, fm_gain=fm_gain)
         from . import native
         self.native = native

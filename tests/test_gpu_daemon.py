@@ -506,3 +506,106 @@ def test_data_plane_32_front_ends_at_20_msps_with_256_subscribed_channels_each(g
     finally:
         plane.stop()
         tb.close()
+
+
+class _CollectingSocket:
+    made = []
+
+    def __init__(self, port):
+        self.port, self.chunks = port, []
+        _CollectingSocket.made.append(self)
+
+    def send(self, payload):
+        self.chunks.append(payload)
+
+    def close(self):
+        pass
+
+
+def test_data_plane_takes_receiver_feed_from_whatever_owns_the_sdr(gpu_required):
+    """a source whose 'type' has no driver here (the reference's rtlsdr / usrp / bladerf blocks, receiver.py:74-191): the
+    owner of the device hands samples to receiver.feed / feed_raw as they arrive -- in pieces of any size -- and under the
+    native data plane they land in the source's counter-fed ring, which the pump takes block by block.  Two sources in two
+    wire formats; what leaves the channels' sockets is the oracle's channel of the fed stream."""
+    import threading
+    from rcf import dataplane, receiver as receiver_mod
+    fs = 2400000
+    D, taps = G.channel_params(fs, CR)
+
+    class Cfg:
+        receiver_split2 = False
+        frontend_mode = "xlat"
+        sources = {0: {"type": "usrp", "center_freq": 855000000, "samp_rate": fs, "block_ms": 20.0},
+                   1: {"type": "rtlsdr", "center_freq": 860000000, "samp_rate": fs, "block_ms": 20.0, "wire": "u8"}}
+
+    offs = [-62500, 137500]
+    streams = []
+    for i in range(2):
+        src = dict(type="synthetic", samp_rate=fs, seed=3100 + i, tile_samples=1 << 20,
+                   carriers=[dict(f_off=float(offs[i]), f_mod=800.0 + 100 * i, dev=2500.0, snr_db=30.0)])
+        streams.append(sources.synthetic_tile(src))
+    raw1 = sources.to_wire(streams[1], "u8")
+    scale, off = sources.WIRE_SCALE["u8"]
+    x1 = ((raw1.astype(np.float32) - np.float32(off)) * np.float32(scale)).view(np.complex64)
+    _CollectingSocket.made = []
+    tb = receiver_mod.receiver(Cfg(), device=0)
+    plane = dataplane.NativeDataPlane(tb, socket_factory=_CollectingSocket, period=0.01)
+    assert len(plane.classes) == 2
+    ids = [tb.connect_channel(CR, 855000000 + offs[0])[0], tb.connect_channel(CR, 860000000 + offs[1])[0]]
+    starts = [tb.channels[b].start_sample for b in ids]
+    assert starts == [0, 0]
+    plane.start()
+    n_blocks_fed = 20
+    n_total = n_blocks_fed * 48000                                 # 0.4 s of signal per source (inside the 2^20-sample streams)
+    stop = threading.Event()
+
+    failed = []
+
+    def feeder(i):
+        try:
+            feed_all(i)
+        except Exception as e:                                     # (a thread's exception would otherwise go unseen)
+            failed.append((i, repr(e)))
+
+    def feed_all(i):
+        # pieces of 10 007 samples (nothing to do with the pump's 48 000-sample blocks), at the source's rate
+        piece, at, t0 = 10007, 0, time.perf_counter()
+        while at < n_total and not stop.is_set():
+            n = min(piece, n_total - at)
+            due = t0 + (at + n) / fs
+            now = time.perf_counter()
+            if now < due:
+                time.sleep(due - now)
+            if i == 0:
+                tb.feed(0, streams[0][at:at + n])
+            else:
+                tb.feed_raw(1, raw1[2 * at:2 * (at + n)], 1, scale, off)
+            at += n
+    ths = [threading.Thread(target=feeder, args=(i,)) for i in range(2)]
+    try:
+        with pytest.raises(ValueError):
+            tb.feed_raw(0, raw1[:100], 1, scale, off)              # source 0 is configured for cf32
+        for t_ in ths:
+            t_.start()
+        for t_ in ths:
+            t_.join(timeout=30)
+        _wait(lambda: plane.stats()["rcf_pump_blocks_done"] >= 2 * n_blocks_fed, 20, "the pump never took all the blocks that were fed")
+        time.sleep(0.2)                                            # (the egress thread's last pass)
+        st = plane.stats()
+        assert not failed, failed
+        assert "rcf_pump_error" not in st and st["rcf_pump_blocks_done"] == 2 * n_blocks_fed, (st, plane.detail())
+    finally:
+        stop.set()
+        plane.stop()
+        tb.close()
+    # (sockets are made in channel order: the first made belongs to the first channel)
+    used = [s_ for s_ in _CollectingSocket.made if s_.chunks]
+    assert len(used) == 2
+    for i, x in enumerate((streams[0], x1)):
+        got = np.frombuffer(b"".join(used[i].chunks), dtype=np.complex64)
+        ct, incr = OC.xlating_composite(taps, D, float(offs[i]), float(fs))
+        want, _ = OC.channel_bank(x[:n_total], D, ct[None, :], np.array([incr]), gains=[1.0])
+        want = want[0]
+        assert len(got) == len(want) == n_total // D, (i, len(got), len(want))
+        err = float(np.sqrt(np.mean(np.abs(got - want) ** 2) / np.mean(np.abs(want) ** 2)))
+        assert err < 1e-5, (i, err)
