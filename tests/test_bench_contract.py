@@ -51,7 +51,9 @@ def test_bench_line_has_the_contract_keys_and_adds_up():
         assert r["frac_every_launch_pass"] == pytest.approx(
             r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms_every_launch_pass"] * 1e-3) / 1e9 / 8000.0, rel=1e-9)
     assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-9)
-    assert r["avg_launch_ms"] < d["ms_per_step"]                     # the kernel is a part of the step
+    # the kernel is a part of the step -- up to sampling: the events sit on every 4th launch of the timed region (5 of 20),
+    # the step time is the mean over all of them, and back to back the two differ by parts in a thousand either way
+    assert r["avg_launch_ms"] < d["ms_per_step"] * 1.01
     assert 0.98 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05   # PMC bytes: no wasted re-reads
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
