@@ -150,6 +150,10 @@ def measured_block(R):
                 % (pt["mode"], pt["what"], pt["pfb_ms_per_block"], pt["over_untapped_bank"],
                    "; the bank + `tap_finalize` path: %.4f ms" % fd["two_kernel_path_ms_per_block"] if fd.get("two_kernel_path_ms_per_block") and pt["mode"] == 2 else "",
                    pt["algorithmic_bytes_per_launch"] / 1e6, f3(pt["frac_of_hbm_peak"])))
+    fk = _stats("%s_bench_legs_kernel_stats.csv" % R, r"pfb5_fmlb_kernel<20, 4, 2, 2, false, 2>")
+    if fk:
+        add("| … the fused kernel by `rocprofv3 --kernel-trace --stats` (the untimed legs under the tracer: its warm-up and timed launches) | %.1f µs over %d launches ⇒ %s of 8 TB/s on 16 B × 2^25 | `%s_bench_legs_kernel_stats.csv`, row `pfb5_fmlb_kernel<20, 4, 2, 2, false, 2>` |"
+            % (fk["avg_us"], fk["calls"], f3(16.0 * (1 << 25) / (fk["avg_us"] * 1e-6) / 1e9 / 8000.0), R))
     t32 = [(_j("%s_pfb3200_d1600_pmc.json" % R), 1600), (_j("%s_pfb3200_d800_pmc.json" % R), 800)]
     if all(t and "fetch_x2_over_algorithmic_read" in t for t, _ in t32):
         add("| 3200-bin banks, PMC passes of `tools/pfb_probe.py` | %s | `%s_pfb3200_d1600_pmc.json`, `%s_pfb3200_d800_pmc.json` |"

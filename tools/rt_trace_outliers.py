@@ -13,7 +13,8 @@ t_first = min(int(r["Start_Timestamp"]) for r in grp)
 t_lo = t_first + int(skip_s * 1e9)
 # algorithmic bytes of one workgroup's chunk: 16 frames x 256 bins x (8 read + 8 written) for the 256-bin bank; the 1600-bin
 # bank: 4 frames x (800 x 8 read + 1600 x 8 written)
-chunk_bytes = {"pfb_group_kernel_os<256": 16 * 256 * 16, "pfb5_group_kernel<20, 4, 2, 2>": 4 * (800 * 8 + 1600 * 8)}
+chunk_bytes = {"pfb_group_kernel_os<256": 16 * 256 * 16, "pfb5_group_kernel<20, 4, 2, 2>": 4 * (800 * 8 + 1600 * 8),
+               "pfb5_fmlb_group_kernel<20, 4, 2, 2, 2>": 4 * (800 * 8 + 1600 * 4)}      # (fused discriminator, fm ring only)
 out = {"trace": f, "steady_state_from_s_after_first_group_block": skip_s, "kernels": {}}
 acc = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
 for r in rows:
