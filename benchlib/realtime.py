@@ -226,6 +226,14 @@ def realtime_leg(native, tile, carriers, device, seconds=10.0, block_ms=20.0, k_
                 good = K
             else:
                 bad = K
+        # (the starting point failed and a point a whole step below it held: one more point half-way, so that one hiccup at
+        # the starting point does not cost the shape half its K)
+        if good is not None and bad is not None and bad - good >= step and good + step // 2 < bad and len(pts) >= 2 and not pts[0].get("ok"):
+            mid = good + step // 2
+            if point(mid)["ok"]:
+                good = mid
+            else:
+                bad = mid
         first_attempt = good or 0
         # confirmation: the K the short points found, over the full `seconds`; if it does not hold, one step less
         best = None
